@@ -1,0 +1,126 @@
+/*
+ * rii_amd.h -- C ABI of the MI355X-native IVFPQ query engine (drop-in for the hot path of matsui528/rii).
+ *
+ * One opaque engine == one `rii::RiiCpp` (reference: src/rii.h:40-83) living on one GPU.  Every entry
+ * point below names the reference interface it replaces (paths relative to the reference repo).  Plain
+ * pointers and sizes only; the caller allocates every output.  All functions return RII_OK (0) or a
+ * negative error code; rii_last_error() gives the message (thread-local).  Where the reference aborts the
+ * process (live `assert`, bare `throw;` -- src/rii.h:110-111,166-170,202,219-220,252-253) this library
+ * returns RII_ERR_INVALID / RII_ERR_STATE instead.
+ *
+ * Host-pointer calls copy their inputs during the call exactly like the reference (src/rii.h:93-100,
+ * 177-182); nothing outlives a call.  The *_dev variants take device pointers (HBM-resident batches) and
+ * an optional hipStream_t (as void*, NULL = the engine's stream) and are asynchronous on that stream.
+ *
+ * NEW relative to the reference: every query entry point takes a batch of B queries (the reference is one
+ * query per call: src/main.cpp:17-27).  Row b of the outputs is exactly what the reference returns for
+ * query b alone.
+ */
+#ifndef RII_AMD_H
+#define RII_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rii_engine rii_engine;
+
+enum {
+    RII_OK = 0,
+    RII_ERR_INVALID = -1,      /* violated precondition (the reference's assert()s) */
+    RII_ERR_STATE = -2,        /* e.g. add_codes(update_flag=1) before reconfigure (src/rii.h:166-170) */
+    RII_ERR_HIP = -3,          /* a HIP runtime call failed / no GPU: the product path never falls back */
+    RII_ERR_UNSUPPORTED = -4
+};
+
+/* Which compile-time variant of fvec_L2sqr (src/distance.h:113,172,219) and of the auto-vectorised
+ * PQk-means table loop (src/pqkmeans.cpp:164-173) the reference build being replaced would have used
+ * under its `-march=native` (setup.py:96).  Only matters for Ds >= 8 (LUT) / Ds >= 4 (coarse tables). */
+enum { RII_SIMD_SSE = 0, RII_SIMD_AVX = 1, RII_SIMD_AVX512 = 2 };
+
+/* How the per-query distance table (LUT) is built. */
+enum {
+    RII_LUT_EXACT = 0,   /* VALU, the reference's exact lane/FMA order: bit-identical distances (default) */
+    RII_LUT_MFMA = 1     /* v_mfma_f32_16x16x4_f32 on |q|^2 - 2 q.c + |c|^2: within 1e-4 relative */
+};
+
+const char *rii_last_error(void);
+const char *rii_version(void);
+int rii_device_count(void);
+
+/* RiiCpp(codewords[M,Ks,Ds], verbose) -- src/main.cpp:14, src/rii.h:86-106.  Copies the codewords.
+ * device: HIP device ordinal.  simd_arch: see above. */
+int rii_create(const float *codewords, int M, int Ks, int Ds, int verbose, int simd_arch, int device,
+               rii_engine **out);
+void rii_destroy(rii_engine *e);
+
+/* RiiCpp::AddCodes(codes[n,M], update_flag) -- src/main.cpp:16, src/rii.h:158-193. */
+int rii_add_codes(rii_engine *e, const uint8_t *codes, int64_t n, int update_flag);
+/* RiiCpp::Reconfigure(nlist, iter) -- src/main.cpp:15, src/rii.h:108-156 (sampling, PQk-means fit on the
+ * GPU, posting-list rebuild).  Requires 0 < nlist <= N. */
+int rii_reconfigure(rii_engine *e, int nlist, int iter);
+/* RiiCpp::Clear() -- src/main.cpp:28, src/rii.h:328-333. */
+int rii_clear(rii_engine *e);
+
+/* State import: what the reference does through py::pickle's set-state (src/main.cpp:39-52).
+ * rii_set_coarse_centers replaces the centres and rebuilds all posting lists by coarse assignment
+ * (src/rii.h:150-155); rii_set_state installs centres, codes and lists verbatim. */
+int rii_set_coarse_centers(rii_engine *e, const uint8_t *centers, int64_t nlist);
+int rii_set_state(rii_engine *e, const uint8_t *centers, int64_t nlist, const uint8_t *codes, int64_t N,
+                  const int64_t *pl_off, const int32_t *pl_ids);
+
+/* Properties -- src/main.cpp:29-34.  Getters copy out. */
+int64_t rii_get_N(const rii_engine *e);
+int64_t rii_get_nlist(const rii_engine *e);
+int rii_get_M(const rii_engine *e);
+int rii_get_Ks(const rii_engine *e);
+int rii_get_Ds(const rii_engine *e);
+int rii_get_verbose(const rii_engine *e);
+int rii_set_verbose(rii_engine *e, int verbose);
+int rii_get_codewords(const rii_engine *e, float *out /* M*Ks*Ds */);
+int rii_get_codes(const rii_engine *e, uint8_t *out /* N*M */);                 /* flattened_codes */
+int rii_get_coarse_centers(const rii_engine *e, uint8_t *out /* nlist*M */);    /* coarse_centers */
+int rii_get_posting_lists(const rii_engine *e, int64_t *off /* nlist+1 */, int32_t *ids /* N */);
+
+/* RiiCpp::QueryLinear -- src/main.cpp:17-21, src/rii.h:195-242, for B queries.
+ * queries: [B, M*Ks... D] row-major fp32 (D = M*Ds).  tids: S sorted, duplicate-free int64 ids shared by the
+ * batch, S == 0 means "all".  out_ids [B,topk] int64, out_dists [B,topk] fp32, ascending distance.
+ * Requires topk <= N and (S == 0 || topk <= S <= N). */
+int rii_query_linear(rii_engine *e, const float *queries, int64_t B, int topk, const int64_t *tids, int64_t S,
+                     int64_t *out_ids, float *out_dists);
+/* RiiCpp::QueryIvf -- src/main.cpp:22-27, src/rii.h:244-326, for B queries.
+ * out_counts[b] = topk, or 0 where the reference returns ({}, {}) (src/rii.h:324-325).
+ * Requires topk <= L <= N and (S == 0 || topk <= S <= N). */
+int rii_query_ivf(rii_engine *e, const float *queries, int64_t B, int topk, const int64_t *tids, int64_t S,
+                  int64_t L, int64_t *out_ids, float *out_dists, int64_t *out_counts);
+
+/* The same with every pointer in device memory (HBM-resident batch); asynchronous on `stream`. */
+int rii_query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                         int64_t S, int64_t *d_out_ids, float *d_out_dists, void *stream);
+int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                      int64_t S, int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts,
+                      void *stream);
+
+/* Distance-table build alone (RiiCpp::DTable, src/rii.h:361-373) for B queries -> out[B,M,Ks] (host). */
+int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out);
+/* Coarse assignment alone (PQKMeans::predict_one over codes, src/rii.h:350-354): assign[n] in [0,nlist). */
+int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *assign);
+
+/* Options: "lut_mode" (RII_LUT_*), "scan_chunks" (0 = auto), "timing" (0/1). */
+int rii_set_option(rii_engine *e, const char *key, int64_t value);
+int64_t rii_get_option(const rii_engine *e, const char *key);
+
+/* Per-kernel HIP-event timing (enabled by option "timing"=1): events are recorded on the launch stream
+ * around every launch of the named kernel; reading synchronises the stream.
+ * names: "lut", "scan", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select", "assign", "gather", "select". */
+int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms, int64_t *launches);
+int rii_timing_reset(rii_engine *e);
+int rii_synchronize(rii_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RII_AMD_H */

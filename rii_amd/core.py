@@ -1,0 +1,394 @@
+"""ctypes binding of librii_amd.so -- the thin shim that takes the place of the reference's pybind11 module
+`main` (src/main.cpp:11-61).  `RiiGpu` exposes the same attribute names as `main.RiiCpp` so that the Python
+class `Rii` (rii_amd/rii.py, mirroring rii/rii.py) is written against an identical surface, plus the batched
+entry points the reference does not have.
+
+The product path never falls back to a CPU implementation: if the HIP library is missing it is built with
+hipcc; if there is no GPU, constructing an engine raises RiiAmdError.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SIMD = {"sse": 0, "avx": 1, "avx512": 2}
+LUT_MODES = {"exact": 0, "mfma": 1}
+
+
+class RiiAmdError(RuntimeError):
+    pass
+
+
+def host_simd_arch():
+    """The fvec_L2sqr variant the reference would compile to on this host under its `-march=native`
+    (setup.py:96; src/distance.h:113,172,219).  Override with RII_SIMD_ARCH=sse|avx|avx512."""
+    env = os.environ.get("RII_SIMD_ARCH")
+    if env:
+        if env not in SIMD:
+            raise ValueError("RII_SIMD_ARCH must be one of %s" % list(SIMD))
+        return env
+    flags = set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = set(line.split())
+                    break
+    except OSError:
+        pass
+    if "avx512f" in flags:
+        return "avx512"
+    if "avx" in flags:
+        return "avx"
+    return "sse"
+
+
+def library_path():
+    return os.path.join(_HERE, "librii_amd.so")
+
+
+def build_library(force=False):
+    """Compile rii_amd/csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    so = library_path()
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "rii_amd.h"))
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", csrc, "-j4"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = library_path()
+    if not os.path.exists(so):
+        build_library()
+    L = ctypes.CDLL(so)
+    c_int, c_i64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+    f32p = ctypes.POINTER(ctypes.c_float)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    sig = {
+        "rii_last_error": (ctypes.c_char_p, []),
+        "rii_version": (ctypes.c_char_p, []),
+        "rii_device_count": (c_int, []),
+        "rii_create": (c_int, [f32p, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
+        "rii_destroy": (None, [c_vp]),
+        "rii_add_codes": (c_int, [c_vp, u8p, c_i64, c_int]),
+        "rii_reconfigure": (c_int, [c_vp, c_int, c_int]),
+        "rii_clear": (c_int, [c_vp]),
+        "rii_set_coarse_centers": (c_int, [c_vp, u8p, c_i64]),
+        "rii_set_state": (c_int, [c_vp, u8p, c_i64, u8p, c_i64, i64p, i32p]),
+        "rii_get_N": (c_i64, [c_vp]),
+        "rii_get_nlist": (c_i64, [c_vp]),
+        "rii_get_M": (c_int, [c_vp]),
+        "rii_get_Ks": (c_int, [c_vp]),
+        "rii_get_Ds": (c_int, [c_vp]),
+        "rii_get_verbose": (c_int, [c_vp]),
+        "rii_set_verbose": (c_int, [c_vp, c_int]),
+        "rii_get_codewords": (c_int, [c_vp, f32p]),
+        "rii_get_codes": (c_int, [c_vp, u8p]),
+        "rii_get_coarse_centers": (c_int, [c_vp, u8p]),
+        "rii_get_posting_lists": (c_int, [c_vp, i64p, i32p]),
+        "rii_query_linear": (c_int, [c_vp, f32p, c_i64, c_int, i64p, c_i64, i64p, f32p]),
+        "rii_query_ivf": (c_int, [c_vp, f32p, c_i64, c_int, i64p, c_i64, c_i64, i64p, f32p, i64p]),
+        "rii_query_linear_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+        "rii_query_ivf_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+        "rii_dtable": (c_int, [c_vp, f32p, c_i64, f32p]),
+        "rii_assign": (c_int, [c_vp, u8p, c_i64, i32p]),
+        "rii_set_option": (c_int, [c_vp, ctypes.c_char_p, c_i64]),
+        "rii_get_option": (c_i64, [c_vp, ctypes.c_char_p]),
+        "rii_timing_read": (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), i64p]),
+        "rii_timing_reset": (c_int, [c_vp]),
+        "rii_synchronize": (c_int, [c_vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L._rii_signatures = sig
+    _LIB = L
+    return L
+
+
+def exported_symbols():
+    """Names declared in include/rii_amd.h that the loaded library must export (used by the CPU tests)."""
+    return sorted(_lib()._rii_signatures.keys())
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _check(rc):
+    if rc != 0:
+        msg = _lib().rii_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise RiiAmdError("[%d] %s" % (rc, msg))
+
+
+_EMPTY_I64 = np.zeros(0, np.int64)
+
+
+class RiiGpu(object):
+    """MI355X engine with the surface of `main.RiiCpp` (src/main.cpp:12-54)."""
+
+    def __init__(self, codewords=None, verbose=False, simd_arch=None, device=None):
+        self._h = ctypes.c_void_p()
+        if codewords is None:            # RiiCpp() -- "required in pickle" (main.cpp:13)
+            return
+        self._create(np.asarray(codewords), bool(verbose), simd_arch, device)
+
+    def _create(self, codewords, verbose, simd_arch, device):
+        if codewords.dtype != np.float32:
+            raise TypeError("codewords must be float32 (pybind11 array_t<float>, src/main.cpp:14)")
+        if codewords.ndim != 3:
+            raise ValueError("codewords must have ndim=3 (M, Ks, Ds)")
+        cw = np.ascontiguousarray(codewords)
+        self._simd = simd_arch or host_simd_arch()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", os.environ.get("RII_DEVICE", "0")))
+            if device >= max(_lib().rii_device_count(), 1):
+                device = 0
+        self._device = int(device)
+        M, Ks, Ds = cw.shape
+        h = ctypes.c_void_p()
+        _check(_lib().rii_create(_ptr(cw, ctypes.c_float), M, Ks, Ds, int(verbose), SIMD[self._simd], self._device,
+                                 ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib().rii_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---- main.cpp:15-16,28 ----
+    def reconfigure(self, nlist, iter):
+        _check(_lib().rii_reconfigure(self._h, int(nlist), int(iter)))
+
+    def add_codes(self, codes, update_flag):
+        codes = np.asarray(codes)
+        if codes.dtype != np.uint8:
+            raise TypeError("codes must be uint8")
+        if codes.ndim != 2 or codes.shape[1] != self.M:
+            raise ValueError("codes must have shape (N, M=%d)" % self.M)
+        c = np.ascontiguousarray(codes)
+        _check(_lib().rii_add_codes(self._h, _ptr(c, ctypes.c_uint8), c.shape[0], int(bool(update_flag))))
+
+    def clear(self):
+        _check(_lib().rii_clear(self._h))
+
+    def set_coarse_centers(self, centers):
+        """Import coarse centres and rebuild the posting lists by coarse assignment (what the reference reaches
+        through its pickle set-state, src/main.cpp:39-52, followed by rii.h:150-155)."""
+        c = np.ascontiguousarray(centers, dtype=np.uint8)
+        assert c.ndim == 2 and c.shape[1] == self.M
+        _check(_lib().rii_set_coarse_centers(self._h, _ptr(c, ctypes.c_uint8), c.shape[0]))
+
+    # ---- helpers ----
+    @staticmethod
+    def _as_query_batch(q, D):
+        q = np.asarray(q)
+        if q.dtype != np.float32:
+            raise TypeError("query must be float32 (py::arg(\"query\").noconvert(), src/main.cpp:18)")
+        if q.ndim != 2 or q.shape[1] != D:
+            raise ValueError("queries must have shape (B, D=%d)" % D)
+        return np.ascontiguousarray(q)
+
+    @staticmethod
+    def _as_tids(t):
+        if t is None:
+            return _EMPTY_I64
+        t = np.asarray(t)
+        if t.dtype != np.int64:
+            raise TypeError("target_ids must be int64 (py::arg(\"target_ids\").noconvert(), src/main.cpp:20)")
+        if t.ndim != 1:
+            raise ValueError("target_ids must be 1-D")
+        return np.ascontiguousarray(t)
+
+    # ---- batched entry points (NEW) ----
+    def query_linear_batch(self, queries, topk, target_ids=None):
+        Q = self._as_query_batch(queries, self.M * self.Ds)
+        t = self._as_tids(target_ids)
+        B = Q.shape[0]
+        ids = np.empty((B, topk), np.int64)
+        d = np.empty((B, topk), np.float32)
+        _check(_lib().rii_query_linear(self._h, _ptr(Q, ctypes.c_float), B, int(topk), _ptr(t, ctypes.c_int64), t.size,
+                                       _ptr(ids, ctypes.c_int64), _ptr(d, ctypes.c_float)))
+        return ids, d
+
+    def query_ivf_batch(self, queries, topk, target_ids, L):
+        Q = self._as_query_batch(queries, self.M * self.Ds)
+        t = self._as_tids(target_ids)
+        B = Q.shape[0]
+        ids = np.empty((B, topk), np.int64)
+        d = np.empty((B, topk), np.float32)
+        cnt = np.empty(B, np.int64)
+        _check(_lib().rii_query_ivf(self._h, _ptr(Q, ctypes.c_float), B, int(topk), _ptr(t, ctypes.c_int64), t.size,
+                                    int(L), _ptr(ids, ctypes.c_int64), _ptr(d, ctypes.c_float),
+                                    _ptr(cnt, ctypes.c_int64)))
+        return ids, d, cnt
+
+    def query_linear_dev(self, d_queries, B, topk, d_tids, S, d_out_ids, d_out_dists, stream=0):
+        """Raw device pointers (ints); asynchronous on `stream` (0/None = the engine's own stream)."""
+        _check(_lib().rii_query_linear_dev(self._h, d_queries, B, int(topk), d_tids or None, S, d_out_ids,
+                                           d_out_dists, stream or None))
+
+    def query_ivf_dev(self, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts, stream=0):
+        _check(_lib().rii_query_ivf_dev(self._h, d_queries, B, int(topk), d_tids or None, S, int(L), d_out_ids,
+                                        d_out_dists, d_out_counts, stream or None))
+
+    # ---- main.cpp:17-27: one query per call, python lists out ----
+    def query_linear(self, query, topk, target_ids):
+        q = np.asarray(query)
+        if q.ndim != 1:
+            raise ValueError("query must be 1-D")
+        ids, d = self.query_linear_batch(q.reshape(1, -1), topk, target_ids)
+        return ids[0].tolist(), [float(x) for x in d[0]]
+
+    def query_ivf(self, query, topk, target_ids, L):
+        q = np.asarray(query)
+        if q.ndim != 1:
+            raise ValueError("query must be 1-D")
+        ids, d, cnt = self.query_ivf_batch(q.reshape(1, -1), topk, target_ids, L)
+        n = int(cnt[0])
+        return ids[0, :n].tolist(), [float(x) for x in d[0, :n]]
+
+    def dtable(self, queries):
+        Q = self._as_query_batch(np.atleast_2d(queries), self.M * self.Ds)
+        out = np.empty((Q.shape[0], self.M, self.Ks), np.float32)
+        _check(_lib().rii_dtable(self._h, _ptr(Q, ctypes.c_float), Q.shape[0], _ptr(out, ctypes.c_float)))
+        return out
+
+    def assign(self, codes):
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        out = np.empty(c.shape[0], np.int32)
+        _check(_lib().rii_assign(self._h, _ptr(c, ctypes.c_uint8), c.shape[0], _ptr(out, ctypes.c_int32)))
+        return out
+
+    # ---- options / timing ----
+    def set_option(self, key, value):
+        if key == "lut_mode" and isinstance(value, str):
+            value = LUT_MODES[value]
+        _check(_lib().rii_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        return int(_lib().rii_get_option(self._h, key.encode()))
+
+    def timing_read(self, kernel):
+        ms = ctypes.c_double()
+        n = ctypes.c_int64()
+        _check(_lib().rii_timing_read(self._h, kernel.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def timing_reset(self):
+        _check(_lib().rii_timing_reset(self._h))
+
+    def synchronize(self):
+        _check(_lib().rii_synchronize(self._h))
+
+    # ---- properties, main.cpp:29-34 ----
+    @property
+    def M(self):
+        return _lib().rii_get_M(self._h)
+
+    @property
+    def Ks(self):
+        return _lib().rii_get_Ks(self._h)
+
+    @property
+    def Ds(self):
+        return _lib().rii_get_Ds(self._h)
+
+    @property
+    def N(self):
+        return int(_lib().rii_get_N(self._h))
+
+    @property
+    def nlist(self):
+        return int(_lib().rii_get_nlist(self._h))
+
+    @property
+    def verbose(self):
+        return bool(_lib().rii_get_verbose(self._h))
+
+    @verbose.setter
+    def verbose(self, v):
+        _check(_lib().rii_set_verbose(self._h, int(bool(v))))
+
+    @property
+    def codewords(self):
+        out = np.empty((self.M, self.Ks, self.Ds), np.float32)
+        _check(_lib().rii_get_codewords(self._h, _ptr(out, ctypes.c_float)))
+        return out
+
+    def codes_array(self):
+        out = np.empty((self.N, self.M), np.uint8)
+        _check(_lib().rii_get_codes(self._h, _ptr(out, ctypes.c_uint8)))
+        return out
+
+    def coarse_centers_array(self):
+        out = np.empty((self.nlist, self.M), np.uint8)
+        _check(_lib().rii_get_coarse_centers(self._h, _ptr(out, ctypes.c_uint8)))
+        return out
+
+    def posting_lists_csr(self):
+        off = np.zeros(self.nlist + 1, np.int64)
+        ids = np.empty(max(self.N, 1), np.int32)
+        _check(_lib().rii_get_posting_lists(self._h, _ptr(off, ctypes.c_int64), _ptr(ids, ctypes.c_int32)))
+        return off, ids[:off[-1]]
+
+    @property
+    def coarse_centers(self):            # list[list[int]] like def_readonly of vector<vector<uchar>>
+        return self.coarse_centers_array().tolist()
+
+    @property
+    def flattened_codes(self):           # list[int] of N*M
+        return self.codes_array().reshape(-1).tolist()
+
+    @property
+    def posting_lists(self):             # list[list[int]]
+        off, ids = self.posting_lists_csr()
+        return [ids[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+
+    # ---- pickle: the same 5 logical fields as py::pickle in src/main.cpp:35-53 ----
+    def __getstate__(self):
+        off, ids = self.posting_lists_csr()
+        return (self.codewords, self.verbose, self.coarse_centers_array(), self.codes_array(), (off, ids),
+                self._simd)
+
+    def __setstate__(self, t):
+        if len(t) not in (5, 6):
+            raise RuntimeError("Invalid state when reading pickled item")
+        cw, verbose, centers, codes, lists = t[:5]
+        simd = t[5] if len(t) == 6 else None
+        self._h = ctypes.c_void_p()
+        cw = np.asarray(cw, np.float32)
+        self._create(cw, bool(verbose), simd, None)
+        M = cw.shape[0]
+        centers = np.ascontiguousarray(np.asarray(centers, np.uint8).reshape(-1, M))
+        codes = np.ascontiguousarray(np.asarray(codes, np.uint8).reshape(-1, M))
+        if isinstance(lists, tuple):
+            off, ids = lists
+        else:                              # reference layout: list of lists
+            off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+            ids = np.concatenate([np.asarray(l, np.int32) for l in lists]) if len(lists) else np.zeros(0, np.int32)
+        off = np.ascontiguousarray(off, np.int64)
+        ids = np.ascontiguousarray(ids, np.int32)
+        if ids.size == 0:
+            ids = np.zeros(1, np.int32)
+        _check(_lib().rii_set_state(self._h, _ptr(centers, ctypes.c_uint8), centers.shape[0],
+                                    _ptr(codes, ctypes.c_uint8), codes.shape[0], _ptr(off, ctypes.c_int64),
+                                    _ptr(ids, ctypes.c_int32)))

@@ -1,0 +1,859 @@
+// engine.hip -- host side of the engine: device-buffer ownership, batching/chunking policy, posting-list
+// bookkeeping and the C ABI of include/rii_amd.h.  Mirrors rii::RiiCpp (src/rii.h:40-419) one-to-one; every
+// arithmetic step happens in the HIP kernels of kernels.hip.  There is NO CPU fallback anywhere in this
+// file: without a working HIP device rii_create() fails with RII_ERR_HIP.
+#include "rii_amd.h"
+#include "rii_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+#define RII_API extern "C" __attribute__((visibility("default")))
+
+using namespace riiamd;
+
+static thread_local std::string g_err;
+static int set_err(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return set_err(RII_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                               \
+    } while (0)
+#define RII_TRY(expr)                 \
+    do {                              \
+        int _r = (expr);              \
+        if (_r != RII_OK) return _r;  \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // grow-only; contents are NOT preserved unless keep > 0 (bytes to carry over)
+    int ensure(size_t bytes, size_t keep = 0, hipStream_t st = nullptr)
+    {
+        if (bytes <= cap) return RII_OK;
+        size_t ncap = std::max(bytes, cap + cap / 2);
+        void *np = nullptr;
+        HIP_TRY(hipMalloc(&np, ncap));
+        if (keep && p) {
+            HIP_TRY(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (p) HIP_TRY(hipFree(p));
+        p = np;
+        cap = ncap;
+        return RII_OK;
+    }
+    void release()
+    {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+}  // namespace
+
+struct rii_engine {
+    int M = 0, Ks = 0, Ds = 0, arch = RII_SIMD_AVX512, verbose = 0, device = 0;
+    int QT = 4;
+    int lut_mode = RII_LUT_EXACT;
+    int scan_chunks = 0;        // 0 = auto
+    int timing = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+
+    // host mirrors (the reference keeps everything in host memory: src/rii.h:77-82)
+    std::vector<float> codewords;
+    std::vector<uint8_t> codes;                      // N*M
+    std::vector<uint8_t> centers;                    // nlist*M
+    std::vector<std::vector<int32_t>> lists;         // posting lists
+    int64_t N = 0;
+
+    // device state
+    DevBuf d_codewords, d_cnorm, d_codes, d_centers, d_symtab, d_pl_off, d_pl_ids, d_list_len;
+    bool have_symtab = false, have_cnorm = false, lists_dirty = true;
+    int64_t d_codes_n = 0;                           // codes resident on the device
+
+    // scratch
+    DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
+        s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
+        s_hist, s_cnt, s_sample;
+    void *sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+
+    std::map<std::string, KernelTimer> timers;
+};
+
+namespace {
+
+int64_t nlist_of(const rii_engine *e) { return e->M ? (int64_t) (e->centers.size() / (size_t) e->M) : 0; }
+
+struct ScopedTimer {
+    rii_engine *e;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char *name;
+    ScopedTimer(rii_engine *e_, const char *name_, hipStream_t st_) : e(e_), st(st_), name(name_)
+    {
+        if (e->timing) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+            (void) hipEventRecord(a, st);
+        }
+    }
+    ~ScopedTimer()
+    {
+        if (a && b) {
+            (void) hipEventRecord(b, st);
+            e->timers[name].pending.emplace_back(a, b);
+        }
+    }
+};
+
+int ensure_symtab(rii_engine *e)
+{
+    if (e->have_symtab) return RII_OK;
+    RII_TRY(e->d_symtab.ensure((size_t) e->M * e->Ks * e->Ks * sizeof(float)));
+    HIP_TRY(launch_symtab(e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch, e->d_symtab.as<float>(),
+                          e->stream));
+    e->have_symtab = true;
+    return RII_OK;
+}
+
+int upload_centers(rii_engine *e)
+{
+    if (e->centers.empty()) return RII_OK;
+    RII_TRY(e->d_centers.ensure(e->centers.size()));
+    HIP_TRY(hipMemcpyAsync(e->d_centers.p, e->centers.data(), e->centers.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RII_OK;
+}
+
+// device CSR of the posting lists (rebuilt lazily after mutations)
+int sync_lists(rii_engine *e)
+{
+    if (!e->lists_dirty) return RII_OK;
+    const int64_t nlist = (int64_t) e->lists.size();
+    std::vector<int64_t> off((size_t) nlist + 1, 0);
+    std::vector<int32_t> len((size_t) nlist, 0);
+    for (int64_t i = 0; i < nlist; ++i) {
+        len[(size_t) i] = (int32_t) e->lists[(size_t) i].size();
+        off[(size_t) i + 1] = off[(size_t) i] + (int64_t) e->lists[(size_t) i].size();
+    }
+    std::vector<int32_t> ids((size_t) std::max<int64_t>(off[(size_t) nlist], 1));
+    for (int64_t i = 0; i < nlist; ++i)
+        std::copy(e->lists[(size_t) i].begin(), e->lists[(size_t) i].end(), ids.begin() + off[(size_t) i]);
+    RII_TRY(e->d_pl_off.ensure(off.size() * sizeof(int64_t)));
+    RII_TRY(e->d_pl_ids.ensure(ids.size() * sizeof(int32_t)));
+    RII_TRY(e->d_list_len.ensure(std::max<size_t>(len.size(), 1) * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(e->d_pl_off.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_pl_ids.p, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    if (!len.empty())
+        HIP_TRY(hipMemcpyAsync(e->d_list_len.p, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                               e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->lists_dirty = false;
+    return RII_OK;
+}
+
+// coarse assignment of device-resident codes [d_codes, d_codes + num) -> host vector
+int assign_device_codes(rii_engine *e, const uint8_t *d_codes, int64_t num, std::vector<int32_t> &out)
+{
+    out.resize((size_t) num);
+    if (num == 0) return RII_OK;
+    RII_TRY(ensure_symtab(e));
+    RII_TRY(e->s_assign.ensure((size_t) num * sizeof(int32_t)));
+    {
+        ScopedTimer t(e, "assign", e->stream);
+        HIP_TRY(launch_assign(d_codes, num, e->M, e->Ks, e->d_symtab.as<float>(), e->d_centers.as<uint8_t>(),
+                              (int) nlist_of(e), e->s_assign.as<int32_t>(), e->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(out.data(), e->s_assign.p, (size_t) num * sizeof(int32_t), hipMemcpyDeviceToHost,
+                           e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RII_OK;
+}
+
+// RiiCpp::UpdatePostingLists, src/rii.h:335-359
+int update_posting_lists(rii_engine *e, int64_t start, int64_t num)
+{
+    if (num == 0) return RII_OK;
+    std::vector<int32_t> assign;
+    RII_TRY(assign_device_codes(e, e->d_codes.as<uint8_t>() + (size_t) start * e->M, num, assign));
+    for (int64_t n = 0; n < num; ++n) {
+        const int32_t a = assign[(size_t) n];
+        if (a < 0 || a >= (int32_t) e->lists.size())
+            return set_err(RII_ERR_HIP, "coarse assignment produced an invalid list id %d", a);
+        e->lists[(size_t) a].push_back((int32_t) (start + n));
+    }
+    e->lists_dirty = true;
+    return RII_OK;
+}
+
+int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
+{
+    if (n == 0) return RII_OK;
+    const size_t M = (size_t) e->M;
+    const size_t old_bytes = (size_t) e->N * M, add = (size_t) n * M;
+    e->codes.insert(e->codes.end(), codes, codes + add);
+    RII_TRY(e->d_codes.ensure(old_bytes + add, old_bytes, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_codes.as<uint8_t>() + old_bytes, codes, add, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->N += n;
+    e->d_codes_n = e->N;
+    return RII_OK;
+}
+
+int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st)
+{
+    const size_t tiles = (size_t) ((B + e->QT - 1) / e->QT);
+    RII_TRY(e->s_lut.ensure(tiles * (size_t) e->M * e->Ks * e->QT * sizeof(float)));
+    ScopedTimer t(e, "lut", st);
+    if (e->lut_mode == RII_LUT_MFMA) {
+        if (!e->have_cnorm) {
+            RII_TRY(e->d_cnorm.ensure((size_t) e->M * e->Ks * sizeof(float)));
+            HIP_TRY(launch_codeword_norms(e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->d_cnorm.as<float>(), st));
+            e->have_cnorm = true;
+        }
+        HIP_TRY(launch_lut_build_mfma(d_queries, B, e->d_codewords.as<float>(), e->d_cnorm.as<float>(), e->M, e->Ks,
+                                      e->Ds, e->QT, e->s_lut.as<float>(), st));
+    } else {
+        HIP_TRY(launch_lut_build(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch, e->QT,
+                                 e->s_lut.as<float>(), st));
+    }
+    return RII_OK;
+}
+
+void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, int64_t *chunk_len)
+{
+    const int64_t tiles = (B + e->QT - 1) / e->QT;
+    int64_t c = e->scan_chunks;
+    if (c <= 0) {
+        // ~2 workgroups' worth of tiles per CU, but never chunks shorter than 8K codes (table staging cost)
+        const int64_t target = 2LL * e->n_cu;
+        c = (target + tiles - 1) / tiles;
+        const int64_t max_c = std::max<int64_t>(1, n_codes / 8192);
+        c = std::max<int64_t>(1, std::min(c, max_c));
+        if (tiles >= e->n_cu) c = 1;
+    }
+    c = std::max<int64_t>(1, std::min<int64_t>(c, 65535));
+    int64_t len = (n_codes + c - 1) / c;
+    len = std::max<int64_t>(len, 1);
+    *chunks = (int) ((n_codes + len - 1) / len);
+    *chunk_len = len;
+}
+
+// the scan over `n_codes` codes at d_codes for B queries whose tables are in s_lut; ids are local indices
+// translated through d_remap (subset search) when given.
+int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B, int topk, const int64_t *d_remap,
+              int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+{
+    ScanParams sp;
+    sp.codes = d_codes; sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks; sp.lut = e->s_lut.as<float>();
+    sp.B = (int) B; sp.QT = e->QT; sp.best = nullptr; sp.keys = nullptr; sp.b0 = 0; sp.bc = 0;
+    if (topk == 1) {
+        pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len);
+        RII_TRY(e->s_best.ensure((size_t) B * sizeof(unsigned long long)));
+        sp.best = e->s_best.as<unsigned long long>();
+        HIP_TRY(hipMemsetAsync(sp.best, 0xff, (size_t) B * sizeof(unsigned long long), st));
+        {
+            ScopedTimer t(e, "scan", st);
+            HIP_TRY(launch_scan(sp, st));
+        }
+        HIP_TRY(launch_finalize_top1(sp.best, B, d_remap, d_out_ids, d_out_dists, topk, st));
+        return RII_OK;
+    }
+    // general top-k: emit all packed keys for a chunk of queries, fully sort each row, keep the first topk.
+    const int64_t budget_keys = (int64_t) 1 << 27;                 // 1 GiB per key buffer
+    int64_t bc = std::max<int64_t>(e->QT, (budget_keys / std::max<int64_t>(n_codes, 1)) / e->QT * e->QT);
+    bc = std::min<int64_t>(bc, (B + e->QT - 1) / e->QT * e->QT);
+    while (bc > e->QT && bc * n_codes >= ((int64_t) 1 << 31)) bc -= e->QT;
+    if (bc * n_codes >= ((int64_t) 1 << 31))
+        return set_err(RII_ERR_UNSUPPORTED, "topk>1 over %lld codes exceeds the sort fallback's 2^31 key limit",
+                       (long long) n_codes);
+    RII_TRY(e->s_keys_a.ensure((size_t) bc * n_codes * sizeof(unsigned long long)));
+    RII_TRY(e->s_keys_b.ensure((size_t) bc * n_codes * sizeof(unsigned long long)));
+    for (int64_t b0 = 0; b0 < B; b0 += bc) {
+        const int64_t cur = std::min<int64_t>(bc, B - b0);
+        sp.keys = e->s_keys_a.as<unsigned long long>();
+        sp.b0 = (int) b0; sp.bc = (int) cur;
+        pick_chunks(e, n_codes, cur, &sp.chunks, &sp.chunk_len);
+        {
+            ScopedTimer t(e, "scan", st);
+            HIP_TRY(launch_scan(sp, st));
+        }
+        {
+            ScopedTimer t(e, "select", st);
+            HIP_TRY(segmented_sort_keys(e->s_keys_a.as<unsigned long long>(), e->s_keys_b.as<unsigned long long>(),
+                                        cur, n_codes, &e->sort_temp, &e->sort_temp_bytes, st));
+            HIP_TRY(launch_gather_sorted_topk(e->s_keys_b.as<unsigned long long>(), cur, n_codes, topk, d_remap,
+                                              d_out_ids + b0 * topk, d_out_dists + b0 * topk, st));
+        }
+    }
+    return RII_OK;
+}
+
+int check_query_args(const rii_engine *e, int64_t B, int topk, int64_t S)
+{
+    if (B < 0) return set_err(RII_ERR_INVALID, "negative batch size");
+    if (topk < 1 || (int64_t) topk > e->N)
+        return set_err(RII_ERR_INVALID, "topk=%d must satisfy 1 <= topk <= N=%lld (src/rii.h:202)", topk,
+                       (long long) e->N);
+    if (S < 0 || S > e->N) return set_err(RII_ERR_INVALID, "S=%lld must satisfy S <= N (src/rii.h:220)", (long long) S);
+    if (S != 0 && (int64_t) topk > S)
+        return set_err(RII_ERR_INVALID, "topk=%d must be <= len(target_ids)=%lld (src/rii.h:219)", topk, (long long) S);
+    if (e->QT == 0)
+        return set_err(RII_ERR_UNSUPPORTED, "M*Ks=%d tables do not fit the 160 KiB LDS", e->M * e->Ks);
+    return RII_OK;
+}
+
+int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
+                     int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+{
+    if (B == 0) return RII_OK;
+    RII_TRY(build_lut(e, d_queries, B, st));
+    if (S == 0)
+        return scan_topk(e, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
+    // subset search: gather the S target codes once for the whole batch, scan them, map ids back
+    RII_TRY(e->s_sub_codes.ensure((size_t) S * e->M));
+    {
+        ScopedTimer t(e, "gather", st);
+        HIP_TRY(launch_gather_codes(e->d_codes.as<uint8_t>(), e->M, d_tids, S, e->s_sub_codes.as<uint8_t>(), st));
+    }
+    return scan_topk(e, e->s_sub_codes.as<uint8_t>(), S, B, topk, d_tids, d_out_ids, d_out_dists, st);
+}
+
+int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
+                  int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st)
+{
+    if (B == 0) return RII_OK;
+    const int64_t nlist = nlist_of(e);
+    RII_TRY(sync_lists(e));
+    RII_TRY(build_lut(e, d_queries, B, st));
+
+    IvfParams p;
+    p.codes = e->d_codes.as<uint8_t>(); p.N = e->N; p.M = e->M; p.Ks = e->Ks;
+    p.lut = e->s_lut.as<float>(); p.QT = e->QT;
+    p.centers = e->d_centers.as<uint8_t>(); p.nlist = (int) nlist;
+    p.pl_off = e->d_pl_off.as<int64_t>();
+    p.pl_ids = e->d_pl_ids.as<int32_t>();
+    p.list_len = e->d_list_len.as<int32_t>();
+    p.topk = topk; p.L = L;
+    // w of src/rii.h:266-277
+    double wd = (S == 0) ? std::round((double) L * (double) nlist / (double) e->N)
+                         : std::round((double) L * (double) nlist / (double) S);
+    int64_t w = (int64_t) (size_t) wd + 3;
+    if (nlist < w) w = nlist;
+    p.w = w;
+
+    if (S != 0) {       // order-preserving filter of every list by the batch's target ids
+        const size_t words = (size_t) ((e->N + 31) / 32);
+        RII_TRY(e->s_bitmap.ensure(words * sizeof(uint32_t)));
+        RII_TRY(e->s_fids.ensure((size_t) std::max<int64_t>(e->N, 1) * sizeof(int32_t)));
+        RII_TRY(e->s_flen.ensure((size_t) nlist * sizeof(int32_t)));
+        HIP_TRY(hipMemsetAsync(e->s_bitmap.p, 0, words * sizeof(uint32_t), st));
+        HIP_TRY(launch_bitmap_set(d_tids, S, e->s_bitmap.as<uint32_t>(), st));
+        HIP_TRY(launch_filter_lists(p.pl_off, p.pl_ids, (int) nlist, e->s_bitmap.as<uint32_t>(),
+                                    e->s_fids.as<int32_t>(), e->s_flen.as<int32_t>(), st));
+        p.pl_ids = e->s_fids.as<int32_t>();
+        p.list_len = e->s_flen.as<int32_t>();
+    }
+
+    // chunk the batch so that the candidate scratch stays below ~1 GiB
+    const int64_t stride = (topk == 1) ? 1 : L;
+    int64_t bc = B;
+    if (topk != 1) bc = std::max<int64_t>(1, std::min<int64_t>(B, ((int64_t) 1 << 27) / std::max<int64_t>(L, 1)));
+    RII_TRY(e->s_coarse_d.ensure((size_t) bc * nlist * sizeof(float)));
+    RII_TRY(e->s_coarse_i.ensure((size_t) bc * nlist * sizeof(int32_t)));
+    RII_TRY(e->s_cum.ensure((size_t) bc * (nlist + 1) * sizeof(int32_t)));
+    RII_TRY(e->s_ncand.ensure((size_t) bc * sizeof(int32_t)));
+    RII_TRY(e->s_nvis.ensure((size_t) bc * sizeof(int32_t)));
+    RII_TRY(e->s_cand_i.ensure((size_t) bc * stride * sizeof(int32_t)));
+    RII_TRY(e->s_cand_d.ensure((size_t) bc * stride * sizeof(float)));
+    p.coarse_dist = e->s_coarse_d.as<float>(); p.coarse_id = e->s_coarse_i.as<int32_t>();
+    p.cum = e->s_cum.as<int32_t>(); p.ncand = e->s_ncand.as<int32_t>(); p.nvis = e->s_nvis.as<int32_t>();
+    p.cand_id = e->s_cand_i.as<int32_t>(); p.cand_dist = e->s_cand_d.as<float>(); p.cand_stride = stride;
+
+    for (int64_t b0 = 0; b0 < B; b0 += bc) {
+        p.B = std::min<int64_t>(bc, B - b0);
+        p.b0 = (int) b0;
+        p.out_ids = d_out_ids + b0 * topk;
+        p.out_dists = d_out_dists + b0 * topk;
+        p.out_counts = d_out_counts + b0;
+        { ScopedTimer t(e, "ivf_coarse", st); HIP_TRY(launch_ivf_coarse(p, st)); }
+        { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
+        { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
+        if (topk != 1) { ScopedTimer t(e, "ivf_select", st); HIP_TRY(launch_ivf_select(p, st)); }
+    }
+    return RII_OK;
+}
+
+int stage_inputs(rii_engine *e, const float *queries, int64_t B, const int64_t *tids, int64_t S, int topk)
+{
+    const size_t D = (size_t) e->M * e->Ds;
+    RII_TRY(e->s_queries.ensure(std::max<size_t>((size_t) B * D * sizeof(float), 16)));
+    RII_TRY(e->s_tids.ensure(std::max<size_t>((size_t) S * sizeof(int64_t), 16)));
+    RII_TRY(e->s_out_ids.ensure(std::max<size_t>((size_t) B * topk * sizeof(int64_t), 16)));
+    RII_TRY(e->s_out_dists.ensure(std::max<size_t>((size_t) B * topk * sizeof(float), 16)));
+    RII_TRY(e->s_out_counts.ensure(std::max<size_t>((size_t) B * sizeof(int64_t), 16)));
+    if (B) HIP_TRY(hipMemcpyAsync(e->s_queries.p, queries, (size_t) B * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if (S) HIP_TRY(hipMemcpyAsync(e->s_tids.p, tids, (size_t) S * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+    return RII_OK;
+}
+
+int check_tids_host(const rii_engine *e, const int64_t *tids, int64_t S)
+{
+    // the reference requires sorted, duplicate-free ids in range (docs tutorial.rst:190-204, rii.h:294)
+    for (int64_t s = 0; s < S; ++s) {
+        if (tids[s] < 0 || tids[s] >= e->N)
+            return set_err(RII_ERR_INVALID, "target id %lld out of range [0, %lld)", (long long) tids[s], (long long) e->N);
+        if (s && tids[s] <= tids[s - 1])
+            return set_err(RII_ERR_INVALID, "target_ids must be sorted ascending without duplicates");
+    }
+    return RII_OK;
+}
+
+void free_all(rii_engine *e)
+{
+    DevBuf *bufs[] = {&e->d_codewords, &e->d_cnorm, &e->d_codes, &e->d_centers, &e->d_symtab, &e->d_pl_off,
+                      &e->d_pl_ids, &e->d_list_len, &e->s_queries, &e->s_tids, &e->s_lut, &e->s_best, &e->s_out_ids,
+                      &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
+                      &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
+                      &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample};
+    for (DevBuf *b : bufs) b->release();
+    if (e->sort_temp) (void) hipFree(e->sort_temp);
+    e->sort_temp = nullptr;
+    for (auto &kv : e->timers)
+        for (auto &pr : kv.second.pending) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
+    e->timers.clear();
+    if (e->stream) (void) hipStreamDestroy(e->stream);
+    e->stream = nullptr;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+RII_API const char *rii_last_error(void) { return g_err.c_str(); }
+RII_API const char *rii_version(void) { return "rii_amd 0.1.0 (gfx950)"; }
+RII_API int rii_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+RII_API int rii_create(const float *codewords, int M, int Ks, int Ds, int verbose, int simd_arch, int device,
+                       rii_engine **out)
+{
+    if (!out) return set_err(RII_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!codewords || M <= 0 || Ks <= 0 || Ds <= 0) return set_err(RII_ERR_INVALID, "codewords must be a non-empty (M,Ks,Ds) array");
+    if (Ks > 256) return set_err(RII_ERR_INVALID, "Ks=%d: only Ks <= 256 is supported (uint8 codes; src/pqkmeans.cpp:15-21)", Ks);
+    if (simd_arch < RII_SIMD_SSE || simd_arch > RII_SIMD_AVX512) return set_err(RII_ERR_INVALID, "bad simd_arch %d", simd_arch);
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0)
+        return set_err(RII_ERR_HIP, "no HIP device available (%s): the engine has no CPU fallback",
+                       he == hipSuccess ? "device count is 0" : hipGetErrorString(he));
+    if (device < 0 || device >= ndev) return set_err(RII_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    rii_engine *e = new rii_engine();
+    e->M = M; e->Ks = Ks; e->Ds = Ds; e->verbose = verbose; e->arch = simd_arch; e->device = device;
+    e->QT = lut_tile_for(M, Ks);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->n_cu = prop.multiProcessorCount;
+    e->codewords.assign(codewords, codewords + (size_t) M * Ks * Ds);
+    int r = RII_OK;
+    do {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { r = set_err(RII_ERR_HIP, "hipStreamCreate failed"); break; }
+        if ((r = e->d_codewords.ensure(e->codewords.size() * sizeof(float))) != RII_OK) break;
+        if (hipMemcpy(e->d_codewords.p, e->codewords.data(), e->codewords.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            r = set_err(RII_ERR_HIP, "codeword upload failed");
+            break;
+        }
+    } while (0);
+    if (r != RII_OK) { free_all(e); delete e; return r; }
+    if (verbose) {
+        const char *names[] = {"sse", "avx", "avx512"};
+        printf("rii_amd: device %d (%d CUs), M=%d Ks=%d Ds=%d, table tile QT=%d, reference SIMD order: %s\n", device,
+               e->n_cu, M, Ks, Ds, e->QT, names[simd_arch]);
+    }
+    *out = e;
+    return RII_OK;
+}
+
+RII_API void rii_destroy(rii_engine *e)
+{
+    if (!e) return;
+    (void) hipSetDevice(e->device);
+    free_all(e);
+    delete e;
+}
+
+RII_API int rii_add_codes(rii_engine *e, const uint8_t *codes, int64_t n, int update_flag)
+{
+    if (!e || (n > 0 && !codes) || n < 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    if (update_flag && e->centers.empty())
+        return set_err(RII_ERR_STATE,
+                       "reconfigure() must be called before add(vecs=X, update_posting_lists=True). If this is the "
+                       "first addition, please call add_configure(vecs=X)");
+    if ((e->N + n) > (int64_t) INT32_MAX) return set_err(RII_ERR_UNSUPPORTED, "more than 2^31-1 codes per engine (posting ids are int, src/rii.h:82)");
+    const int64_t N0 = e->N;
+    RII_TRY(append_codes(e, codes, n));
+    if (e->verbose) {
+        printf("%lld new vectors are added.\nTotal number of codes is %lld\n", (long long) n, (long long) e->N);
+    }
+    if (update_flag) {
+        if (e->verbose) printf("Start to update posting lists\n");
+        RII_TRY(update_posting_lists(e, N0, n));
+    }
+    return RII_OK;
+}
+
+RII_API int rii_set_coarse_centers(rii_engine *e, const uint8_t *centers, int64_t nlist)
+{
+    if (!e || !centers || nlist <= 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    e->centers.assign(centers, centers + (size_t) nlist * e->M);
+    RII_TRY(upload_centers(e));
+    e->lists.assign((size_t) nlist, std::vector<int32_t>());
+    for (auto &l : e->lists) l.reserve((size_t) (e->N / nlist));
+    e->lists_dirty = true;
+    return update_posting_lists(e, 0, e->N);
+}
+
+RII_API int rii_set_state(rii_engine *e, const uint8_t *centers, int64_t nlist, const uint8_t *codes, int64_t N,
+                          const int64_t *pl_off, const int32_t *pl_ids)
+{
+    if (!e || nlist < 0 || N < 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    e->codes.clear(); e->N = 0; e->d_codes_n = 0;
+    RII_TRY(append_codes(e, codes, N));
+    e->centers.assign(centers, centers + (size_t) nlist * e->M);
+    RII_TRY(upload_centers(e));
+    e->lists.assign((size_t) nlist, std::vector<int32_t>());
+    for (int64_t i = 0; i < nlist; ++i) e->lists[(size_t) i].assign(pl_ids + pl_off[i], pl_ids + pl_off[i + 1]);
+    e->lists_dirty = true;
+    return RII_OK;
+}
+
+// RiiCpp::Reconfigure, src/rii.h:108-156.  Sampling and centre initialisation call the very same libstdc++
+// facilities as the reference (std::shuffle with default_random_engine(123) / mt19937(0)) so that the
+// permutations are identical; assignment, histogram and vote run on the GPU.
+RII_API int rii_reconfigure(rii_engine *e, int nlist, int iter)
+{
+    if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    if (nlist <= 0 || (int64_t) nlist > e->N)
+        return set_err(RII_ERR_INVALID, "reconfigure: need 0 < nlist=%d <= N=%lld (src/rii.h:110-111)", nlist, (long long) e->N);
+    if (iter < 0) return set_err(RII_ERR_INVALID, "iter must be >= 0");
+    if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
+    const int M = e->M, Ks = e->Ks;
+    const size_t len = (size_t) std::min<int64_t>(e->N, (int64_t) nlist * 100);
+    if (e->verbose) printf("The number of vectors used for training of coarse centers: %zu\n", len);
+    // (1) sampling, rii.h:113-133
+    std::vector<size_t> ids((size_t) e->N);
+    std::iota(ids.begin(), ids.end(), 0);
+    std::shuffle(ids.begin(), ids.end(), std::default_random_engine(123));
+    ids.resize(len);
+    std::vector<uint8_t> sample(len * M);
+    for (size_t i = 0; i < len; ++i) memcpy(&sample[i * M], &e->codes[ids[i] * M], (size_t) M);
+    // (2) PQk-means, pqkmeans.cpp:46-133
+    if (e->verbose) printf("Start to run PQk-means\n");
+    std::vector<int> pick(len);
+    std::iota(pick.begin(), pick.end(), 0);
+    std::mt19937 random_engine(0);
+    std::shuffle(pick.begin(), pick.end(), random_engine);
+    std::vector<uint8_t> centers((size_t) nlist * M);
+    for (int k = 0; k < nlist; ++k) memcpy(&centers[(size_t) k * M], &sample[(size_t) pick[(size_t) k] * M], (size_t) M);
+
+    RII_TRY(ensure_symtab(e));
+    RII_TRY(e->s_sample.ensure(sample.size()));
+    RII_TRY(e->d_centers.ensure(centers.size()));
+    RII_TRY(e->s_assign.ensure(len * sizeof(int32_t)));
+    RII_TRY(e->s_hist.ensure((size_t) nlist * M * Ks * sizeof(int32_t)));
+    RII_TRY(e->s_cnt.ensure((size_t) nlist * sizeof(int32_t)));
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->s_sample.p, sample.data(), sample.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(e->d_centers.p, centers.data(), centers.size(), hipMemcpyHostToDevice, st));
+    for (int itr = 0; itr < iter; ++itr) {
+        if (e->verbose) printf("Iteration start: %d / %d\n", itr, iter);
+        auto t0 = std::chrono::system_clock::now();
+        {
+            ScopedTimer t(e, "assign", st);
+            HIP_TRY(launch_assign(e->s_sample.as<uint8_t>(), (int64_t) len, M, Ks, e->d_symtab.as<float>(),
+                                  e->d_centers.as<uint8_t>(), nlist, e->s_assign.as<int32_t>(), st));
+        }
+        if (itr != iter - 1) {
+            HIP_TRY(hipMemsetAsync(e->s_hist.p, 0, (size_t) nlist * M * Ks * sizeof(int32_t), st));
+            HIP_TRY(hipMemsetAsync(e->s_cnt.p, 0, (size_t) nlist * sizeof(int32_t), st));
+            HIP_TRY(launch_pqk_hist(e->s_sample.as<uint8_t>(), e->s_assign.as<int32_t>(), (int64_t) len, M, Ks,
+                                    e->s_hist.as<int32_t>(), e->s_cnt.as<int32_t>(), st));
+            HIP_TRY(launch_pqk_vote(e->s_hist.as<int32_t>(), e->s_cnt.as<int32_t>(), e->d_symtab.as<float>(), nlist, M, Ks,
+                                    e->d_centers.as<uint8_t>(), st));
+        }
+        if (e->verbose) {
+            HIP_TRY(hipStreamSynchronize(st));
+            printf("find_nn+update_center_time,%lld\n",
+                   (long long) std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - t0).count());
+        }
+    }
+    // (3) centres back to the host mirror, rii.h:143
+    e->centers.resize(centers.size());
+    HIP_TRY(hipMemcpyAsync(e->centers.data(), e->d_centers.p, centers.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // (4) posting lists, rii.h:147-155
+    if (e->verbose) printf("Start to update posting lists\n");
+    e->lists.assign((size_t) nlist, std::vector<int32_t>());
+    for (auto &l : e->lists) l.reserve((size_t) (e->N / nlist));
+    e->lists_dirty = true;
+    return update_posting_lists(e, 0, e->N);
+}
+
+RII_API int rii_clear(rii_engine *e)
+{
+    if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    e->centers.clear();
+    e->codes.clear();
+    e->lists.clear();
+    e->N = 0;
+    e->d_codes_n = 0;
+    e->lists_dirty = true;
+    return RII_OK;
+}
+
+RII_API int64_t rii_get_N(const rii_engine *e) { return e ? e->N : 0; }
+RII_API int64_t rii_get_nlist(const rii_engine *e) { return e ? nlist_of(e) : 0; }
+RII_API int rii_get_M(const rii_engine *e) { return e ? e->M : 0; }
+RII_API int rii_get_Ks(const rii_engine *e) { return e ? e->Ks : 0; }
+RII_API int rii_get_Ds(const rii_engine *e) { return e ? e->Ds : 0; }
+RII_API int rii_get_verbose(const rii_engine *e) { return e ? e->verbose : 0; }
+RII_API int rii_set_verbose(rii_engine *e, int verbose)
+{
+    if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    e->verbose = verbose;
+    return RII_OK;
+}
+RII_API int rii_get_codewords(const rii_engine *e, float *out)
+{
+    if (!e || !out) return set_err(RII_ERR_INVALID, "bad arguments");
+    memcpy(out, e->codewords.data(), e->codewords.size() * sizeof(float));
+    return RII_OK;
+}
+RII_API int rii_get_codes(const rii_engine *e, uint8_t *out)
+{
+    if (!e || (!out && e->N)) return set_err(RII_ERR_INVALID, "bad arguments");
+    if (e->N) memcpy(out, e->codes.data(), e->codes.size());
+    return RII_OK;
+}
+RII_API int rii_get_coarse_centers(const rii_engine *e, uint8_t *out)
+{
+    if (!e || (!out && !e->centers.empty())) return set_err(RII_ERR_INVALID, "bad arguments");
+    if (!e->centers.empty()) memcpy(out, e->centers.data(), e->centers.size());
+    return RII_OK;
+}
+RII_API int rii_get_posting_lists(const rii_engine *e, int64_t *off, int32_t *ids)
+{
+    if (!e || !off) return set_err(RII_ERR_INVALID, "bad arguments");
+    off[0] = 0;
+    for (size_t i = 0; i < e->lists.size(); ++i) {
+        if (ids && !e->lists[i].empty()) memcpy(ids + off[i], e->lists[i].data(), e->lists[i].size() * sizeof(int32_t));
+        off[i + 1] = off[i] + (int64_t) e->lists[i].size();
+    }
+    return RII_OK;
+}
+
+RII_API int rii_query_linear(rii_engine *e, const float *queries, int64_t B, int topk, const int64_t *tids, int64_t S,
+                             int64_t *out_ids, float *out_dists)
+{
+    if (!e || (B > 0 && (!queries || !out_ids || !out_dists)) || (S > 0 && !tids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(check_query_args(e, B, topk, S));
+    RII_TRY(check_tids_host(e, tids, S));
+    if (B == 0) return RII_OK;
+    RII_TRY(stage_inputs(e, queries, B, tids, S, topk));
+    RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, e->s_out_ids.as<int64_t>(),
+                             e->s_out_dists.as<float>(), e->stream));
+    HIP_TRY(hipMemcpyAsync(out_ids, e->s_out_ids.p, (size_t) B * topk * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out_dists, e->s_out_dists.p, (size_t) B * topk * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RII_OK;
+}
+
+static int check_ivf_args(const rii_engine *e, int topk, int64_t L)
+{
+    if (nlist_of(e) == 0) return set_err(RII_ERR_STATE, "query_ivf needs posting lists: call reconfigure() first");
+    if ((int64_t) topk > L || L > e->N)
+        return set_err(RII_ERR_INVALID, "need topk <= L <= N: topk=%d, L=%lld, N=%lld (src/rii.h:253)", topk, (long long) L, (long long) e->N);
+    return RII_OK;
+}
+
+RII_API int rii_query_ivf(rii_engine *e, const float *queries, int64_t B, int topk, const int64_t *tids, int64_t S,
+                          int64_t L, int64_t *out_ids, float *out_dists, int64_t *out_counts)
+{
+    if (!e || (B > 0 && (!queries || !out_ids || !out_dists || !out_counts)) || (S > 0 && !tids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(check_query_args(e, B, topk, S));
+    RII_TRY(check_ivf_args(e, topk, L));
+    RII_TRY(check_tids_host(e, tids, S));
+    if (B == 0) return RII_OK;
+    RII_TRY(stage_inputs(e, queries, B, tids, S, topk));
+    RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, L, e->s_out_ids.as<int64_t>(),
+                          e->s_out_dists.as<float>(), e->s_out_counts.as<int64_t>(), e->stream));
+    HIP_TRY(hipMemcpyAsync(out_ids, e->s_out_ids.p, (size_t) B * topk * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out_dists, e->s_out_dists.p, (size_t) B * topk * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out_counts, e->s_out_counts.p, (size_t) B * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RII_OK;
+}
+
+RII_API int rii_query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                                 int64_t S, int64_t *d_out_ids, float *d_out_dists, void *stream)
+{
+    if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(check_query_args(e, B, topk, S));
+    return query_linear_dev(e, d_queries, B, topk, d_tids, S, d_out_ids, d_out_dists,
+                            stream ? (hipStream_t) stream : e->stream);
+}
+
+RII_API int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                              int64_t S, int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts,
+                              void *stream)
+{
+    if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(check_query_args(e, B, topk, S));
+    RII_TRY(check_ivf_args(e, topk, L));
+    return query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts,
+                         stream ? (hipStream_t) stream : e->stream);
+}
+
+RII_API int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out)
+{
+    if (!e || !queries || !out || B < 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
+    if (B == 0) return RII_OK;
+    RII_TRY(stage_inputs(e, queries, B, nullptr, 0, 1));
+    RII_TRY(build_lut(e, e->s_queries.as<float>(), B, e->stream));
+    const size_t bytes = (size_t) B * e->M * e->Ks * sizeof(float);
+    RII_TRY(e->s_keys_a.ensure(bytes));
+    HIP_TRY(launch_lut_untile(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_keys_a.as<float>(), e->stream));
+    HIP_TRY(hipMemcpyAsync(out, e->s_keys_a.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RII_OK;
+}
+
+RII_API int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *assign)
+{
+    if (!e || n < 0 || (n > 0 && (!codes || !assign))) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->centers.empty()) return set_err(RII_ERR_STATE, "no coarse centres");
+    if (n == 0) return RII_OK;
+    RII_TRY(e->s_sub_codes.ensure((size_t) n * e->M));
+    HIP_TRY(hipMemcpyAsync(e->s_sub_codes.p, codes, (size_t) n * e->M, hipMemcpyHostToDevice, e->stream));
+    std::vector<int32_t> a;
+    RII_TRY(assign_device_codes(e, e->s_sub_codes.as<uint8_t>(), n, a));
+    memcpy(assign, a.data(), (size_t) n * sizeof(int32_t));
+    return RII_OK;
+}
+
+RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
+{
+    if (!e || !key) return set_err(RII_ERR_INVALID, "bad arguments");
+    const std::string k(key);
+    if (k == "lut_mode") {
+        if (value != RII_LUT_EXACT && value != RII_LUT_MFMA) return set_err(RII_ERR_INVALID, "bad lut_mode");
+        e->lut_mode = (int) value;
+    } else if (k == "scan_chunks") {
+        e->scan_chunks = (int) value;
+    } else if (k == "timing") {
+        e->timing = value ? 1 : 0;
+    } else {
+        return set_err(RII_ERR_INVALID, "unknown option '%s'", key);
+    }
+    return RII_OK;
+}
+RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
+{
+    if (!e || !key) return -1;
+    const std::string k(key);
+    if (k == "lut_mode") return e->lut_mode;
+    if (k == "scan_chunks") return e->scan_chunks;
+    if (k == "timing") return e->timing;
+    if (k == "lut_tile") return e->QT;
+    if (k == "n_cu") return e->n_cu;
+    return -1;
+}
+
+RII_API int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms, int64_t *launches)
+{
+    if (!e || !kernel) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    KernelTimer &t = e->timers[kernel];
+    for (auto &pr : t.pending) {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        t.total_ms += ms;
+        t.launches += 1;
+        (void) hipEventDestroy(pr.first);
+        (void) hipEventDestroy(pr.second);
+    }
+    t.pending.clear();
+    if (total_ms) *total_ms = t.total_ms;
+    if (launches) *launches = t.launches;
+    return RII_OK;
+}
+RII_API int rii_timing_reset(rii_engine *e)
+{
+    if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    for (auto &kv : e->timers) {
+        for (auto &pr : kv.second.pending) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
+        kv.second.pending.clear();
+        kv.second.total_ms = 0.0;
+        kv.second.launches = 0;
+    }
+    return RII_OK;
+}
+RII_API int rii_synchronize(rii_engine *e)
+{
+    if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RII_OK;
+}

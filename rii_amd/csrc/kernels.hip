@@ -1,0 +1,1028 @@
+// kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the IVFPQ query hot path.
+//
+// Reference functions restated on the GPU (paths relative to the reference repo):
+//   lut_build_kernel        fvec_L2sqr (src/distance.h:117-252) inside RiiCpp::DTable (src/rii.h:361-373)
+//   scan_kernel             RiiCpp::ADist over all codes + top-1 (src/rii.h:195-242, 386-394)
+//   ivf_*_kernel            RiiCpp::QueryIvf (src/rii.h:244-326) incl. libstdc++'s std::partial_sort order
+//   symtab/assign kernels   PQKMeans tables + predict_one (src/pqkmeans.cpp:23-42,152-173,193-218) as used by
+//                           RiiCpp::UpdatePostingLists (src/rii.h:335-359)
+//   pqk_hist/vote kernels   PQKMeans::fit centre update (src/pqkmeans.cpp:109-123,223-260)
+//
+// Numerics contract: every fp32 operation that decides a result is written with an explicit
+// round-to-nearest intrinsic (__fadd_rn/__fsub_rn/__fmul_rn/__fmaf_rn) in the reference's order, and the
+// file is compiled with -ffp-contract=off, so distances are bit-identical to the reference's.
+//
+// Why the scan is not a GEMM: see DESIGN.md.  The scan is an LDS-gather kernel: the M x Ks table of QT
+// queries lives in LDS as [m][ks][QT] so that ONE ds_read_b128 returns the entries of four queries for one
+// code byte; codes stream from HBM/L2 as coalesced 16-byte loads; accumulation is sequential over m.
+#include "rii_internal.h"
+#include <float.h>
+
+namespace riiamd {
+
+#define RII_SIMD_SSE 0
+#define RII_SIMD_AVX 1
+#define RII_SIMD_AVX512 2
+
+// ===================================================================================================
+// exact arithmetic helpers
+// ===================================================================================================
+__device__ __forceinline__ float sq_acc(float acc, float d, bool fused)
+{
+    return fused ? __fmaf_rn(d, d, acc) : __fadd_rn(acc, __fmul_rn(d, d));
+}
+
+// fvec_L2sqr, src/distance.h:117-252, all three compile-time variants (see oracle/rii_oracle.c for the
+// derivation of the lane order and FMA contraction).
+__device__ float fvec_l2sqr_dev(const float *__restrict__ x, const float *__restrict__ y, int d, int arch)
+{
+    const bool fused = (arch != RII_SIMD_SSE);
+    float l16[16], l8[8], l4[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) l16[i] = 0.f;
+    if (arch == RII_SIMD_AVX512) {
+        while (d >= 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) l16[i] = sq_acc(l16[i], __fsub_rn(x[i], y[i]), fused);
+            x += 16; y += 16; d -= 16;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l8[i] = __fadd_rn(l16[8 + i], l16[i]);
+    if (arch == RII_SIMD_AVX512 || arch == RII_SIMD_AVX) {
+        while (d >= 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) l8[i] = sq_acc(l8[i], __fsub_rn(x[i], y[i]), fused);
+            x += 8; y += 8; d -= 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l4[i] = __fadd_rn(l8[4 + i], l8[i]);
+    if (arch == RII_SIMD_SSE) {
+        while (d >= 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l4[i] = sq_acc(l4[i], __fsub_rn(x[i], y[i]), fused);
+            x += 4; y += 4; d -= 4;
+        }
+    } else if (d >= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l4[i] = sq_acc(l4[i], __fsub_rn(x[i], y[i]), fused);
+        x += 4; y += 4; d -= 4;
+    }
+    if (d > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = (i < d) ? __fsub_rn(x[i], y[i]) : 0.f;
+            l4[i] = sq_acc(l4[i], t, fused);
+        }
+    }
+    return __fadd_rn(__fadd_rn(l4[0], l4[1]), __fadd_rn(l4[2], l4[3]));
+}
+
+// L2SquaredDistance of src/pqkmeans.cpp:164-173 as auto-vectorised by GCC -Ofast ([objcode] in the oracle).
+__device__ __forceinline__ float hsum_tree(float *t, int w)
+{
+    while (w > 4) {
+        w >>= 1;
+        for (int i = 0; i < w; ++i) t[i] = __fadd_rn(t[w + i], t[i]);
+    }
+    float a = __fadd_rn(t[2], t[0]), b = __fadd_rn(t[3], t[1]);
+    return __fadd_rn(b, a);
+}
+
+__device__ float l2sq_pqk_dev(const float *__restrict__ a, const float *__restrict__ b, int n, int arch)
+{
+    const int W = (arch == RII_SIMD_AVX512) ? 16 : (arch == RII_SIMD_AVX ? 8 : 4);
+    const bool fused = (arch != RII_SIMD_SSE);
+    int i = 0;
+    float acc = 0.f;
+    float lanes[16];
+    if (n >= W) {
+        for (int l = 0; l < W; ++l) lanes[l] = 0.f;
+        for (; i + W <= n; i += W)
+            for (int l = 0; l < W; ++l) lanes[l] = sq_acc(lanes[l], __fsub_rn(a[i + l], b[i + l]), fused);
+        acc = hsum_tree(lanes, W);
+    }
+    const int H = W / 2;
+    if (H >= 4 && n - i >= H) {
+        for (int l = 0; l < H; ++l) {
+            float d = __fsub_rn(a[i + l], b[i + l]);
+            lanes[l] = __fmul_rn(d, d);
+        }
+        acc = __fadd_rn(acc, hsum_tree(lanes, H));
+        i += H;
+    }
+    for (; i < n; ++i) acc = sq_acc(acc, __fsub_rn(a[i], b[i]), fused);
+    return acc;
+}
+
+int lut_tile_for(int M, int Ks)
+{
+    const size_t one = (size_t) M * Ks * sizeof(float);
+    if (one * 4 <= (size_t) kMaxLutLdsBytes) return 4;
+    if (one * 2 <= (size_t) kMaxLutLdsBytes) return 2;
+    if (one <= (size_t) kMaxLutLdsBytes) return 1;
+    return 0;
+}
+
+__device__ __forceinline__ size_t lut_index(int64_t b, int i, int MK, int QT)
+{
+    return ((size_t) (b / QT) * MK + i) * QT + (size_t) (b % QT);
+}
+
+// ===================================================================================================
+// (a1,a2) distance-table build, exact VALU path.  One thread per (query, m, ks).
+// ===================================================================================================
+__global__ __launch_bounds__(256) void lut_build_kernel(const float *__restrict__ queries, int64_t B,
+                                                        const float *__restrict__ codewords, int M, int Ks,
+                                                        int Ds, int arch, int QT, float *__restrict__ lut)
+{
+    const int MK = M * Ks;
+    const int64_t total = B * (int64_t) MK;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t b = t / MK;
+        const int i = (int) (t - b * MK);
+        const int m = i / Ks;
+        const float *q = queries + b * (int64_t) (M * Ds) + (int64_t) m * Ds;
+        const float *c = codewords + (size_t) i * Ds;
+        lut[lut_index(b, i, MK, QT)] = fvec_l2sqr_dev(q, c, Ds, arch);
+    }
+}
+
+hipError_t launch_lut_build(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
+                            int arch, int QT, float *d_lut, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    const int64_t total = B * (int64_t) M * Ks;
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(lut_build_kernel, dim3(blocks), dim3(256), 0, st, d_queries, B, d_codewords, M, Ks, Ds,
+                       arch, QT, d_lut);
+    return hipGetLastError();
+}
+
+// tile-interleaved -> [B][M][Ks] (only for the rii_dtable() debug/parity entry point)
+__global__ void lut_untile_kernel(const float *__restrict__ lut, int64_t B, int MK, int QT, float *__restrict__ out)
+{
+    const int64_t total = B * (int64_t) MK;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t b = t / MK;
+        const int i = (int) (t - b * MK);
+        out[t] = lut[lut_index(b, i, MK, QT)];
+    }
+}
+hipError_t launch_lut_untile(const float *d_lut, int64_t B, int M, int Ks, int QT, float *d_out, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    const int64_t total = B * (int64_t) M * Ks;
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(lut_untile_kernel, dim3(blocks), dim3(256), 0, st, d_lut, B, M * Ks, QT, d_out);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// (a2, measured variant) distance-table build on the matrix cores: T = |q_m|^2 - 2 q_m.c + |c|^2 with the
+// cross term as one v_mfma_f32_16x16x4_f32 per 16 queries x 16 codewords x 4 dims.  Not bit-identical to
+// the reference (different rounding points): opt-in through option "lut_mode" = RII_LUT_MFMA.
+// ===================================================================================================
+__global__ void codeword_norms_kernel(const float *__restrict__ cw, int MK, int Ds, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MK) return;
+    float s = 0.f;
+    for (int d = 0; d < Ds; ++d) s = __fmaf_rn(cw[(size_t) i * Ds + d], cw[(size_t) i * Ds + d], s);
+    out[i] = s;
+}
+hipError_t launch_codeword_norms(const float *d_codewords, int M, int Ks, int Ds, float *d_cnorm, hipStream_t st)
+{
+    const int MK = M * Ks;
+    hipLaunchKernelGGL(codeword_norms_kernel, dim3((MK + 255) / 256), dim3(256), 0, st, d_codewords, MK, Ds,
+                       d_cnorm);
+    return hipGetLastError();
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// grid: (ceil(Ks/16), M, ceil(B/16)); one wave per block computes a 16(query) x 16(codeword) tile of one m.
+// A[i=lane&15][k=lane>>4] = q[b0+i][m*Ds + kk + k],  B[k=lane>>4][j=lane&15] = cw[m][ks0+j][kk + k]
+// D: col = lane&15 (codeword), row = (lane>>4)*4 + r (query).
+__global__ __launch_bounds__(64) void lut_build_mfma_kernel(const float *__restrict__ queries, int64_t B,
+                                                            const float *__restrict__ codewords,
+                                                            const float *__restrict__ cnorm, int M, int Ks,
+                                                            int Ds, int QT, float *__restrict__ lut)
+{
+    const int lane = threadIdx.x;
+    const int ks0 = blockIdx.x * 16, m = blockIdx.y;
+    const int64_t b0 = (int64_t) blockIdx.z * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t bq = b0 + li;                 // query row this lane feeds into A
+    const int ksb = ks0 + li;                   // codeword column this lane feeds into B
+    const float *q = queries + (bq < B ? bq : 0) * (int64_t) (M * Ds) + (int64_t) m * Ds;
+    const float *c = codewords + ((size_t) m * Ks + (ksb < Ks ? ksb : 0)) * Ds;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float qn = 0.f;                              // |q_m|^2 partial for row li over this lane's k slots
+    for (int kk = 0; kk < Ds; kk += 4) {
+        const int k = kk + lk;
+        float a = (k < Ds && bq < B) ? q[k] : 0.f;
+        float bv = (k < Ds && ksb < Ks) ? c[k] : 0.f;
+        qn = __fmaf_rn(a, a, qn);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+    }
+    // reduce |q|^2 over the 4 k-slots: lanes li, li+16, li+32, li+48
+    qn += __shfl_xor(qn, 16);
+    qn += __shfl_xor(qn, 32);
+    const int MK = M * Ks;
+    const int col = lane & 15;
+    if (ks0 + col < Ks) {
+        const float cn = cnorm[m * Ks + ks0 + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) * 4 + r;
+            const float qnr = __shfl(qn, row);   // lane `row` (< 16) holds |q_row|^2
+            const int64_t b = b0 + row;
+            if (b < B) {
+                float v = qnr - 2.f * acc[r] + cn;
+                lut[lut_index(b, m * Ks + ks0 + col, MK, QT)] = v < 0.f ? 0.f : v;
+            }
+        }
+    }
+}
+hipError_t launch_lut_build_mfma(const float *d_queries, int64_t B, const float *d_codewords,
+                                 const float *d_cnorm, int M, int Ks, int Ds, int QT, float *d_lut,
+                                 hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    dim3 grid((Ks + 15) / 16, M, (unsigned) ((B + 15) / 16));
+    hipLaunchKernelGGL(lut_build_mfma_kernel, grid, dim3(64), 0, st, d_queries, B, d_codewords, d_cnorm, M, Ks, Ds,
+                       QT, d_lut);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// (a3,a5) linear ADC scan + top-1 / key emission.
+//   grid = (chunks, query tiles); block = 1024 threads = 16 waves; LDS = [M][Ks][QT] fp32 table.
+//   lane = code, QT queries per lane; codes are read as 16-byte words; sum over m is sequential fp32.
+// ===================================================================================================
+template <int QT> struct LutT;
+template <> struct LutT<1> { typedef float T; };
+template <> struct LutT<2> { typedef float2 T; };
+template <> struct LutT<4> { typedef float4 T; };
+
+template <int QT> __device__ __forceinline__ void acc_add(float (&acc)[QT], const typename LutT<QT>::T &v);
+template <> __device__ __forceinline__ void acc_add<1>(float (&acc)[1], const float &v)
+{
+    acc[0] = __fadd_rn(acc[0], v);
+}
+template <> __device__ __forceinline__ void acc_add<2>(float (&acc)[2], const float2 &v)
+{
+    acc[0] = __fadd_rn(acc[0], v.x);
+    acc[1] = __fadd_rn(acc[1], v.y);
+}
+template <> __device__ __forceinline__ void acc_add<4>(float (&acc)[4], const float4 &v)
+{
+    acc[0] = __fadd_rn(acc[0], v.x);
+    acc[1] = __fadd_rn(acc[1], v.y);
+    acc[2] = __fadd_rn(acc[2], v.z);
+    acc[3] = __fadd_rn(acc[3], v.w);
+}
+
+// ADC of one code whose M = 4*MW bytes are already in registers
+template <int QT, int MW, int KST>
+__device__ __forceinline__ void adc_words(const uint32_t (&w)[MW], const typename LutT<QT>::T *__restrict__ lut,
+                                          float (&acc)[QT])
+{
+#pragma unroll
+    for (int q = 0; q < QT; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ks = (w[i] >> (8 * j)) & 0xffu;
+            acc_add<QT>(acc, lut[(i * 4 + j) * KST + ks]);
+        }
+    }
+}
+
+template <int MW> __device__ __forceinline__ void load_code_words(const uint8_t *__restrict__ p, uint32_t (&w)[MW])
+{
+    if constexpr (MW % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < MW / 4; ++i) {
+            const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    } else if constexpr (MW % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < MW / 2; ++i) {
+            const uint2 v = reinterpret_cast<const uint2 *>(p)[i];
+            w[2 * i] = v.x; w[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MW; ++i) w[i] = reinterpret_cast<const uint32_t *>(p)[i];
+    }
+}
+
+struct ScanArgs {
+    const uint8_t *codes;
+    int64_t n_codes;
+    int M, Ks;
+    const float *lut;
+    int B;
+    int tile0;
+    int64_t chunk_len;
+    unsigned long long *best;
+    unsigned long long *keys;
+    int b0;
+};
+
+template <int QT, int MW, int KST, bool WRITE_KEYS>
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename LutT<QT>::T LT;
+    const int M = MW ? MW * 4 : p.M;
+    const int Ks = KST ? KST : p.Ks;
+    const int tid = threadIdx.x;
+    const int tile = p.tile0 + blockIdx.y;
+    const size_t lut_elems = (size_t) M * Ks * QT;
+    float *lds = reinterpret_cast<float *>(smem);
+    unsigned long long *red =
+        reinterpret_cast<unsigned long long *>(smem + ((lut_elems * sizeof(float) + 15) & ~(size_t) 15));
+
+    // ---- stage this tile's table: contiguous M*Ks*QT floats -> LDS (same layout) ----
+    {
+        const float *src = p.lut + (size_t) tile * lut_elems;
+        if ((lut_elems & 3) == 0) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(lds);
+            for (size_t i = tid; i < lut_elems / 4; i += kScanThreads) d4[i] = s4[i];
+        } else {
+            for (size_t i = tid; i < lut_elems; i += kScanThreads) lds[i] = src[i];
+        }
+        if (tid < QT) red[tid] = ~0ull;
+    }
+    __syncthreads();
+    const LT *lut = reinterpret_cast<const LT *>(lds);
+
+    const int64_t c_begin = (int64_t) blockIdx.x * p.chunk_len;
+    int64_t c_end = c_begin + p.chunk_len;
+    if (c_end > p.n_codes) c_end = p.n_codes;
+
+    float bestd[QT];
+    uint32_t besti[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) { bestd[q] = INFINITY; besti[q] = 0xffffffffu; }
+
+    for (int64_t n = c_begin + tid; n < c_end; n += kScanThreads) {
+        float acc[QT];
+        if constexpr (MW != 0) {
+            uint32_t w[MW ? MW : 1];
+            load_code_words<MW>(p.codes + (size_t) n * (MW * 4), w);
+            adc_words<QT, MW, KST>(w, lut, acc);
+        } else {
+            const uint8_t *c = p.codes + (size_t) n * M;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) acc[q] = 0.f;
+            for (int m = 0; m < M; ++m) acc_add<QT>(acc, lut[m * Ks + c[m]]);
+        }
+        if constexpr (WRITE_KEYS) {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const int b = tile * QT + q;
+                if (b < p.B)
+                    p.keys[(size_t) (b - p.b0) * p.n_codes + n] =
+                        ((unsigned long long) f32_orderable(__float_as_uint(acc[q])) << 32) | (uint32_t) n;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                // strict '<' + ascending n per lane => the first minimum wins, like a size-1 heap-select
+                if (acc[q] < bestd[q]) { bestd[q] = acc[q]; besti[q] = (uint32_t) n; }
+            }
+        }
+    }
+
+    if constexpr (!WRITE_KEYS) {
+        // wave -> block -> global reduction of the packed key (orderable distance bits, then index):
+        // min over the key == (dist asc, id asc), which for top-1 is exactly std::partial_sort's answer.
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            unsigned long long key =
+                besti[q] == 0xffffffffu
+                    ? ~0ull
+                    : (((unsigned long long) f32_orderable(__float_as_uint(bestd[q])) << 32) | besti[q]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(key, off);
+                key = o < key ? o : key;
+            }
+            if ((tid & 63) == 0 && key != ~0ull) atomicMin(&red[q], key);
+        }
+        __syncthreads();
+        if (tid < QT) {
+            const int b = tile * QT + tid;
+            if (b < p.B && red[tid] != ~0ull) atomicMin(&p.best[b], red[tid]);
+        }
+    }
+}
+
+template <int QT, int MW, int KST, bool WK>
+static hipError_t launch_scan_t(const ScanParams &sp, int tile0, int ntiles, hipStream_t st)
+{
+    const size_t lut_bytes = (size_t) sp.M * sp.Ks * QT * sizeof(float);
+    const size_t smem = ((lut_bytes + 15) & ~(size_t) 15) + 64;
+    auto kern = scan_kernel<QT, MW, KST, WK>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    ScanArgs a;
+    a.codes = sp.codes; a.n_codes = sp.n_codes; a.M = sp.M; a.Ks = sp.Ks; a.lut = sp.lut; a.B = sp.B;
+    a.tile0 = tile0; a.chunk_len = sp.chunk_len; a.best = sp.best; a.keys = sp.keys; a.b0 = sp.b0;
+    hipLaunchKernelGGL(kern, dim3(sp.chunks, ntiles), dim3(kScanThreads), smem, st, a);
+    return hipGetLastError();
+}
+
+template <bool WK> static hipError_t launch_scan_wk(const ScanParams &sp, hipStream_t st)
+{
+    if (sp.n_codes == 0 || sp.B == 0) return hipSuccess;
+    int tile0 = 0, ntiles = (sp.B + sp.QT - 1) / sp.QT;
+    if (WK) { tile0 = sp.b0 / sp.QT; ntiles = (sp.b0 + sp.bc + sp.QT - 1) / sp.QT - tile0; }
+    const bool fast = (sp.Ks == 256) && (sp.M % 4 == 0);
+    if (fast && sp.QT == 4 && sp.M == 8) return launch_scan_t<4, 2, 256, WK>(sp, tile0, ntiles, st);
+    if (fast && sp.QT == 4 && sp.M == 16) return launch_scan_t<4, 4, 256, WK>(sp, tile0, ntiles, st);
+    if (fast && sp.QT == 4 && sp.M == 32) return launch_scan_t<4, 8, 256, WK>(sp, tile0, ntiles, st);
+    if (fast && sp.QT == 2 && sp.M == 64) return launch_scan_t<2, 16, 256, WK>(sp, tile0, ntiles, st);
+    if (sp.QT == 4) return launch_scan_t<4, 0, 0, WK>(sp, tile0, ntiles, st);
+    if (sp.QT == 2) return launch_scan_t<2, 0, 0, WK>(sp, tile0, ntiles, st);
+    return launch_scan_t<1, 0, 0, WK>(sp, tile0, ntiles, st);
+}
+
+hipError_t launch_scan(const ScanParams &sp, hipStream_t st)
+{
+    return sp.keys ? launch_scan_wk<true>(sp, st) : launch_scan_wk<false>(sp, st);
+}
+
+__global__ void finalize_top1_kernel(const unsigned long long *__restrict__ best, int64_t B,
+                                     const int64_t *__restrict__ remap, int64_t *__restrict__ out_ids,
+                                     float *__restrict__ out_dists, int topk)
+{
+    const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long k = best[b];
+    const uint32_t idx = (uint32_t) (k & 0xffffffffu);
+    int64_t id = (k == ~0ull) ? -1 : (remap ? remap[idx] : (int64_t) idx);
+    out_ids[b * topk] = id;
+    out_dists[b * topk] = (k == ~0ull) ? INFINITY : __uint_as_float(f32_unorderable((uint32_t) (k >> 32)));
+}
+hipError_t launch_finalize_top1(const unsigned long long *d_best, int64_t B, const int64_t *d_remap,
+                                int64_t *d_out_ids, float *d_out_dists, int topk, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(finalize_top1_kernel, dim3((unsigned) ((B + 255) / 256)), dim3(256), 0, st, d_best, B,
+                       d_remap, d_out_ids, d_out_dists, topk);
+    return hipGetLastError();
+}
+
+// rows of fully sorted packed keys -> first topk (ids, dists)
+__global__ void gather_sorted_topk_kernel(const unsigned long long *__restrict__ sorted, int64_t bc,
+                                          int64_t n_codes, int topk, const int64_t *__restrict__ remap,
+                                          int64_t *__restrict__ out_ids, float *__restrict__ out_dists)
+{
+    const int64_t total = bc * topk;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t b = t / topk, k = t - b * topk;
+        const unsigned long long key = sorted[b * n_codes + k];
+        const uint32_t idx = (uint32_t) (key & 0xffffffffu);
+        out_ids[t] = remap ? remap[idx] : (int64_t) idx;
+        out_dists[t] = __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
+    }
+}
+hipError_t launch_gather_sorted_topk(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
+                                     const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists,
+                                     hipStream_t st)
+{
+    const int64_t total = bc * topk;
+    if (total == 0) return hipSuccess;
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(gather_sorted_topk_kernel, dim3(blocks), dim3(256), 0, st, d_sorted, bc, n_codes, topk,
+                       d_remap, d_out_ids, d_out_dists);
+    return hipGetLastError();
+}
+
+// subset search: compact the target codes once per batch (src/rii.h:218-228 gathers per query)
+__global__ void gather_codes_kernel(const uint8_t *__restrict__ codes, int M, const int64_t *__restrict__ ids,
+                                    int64_t S, uint8_t *__restrict__ out)
+{
+    const int64_t total = S * M;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t s = t / M;
+        const int m = (int) (t - s * M);
+        out[t] = codes[(size_t) ids[s] * M + m];
+    }
+}
+hipError_t launch_gather_codes(const uint8_t *d_codes, int M, const int64_t *d_ids, int64_t S, uint8_t *d_out,
+                               hipStream_t st)
+{
+    const int64_t total = S * M;
+    if (total == 0) return hipSuccess;
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(gather_codes_kernel, dim3(blocks), dim3(256), 0, st, d_codes, M, d_ids, S, d_out);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// std::partial_sort (libstdc++: __heap_select + __sort_heap over __adjust_heap/__push_heap), run by ONE
+// lane per query on (id, dist) pairs compared on dist only -- the comparator of src/rii.h:234,279,312.
+// Re-running the library's exact sequence of moves reproduces (i) which of several exactly tied
+// candidates the reference returns and (ii) the order of the coarse lists *past* w, which QueryIvf walks
+// when the first w lists hold fewer than topk hits (src/rii.h:283-326).
+// ===================================================================================================
+__device__ void pq_adjust_heap(int32_t *ids, float *ds, long hole, long len, int32_t vid, float vd)
+{
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (ds[child] < ds[child - 1]) child--;
+        ids[hole] = ids[child]; ds[hole] = ds[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        ids[hole] = ids[child - 1]; ds[hole] = ds[child - 1];
+        hole = child - 1;
+    }
+    long parent = (hole - 1) / 2;
+    while (hole > top && ds[parent] < vd) {
+        ids[hole] = ids[parent]; ds[hole] = ds[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    ids[hole] = vid; ds[hole] = vd;
+}
+
+__device__ void pq_partial_sort(int32_t *ids, float *ds, long middle, long n)
+{
+    long len = middle;
+    if (len >= 2) {
+        long parent = (len - 2) / 2;
+        for (;;) {
+            pq_adjust_heap(ids, ds, parent, len, ids[parent], ds[parent]);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    if (len > 0) {
+        for (long i = middle; i < n; ++i) {
+            if (ds[i] < ds[0]) {
+                const int32_t vid = ids[i];
+                const float vd = ds[i];
+                ids[i] = ids[0]; ds[i] = ds[0];
+                pq_adjust_heap(ids, ds, 0, len, vid, vd);
+            }
+        }
+    }
+    while (len > 1) {
+        --len;
+        const int32_t vid = ids[len];
+        const float vd = ds[len];
+        ids[len] = ids[0]; ds[len] = ds[0];
+        pq_adjust_heap(ids, ds, 0, len, vid, vd);
+    }
+}
+
+// ===================================================================================================
+// (a6) coarse scoring: one block per query, table of that query in LDS, lane = coarse centre.
+// ===================================================================================================
+__device__ __forceinline__ void stage_single_lut(const float *__restrict__ lut, int64_t b, int MK, int QT,
+                                                 float *lds)
+{
+    const float *src = lut + (size_t) (b / QT) * MK * QT + (b % QT);
+    for (int i = threadIdx.x; i < MK; i += blockDim.x) lds[i] = src[(size_t) i * QT];
+}
+
+__global__ __launch_bounds__(256) void ivf_coarse_kernel(IvfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    const int64_t bl = blockIdx.x;                   // local query index
+    const int MK = p.M * p.Ks;
+    stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.nlist; c += blockDim.x) {
+        const uint8_t *code = p.centers + (size_t) c * p.M;
+        float dist = 0.f;
+        for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+        p.coarse_dist[bl * p.nlist + c] = dist;
+        p.coarse_id[bl * p.nlist + c] = c;
+    }
+}
+hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st)
+{
+    if (p.B == 0) return hipSuccess;
+    const size_t smem = (size_t) p.M * p.Ks * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_coarse_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_coarse_kernel, dim3((unsigned) p.B), dim3(256), smem, st, p);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// (a6,a7) traversal plan: one lane per query: partial_sort the coarse scores (first w), then walk the
+// lists in that order accumulating candidate counts until the reference's stop rule fires
+// (src/rii.h:286-321): exactly L candidates, or >= topk after list number w, else "not found".
+// ===================================================================================================
+__global__ __launch_bounds__(64) void ivf_plan_kernel(IvfParams p)
+{
+    const int64_t bl = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (bl >= p.B) return;
+    int32_t *ids = p.coarse_id + bl * p.nlist;
+    float *ds = p.coarse_dist + bl * p.nlist;
+    pq_partial_sort(ids, ds, (long) p.w, (long) p.nlist);
+    int32_t *cum = p.cum + bl * (int64_t) (p.nlist + 1);
+    int64_t cnt = 0;
+    int nv = 0;
+    bool finished = false;
+    for (int c = 0; c < p.nlist; ++c) {
+        const int no = ids[c];
+        const int64_t len = p.list_len[no];
+        cum[c] = (int32_t) cnt;
+        if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+        cnt += len;
+        if ((int64_t) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+    }
+    if (!finished) { cnt = 0; nv = 0; }
+    cum[nv] = (int32_t) cnt;
+    p.ncand[bl] = (int32_t) cnt;
+    p.nvis[bl] = nv;
+}
+hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st)
+{
+    if (p.B == 0) return hipSuccess;
+    hipLaunchKernelGGL(ivf_plan_kernel, dim3((unsigned) ((p.B + 63) / 64)), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// (a7) candidate scan: one block per query; candidate p of the traversal is located by binary search in
+// the per-query cumulative counts, its code gathered by id (one contiguous M-byte read), ADC'd against the
+// LDS table.  topk == 1: block arg-min over (dist, traversal position) == the reference's answer.
+// ===================================================================================================
+__global__ __launch_bounds__(256) void ivf_scan_kernel(IvfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    const int64_t bl = blockIdx.x;
+    const int MK = p.M * p.Ks;
+    unsigned long long &red = *reinterpret_cast<unsigned long long *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));
+    const int ncand = p.ncand[bl];
+    const int nv = p.nvis[bl];
+    const bool top1 = (p.topk == 1);
+    if (threadIdx.x == 0) red = ~0ull;
+    if (ncand == 0) {
+        if (threadIdx.x == 0) p.out_counts[bl] = 0;
+        return;
+    }
+    stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
+    __syncthreads();
+    const int32_t *cum = p.cum + bl * (int64_t) (p.nlist + 1);
+    const int32_t *order = p.coarse_id + bl * p.nlist;
+    float bestd = INFINITY;
+    uint32_t bestp = 0xffffffffu;
+    int32_t bestid = -1;
+    for (int pos = threadIdx.x; pos < ncand; pos += blockDim.x) {
+        int lo = 0, hi = nv;                       // largest j with cum[j] <= pos
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cum[mid] <= pos) lo = mid; else hi = mid;
+        }
+        const int no = order[lo];
+        const int32_t id = p.pl_ids[p.pl_off[no] + (pos - cum[lo])];
+        const uint8_t *code = p.codes + (size_t) id * p.M;
+        float dist = 0.f;
+        if ((p.M & 3) == 0) {
+            const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
+            for (int i = 0; i < p.M / 4; ++i) {
+                const uint32_t w = cw[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dist = __fadd_rn(dist, lds[(i * 4 + j) * p.Ks + ((w >> (8 * j)) & 0xffu)]);
+            }
+        } else {
+            for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+        }
+        if (top1) {
+            if (dist < bestd) { bestd = dist; bestp = (uint32_t) pos; bestid = id; }
+        } else {
+            p.cand_id[bl * p.cand_stride + pos] = id;
+            p.cand_dist[bl * p.cand_stride + pos] = dist;
+        }
+    }
+    if (top1) {
+        unsigned long long key =
+            bestp == 0xffffffffu ? ~0ull
+                                 : (((unsigned long long) f32_orderable(__float_as_uint(bestd)) << 32) | bestp);
+        const unsigned long long mine = key;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off);
+            key = o < key ? o : key;
+        }
+        if ((threadIdx.x & 63) == 0 && key != ~0ull) atomicMin(&red, key);
+        __syncthreads();
+        if (mine != ~0ull && mine == red) {
+            p.out_ids[bl] = bestid;
+            p.out_dists[bl] = bestd;
+            p.out_counts[bl] = 1;
+        }
+    }
+}
+hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st)
+{
+    if (p.B == 0) return hipSuccess;
+    const size_t smem = (((size_t) p.M * p.Ks * sizeof(float) + 15) & ~(size_t) 15) + 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_scan_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_scan_kernel, dim3((unsigned) p.B), dim3(256), smem, st, p);
+    return hipGetLastError();
+}
+
+// final re-ranking (src/rii.h:312-319): std::partial_sort over the candidates in traversal order
+__global__ __launch_bounds__(64) void ivf_select_kernel(IvfParams p)
+{
+    const int64_t bl = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (bl >= p.B) return;
+    const int n = p.ncand[bl];
+    if (n == 0) { p.out_counts[bl] = 0; return; }
+    int32_t *ids = p.cand_id + bl * p.cand_stride;
+    float *ds = p.cand_dist + bl * p.cand_stride;
+    pq_partial_sort(ids, ds, (long) p.topk, (long) n);
+    for (int k = 0; k < p.topk; ++k) {
+        p.out_ids[bl * p.topk + k] = ids[k];
+        p.out_dists[bl * p.topk + k] = ds[k];
+    }
+    p.out_counts[bl] = p.topk;
+}
+hipError_t launch_ivf_select(const IvfParams &p, hipStream_t st)
+{
+    if (p.B == 0) return hipSuccess;
+    hipLaunchKernelGGL(ivf_select_kernel, dim3((unsigned) ((p.B + 63) / 64)), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---- target-id filtering (src/rii.h:294-296 does a binary search per posting; here: one bitmap per batch
+// and an order-preserving compaction of every list, so the traversal above is oblivious to S) ----
+__global__ void bitmap_set_kernel(const int64_t *__restrict__ tids, int64_t S, uint32_t *__restrict__ bitmap)
+{
+    const int64_t s = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int64_t t = tids[s];
+    atomicOr(&bitmap[t >> 5], 1u << (t & 31));
+}
+hipError_t launch_bitmap_set(const int64_t *d_tids, int64_t S, uint32_t *d_bitmap, hipStream_t st)
+{
+    if (S == 0) return hipSuccess;
+    hipLaunchKernelGGL(bitmap_set_kernel, dim3((unsigned) ((S + 255) / 256)), dim3(256), 0, st, d_tids, S,
+                       d_bitmap);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void filter_lists_kernel(const int64_t *__restrict__ pl_off,
+                                                           const int32_t *__restrict__ pl_ids,
+                                                           const uint32_t *__restrict__ bitmap,
+                                                           int32_t *__restrict__ fids, int32_t *__restrict__ flen)
+{
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    const int no = blockIdx.x;
+    const int64_t beg = pl_off[no], end = pl_off[no + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int64_t i = beg; i < end; i += 256) {
+        const int64_t idx = i + threadIdx.x;
+        int32_t id = 0;
+        bool keep = false;
+        if (idx < end) {
+            id = pl_ids[idx];
+            keep = (bitmap[id >> 5] >> (id & 31)) & 1u;
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
+        if (keep) fids[beg + off + prefix] = id;
+        __syncthreads();
+        if (threadIdx.x == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) flen[no] = base;
+}
+hipError_t launch_filter_lists(const int64_t *d_pl_off, const int32_t *d_pl_ids, int nlist,
+                               const uint32_t *d_bitmap, int32_t *d_fids, int32_t *d_flen, hipStream_t st)
+{
+    if (nlist == 0) return hipSuccess;
+    hipLaunchKernelGGL(filter_lists_kernel, dim3(nlist), dim3(256), 0, st, d_pl_off, d_pl_ids, d_bitmap, d_fids,
+                       d_flen);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// (a8) coarse assignment.  Symmetric tables D[m][k1][k2]; T_c[m][ks] = D[m][centre_c[m]][ks] (a row of D) so
+// the assignment is the ADC scan with the centres in the role of queries and an arg-min over centres.
+// ===================================================================================================
+__global__ __launch_bounds__(256) void symtab_kernel(const float *__restrict__ cw, int M, int Ks, int Ds, int arch,
+                                                     float *__restrict__ D)
+{
+    const int64_t total = (int64_t) M * Ks * Ks;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t) gridDim.x * blockDim.x) {
+        const int k2 = (int) (t % Ks);
+        const int64_t r = t / Ks;
+        const int k1 = (int) (r % Ks);
+        const int m = (int) (r / Ks);
+        D[t] = l2sq_pqk_dev(cw + ((size_t) m * Ks + k1) * Ds, cw + ((size_t) m * Ks + k2) * Ds, Ds, arch);
+    }
+}
+hipError_t launch_symtab(const float *d_codewords, int M, int Ks, int Ds, int arch, float *d_symtab, hipStream_t st)
+{
+    const int64_t total = (int64_t) M * Ks * Ks;
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(symtab_kernel, dim3(blocks), dim3(256), 0, st, d_codewords, M, Ks, Ds, arch, d_symtab);
+    return hipGetLastError();
+}
+
+constexpr int kAssignThreads = 512;
+constexpr int kAssignCPT = 4;     // codes per thread
+
+template <int QT>
+__global__ __launch_bounds__(kAssignThreads) void assign_kernel(const uint8_t *__restrict__ codes, int64_t num,
+                                                                int M, int Ks, const float *__restrict__ D,
+                                                                const uint8_t *__restrict__ centers, int nlist,
+                                                                int32_t *__restrict__ assign)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename LutT<QT>::T LT;
+    float *lds = reinterpret_cast<float *>(smem);
+    const LT *lut = reinterpret_cast<const LT *>(lds);
+    const int tid = threadIdx.x;
+    const int MK = M * Ks;
+    const int64_t base = (int64_t) blockIdx.x * (kAssignThreads * kAssignCPT);
+    float bestd[kAssignCPT];
+    int32_t besti[kAssignCPT];
+#pragma unroll
+    for (int k = 0; k < kAssignCPT; ++k) { bestd[k] = FLT_MAX; besti[k] = -1; }
+
+    for (int c0 = 0; c0 < nlist; c0 += QT) {
+        __syncthreads();
+        // stage T for centres c0..c0+QT-1: lds[(m*Ks+ks)*QT + q] = D[m][centre[c0+q][m]][ks]
+        for (int i = tid; i < MK * QT; i += kAssignThreads) {
+            const int q = i % QT;
+            const int mk = i / QT;
+            const int m = mk / Ks, ks = mk - m * Ks;
+            const int c = c0 + q;
+            float v = 0.f;
+            if (c < nlist) v = D[((size_t) m * Ks + centers[(size_t) c * M + m]) * Ks + ks];
+            lds[i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kAssignCPT; ++k) {
+            const int64_t n = base + (int64_t) k * kAssignThreads + tid;
+            if (n >= num) continue;
+            const uint8_t *code = codes + (size_t) n * M;
+            float acc[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) acc[q] = 0.f;
+            if ((M & 3) == 0) {
+                const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
+                for (int i = 0; i < M / 4; ++i) {
+                    const uint32_t w = cw[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc_add<QT>(acc, lut[(i * 4 + j) * Ks + ((w >> (8 * j)) & 0xffu)]);
+                }
+            } else {
+                for (int m = 0; m < M; ++m) acc_add<QT>(acc, lut[m * Ks + code[m]]);
+            }
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                // ascending centre index + strict '<' == first minimum (src/pqkmeans.cpp:209-215)
+                if (c0 + q < nlist && acc[q] < bestd[k]) { bestd[k] = acc[q]; besti[k] = c0 + q; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kAssignCPT; ++k) {
+        const int64_t n = base + (int64_t) k * kAssignThreads + tid;
+        if (n < num) assign[n] = besti[k];
+    }
+}
+
+template <int QT>
+static hipError_t launch_assign_t(const uint8_t *d_codes, int64_t num, int M, int Ks, const float *d_symtab,
+                                  const uint8_t *d_centers, int nlist, int32_t *d_assign, hipStream_t st)
+{
+    const size_t smem = (size_t) M * Ks * QT * sizeof(float);
+    auto kern = assign_kernel<QT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    const int64_t per_block = (int64_t) kAssignThreads * kAssignCPT;
+    hipLaunchKernelGGL(kern, dim3((unsigned) ((num + per_block - 1) / per_block)), dim3(kAssignThreads), smem, st,
+                       d_codes, num, M, Ks, d_symtab, d_centers, nlist, d_assign);
+    return hipGetLastError();
+}
+hipError_t launch_assign(const uint8_t *d_codes, int64_t num, int M, int Ks, const float *d_symtab,
+                         const uint8_t *d_centers, int nlist, int32_t *d_assign, hipStream_t st)
+{
+    if (num == 0) return hipSuccess;
+    const int QT = lut_tile_for(M, Ks);
+    if (QT == 4) return launch_assign_t<4>(d_codes, num, M, Ks, d_symtab, d_centers, nlist, d_assign, st);
+    if (QT == 2) return launch_assign_t<2>(d_codes, num, M, Ks, d_symtab, d_centers, nlist, d_assign, st);
+    return launch_assign_t<1>(d_codes, num, M, Ks, d_symtab, d_centers, nlist, d_assign, st);
+}
+
+// ===================================================================================================
+// (f1) PQk-means centre update (src/pqkmeans.cpp:109-123, 223-260): per (cluster, m) histogram of the
+// assigned codes' bytes, distance-weighted vote with one FMA per (k1,k2) in ascending k1, first arg-min.
+// ===================================================================================================
+__global__ void pqk_hist_kernel(const uint8_t *__restrict__ data, const int32_t *__restrict__ assign, int64_t n,
+                                int M, int Ks, int32_t *__restrict__ hist, int32_t *__restrict__ cnt)
+{
+    const int64_t total = n * M;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t i = t / M;
+        const int m = (int) (t - i * M);
+        const int k = assign[i];
+        atomicAdd(&hist[((size_t) k * M + m) * Ks + data[t]], 1);
+        if (m == 0) atomicAdd(&cnt[k], 1);
+    }
+}
+hipError_t launch_pqk_hist(const uint8_t *d_data, const int32_t *d_assign, int64_t n, int M, int Ks,
+                           int32_t *d_hist, int32_t *d_cnt, hipStream_t st)
+{
+    const int64_t total = n * M;
+    if (total == 0) return hipSuccess;
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pqk_hist_kernel, dim3(blocks), dim3(256), 0, st, d_data, d_assign, n, M, Ks, d_hist, d_cnt);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void pqk_vote_kernel(const int32_t *__restrict__ hist,
+                                                       const int32_t *__restrict__ cnt,
+                                                       const float *__restrict__ D, int K, int M, int Ks,
+                                                       uint8_t *__restrict__ centers)
+{
+    __shared__ int sh_hist[256];
+    __shared__ unsigned long long red;
+    const int k = blockIdx.x / M, m = blockIdx.x - k * M;
+    if (cnt[k] == 0) return;                                   // empty cluster keeps its old centre
+    const int k2 = threadIdx.x;
+    if (k2 < Ks) sh_hist[k2] = hist[((size_t) k * M + m) * Ks + k2];
+    if (threadIdx.x == 0) red = ~0ull;
+    __syncthreads();
+    unsigned long long key = ~0ull;
+    if (k2 < Ks) {
+        float vote = 0.f;
+        for (int k1 = 0; k1 < Ks; ++k1) {
+            const int f = sh_hist[k1];
+            if (f == 0) continue;
+            vote = __fmaf_rn((float) f, D[((size_t) m * Ks + k1) * Ks + k2], vote);
+        }
+        // first minimum under strict '<' against FLT_MAX (pqkmeans.cpp:248-256): votes >= FLT_MAX never win
+        if (vote < FLT_MAX) key = ((unsigned long long) f32_orderable(__float_as_uint(vote)) << 32) | (uint32_t) k2;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off);
+        key = o < key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key != ~0ull) atomicMin(&red, key);
+    __syncthreads();
+    if (threadIdx.x == 0 && red != ~0ull) centers[(size_t) k * M + m] = (uint8_t) (red & 0xffu);
+}
+hipError_t launch_pqk_vote(const int32_t *d_hist, const int32_t *d_cnt, const float *d_symtab, int K, int M,
+                           int Ks, uint8_t *d_centers, hipStream_t st)
+{
+    if (K == 0) return hipSuccess;
+    hipLaunchKernelGGL(pqk_vote_kernel, dim3((unsigned) (K * M)), dim3(256), 0, st, d_hist, d_cnt, d_symtab, K, M,
+                       Ks, d_centers);
+    return hipGetLastError();
+}
+
+}  // namespace riiamd

@@ -1,0 +1,111 @@
+// rii_internal.h -- shared declarations between the HIP kernels (kernels.hip, sortsel.hip) and the host
+// engine (engine.cpp).  gfx950 / CDNA4 only.  Nothing here is part of the public C ABI (include/rii_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace riiamd {
+
+// ---------------------------------------------------------------------------------------------------
+// Device data layouts (all in HBM, owned by the engine)
+//   codes      : u8  [N][M] row-major -- identical to the reference's flattened_codes_ (src/rii.h:80), so
+//                a posting-list hit is ONE contiguous M-byte gather and a linear scan is a pure stream.
+//   codewords  : f32 [M][Ks][Ds]
+//   lut        : f32 tile-interleaved [ceil(B/QT)][M][Ks][QT]: the QT queries of one scan tile sit side by
+//                side so one ds_read_b128 (QT=4) serves four queries' table entries for one (m, code byte).
+//   symtab     : f32 [M][Ks][Ks]  (PQk-means symmetric tables, src/pqkmeans.cpp:23-34)
+//   centers    : u8  [nlist][M]
+//   pl_off/ids : CSR posting lists (ids ascending inside a list, src/rii.h:356-358)
+// ---------------------------------------------------------------------------------------------------
+
+constexpr int kScanThreads = 1024;       // 16 waves: 4 per SIMD, 1 workgroup per CU (LDS-bound)
+constexpr int kMaxLutLdsBytes = 144 * 1024;
+
+struct ScanParams {
+    const uint8_t *codes;        // [n_codes][M]
+    int64_t n_codes;
+    int M, Ks;
+    const float *lut;            // tile-interleaved, see above
+    int B;                       // number of real queries (tiles are padded)
+    int QT;
+    int chunks;                  // grid.x
+    int64_t chunk_len;           // codes per chunk
+    unsigned long long *best;    // [B] packed (orderable dist bits << 32 | local index), pre-set to ~0
+    unsigned long long *keys;    // optional [Bc][n_codes] packed keys (general top-k path), else nullptr
+    int b0, bc;                  // query range written to `keys`
+};
+
+// orderable mapping of an fp32 to u32 (monotone for all finite values incl. negatives)
+__host__ __device__ inline uint32_t f32_orderable(uint32_t bits)
+{
+    return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+__host__ __device__ inline uint32_t f32_unorderable(uint32_t u)
+{
+    return (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+}
+
+// ---- kernel launchers (kernels.hip) ---------------------------------------------------------------
+hipError_t launch_lut_build(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
+                            int arch, int QT, float *d_lut, hipStream_t st);
+hipError_t launch_lut_build_mfma(const float *d_queries, int64_t B, const float *d_codewords,
+                                 const float *d_cnorm, int M, int Ks, int Ds, int QT, float *d_lut,
+                                 hipStream_t st);
+hipError_t launch_codeword_norms(const float *d_codewords, int M, int Ks, int Ds, float *d_cnorm, hipStream_t st);
+hipError_t launch_lut_untile(const float *d_lut, int64_t B, int M, int Ks, int QT, float *d_out, hipStream_t st);
+
+hipError_t launch_scan(const ScanParams &p, hipStream_t st);
+hipError_t launch_finalize_top1(const unsigned long long *d_best, int64_t B, const int64_t *d_remap,
+                                int64_t *d_out_ids, float *d_out_dists, int topk, hipStream_t st);
+hipError_t launch_gather_sorted_topk(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
+                                     const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists,
+                                     hipStream_t st);
+hipError_t launch_gather_codes(const uint8_t *d_codes, int M, const int64_t *d_ids, int64_t S, uint8_t *d_out,
+                               hipStream_t st);
+
+// IVF
+struct IvfParams {
+    const uint8_t *codes; int64_t N; int M, Ks;
+    const float *lut; int QT;
+    const uint8_t *centers; int nlist;
+    const int64_t *pl_off;        // [nlist+1] offsets into ids buffers
+    const int32_t *pl_ids;        // ids actually traversed (filtered copy when S>0)
+    const int32_t *list_len;      // [nlist] lengths actually traversed (filtered when S>0)
+    int64_t B; int b0;            // queries [b0, b0+B) of the batch are processed by this launch group
+    int topk; int64_t L; int64_t w;
+    float *coarse_dist;           // [B][nlist]
+    int32_t *coarse_id;           // [B][nlist]
+    int32_t *cum;                 // [B][nlist+1]
+    int32_t *ncand;               // [B]
+    int32_t *nvis;                // [B]
+    int32_t *cand_id;             // [B][cand_stride]
+    float *cand_dist;             // [B][cand_stride]
+    int64_t cand_stride;
+    int64_t *out_ids; float *out_dists; int64_t *out_counts;   // rows b0.. of the caller's outputs
+};
+hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
+hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st);
+hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st);
+hipError_t launch_ivf_select(const IvfParams &p, hipStream_t st);
+hipError_t launch_bitmap_set(const int64_t *d_tids, int64_t S, uint32_t *d_bitmap, hipStream_t st);
+hipError_t launch_filter_lists(const int64_t *d_pl_off, const int32_t *d_pl_ids, int nlist,
+                               const uint32_t *d_bitmap, int32_t *d_fids, int32_t *d_flen, hipStream_t st);
+
+// coarse assignment / PQk-means
+hipError_t launch_symtab(const float *d_codewords, int M, int Ks, int Ds, int arch, float *d_symtab,
+                         hipStream_t st);
+hipError_t launch_assign(const uint8_t *d_codes, int64_t num, int M, int Ks, const float *d_symtab,
+                         const uint8_t *d_centers, int nlist, int32_t *d_assign, hipStream_t st);
+hipError_t launch_pqk_hist(const uint8_t *d_data, const int32_t *d_assign, int64_t n, int M, int Ks,
+                           int32_t *d_hist, int32_t *d_cnt, hipStream_t st);
+hipError_t launch_pqk_vote(const int32_t *d_hist, const int32_t *d_cnt, const float *d_symtab, int K, int M,
+                           int Ks, uint8_t *d_centers, hipStream_t st);
+
+// segmented sort of packed keys (sortsel.hip, rocPRIM): sorts each of `segs` rows of length `len`
+hipError_t segmented_sort_keys(unsigned long long *d_keys_in, unsigned long long *d_keys_out, int64_t segs,
+                               int64_t len, void **d_temp, size_t *temp_bytes, hipStream_t st);
+
+int lut_tile_for(int M, int Ks);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
+
+}  // namespace riiamd

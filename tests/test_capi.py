@@ -1,0 +1,46 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/rii_amd.h declares; without a GPU
+the product path fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "rii_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rii_[a-z_0-9A-Z]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rii_amd import core
+    so = core.build_library()
+    lib = ctypes.CDLL(so)
+    names = header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "librii_amd.so does not export %s" % n
+    assert set(core.exported_symbols()) == set(names), "ctypes signature table out of sync with the header"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from rii_amd import core, RiiGpu, RiiAmdError
+    if core._lib().rii_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RiiAmdError):
+        RiiGpu(np.zeros((2, 4, 3), np.float32), False)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "rii_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("rii_oracle", "").lower() or f == "csrc_notes.txt" or \
+                    all("import" not in line and "include" not in line
+                        for line in txt.splitlines() if "oracle" in line.lower()), f
