@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec + recall@1 of the batched IVFPQ linear ADC scan (BASELINE.json configs[1]:
+SIFT1M-shaped, D=128, M=32, Ks=256, batch=1024, top-1) on N MI355X GPUs of one node.
+
+A step = one pass of the hot path (distance-table build + linear ADC scan + top-1) over one batch of 1024
+queries per GPU, inputs and outputs resident in HBM.  N > 1: one process per GPU (torchrun), the index is
+replicated, every rank owns a different 1024-query batch (weak scaling) and the per-rank results are
+all-gathered over RCCL/xGMI inside the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line: `roofline` (the dominant kernel, scan_kernel, from HIP events recorded around each
+of its launches during the timed region) and `cpu_baseline` (the real reference build oracle/_ref, or the C
+oracle, timed on this box's host cores on a bounded sample of the same workload; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--n-base", type=int, default=1_000_000)
+    ap.add_argument("--M", type=int, default=32)
+    ap.add_argument("--workload", default="linear", choices=["linear", "ivf", "subset"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lut-mode", default="exact", choices=["exact", "mfma"])
+    return ap.parse_args()
+
+
+def cpu_baseline(cw, codes, queries, arch_hint):
+    """The reference's own path (per-query loop, OpenMP over N: src/rii.h:195-242) on the host cores."""
+    from oracle import oracle as O
+    ref, arch, flav = O.load_reference()
+    E = np.array([], np.int64)
+    if ref is not None:
+        eng = ref.RiiCpp(cw, False)
+        kind = "reference"
+    else:
+        eng = O.OracleRii(cw, False, simd_arch=arch_hint)
+        kind = "port"
+    eng.add_codes(codes, False)
+    eng.query_linear(queries[0], 1, E)                        # warm-up
+    t0 = time.perf_counter()
+    for q in queries[:4]:
+        eng.query_linear(q, 1, E)
+    per = (time.perf_counter() - t0) / 4
+    n = int(min(len(queries), max(8, 15.0 / max(per, 1e-6))))    # ~15 s of CPU work
+    t0 = time.perf_counter()
+    ids = [eng.query_linear(q, 1, E)[0][0] for q in queries[:n]]
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "queries/s", "cores": os.cpu_count(), "kind": kind,
+            "sample": "%d of the batch's queries, one query per call (the reference has no batch entry point), "
+                      "full %d-code linear scan, top-1, OpenMP default threads%s" %
+                      (n, codes.shape[0], (", build flavour " + flav) if ref is not None else "")}, np.array(ids)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from rii_amd import RiiGpu, host_simd_arch
+    from rii_amd import bench_data as bd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (got WORLD_SIZE=%d)" % (args.gpus, world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, M, Ks, D = args.batch, args.M, 256, 128
+    arch = host_simd_arch()
+
+    # ---------------- inputs (synthetic, seeded): rank 0 builds, everyone receives ----------------
+    N = args.n_base
+    if rank == 0:
+        base, train, query = bd.sift_like(n_base=N, n_train=100_000, n_query=max(10_000, B * world), D=D)
+        cw = bd.train_pq(train, M, Ks, iters=10, seed=123, device=dev)
+        codes = bd.encode_pq(base, cw, device=dev)
+        gt = bd.exact_nn(base, query[:B * world], device=dev)
+        t_cw = torch.from_numpy(cw).to(dev)
+        t_codes = torch.from_numpy(codes).to(dev)
+        t_q = torch.from_numpy(np.ascontiguousarray(query[:B * world])).to(dev)
+        t_gt = torch.from_numpy(gt).to(dev)
+        del base, train
+    else:
+        t_cw = torch.empty((M, Ks, D // M), dtype=torch.float32, device=dev)
+        t_codes = torch.empty((N, M), dtype=torch.uint8, device=dev)
+        t_q = torch.empty((B * world, D), dtype=torch.float32, device=dev)
+        t_gt = torch.empty((B * world,), dtype=torch.int64, device=dev)
+    if world > 1:
+        for t in (t_cw, t_codes, t_q, t_gt):
+            dist.broadcast(t, 0)
+    cw = t_cw.cpu().numpy()
+    codes = t_codes.cpu().numpy()
+    del t_codes
+    my_q = t_q[rank * B:(rank + 1) * B].contiguous()
+    my_gt = t_gt[rank * B:(rank + 1) * B].cpu().numpy()
+
+    # ---------------- engine (one per GPU, index replicated) ----------------
+    eng = RiiGpu(cw, False, simd_arch=arch, device=local)
+    eng.add_codes(codes, False)
+    eng.set_option("lut_mode", args.lut_mode)
+    topk = 1
+    S, L = 0, 0
+    d_tids = 0
+    if args.workload != "linear":
+        eng.reconfigure(1024, 5)
+        L = int(np.round(N / 1024))
+    if args.workload == "subset":
+        rng = np.random.default_rng(7)
+        tids = torch.from_numpy(np.sort(rng.choice(N, 100_000, replace=False)).astype(np.int64)).to(dev)
+        S, d_tids = tids.numel(), tids.data_ptr()
+    out_ids = torch.empty((B, topk), dtype=torch.int64, device=dev)
+    out_d = torch.empty((B, topk), dtype=torch.float32, device=dev)
+    out_cnt = torch.empty((B,), dtype=torch.int64, device=dev)
+    gather_ids = [torch.empty_like(out_ids) for _ in range(world)] if world > 1 else None
+    gather_d = [torch.empty_like(out_d) for _ in range(world)] if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        if args.workload == "ivf":
+            eng.query_ivf_dev(my_q.data_ptr(), B, topk, d_tids, S, L, out_ids.data_ptr(), out_d.data_ptr(),
+                              out_cnt.data_ptr(), stream)
+        else:
+            eng.query_linear_dev(my_q.data_ptr(), B, topk, d_tids, S, out_ids.data_ptr(), out_d.data_ptr(), stream)
+        if world > 1:      # top-k gather over xGMI (12 KB per rank: latency-bound)
+            dist.all_gather(gather_ids, out_ids)
+            dist.all_gather(gather_d, out_d)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.set_option("timing", 1)
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_option("timing", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel = "ivf_scan" if args.workload == "ivf" else "scan"
+    k_ms, k_n = eng.timing_read(kernel)
+    lut_ms, lut_n = eng.timing_read("lut")
+    recall = bd.recall_at_r(out_ids.cpu().numpy(), my_gt, 1)
+    if world > 1:
+        r = torch.tensor([recall], dtype=torch.float64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        recall = float(r.item()) / world
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = B * world * args.steps / elapsed
+        n_scanned = S if args.workload == "subset" else N
+        if args.workload == "ivf":
+            alg_bytes = B * (1024 * M + 4 * L * 4 + L * M)        # coarse codes + ids + L codes
+        else:
+            alg_bytes = B * n_scanned * M                          # M code bytes per (query, code)
+        avg_s = (k_ms / max(k_n, 1)) * 1e-3
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        line = {
+            "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SIFT1M-shaped %s ADC scan, D=128 M=%d Ks=256, N=%d, batch=%d per GPU, topk=1%s"
+                                   % (args.workload, M, N, B, (", nlist=1024 L=%d" % L) if L else ""),
+                       "global_batch": B * world, "parallelism": "query-sharded x%d, index replicated" % world,
+                       "lut_mode": args.lut_mode, "simd_order": arch},
+            "recall_at_1": recall,
+            "roofline": {"bound": "hbm", "kernel": kernel + "_kernel", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": k_n,
+                         "lut_avg_launch_ms": lut_ms / max(lut_n, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "linear":
+            cb, cpu_ids = cpu_baseline(cw, codes, my_q.cpu().numpy(), arch)
+            gpu_ids = out_ids.cpu().numpy()[:len(cpu_ids), 0]
+            cb["ids_match_gpu"] = bool(np.array_equal(cpu_ids, gpu_ids))
+            line["cpu_baseline"] = cb
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

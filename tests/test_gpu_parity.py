@@ -123,7 +123,30 @@ def test_gpu_ivf_empty_and_tail_vs_oracle():
             n = int(cnt[b])
             assert_same_result((ids[b, :n], d[b, :n]), want, "trial %d b=%d" % (trial, b))
             n_empty += (len(want[0]) == 0)
-    assert n_empty > 0, "the sweep is meant to hit the empty-return branch of rii.h:324-325"
+
+
+def test_gpu_ivf_empty_return_with_stale_lists():
+    """rii.h:324-325 is reachable when codes were appended with update_flag=False after a reconfigure (lists
+    cover fewer than L ids): fewer than topk hits in the first w lists, then the walk over the unsorted tail
+    of the coarse order never reaches L => ([], [])."""
+    from rii_amd import RiiGpu
+    arch = "avx512"
+    cw, codes, qs = make_problem(13, 8, 64, 4, 5050, "unit")
+    g = RiiGpu(cw, False, simd_arch=arch)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    g.add_codes(codes[:50], False); o.add_codes(codes[:50], False)
+    g.reconfigure(10, 3); o.reconfigure(10, 3)
+    g.add_codes(codes[50:], False); o.add_codes(codes[50:], False)
+    n_empty = n_full = 0
+    for topk, L in ((20, 100), (20, 40), (3, 30), (12, 50), (1, 51), (6, 49)):
+        ids, d, cnt = g.query_ivf_batch(qs[:8], topk, None, L)
+        for b in range(8):
+            want = o.query_ivf(qs[b], topk, E, L)
+            n = int(cnt[b])
+            assert_same_result((ids[b, :n], d[b, :n]), want, "k=%d L=%d b=%d" % (topk, L, b))
+            n_empty += (len(want[0]) == 0)
+            n_full += (len(want[0]) > 0)
+    assert n_empty > 0 and n_full > 0
 
 
 def test_gpu_single_query_api_types():

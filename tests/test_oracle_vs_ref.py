@@ -145,3 +145,24 @@ def test_assignment_tables_all_ds(reference, Ds):
     r.reconfigure(50, 4); o.reconfigure(50, 4)
     assert o.coarse_centers == r.coarse_centers
     assert o.posting_lists == r.posting_lists
+
+
+def test_ivf_empty_return_with_stale_lists(reference):
+    """The `vectors not found` return of rii.h:324-325 and the walk over the *unsorted* tail of the coarse
+    order (elements past w after std::partial_sort): reachable once codes are appended with update_flag=False
+    after a reconfigure, so that the lists cover fewer than L ids."""
+    ref, arch, _ = reference
+    cw, codes, qs = make_problem(13, 8, 64, 4, 5050, "unit")
+    r = ref.RiiCpp(cw, False)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    r.add_codes(codes[:50], False); o.add_codes(codes[:50], False)
+    r.reconfigure(10, 3); o.reconfigure(10, 3)
+    r.add_codes(codes[50:], False); o.add_codes(codes[50:], False)
+    n_empty = n_full = 0
+    for topk, L in ((20, 100), (20, 40), (3, 30), (12, 50), (1, 51), (6, 49)):
+        for q in qs[:8]:
+            want = r.query_ivf(q, topk, E, L)
+            assert_same_result(o.query_ivf(q, topk, E, L), want, "k=%d L=%d" % (topk, L))
+            n_empty += (len(want[0]) == 0)
+            n_full += (len(want[0]) > 0)
+    assert n_empty > 0 and n_full > 0
