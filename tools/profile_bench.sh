@@ -1,0 +1,29 @@
+#!/bin/bash
+# Runs bench.py under rocprofv3 on the GPU box and leaves SMALL text summaries under gpurun_out/prof_summary/
+# (copy the ones to be judged into profiles/).  Counters are collected in their own passes (no trace domains
+# mixed with --pmc), as the MI355X guide prescribes.
+#   usage: tools/profile_bench.sh <tag> [extra bench.py args]
+set -u
+TAG=${1:-r01}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp && export TMPDIR=/tmp
+cd "$REPO"
+OUT=gpurun_out/prof_summary; RAW=/tmp/rii_prof_raw
+mkdir -p $OUT; rm -rf $RAW; mkdir -p $RAW
+KREGEX='scan_kernel|lut_build|ivf_|assign_kernel|finalize|fscan'
+BENCH="python bench.py --no-cpu-baseline $*"
+
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/kt -o kt -- $BENCH --steps 10 --warmup 2 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $RAW/kt.err
+python tools/summarize_prof.py stats $RAW/kt > $OUT/${TAG}_kernel_stats.txt
+
+i=0
+for CTRS in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" \
+            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE" \
+            "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
+  i=$((i+1))
+  rocprofv3 --pmc $CTRS --kernel-include-regex "$KREGEX" --output-format csv -d $RAW/pmc$i -o pmc -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $RAW/pmc$i.err
+done
+python tools/summarize_prof.py pmc $RAW/pmc* > $OUT/${TAG}_pmc_counters.txt
+tail -3 $RAW/*.err > $OUT/${TAG}_rocprof_stderr_tail.txt 2>/dev/null
+rm -rf $RAW
+ls -la $OUT
