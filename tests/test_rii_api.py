@@ -1,0 +1,228 @@
+"""The API-level invariants the reference's own test-suite holds (tests/test_rii.py:11-289), restated against
+`rii_amd.Rii` with our codec stand-ins (nanopq is not installable here).  Each test runs twice: with the CPU oracle
+injected as `impl_cpp` (CPU suite: exercises the host-side Python logic) and with the HIP engine (`-m gpu`)."""
+import copy
+import pickle
+from itertools import chain
+
+import numpy as np
+import pytest
+
+from rii_amd import Rii
+from rii_amd.codec import PQ, OPQ
+
+BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("gpu", id="gpu", marks=pytest.mark.gpu)]
+S12 = np.array([2, 24, 43, 55, 102, 139, 221, 542, 667, 873, 874, 899], dtype=np.int64)
+
+
+def make(fq, backend):
+    if backend == "gpu":
+        return Rii(fine_quantizer=fq)
+    from oracle import oracle as O
+    return Rii(fine_quantizer=fq, _impl_factory=lambda cw, verbose: O.OracleRii(cw, verbose))
+
+
+@pytest.fixture(autouse=True)
+def _seed():
+    np.random.seed(123)
+
+
+def data(N=1000, D=40):
+    return np.random.random((N, D)).astype(np.float32)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_construct(backend):                       # test_rii.py:11-20
+    X = data()
+    e = make(PQ(M=4, Ks=20, verbose=True).fit(vecs=X, iter=3), backend)
+    assert e.fine_quantizer.codewords.shape == (4, 20, 10)
+    assert (e.M, e.Ks) == (4, 20)
+    assert e.verbose is True
+    e.verbose = False
+    assert e.verbose is False
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("codec", [PQ, OPQ])
+def test_add(backend, codec):                      # test_rii.py:22-40
+    X = data()
+    fq = codec(M=4, Ks=20, verbose=False)
+    fq = fq.fit(vecs=X, iter=3) if codec is PQ else fq.fit(vecs=X, pq_iter=3, rotation_iter=2)
+    e = make(fq, backend)
+    assert e.N == 0
+    e.add(vecs=X, update_posting_lists=False)
+    assert e.N == 1000
+    assert np.array_equal(e.fine_quantizer.encode(X), e.codes)
+    e.add(vecs=X, update_posting_lists=False)
+    assert e.N == 2000
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_reconfigure_and_simple_add(backend):      # test_rii.py:42-71
+    X1, X2 = data(300), data(700)
+    e = make(PQ(M=4, Ks=20, verbose=False).fit(vecs=X1, iter=3), backend)
+    e.add(vecs=X1)
+    assert e.N == 300
+    e.add(vecs=X2)
+    assert e.N == 1000
+    for nlist in (5, 100):
+        e.reconfigure(nlist=nlist)
+        assert e.nlist == nlist
+        assert e.coarse_centers.shape == (nlist, 4)
+        assert len(e.posting_lists) == nlist
+        assert sum(len(p) for p in e.posting_lists) == 1000
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_add_configure_equivalences(backend):      # test_rii.py:73-113
+    X = data()
+    fq = PQ(M=4, Ks=20, verbose=False).fit(vecs=X, iter=3)
+    e1 = make(fq, backend).add_configure(vecs=X, nlist=20)
+    e2 = make(fq, backend)
+    e2.add(vecs=X, update_posting_lists=False)
+    e2.reconfigure(nlist=20)
+    assert np.array_equal(e1.codes, e2.codes)
+    assert e1.posting_lists == e2.posting_lists
+    # one-by-one additions
+    a, b, c = make(fq, backend), make(fq, backend), make(fq, backend)
+    for x in X[:10]:
+        a.add_configure(vecs=x.reshape(1, -1))
+    assert a.N == 10
+    b.add_configure(vecs=X[:10])
+    assert np.array_equal(a.codes, b.codes) and a.posting_lists == b.posting_lists
+    for x in X[:10]:
+        c.add(x.reshape(1, -1))
+    c.reconfigure()
+    assert np.array_equal(a.codes, c.codes) and a.posting_lists == c.posting_lists
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_query_linear_and_ivf_identities(backend):   # test_rii.py:117-187
+    X = data()
+    e = make(PQ(M=20, Ks=256, verbose=False).fit(vecs=X, iter=3), backend)
+    e.add_configure(vecs=X, nlist=20)
+    E = np.array([], dtype=np.int64)
+    full = np.arange(1000, dtype=np.int64)
+    for n, q in enumerate(X[:10]):
+        ids1, d1 = e.impl_cpp.query_linear(q, 10, E)
+        assert isinstance(ids1, list) and isinstance(ids1[0], int)
+        assert isinstance(d1, list) and isinstance(d1[0], float)
+        assert len(ids1) == 10 == len(d1)
+        assert np.all(np.diff(d1) >= 0)
+        assert n in ids1
+        assert (ids1, d1) == tuple(e.impl_cpp.query_linear(q, 10, full))
+        ids3, _ = e.impl_cpp.query_linear(q, 10, S12)
+        assert all(i in S12 for i in ids3)
+        L = 200
+        i1, dd1 = e.impl_cpp.query_ivf(q, 10, E, L)
+        assert len(i1) == 10 and np.all(np.diff(dd1) >= 0) and n in i1
+        assert (i1, dd1) == tuple(e.impl_cpp.query_ivf(q, 10, full, L))
+        assert tuple(e.impl_cpp.query_ivf(q, 10, full, 1000)) == (ids1, d1)            # ivf(L=N) == linear
+        assert tuple(e.impl_cpp.query_ivf(q, 10, S12, L)) == tuple(e.impl_cpp.query_linear(q, 10, S12))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("codec", [PQ, OPQ])
+def test_query(backend, codec):                     # test_rii.py:189-218
+    X = data()
+    fq = codec(M=20, Ks=256, verbose=False)
+    fq = fq.fit(vecs=X, iter=3) if codec is PQ else fq.fit(vecs=X, pq_iter=3, rotation_iter=2)
+    e = make(fq, backend)
+    e.add_configure(vecs=X, nlist=20)
+    for n, q in enumerate(X[:10]):
+        ids1, d1 = e.query(q=q, topk=50)
+        assert isinstance(ids1, np.ndarray) and ids1.dtype == np.int64
+        assert isinstance(d1, np.ndarray) and d1.dtype == np.float64
+        assert len(ids1) == 50 == len(d1)
+        assert np.all(np.diff(d1) >= 0)
+        assert n in ids1
+        ids2, d2 = e.query(q=q, topk=50, target_ids=np.arange(1000, dtype=np.int64))
+        assert np.allclose(ids1, ids2) and np.allclose(d1, d2)
+        ids3, _ = e.query(q=q, topk=5, target_ids=S12)
+        assert all(i in S12 for i in ids3)
+        for method in ("linear", "ivf", "auto"):
+            e.query(q=q, topk=3, method=method)
+    with pytest.raises(AssertionError):
+        e.query(q=X[0], topk=5000)
+    with pytest.raises(AssertionError):
+        e.query(q=X[0], topk=5, target_ids=np.arange(10, dtype=np.int32))   # target_ids must be int64 (rii.py:294)
+    if backend == "gpu":
+        ids, d, cnt = e.query_batch(X[:10], topk=7, method="linear")
+        for b in range(10):
+            i1, dd1 = e.query(q=X[b], topk=7, method="linear")
+            assert np.array_equal(ids[b], i1) and np.array_equal(d[b].astype(np.float64), dd1)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_pickle(backend):                           # test_rii.py:220-236
+    X = data()
+    e1 = make(PQ(M=10, Ks=256, verbose=False).fit(vecs=X, iter=3), backend)
+    e1.add_configure(vecs=X, nlist=20)
+    e2 = pickle.loads(pickle.dumps(e1))
+    assert (e1.M, e1.Ks) == (e2.M, e2.Ks)
+    assert np.array_equal(e1.threshold.coeffs, e2.threshold.coeffs)
+    assert np.array_equal(e1.coarse_centers, e2.coarse_centers)
+    assert np.array_equal(e1.codes, e2.codes)
+    assert e1.posting_lists == e2.posting_lists
+    assert tuple(map(list, e1.query(X[3], topk=5))) == tuple(map(list, e2.query(X[3], topk=5)))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_clear(backend):                            # test_rii.py:238-250
+    X = data()
+    e = make(PQ(M=4, Ks=20, verbose=False).fit(vecs=X, iter=3), backend)
+    e.add_configure(vecs=X, nlist=20)
+    e.clear()
+    assert e.threshold is None and e.N == 0 and e.nlist == 0
+    assert e.coarse_centers is None and e.codes is None and len(e.posting_lists) == 0
+    e.add_configure(vecs=X, nlist=10)               # usable again after clear
+    assert e.N == 1000 and e.nlist == 10
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_merge(backend):                            # test_rii.py:252-289
+    X1, X2 = data(1000), data(500)
+    codec = PQ(M=4, Ks=20, verbose=False).fit(vecs=X1, iter=3)
+    e1, e2 = make(codec, backend), make(codec, backend)
+    e1.merge(e2)
+    assert (e1.N, e2.N) == (0, 0)
+    e1.add_configure(vecs=X1)
+    e1.merge(e2)
+    assert e1.N == 1000 and e1.nlist == int(np.sqrt(1000))
+    e1.clear()
+    e2.add_configure(vecs=X2)
+    e1.merge(e2)
+    assert e1.N == 500 and e1.nlist == 0
+    e1.clear(); e2.clear()
+    e1.add_configure(vecs=X1)
+    e2.add_configure(vecs=X2)
+    e1.merge(e2)
+    assert e1.N == 1500 and e1.nlist == int(np.sqrt(1000))
+    assert np.array_equal(e1.codes, codec.encode(np.vstack((X1, X2))))
+    assert sorted(chain(*e1.posting_lists)) == list(range(1500))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_print_params_and_helpers(backend, capsys):
+    X = data()
+    e = make(PQ(M=4, Ks=20, verbose=False).fit(vecs=X, iter=3), backend)
+    e.print_params()
+    e.add_configure(vecs=X, nlist=20)
+    e.print_params()
+    out = capsys.readouterr().out
+    assert "threshold function" in out and "L0: 50" in out
+    assert e.L0 == 50 and e._multiple_of_L0_covering_topk(1) == 50 and e._multiple_of_L0_covering_topk(120) == 150
+    assert e._resolve_update_posting_lists_flag("auto") is True
+
+
+def test_codec_roundtrip_and_eq():
+    X = data()
+    pq = PQ(M=4, Ks=64, verbose=False).fit(vecs=X, iter=5)
+    codes = pq.encode(X)
+    assert codes.dtype == np.uint8 and codes.shape == (1000, 4)
+    err = np.mean((pq.decode(codes) - X) ** 2)
+    assert err < np.mean((X - X.mean(0)) ** 2)
+    assert pq == copy.deepcopy(pq)
+    opq = OPQ(M=4, Ks=64, verbose=False).fit(vecs=X, pq_iter=3, rotation_iter=3)
+    assert np.allclose(opq.R @ opq.R.T, np.eye(40), atol=1e-4)
+    assert np.allclose(opq.rotate(X[0]), opq.rotate(X[:1])[0])
