@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--workload", default="linear", choices=["linear", "ivf", "subset"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lut-mode", default="exact", choices=["exact", "mfma"])
+    ap.add_argument("--scan-mode", type=int, default=1, choices=[0, 1],
+                    help="1: 8-bit filter + exact re-rank (default), 0: exact scan of every code; identical results")
     return ap.parse_args()
 
 
@@ -113,6 +115,7 @@ def main():
     eng = RiiGpu(cw, False, simd_arch=arch, device=local)
     eng.add_codes(codes, False)
     eng.set_option("lut_mode", args.lut_mode)
+    eng.set_option("scan_mode", args.scan_mode)
     topk = 1
     S, L = 0, 0
     d_tids = 0
@@ -164,6 +167,11 @@ def main():
     kernel = "ivf_scan" if args.workload == "ivf" else "scan"
     k_ms, k_n = eng.timing_read(kernel)
     lut_ms, lut_n = eng.timing_read("lut")
+    extra = {}
+    for kn in ("quant", "rerank", "gather", "ivf_coarse", "ivf_plan", "finalize"):
+        ms_, n_ = eng.timing_read(kn)
+        if n_:
+            extra[kn + "_avg_launch_ms"] = ms_ / n_
     recall = bd.recall_at_r(out_ids.cpu().numpy(), my_gt, 1)
     if world > 1:
         r = torch.tensor([recall], dtype=torch.float64, device=dev)
@@ -187,12 +195,13 @@ def main():
             "config": {"workload": "SIFT1M-shaped %s ADC scan, D=128 M=%d Ks=256, N=%d, batch=%d per GPU, topk=1%s"
                                    % (args.workload, M, N, B, (", nlist=1024 L=%d" % L) if L else ""),
                        "global_batch": B * world, "parallelism": "query-sharded x%d, index replicated" % world,
-                       "lut_mode": args.lut_mode, "simd_order": arch},
+                       "lut_mode": args.lut_mode, "simd_order": arch,
+                       "scan_mode": "8-bit filter + exact fp32 re-rank" if args.scan_mode else "exact fp32 scan"},
             "recall_at_1": recall,
-            "roofline": {"bound": "hbm", "kernel": kernel + "_kernel", "achieved": achieved, "peak": 8000.0,
+            "roofline": {"bound": "hbm", "kernel": ("fscan" if (args.scan_mode and kernel == "scan") else kernel) + "_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": k_n,
-                         "lut_avg_launch_ms": lut_ms / max(lut_n, 1)},
+                         "lut_avg_launch_ms": lut_ms / max(lut_n, 1), **extra},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "linear":
             cb, cpu_ids = cpu_baseline(cw, codes, my_q.cpu().numpy(), arch)

@@ -89,6 +89,8 @@ struct rii_engine {
     int QT = 4;
     int lut_mode = RII_LUT_EXACT;
     int scan_chunks = 0;        // 0 = auto
+    int scan_mode = 1;          // 1 = 8-bit filter + exact re-rank for top-1 (fastscan.hip), 0 = exact scan only
+    int cand_cap = 2048;        // candidate slots per query for the re-rank stage
     int timing = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
@@ -108,7 +110,7 @@ struct rii_engine {
     // scratch
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
-        s_hist, s_cnt, s_sample;
+        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
 
@@ -281,6 +283,41 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
     ScanParams sp;
     sp.codes = d_codes; sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks; sp.lut = e->s_lut.as<float>();
     sp.B = (int) B; sp.QT = e->QT; sp.best = nullptr; sp.keys = nullptr; sp.b0 = 0; sp.bc = 0;
+    if (topk == 1 && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
+        // stage 0: quantise the tables; stage 1: 8-bit scan -> candidates; stage 2: exact re-rank
+        const int64_t tiles = (B + 15) / 16;
+        RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * 16));
+        RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
+        RII_TRY(e->s_cand.ensure((size_t) B * e->cand_cap * sizeof(unsigned long long)));
+        RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
+        {
+            ScopedTimer t(e, "quant", st);
+            HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_qlut.as<uint8_t>(),
+                                        e->s_slack.as<int32_t>(), st));
+        }
+        HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
+        int64_t c = e->scan_chunks;
+        if (c <= 0) {
+            c = std::max<int64_t>(1, (e->n_cu + tiles - 1) / tiles);
+            c = std::min<int64_t>(c, std::max<int64_t>(1, n_codes / 4096));
+        }
+        c = std::max<int64_t>(1, std::min<int64_t>(c, 65535));
+        const int64_t len = std::max<int64_t>(1, (n_codes + c - 1) / c);
+        const int chunks = (int) ((n_codes + len - 1) / len);
+        {
+            ScopedTimer t(e, "scan", st);
+            HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
+                                 chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(),
+                                 e->cand_cap, st));
+        }
+        {
+            ScopedTimer t(e, "rerank", st);
+            HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT, e->s_slack.as<int32_t>(),
+                                       e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), e->cand_cap,
+                                       d_remap, B, d_out_ids, d_out_dists, topk, st));
+        }
+        return RII_OK;
+    }
     if (topk == 1) {
         pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len);
         RII_TRY(e->s_best.ensure((size_t) B * sizeof(unsigned long long)));
@@ -449,7 +486,8 @@ void free_all(rii_engine *e)
                       &e->d_pl_ids, &e->d_list_len, &e->s_queries, &e->s_tids, &e->s_lut, &e->s_best, &e->s_out_ids,
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
-                      &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample};
+                      &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
+                      &e->s_cand, &e->s_cand_cnt};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;
@@ -803,6 +841,12 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->scan_chunks = (int) value;
     } else if (k == "timing") {
         e->timing = value ? 1 : 0;
+    } else if (k == "scan_mode") {
+        if (value != 0 && value != 1) return set_err(RII_ERR_INVALID, "scan_mode must be 0 (exact) or 1 (filter + re-rank)");
+        e->scan_mode = (int) value;
+    } else if (k == "cand_cap") {
+        if (value < 1 || value > (1 << 20)) return set_err(RII_ERR_INVALID, "bad cand_cap");
+        e->cand_cap = (int) value;
     } else {
         return set_err(RII_ERR_INVALID, "unknown option '%s'", key);
     }
@@ -815,6 +859,8 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "lut_mode") return e->lut_mode;
     if (k == "scan_chunks") return e->scan_chunks;
     if (k == "timing") return e->timing;
+    if (k == "scan_mode") return e->scan_mode;
+    if (k == "cand_cap") return e->cand_cap;
     if (k == "lut_tile") return e->QT;
     if (k == "n_cu") return e->n_cu;
     return -1;

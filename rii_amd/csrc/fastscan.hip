@@ -1,0 +1,387 @@
+// fastscan.hip -- top-1 linear ADC scan as an exact two-stage search (gfx950).
+//
+// The exact scan (kernels.hip: scan_kernel) is bound by LDS bank conflicts on 4-byte table entries: one
+// ds_read_b128 serves 4 queries for one code byte.  Here the SAME ds_read_b128 serves 16 queries: stage 1
+// scans all codes against an 8-bit quantisation of every query's table and keeps, per query, only the codes whose
+// quantised sum is within a *proven* slack of the smallest quantised sum; stage 2 re-evaluates those few
+// candidates with the exact fp32 table in the reference's order (RiiCpp::ADist, src/rii.h:386-394) and takes the
+// (dist, id) minimum.  The result is bit-identical to scan_kernel's (and so to RiiCpp::QueryLinear for topk=1).
+//
+// Proof sketch (details next to lut_quantize_kernel): with T[m][ks] = lo_m + delta*c[m][ks] + r[m][ks],
+//   d(n) = sum_m lo_m + delta*a(n) + sum_m r[m][code_m(n)],  a(n) = sum_m c[m][code_m(n)]  (integer).
+// Rlo = sum_m min_ks r, Rhi = sum_m max_ks r bound the residual term for EVERY code; eps bounds the difference between
+// the real-number sum d(n) and its sequentially rounded fp32 value.  If n* is the exact winner and n0 minimises a(),
+// then a(n*) <= a(n0) + floor((Rhi - Rlo + 2*eps)/delta) =: a_min + slack.  All codes tied with n* at the exact minimum
+// satisfy the same inequality, so the (dist, id) minimum over the candidate set equals the one over all codes.
+#include "rii_internal.h"
+#include <float.h>
+
+namespace riiamd {
+
+constexpr int kFsThreads = 1024;
+constexpr int kFsQ = 16;               // queries per stage-1 tile (one byte each in a 16-byte LDS row)
+
+// ---------------------------------------------------------------------------------------------------
+// per-query 8-bit quantisation of the exact table + slack.  One block (256 threads) per query.
+//   qlut layout: [tile = b/16][m][ks][16 queries] u8
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restrict__ lut, int64_t B, int M, int Ks,
+                                                           int QT, uint8_t *__restrict__ qlut,
+                                                           int32_t *__restrict__ slack)
+{
+    __shared__ float s_lo[256], s_hi[256];          // per-m extrema (M <= 256)
+    __shared__ double s_rlo[256], s_rhi[256];
+    __shared__ float s_delta;
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int MK = M * Ks;
+    const float *src = lut + (size_t) (b / QT) * MK * QT + (b % QT);       // element i at src[i*QT]
+    const int wave = tid >> 6, lane = tid & 63;
+    // 1. per-m min / max: one wave per m, lanes over ks
+    for (int m = wave; m < M; m += 4) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int ks = lane; ks < Ks; ks += 64) {
+            const float t = src[(size_t) (m * Ks + ks) * QT];
+            lo = fminf(lo, t);
+            hi = fmaxf(hi, t);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off));
+            hi = fmaxf(hi, __shfl_xor(hi, off));
+        }
+        if (lane == 0) { s_lo[m] = lo; s_hi[m] = hi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float range = 0.f;
+        for (int m = 0; m < M; ++m) range = fmaxf(range, s_hi[m] - s_lo[m]);
+        float d = range / 255.0f;
+        if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
+        s_delta = d * 1.000001f;
+    }
+    __syncthreads();
+    const float delta = s_delta;
+    const double ddelta = (double) delta;
+    // 2. codes + residual extrema per m
+    uint8_t *dst = qlut + (size_t) (b / kFsQ) * MK * kFsQ + (b % kFsQ);     // element i at dst[i*16]
+    for (int m = wave; m < M; m += 4) {
+        const float lo = s_lo[m];
+        double rlo = INFINITY, rhi = -INFINITY;
+        for (int ks = lane; ks < Ks; ks += 64) {
+            const float t = src[(size_t) (m * Ks + ks) * QT];
+            const float x = floorf((t - lo) / delta + 0.5f);
+            const int c = (x >= 255.f) ? 255 : (x > 0.f ? (int) x : 0);
+            dst[(size_t) (m * Ks + ks) * kFsQ] = (uint8_t) c;
+            const double r = (double) t - ((double) lo + (double) c * ddelta);
+            rlo = fmin(rlo, r);
+            rhi = fmax(rhi, r);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rlo = fmin(rlo, __shfl_xor(rlo, off));
+            rhi = fmax(rhi, __shfl_xor(rhi, off));
+        }
+        if (lane == 0) { s_rlo[m] = rlo; s_rhi[m] = rhi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double Rlo = 0.0, Rhi = 0.0, dmax = 0.0;
+        for (int m = 0; m < M; ++m) { Rlo += s_rlo[m]; Rhi += s_rhi[m]; dmax += fabs((double) s_hi[m]) + fabs((double) s_lo[m]); }
+        // |fp32 sequential sum - real sum| <= (M-1) * 2^-24 * sum|t| (standard bound); use M * 2^-23 * dmax
+        const double eps = (double) M * 1.1920928955078125e-07 * dmax;
+        double s = (Rhi - Rlo + 2.0 * eps) / ddelta;
+        s = s * (1.0 + 1e-9) + 2.0;                      // margins for the roundings of this very computation
+        int32_t si = (s >= 0.0 && s < 1.0e9) ? (int32_t) s : 0x3fffffff;
+        slack[b] = si;
+    }
+}
+
+hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qlut,
+                               int32_t *d_slack, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned) B), dim3(256), 0, st, d_lut, B, M, Ks, QT, d_qlut, d_slack);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 1: quantised scan.  grid = (chunks, ceil(B/16)); 1024 threads; LDS = [M][Ks][16] u8 (+ running minima).
+// ---------------------------------------------------------------------------------------------------
+struct FsArgs {
+    const uint8_t *codes;
+    int64_t n_codes;
+    int M, Ks;
+    const uint8_t *qlut;
+    const int32_t *slack;
+    int B;
+    int64_t chunk_len;
+    unsigned long long *cand;      // [B][cap] (a << 32 | local index)
+    unsigned int *cand_count;      // [B]
+    int cap;
+};
+
+// accumulate the 16 one-byte entries of a row into 8 registers of two u16 fields each
+__device__ __forceinline__ void fs_acc(uint32_t (&acc)[8], const uint4 &v)
+{
+    acc[0] += v.x & 0x00ff00ffu;  acc[1] += (v.x >> 8) & 0x00ff00ffu;
+    acc[2] += v.y & 0x00ff00ffu;  acc[3] += (v.y >> 8) & 0x00ff00ffu;
+    acc[4] += v.z & 0x00ff00ffu;  acc[5] += (v.z >> 8) & 0x00ff00ffu;
+    acc[6] += v.w & 0x00ff00ffu;  acc[7] += (v.w >> 8) & 0x00ff00ffu;
+}
+// query q of the tile <-> (register, half): byte j of dword w is query 4w+j; even bytes -> acc[2w], odd -> acc[2w+1]
+__device__ __forceinline__ uint32_t fs_get(const uint32_t (&acc)[8], int q)
+{
+    const int w = q >> 2, j = q & 3;
+    const uint32_t r = acc[2 * w + (j & 1)];
+    return (j & 2) ? (r >> 16) : (r & 0xffffu);
+}
+
+template <int MW, int KST>
+__global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = MW ? MW * 4 : p.M;
+    const int Ks = KST ? KST : p.Ks;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.y;
+    const size_t lut_bytes = (size_t) M * Ks * kFsQ;
+    uint32_t *s_min = reinterpret_cast<uint32_t *>(smem + lut_bytes);          // [16] running minima of a()
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
+        uint4 *d4 = reinterpret_cast<uint4 *>(smem);
+        for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
+        if (tid < kFsQ) s_min[tid] = 0x7fffffffu;
+    }
+    uint32_t slack[kFsQ];
+#pragma unroll
+    for (int q = 0; q < kFsQ; ++q) {
+        const int b = tile * kFsQ + q;
+        slack[q] = (b < p.B) ? (uint32_t) p.slack[b] : 0u;
+    }
+    __syncthreads();
+    const uint4 *lut = reinterpret_cast<const uint4 *>(smem);
+
+    const int64_t c_begin = (int64_t) blockIdx.x * p.chunk_len;
+    int64_t c_end = c_begin + p.chunk_len;
+    if (c_end > p.n_codes) c_end = p.n_codes;
+    const int64_t span = c_end > c_begin ? c_end - c_begin : 0;
+    const int iters = (int) ((span + kFsThreads - 1) / kFsThreads);
+
+    for (int it = 0; it < iters; ++it) {
+        const int64_t n = c_begin + (int64_t) it * kFsThreads + tid;
+        const bool active = n < c_end;
+        uint32_t acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0u;
+        if (active) {
+            if constexpr (MW != 0) {
+                const uint8_t *cp = p.codes + (size_t) n * (MW * 4);
+                uint32_t w[MW ? MW : 1];
+                if constexpr (MW % 4 == 0) {
+#pragma unroll
+                    for (int i = 0; i < MW / 4; ++i) {
+                        const uint4 v = reinterpret_cast<const uint4 *>(cp)[i];
+                        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MW / 2; ++i) {
+                        const uint2 v = reinterpret_cast<const uint2 *>(cp)[i];
+                        w[2 * i] = v.x; w[2 * i + 1] = v.y;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fs_acc(acc, lut[(i * 4 + j) * KST + ((w[i] >> (8 * j)) & 0xffu)]);
+                }
+            } else {
+                const uint8_t *c = p.codes + (size_t) n * M;
+                for (int m = 0; m < M; ++m) fs_acc(acc, lut[m * Ks + c[m]]);
+            }
+        }
+        if (it == 0) {
+            // warm-up: publish the first 1024 codes' sums before anybody tests candidacy against the minima
+            if (active) {
+#pragma unroll
+                for (int q = 0; q < kFsQ; ++q) atomicMin(&s_min[q], fs_get(acc, q));
+            }
+            __syncthreads();
+        }
+        // thresholds from the block-wide running minima (broadcast LDS reads)
+        const uint4 m0 = reinterpret_cast<const uint4 *>(s_min)[0], m1 = reinterpret_cast<const uint4 *>(s_min)[1],
+                    m2 = reinterpret_cast<const uint4 *>(s_min)[2], m3 = reinterpret_cast<const uint4 *>(s_min)[3];
+        const uint32_t mins[kFsQ] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w,
+                                     m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
+        if (active) {
+            uint32_t hit = 0u;
+#pragma unroll
+            for (int q = 0; q < kFsQ; ++q) hit |= (fs_get(acc, q) <= mins[q] + slack[q]) ? (1u << q) : 0u;
+            if (hit) {
+#pragma unroll
+                for (int q = 0; q < kFsQ; ++q) {
+                    const int b = tile * kFsQ + q;
+                    if (((hit >> q) & 1u) && b < p.B) {
+                        const uint32_t a = fs_get(acc, q);
+                        if (a < mins[q]) atomicMin(&s_min[q], a);
+                        const unsigned int pos = atomicAdd(&p.cand_count[b], 1u);
+                        if (pos < (unsigned int) p.cap)
+                            p.cand[(size_t) b * p.cap + pos] = ((unsigned long long) a << 32) | (uint32_t) n;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MW, int KST>
+static hipError_t launch_fscan_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
+{
+    const size_t smem = (size_t) a.M * a.Ks * kFsQ + 64;
+    auto kern = fscan_kernel<MW, KST>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, a);
+    return hipGetLastError();
+}
+
+bool fastscan_supported(int M, int Ks)
+{
+    return (size_t) M * Ks * kFsQ + 64 <= (size_t) kMaxLutLdsBytes && M <= 256;
+}
+
+hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
+                        const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
+                        unsigned int *d_cand_count, int cap, hipStream_t st)
+{
+    if (B == 0 || n_codes == 0) return hipSuccess;
+    FsArgs a;
+    a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
+    a.chunk_len = chunk_len; a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap;
+    const int tiles = (B + kFsQ - 1) / kFsQ;
+    if (Ks == 256 && M == 8) return launch_fscan_t<2, 256>(a, chunks, tiles, st);
+    if (Ks == 256 && M == 16) return launch_fscan_t<4, 256>(a, chunks, tiles, st);
+    if (Ks == 256 && M == 32) return launch_fscan_t<8, 256>(a, chunks, tiles, st);
+    return launch_fscan_t<0, 0>(a, chunks, tiles, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 2: exact re-rank.  One block (256 threads) per query, exact fp32 table of that query in LDS.
+// If the candidate buffer overflowed (pathological: e.g. thousands of duplicate nearest codes) the block falls
+// back to an exact scan of all codes for its query -- still on the GPU, still exact.
+// ---------------------------------------------------------------------------------------------------
+struct RrArgs {
+    const uint8_t *codes;
+    int64_t n_codes;
+    int M, Ks;
+    const float *lut;
+    int QT;
+    const int32_t *slack;
+    const unsigned long long *cand;
+    const unsigned int *cand_count;
+    int cap;
+    const int64_t *remap;
+    int64_t *out_ids;
+    float *out_dists;
+    int topk;
+};
+
+__device__ __forceinline__ float exact_adist(const float *lds, const uint8_t *code, int M, int Ks)
+{
+    float dist = 0.f;
+    if ((M & 3) == 0) {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
+        for (int i = 0; i < M / 4; ++i) {
+            const uint32_t w = cw[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dist = __fadd_rn(dist, lds[(i * 4 + j) * Ks + ((w >> (8 * j)) & 0xffu)]);
+        }
+    } else {
+        for (int m = 0; m < M; ++m) dist = __fadd_rn(dist, lds[m * Ks + code[m]]);
+    }
+    return dist;
+}
+
+__global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    const int MK = p.M * p.Ks;
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    {
+        const float *src = p.lut + (size_t) (b / p.QT) * MK * p.QT + (b % p.QT);
+        for (int i = tid; i < MK; i += blockDim.x) lds[i] = src[(size_t) i * p.QT];
+        if (tid == 0) { red[0] = ~0ull; red[1] = ~0ull; }
+    }
+    __syncthreads();
+    const unsigned int cnt = p.cand_count[b];
+    unsigned long long best = ~0ull;
+    if (cnt <= (unsigned int) p.cap) {
+        const unsigned long long *cand = p.cand + (size_t) b * p.cap;
+        // global minimum of the quantised sums (the arg-min code is always among the candidates)
+        unsigned long long amin = ~0ull;
+        for (unsigned int i = tid; i < cnt; i += blockDim.x) {
+            const unsigned long long a = cand[i] >> 32;
+            amin = a < amin ? a : amin;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(amin, off);
+            amin = o < amin ? o : amin;
+        }
+        if ((tid & 63) == 0) atomicMin(&red[0], amin);
+        __syncthreads();
+        const unsigned long long lim = red[0] + (unsigned long long) (uint32_t) p.slack[b];
+        for (unsigned int i = tid; i < cnt; i += blockDim.x) {
+            const unsigned long long c = cand[i];
+            if ((c >> 32) > lim) continue;
+            const uint32_t n = (uint32_t) (c & 0xffffffffu);
+            const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | n;
+            best = key < best ? key : best;
+        }
+    } else {
+        for (int64_t n = tid; n < p.n_codes; n += blockDim.x) {
+            const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | (uint32_t) n;
+            best = key < best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0 && best != ~0ull) atomicMin(&red[1], best);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long k = red[1];
+        const uint32_t idx = (uint32_t) (k & 0xffffffffu);
+        p.out_ids[b * p.topk] = (k == ~0ull) ? -1 : (p.remap ? p.remap[idx] : (int64_t) idx);
+        p.out_dists[b * p.topk] = (k == ~0ull) ? INFINITY : __uint_as_float(f32_unorderable((uint32_t) (k >> 32)));
+    }
+}
+
+hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
+                              const int32_t *d_slack, const unsigned long long *d_cand,
+                              const unsigned int *d_cand_count, int cap, const int64_t *d_remap, int64_t B,
+                              int64_t *d_out_ids, float *d_out_dists, int topk, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    RrArgs a;
+    a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.slack = d_slack;
+    a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.remap = d_remap; a.out_ids = d_out_ids;
+    a.out_dists = d_out_dists; a.topk = topk;
+    const size_t smem = (((size_t) M * Ks * sizeof(float) + 15) & ~(size_t) 15) + 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rerank_top1_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rerank_top1_kernel, dim3((unsigned) B), dim3(256), smem, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace riiamd

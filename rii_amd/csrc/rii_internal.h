@@ -106,6 +106,18 @@ hipError_t launch_pqk_vote(const int32_t *d_hist, const int32_t *d_cnt, const fl
 hipError_t segmented_sort_keys(unsigned long long *d_keys_in, unsigned long long *d_keys_out, int64_t segs,
                                int64_t len, void **d_temp, size_t *temp_bytes, hipStream_t st);
 
-int lut_tile_for(int M, int Ks);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
+int lut_tile_for(int M, int Ks);
+
+// fast scan (fastscan.hip): 8-bit filter + exact re-rank, top-1
+bool fastscan_supported(int M, int Ks);
+hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qlut,
+                               int32_t *d_slack, hipStream_t st);
+hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
+                        const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
+                        unsigned int *d_cand_count, int cap, hipStream_t st);
+hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
+                              const int32_t *d_slack, const unsigned long long *d_cand,
+                              const unsigned int *d_cand_count, int cap, const int64_t *d_remap, int64_t B,
+                              int64_t *d_out_ids, float *d_out_dists, int topk, hipStream_t st);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
 
 }  // namespace riiamd

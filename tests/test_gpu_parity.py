@@ -211,3 +211,43 @@ def test_gpu_mfma_lut_within_tolerance():
     assert rel.max() < 1e-4, rel.max()
     assert np.allclose(d_m, d_e, rtol=1e-4)
     assert (ids_m == ids_e).mean() >= 0.9          # tie-tolerant: near-ties may flip under different rounding
+
+
+@pytest.mark.parametrize("shape", [(32, 256, 4, 50000, "sift", 0), (32, 256, 4, 30000, "unit", 6000),
+                                   (16, 256, 6, 40000, "unit", 0), (8, 256, 16, 20000, "sift", 2000),
+                                   (4, 20, 10, 5000, "unit", 0), (20, 256, 2, 9000, "unit", 0), (3, 7, 37, 3000, "unit", 500)])
+def test_gpu_filter_rerank_equals_exact_scan(shape):
+    """scan_mode=1 (8-bit filter + exact re-rank, the default) must return exactly what scan_mode=0 (exact scan of
+    every code) returns -- ids and distance bits -- incl. with heavy duplication (tied minima) and for subsets."""
+    from rii_amd import RiiGpu
+    M, Ks, Ds, N, scale, dup = shape
+    cw, codes, qs = make_problem(123, M, Ks, Ds, N, scale, dup=dup)
+    rng = np.random.default_rng(2)
+    Q = np.concatenate([qs, rng.permutation(qs.reshape(-1)).reshape(qs.shape), qs * 0.5, qs[:5] * 0.0 + 1e3], 0)
+    g = RiiGpu(cw, False)
+    g.add_codes(codes, False)
+    sub = np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int64)
+    for tids in (None, sub):
+        g.set_option("scan_mode", 1)
+        i1, d1 = g.query_linear_batch(Q, 1, tids)
+        g.set_option("scan_mode", 0)
+        i0, d0 = g.query_linear_batch(Q, 1, tids)
+        assert np.array_equal(i1, i0)
+        assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
+
+
+def test_gpu_filter_rerank_overflow_falls_back_exactly():
+    """More tied-at-the-minimum codes than candidate slots: the re-rank block scans all codes itself."""
+    from rii_amd import RiiGpu
+    cw, codes, qs = make_problem(7, 32, 256, 4, 40000, "unit")
+    codes[5000:25000] = codes[4999]                      # 20001 identical codes
+    g = RiiGpu(cw, False)
+    g.add_codes(codes, False)
+    from oracle import oracle as O
+    q = O.OracleRii(cw).codewords[:, codes[4999], :][np.arange(32), np.arange(32)].reshape(-1)   # the code's own centroid
+    Q = np.stack([q, qs[0], qs[1]]).astype(np.float32)
+    g.set_option("cand_cap", 64)
+    i1, d1 = g.query_linear_batch(Q, 1, None)
+    g.set_option("scan_mode", 0)
+    i0, d0 = g.query_linear_batch(Q, 1, None)
+    assert i0[0, 0] == 4999 and np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
