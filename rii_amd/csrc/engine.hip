@@ -90,7 +90,8 @@ struct rii_engine {
     int lut_mode = RII_LUT_EXACT;
     int scan_chunks = 0;        // 0 = auto
     int scan_mode = 1;          // 1 = 8-bit filter + exact re-rank for top-1 (fastscan.hip), 0 = exact scan only
-    int cand_cap = 2048;        // candidate slots per query for the re-rank stage
+    int cand_cap = 4096;
+    int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)        // candidate slots per query for the re-rank stage
     int timing = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
@@ -296,6 +297,7 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
                                         e->s_slack.as<int32_t>(), st));
         }
         HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
+        e->last_fs_B = B;
         int64_t c = e->scan_chunks;
         if (c <= 0) {
             c = std::max<int64_t>(1, (e->n_cu + tiles - 1) / tiles);
@@ -861,6 +863,15 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "timing") return e->timing;
     if (k == "scan_mode") return e->scan_mode;
     if (k == "cand_cap") return e->cand_cap;
+    if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
+        if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;
+        std::vector<unsigned int> h((size_t) e->last_fs_B);
+        if (hipDeviceSynchronize() != hipSuccess) return -1;
+        if (hipMemcpy(h.data(), e->s_cand_cnt.p, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        int64_t tot = 0, mx = 0;
+        for (unsigned int v : h) { tot += v; mx = std::max<int64_t>(mx, v); }
+        return k == "cand_total" ? tot : mx;
+    }
     if (k == "lut_tile") return e->QT;
     if (k == "n_cu") return e->n_cu;
     return -1;

@@ -20,9 +20,11 @@ namespace riiamd {
 
 constexpr int kFsThreads = 1024;
 constexpr int kFsQ = 16;               // queries per stage-1 tile (one byte each in a 16-byte LDS row)
+constexpr int kFsLevels = 63;          // quantisation levels - 1 (6 bits) ...
+constexpr int kFsFlush = 4;            // ... so that kFsFlush entries add up inside a byte: 4 * 63 = 252 < 256
 
 // ---------------------------------------------------------------------------------------------------
-// per-query 8-bit quantisation of the exact table + slack.  One block (256 threads) per query.
+// per-query quantisation of the exact table to kFsLevels+1 levels (one byte per entry) + slack.  One block (256 threads) per query.
 //   qlut layout: [tile = b/16][m][ks][16 queries] u8
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restrict__ lut, int64_t B, int M, int Ks,
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restri
     if (tid == 0) {
         float range = 0.f;
         for (int m = 0; m < M; ++m) range = fmaxf(range, s_hi[m] - s_lo[m]);
-        float d = range / 255.0f;
+        float d = range / (float) kFsLevels;
         if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
         s_delta = d * 1.000001f;
     }
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restri
         for (int ks = lane; ks < Ks; ks += 64) {
             const float t = src[(size_t) (m * Ks + ks) * QT];
             const float x = floorf((t - lo) / delta + 0.5f);
-            const int c = (x >= 255.f) ? 255 : (x > 0.f ? (int) x : 0);
+            const int c = (x >= (float) kFsLevels) ? kFsLevels : (x > 0.f ? (int) x : 0);
             dst[(size_t) (m * Ks + ks) * kFsQ] = (uint8_t) c;
             const double r = (double) t - ((double) lo + (double) c * ddelta);
             rlo = fmin(rlo, r);
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restri
         const double eps = (double) M * 1.1920928955078125e-07 * dmax;
         double s = (Rhi - Rlo + 2.0 * eps) / ddelta;
         s = s * (1.0 + 1e-9) + 2.0;                      // margins for the roundings of this very computation
-        int32_t si = (s >= 0.0 && s < 1.0e9) ? (int32_t) s : 0x3fffffff;
+        int32_t si = (s >= 0.0 && s < 60000.0) ? (int32_t) s : 60000;      // >= 0xffff - max a(): everything is a candidate
         slack[b] = si;
     }
 }
@@ -106,7 +108,13 @@ hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-// stage 1: quantised scan.  grid = (chunks, ceil(B/16)); 1024 threads; LDS = [M][Ks][16] u8 (+ running minima).
+// stage 1: quantised scan.  grid = (chunks, ceil(B/16)); 1024 threads; LDS = [M][Ks][16] u8 (+ thresholds).
+//
+// VALU budget is what bounds this kernel once the table entries are one byte (integer VALU ops issue at 4 cycles
+// per wave64 on gfx950: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1 quad-cycle in profiles/), so the inner loop is
+// built to spend ~1 VALU op per dword of table data: entries have kFsLevels = 63 levels, so kFsFlush = 4
+// consecutive lookups can be added AS PACKED BYTES (4 x 63 < 256: no carry between the four queries of a dword)
+// and only every 4th lookup is widened into the 16-bit pair accumulators.
 // ---------------------------------------------------------------------------------------------------
 struct FsArgs {
     const uint8_t *codes;
@@ -121,20 +129,47 @@ struct FsArgs {
     int cap;
 };
 
-// accumulate the 16 one-byte entries of a row into 8 registers of two u16 fields each
-__device__ __forceinline__ void fs_acc(uint32_t (&acc)[8], const uint4 &v)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// widen the four byte-packed partial sums of a row into 8 registers of two u16 fields each:
+// byte j of dword w is query 4w+j; even bytes -> acc[2w] (queries 4w, 4w+2), odd bytes -> acc[2w+1] (4w+1, 4w+3)
+__device__ __forceinline__ void fs_flush(uint32_t (&acc)[8], uint32_t (&pb)[4])
 {
-    acc[0] += v.x & 0x00ff00ffu;  acc[1] += (v.x >> 8) & 0x00ff00ffu;
-    acc[2] += v.y & 0x00ff00ffu;  acc[3] += (v.y >> 8) & 0x00ff00ffu;
-    acc[4] += v.z & 0x00ff00ffu;  acc[5] += (v.z >> 8) & 0x00ff00ffu;
-    acc[6] += v.w & 0x00ff00ffu;  acc[7] += (v.w >> 8) & 0x00ff00ffu;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        acc[2 * w] += pb[w] & 0x00ff00ffu;
+        acc[2 * w + 1] += (pb[w] >> 8) & 0x00ff00ffu;
+        pb[w] = 0u;
+    }
 }
-// query q of the tile <-> (register, half): byte j of dword w is query 4w+j; even bytes -> acc[2w], odd -> acc[2w+1]
+__device__ __forceinline__ void fs_add(uint32_t (&pb)[4], const uint4 &v)
+{
+    pb[0] += v.x; pb[1] += v.y; pb[2] += v.z; pb[3] += v.w;
+}
 __device__ __forceinline__ uint32_t fs_get(const uint32_t (&acc)[8], int q)
 {
     const int w = q >> 2, j = q & 3;
     const uint32_t r = acc[2 * w + (j & 1)];
     return (j & 2) ? (r >> 16) : (r & 0xffffu);
+}
+// thresholds live in LDS as 8 words in the SAME packing as acc[]: field = (running minimum + slack + 1), <= 0xffff.
+// Lowering one 16-bit field is a rare event: CAS loop on the containing word.
+__device__ __forceinline__ void fs_thr_lower(uint32_t *word, int high, uint32_t v16)
+{
+    uint32_t old = *reinterpret_cast<volatile uint32_t *>(word);
+    for (;;) {
+        const uint32_t cur = high ? (old >> 16) : (old & 0xffffu);
+        if (v16 >= cur) return;
+        const uint32_t nw = high ? ((old & 0xffffu) | (v16 << 16)) : ((old & 0xffff0000u) | v16);
+        const uint32_t prev = atomicCAS(word, old, nw);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+__device__ __forceinline__ uint32_t fs_thr_of(uint32_t a, uint32_t slack)
+{
+    const uint32_t t = a + slack + 1u;
+    return t > 0xffffu ? 0xffffu : t;
 }
 
 template <int MW, int KST>
@@ -146,18 +181,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
     const size_t lut_bytes = (size_t) M * Ks * kFsQ;
-    uint32_t *s_min = reinterpret_cast<uint32_t *>(smem + lut_bytes);          // [16] running minima of a()
+    uint32_t *s_thr = reinterpret_cast<uint32_t *>(smem + lut_bytes);          // [8] packed thresholds
     {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
         uint4 *d4 = reinterpret_cast<uint4 *>(smem);
         for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
-        if (tid < kFsQ) s_min[tid] = 0x7fffffffu;
-    }
-    uint32_t slack[kFsQ];
-#pragma unroll
-    for (int q = 0; q < kFsQ; ++q) {
-        const int b = tile * kFsQ + q;
-        slack[q] = (b < p.B) ? (uint32_t) p.slack[b] : 0u;
+        if (tid < 8) s_thr[tid] = 0xffffffffu;
     }
     __syncthreads();
     const uint4 *lut = reinterpret_cast<const uint4 *>(smem);
@@ -171,9 +200,11 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     for (int it = 0; it < iters; ++it) {
         const int64_t n = c_begin + (int64_t) it * kFsThreads + tid;
         const bool active = n < c_end;
-        uint32_t acc[8];
+        uint32_t acc[8], pb[4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pb[i] = 0u;
         if (active) {
             if constexpr (MW != 0) {
                 const uint8_t *cp = p.codes + (size_t) n * (MW * 4);
@@ -192,39 +223,58 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < MW; ++i) {
+                for (int i = 0; i < MW; ++i) {          // 4 lookups per code word == one flush group
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fs_acc(acc, lut[(i * 4 + j) * KST + ((w[i] >> (8 * j)) & 0xffu)]);
+                    for (int j = 0; j < 4; ++j) fs_add(pb, lut[(i * 4 + j) * KST + ((w[i] >> (8 * j)) & 0xffu)]);
+                    fs_flush(acc, pb);
                 }
             } else {
                 const uint8_t *c = p.codes + (size_t) n * M;
-                for (int m = 0; m < M; ++m) fs_acc(acc, lut[m * Ks + c[m]]);
+                int pend = 0;
+                for (int m = 0; m < M; ++m) {
+                    fs_add(pb, lut[m * Ks + c[m]]);
+                    if (++pend == kFsFlush) { fs_flush(acc, pb); pend = 0; }
+                }
+                fs_flush(acc, pb);
             }
         }
         if (it == 0) {
-            // warm-up: publish the first 1024 codes' sums before anybody tests candidacy against the minima
-            if (active) {
+            // warm-up: publish thresholds from the first <=1024 codes before anybody tests candidacy
 #pragma unroll
-                for (int q = 0; q < kFsQ; ++q) atomicMin(&s_min[q], fs_get(acc, q));
+            for (int q = 0; q < kFsQ; ++q) {
+                const int b = tile * kFsQ + q;
+                uint32_t t = active ? fs_get(acc, q) : 0xffffffffu;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t o = __shfl_xor(t, off);
+                    t = o < t ? o : t;
+                }
+                if ((tid & 63) == 0 && t != 0xffffffffu && b < p.B)
+                    fs_thr_lower(&s_thr[2 * (q >> 2) + (q & 1)], (q >> 1) & 1, fs_thr_of(t, (uint32_t) p.slack[b]));
             }
             __syncthreads();
         }
-        // thresholds from the block-wide running minima (broadcast LDS reads)
-        const uint4 m0 = reinterpret_cast<const uint4 *>(s_min)[0], m1 = reinterpret_cast<const uint4 *>(s_min)[1],
-                    m2 = reinterpret_cast<const uint4 *>(s_min)[2], m3 = reinterpret_cast<const uint4 *>(s_min)[3];
-        const uint32_t mins[kFsQ] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w,
-                                     m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
         if (active) {
+            // candidate test on the packed pairs: sat(thr+1 - a) != 0  <=>  a <= thr
+            const uint4 t0 = reinterpret_cast<const uint4 *>(s_thr)[0], t1 = reinterpret_cast<const uint4 *>(s_thr)[1];
+            const uint32_t thr[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
             uint32_t hit = 0u;
 #pragma unroll
-            for (int q = 0; q < kFsQ; ++q) hit |= (fs_get(acc, q) <= mins[q] + slack[q]) ? (1u << q) : 0u;
+            for (int i = 0; i < 8; ++i) {
+                const u16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, thr[i]),
+                                                              __builtin_bit_cast(u16x2, acc[i]));
+                hit |= __builtin_bit_cast(uint32_t, d);
+            }
             if (hit) {
 #pragma unroll
                 for (int q = 0; q < kFsQ; ++q) {
                     const int b = tile * kFsQ + q;
-                    if (((hit >> q) & 1u) && b < p.B) {
-                        const uint32_t a = fs_get(acc, q);
-                        if (a < mins[q]) atomicMin(&s_min[q], a);
+                    const int reg = 2 * (q >> 2) + (q & 1), high = (q >> 1) & 1;
+                    const uint32_t a = fs_get(acc, q);
+                    const uint32_t t = high ? (thr[reg] >> 16) : (thr[reg] & 0xffffu);
+                    if (a < t && b < p.B) {
+                        const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
+                        if (nt < t) fs_thr_lower(&s_thr[reg], high, nt);
                         const unsigned int pos = atomicAdd(&p.cand_count[b], 1u);
                         if (pos < (unsigned int) p.cap)
                             p.cand[(size_t) b * p.cap + pos] = ((unsigned long long) a << 32) | (uint32_t) n;
