@@ -91,6 +91,8 @@ struct rii_engine {
     int scan_chunks = 0;        // 0 = auto
     int scan_mode = 1;          // 1 = 8-bit filter + exact re-rank for top-1 (fastscan.hip), 0 = exact scan only
     int cand_cap = 4096;
+    int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
+    bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
     int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)        // candidate slots per query for the re-rank stage
     int timing = 0;
     hipStream_t stream = nullptr;
@@ -111,7 +113,7 @@ struct rii_engine {
     // scratch
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
-        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt;
+        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
 
@@ -237,10 +239,20 @@ int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
     return RII_OK;
 }
 
-int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st)
+int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, bool want_quant = false)
 {
     const size_t tiles = (size_t) ((B + e->QT - 1) / e->QT);
     RII_TRY(e->s_lut.ensure(tiles * (size_t) e->M * e->Ks * e->QT * sizeof(float)));
+    e->qlut_ready = false;
+    if (want_quant && e->lut_mode == RII_LUT_EXACT && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
+        RII_TRY(e->s_qlut.ensure((size_t) ((B + 15) / 16) * e->M * e->Ks * 16));
+        RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
+        ScopedTimer t(e, "lut", st);
+        HIP_TRY(launch_lut_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch, e->QT,
+                                       e->s_lut.as<float>(), e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), st));
+        e->qlut_ready = true;
+        return RII_OK;
+    }
     ScopedTimer t(e, "lut", st);
     if (e->lut_mode == RII_LUT_MFMA) {
         if (!e->have_cnorm) {
@@ -291,7 +303,7 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
         RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
         RII_TRY(e->s_cand.ensure((size_t) B * e->cand_cap * sizeof(unsigned long long)));
         RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
-        {
+        if (!e->qlut_ready) {
             ScopedTimer t(e, "quant", st);
             HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_qlut.as<uint8_t>(),
                                         e->s_slack.as<int32_t>(), st));
@@ -380,7 +392,7 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
                      int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
     if (B == 0) return RII_OK;
-    RII_TRY(build_lut(e, d_queries, B, st));
+    RII_TRY(build_lut(e, d_queries, B, st, topk == 1));
     if (S == 0)
         return scan_topk(e, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
     // subset search: gather the S target codes once for the whole batch, scan them, map ids back
@@ -442,6 +454,9 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     p.coarse_dist = e->s_coarse_d.as<float>(); p.coarse_id = e->s_coarse_i.as<int32_t>();
     p.cum = e->s_cum.as<int32_t>(); p.ncand = e->s_ncand.as<int32_t>(); p.nvis = e->s_nvis.as<int32_t>();
     p.cand_id = e->s_cand_i.as<int32_t>(); p.cand_dist = e->s_cand_d.as<float>(); p.cand_stride = stride;
+    const bool fused = e->ivf_fused && ivf_fused_supported((int) nlist, w);
+    RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
+    p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
 
     for (int64_t b0 = 0; b0 < B; b0 += bc) {
         p.B = std::min<int64_t>(bc, B - b0);
@@ -449,7 +464,15 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
         p.out_ids = d_out_ids + b0 * topk;
         p.out_dists = d_out_dists + b0 * topk;
         p.out_counts = d_out_counts + b0;
-        { ScopedTimer t(e, "ivf_coarse", st); HIP_TRY(launch_ivf_coarse(p, st)); }
+        if (fused) {
+            // common case answered in one launch; queries whose answer could hinge on std::partial_sort's internal
+            // order raise flag[b] and are redone by the exact emulation kernels below (which skip the others)
+            ScopedTimer t(e, "ivf_fused", st);
+            HIP_TRY(launch_ivf_fused(p, st));
+        } else {
+            ScopedTimer t(e, "ivf_coarse", st);
+            HIP_TRY(launch_ivf_coarse(p, st));
+        }
         { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
         { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
         if (topk != 1) { ScopedTimer t(e, "ivf_select", st); HIP_TRY(launch_ivf_select(p, st)); }
@@ -489,7 +512,7 @@ void free_all(rii_engine *e)
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
-                      &e->s_cand, &e->s_cand_cnt};
+                      &e->s_cand, &e->s_cand_cnt, &e->s_flag};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;
@@ -846,6 +869,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
     } else if (k == "scan_mode") {
         if (value != 0 && value != 1) return set_err(RII_ERR_INVALID, "scan_mode must be 0 (exact) or 1 (filter + re-rank)");
         e->scan_mode = (int) value;
+    } else if (k == "ivf_fused") {
+        e->ivf_fused = value ? 1 : 0;
     } else if (k == "cand_cap") {
         if (value < 1 || value > (1 << 20)) return set_err(RII_ERR_INVALID, "bad cand_cap");
         e->cand_cap = (int) value;
@@ -863,6 +888,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "timing") return e->timing;
     if (k == "scan_mode") return e->scan_mode;
     if (k == "cand_cap") return e->cand_cap;
+    if (k == "ivf_fused") return e->ivf_fused;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;
         std::vector<unsigned int> h((size_t) e->last_fs_B);

@@ -14,6 +14,7 @@
 // then a(n*) <= a(n0) + floor((Rhi - Rlo + 2*eps)/delta) =: a_min + slack.  All codes tied with n* at the exact minimum
 // satisfy the same inequality, so the (dist, id) minimum over the candidate set equals the one over all codes.
 #include "rii_internal.h"
+#include "rii_device.h"
 #include <float.h>
 
 namespace riiamd {
@@ -27,23 +28,22 @@ constexpr int kFsFlush = 4;            // ... so that kFsFlush entries add up in
 // per-query quantisation of the exact table to kFsLevels+1 levels (one byte per entry) + slack.  One block (256 threads) per query.
 //   qlut layout: [tile = b/16][m][ks][16 queries] u8
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restrict__ lut, int64_t B, int M, int Ks,
-                                                           int QT, uint8_t *__restrict__ qlut,
-                                                           int32_t *__restrict__ slack)
+// shared body: T(i) returns the exact fp32 entry i = m*Ks + ks of query b's table
+template <typename Getter>
+__device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M, int Ks, uint8_t *__restrict__ qlut,
+                                               int32_t *__restrict__ slack)
 {
     __shared__ float s_lo[256], s_hi[256];          // per-m extrema (M <= 256)
     __shared__ double s_rlo[256], s_rhi[256];
     __shared__ float s_delta;
-    const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
     const int MK = M * Ks;
-    const float *src = lut + (size_t) (b / QT) * MK * QT + (b % QT);       // element i at src[i*QT]
     const int wave = tid >> 6, lane = tid & 63;
     // 1. per-m min / max: one wave per m, lanes over ks
     for (int m = wave; m < M; m += 4) {
         float lo = INFINITY, hi = -INFINITY;
         for (int ks = lane; ks < Ks; ks += 64) {
-            const float t = src[(size_t) (m * Ks + ks) * QT];
+            const float t = T(m * Ks + ks);
             lo = fminf(lo, t);
             hi = fmaxf(hi, t);
         }
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restri
         const float lo = s_lo[m];
         double rlo = INFINITY, rhi = -INFINITY;
         for (int ks = lane; ks < Ks; ks += 64) {
-            const float t = src[(size_t) (m * Ks + ks) * QT];
+            const float t = T(m * Ks + ks);
             const float x = floorf((t - lo) / delta + 0.5f);
             const int c = (x >= (float) kFsLevels) ? kFsLevels : (x > 0.f ? (int) x : 0);
             dst[(size_t) (m * Ks + ks) * kFsQ] = (uint8_t) c;
@@ -97,6 +97,59 @@ __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restri
         int32_t si = (s >= 0.0 && s < 60000.0) ? (int32_t) s : 60000;      // >= 0xffff - max a(): everything is a candidate
         slack[b] = si;
     }
+}
+
+struct GlobalLutGetter {
+    const float *src; int QT;
+    __device__ __forceinline__ float operator()(int i) const { return src[(size_t) i * QT]; }
+};
+struct LdsLutGetter {
+    const float *lds;
+    __device__ __forceinline__ float operator()(int i) const { return lds[i]; }
+};
+
+__global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restrict__ lut, int64_t B, int M, int Ks,
+                                                           int QT, uint8_t *__restrict__ qlut,
+                                                           int32_t *__restrict__ slack)
+{
+    const int64_t b = blockIdx.x;
+    GlobalLutGetter g{lut + (size_t) (b / QT) * M * Ks * QT + (b % QT), QT};
+    quantize_table(g, b, M, Ks, qlut, slack);
+}
+
+// fused: exact table (fvec_L2sqr order, src/distance.h:117-252) -> global fp32 (for the re-rank) AND its quantisation
+__global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__restrict__ queries, int64_t B,
+                                                              const float *__restrict__ codewords, int M, int Ks, int Ds,
+                                                              int arch, int QT, float *__restrict__ lut,
+                                                              uint8_t *__restrict__ qlut, int32_t *__restrict__ slack)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *s_t = reinterpret_cast<float *>(smem);
+    const int64_t b = blockIdx.x;
+    const int MK = M * Ks;
+    const float *q = queries + b * (int64_t) (M * Ds);
+    for (int i = threadIdx.x; i < MK; i += blockDim.x) {
+        const int m = i / Ks;
+        const float t = fvec_l2sqr_dev(q + (size_t) m * Ds, codewords + (size_t) i * Ds, Ds, arch);
+        s_t[i] = t;
+        lut[lut_index(b, i, MK, QT)] = t;
+    }
+    __syncthreads();
+    LdsLutGetter g{s_t};
+    quantize_table(g, b, M, Ks, qlut, slack);
+}
+
+hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
+                                  int arch, int QT, float *d_lut, uint8_t *d_qlut, int32_t *d_slack, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    const size_t smem = (size_t) M * Ks * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lut_build_quant_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lut_build_quant_kernel, dim3((unsigned) B), dim3(256), smem, st, d_queries, B, d_codewords, M, Ks,
+                       Ds, arch, QT, d_lut, d_qlut, d_slack);
+    return hipGetLastError();
 }
 
 hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qlut,

@@ -16,105 +16,10 @@
 // queries lives in LDS as [m][ks][QT] so that ONE ds_read_b128 returns the entries of four queries for one
 // code byte; codes stream from HBM/L2 as coalesced 16-byte loads; accumulation is sequential over m.
 #include "rii_internal.h"
+#include "rii_device.h"
 #include <float.h>
 
 namespace riiamd {
-
-#define RII_SIMD_SSE 0
-#define RII_SIMD_AVX 1
-#define RII_SIMD_AVX512 2
-
-// ===================================================================================================
-// exact arithmetic helpers
-// ===================================================================================================
-__device__ __forceinline__ float sq_acc(float acc, float d, bool fused)
-{
-    return fused ? __fmaf_rn(d, d, acc) : __fadd_rn(acc, __fmul_rn(d, d));
-}
-
-// fvec_L2sqr, src/distance.h:117-252, all three compile-time variants (see oracle/rii_oracle.c for the
-// derivation of the lane order and FMA contraction).
-__device__ float fvec_l2sqr_dev(const float *__restrict__ x, const float *__restrict__ y, int d, int arch)
-{
-    const bool fused = (arch != RII_SIMD_SSE);
-    float l16[16], l8[8], l4[4];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) l16[i] = 0.f;
-    if (arch == RII_SIMD_AVX512) {
-        while (d >= 16) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) l16[i] = sq_acc(l16[i], __fsub_rn(x[i], y[i]), fused);
-            x += 16; y += 16; d -= 16;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) l8[i] = __fadd_rn(l16[8 + i], l16[i]);
-    if (arch == RII_SIMD_AVX512 || arch == RII_SIMD_AVX) {
-        while (d >= 8) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) l8[i] = sq_acc(l8[i], __fsub_rn(x[i], y[i]), fused);
-            x += 8; y += 8; d -= 8;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) l4[i] = __fadd_rn(l8[4 + i], l8[i]);
-    if (arch == RII_SIMD_SSE) {
-        while (d >= 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) l4[i] = sq_acc(l4[i], __fsub_rn(x[i], y[i]), fused);
-            x += 4; y += 4; d -= 4;
-        }
-    } else if (d >= 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) l4[i] = sq_acc(l4[i], __fsub_rn(x[i], y[i]), fused);
-        x += 4; y += 4; d -= 4;
-    }
-    if (d > 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float t = (i < d) ? __fsub_rn(x[i], y[i]) : 0.f;
-            l4[i] = sq_acc(l4[i], t, fused);
-        }
-    }
-    return __fadd_rn(__fadd_rn(l4[0], l4[1]), __fadd_rn(l4[2], l4[3]));
-}
-
-// L2SquaredDistance of src/pqkmeans.cpp:164-173 as auto-vectorised by GCC -Ofast ([objcode] in the oracle).
-__device__ __forceinline__ float hsum_tree(float *t, int w)
-{
-    while (w > 4) {
-        w >>= 1;
-        for (int i = 0; i < w; ++i) t[i] = __fadd_rn(t[w + i], t[i]);
-    }
-    float a = __fadd_rn(t[2], t[0]), b = __fadd_rn(t[3], t[1]);
-    return __fadd_rn(b, a);
-}
-
-__device__ float l2sq_pqk_dev(const float *__restrict__ a, const float *__restrict__ b, int n, int arch)
-{
-    const int W = (arch == RII_SIMD_AVX512) ? 16 : (arch == RII_SIMD_AVX ? 8 : 4);
-    const bool fused = (arch != RII_SIMD_SSE);
-    int i = 0;
-    float acc = 0.f;
-    float lanes[16];
-    if (n >= W) {
-        for (int l = 0; l < W; ++l) lanes[l] = 0.f;
-        for (; i + W <= n; i += W)
-            for (int l = 0; l < W; ++l) lanes[l] = sq_acc(lanes[l], __fsub_rn(a[i + l], b[i + l]), fused);
-        acc = hsum_tree(lanes, W);
-    }
-    const int H = W / 2;
-    if (H >= 4 && n - i >= H) {
-        for (int l = 0; l < H; ++l) {
-            float d = __fsub_rn(a[i + l], b[i + l]);
-            lanes[l] = __fmul_rn(d, d);
-        }
-        acc = __fadd_rn(acc, hsum_tree(lanes, H));
-        i += H;
-    }
-    for (; i < n; ++i) acc = sq_acc(acc, __fsub_rn(a[i], b[i]), fused);
-    return acc;
-}
 
 int lut_tile_for(int M, int Ks)
 {
@@ -123,11 +28,6 @@ int lut_tile_for(int M, int Ks)
     if (one * 2 <= (size_t) kMaxLutLdsBytes) return 2;
     if (one <= (size_t) kMaxLutLdsBytes) return 1;
     return 0;
-}
-
-__device__ __forceinline__ size_t lut_index(int64_t b, int i, int MK, int QT)
-{
-    return ((size_t) (b / QT) * MK + i) * QT + (size_t) (b % QT);
 }
 
 // ===================================================================================================
@@ -645,6 +545,7 @@ __global__ __launch_bounds__(64) void ivf_plan_kernel(IvfParams p)
 {
     const int64_t bl = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (bl >= p.B) return;
+    if (p.flag && !p.flag[bl]) return;          // already planned by ivf_fused_kernel
     int32_t *ids = p.coarse_id + bl * p.nlist;
     float *ds = p.coarse_dist + bl * p.nlist;
     pq_partial_sort(ids, ds, (long) p.w, (long) p.nlist);
@@ -684,6 +585,7 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(IvfParams p)
     const int64_t bl = blockIdx.x;
     const int MK = p.M * p.Ks;
     unsigned long long &red = *reinterpret_cast<unsigned long long *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));
+    if (p.flag && !p.flag[bl]) return;          // already answered by ivf_fused_kernel
     const int ncand = p.ncand[bl];
     const int nv = p.nvis[bl];
     const bool top1 = (p.topk == 1);
@@ -754,6 +656,162 @@ hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ivf_scan_kernel, dim3((unsigned) p.B), dim3(256), smem, st, p);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// (a6+a7 fused) the common case in ONE launch per batch: block per query -- table staged once, coarse scores kept
+// in LDS, the w nearest lists picked by w+1 rounds of block arg-min over (dist, list id), the stop rule applied to
+// those w lists, candidates scanned.  Whenever the reference's answer could depend on std::partial_sort's internal
+// order -- two of the w+1 smallest coarse distances exactly equal, or the walk has to continue into the unsorted
+// tail past list w (fewer than topk hits so far) -- the block raises flag[b] and the exact emulation kernels
+// (ivf_plan_kernel / ivf_scan_kernel, gated on the flag) take over for that query.
+// ===================================================================================================
+constexpr int kFusedMaxW = 32;
+constexpr int kFusedMaxNlist = 4096;
+
+__global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int MK = p.M * p.Ks;
+    float *lds = reinterpret_cast<float *>(smem);
+    unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
+    unsigned long long *s_sel = reinterpret_cast<unsigned long long *>(base);            // [kFusedMaxW + 2]
+    unsigned long long *s_red = s_sel + (kFusedMaxW + 2);                                // [2]
+    int *s_cum = reinterpret_cast<int *>(s_red + 2);                                     // [kFusedMaxW + 1]
+    int *s_misc = s_cum + (kFusedMaxW + 2);                                              // [4]: ncand, nv, flag
+    float *s_dist = reinterpret_cast<float *>(s_misc + 4);                               // [nlist]
+    const int64_t bl = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nlist = p.nlist;
+    const int w = (int) p.w;
+
+    stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
+    __syncthreads();
+    for (int c = tid; c < nlist; c += blockDim.x) {
+        const uint8_t *code = p.centers + (size_t) c * p.M;
+        float dist = 0.f;
+        for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+        s_dist[c] = dist;
+        p.coarse_dist[bl * nlist + c] = dist;          // kept for the exact-emulation fallback
+        p.coarse_id[bl * nlist + c] = c;
+    }
+    __syncthreads();
+    // ---- w+1 rounds of block arg-min over keys strictly greater than the previous pick ----
+    const int rounds = (w + 1 < nlist) ? w + 1 : nlist;
+    unsigned long long last = 0ull;
+    for (int r = 0; r < rounds; ++r) {
+        if (tid == 0) s_red[0] = ~0ull;
+        __syncthreads();
+        unsigned long long best = ~0ull;
+        for (int c = tid; c < nlist; c += blockDim.x) {
+            const unsigned long long key =
+                ((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c;
+            if ((r == 0 || key > last) && key < best) best = key;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        if ((tid & 63) == 0 && best != ~0ull) atomicMin(&s_red[0], best);
+        __syncthreads();
+        last = s_red[0];
+        if (tid == 0) s_sel[r] = last;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int flag = 0;
+        for (int r = 0; r + 1 < rounds; ++r)
+            if ((s_sel[r] >> 32) == (s_sel[r + 1] >> 32)) flag = 1;         // exactly tied coarse distances
+        long long cnt = 0;
+        int nv = 0;
+        bool finished = false;
+        const int wl = w < nlist ? w : nlist;
+        for (int c = 0; c < wl && !flag; ++c) {
+            const int no = (int) (s_sel[c] & 0xffffffffu);
+            const long long len = p.list_len[no];
+            s_cum[c] = (int) cnt;
+            if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+            cnt += len;
+            if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+        }
+        if (!finished) flag = 1;                                             // tail walk / empty return: exact path
+        s_cum[nv] = (int) cnt;
+        s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = flag;
+        p.flag[bl] = flag;
+        if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
+        s_red[1] = ~0ull;
+    }
+    __syncthreads();
+    if (s_misc[2]) return;
+    const int ncand = s_misc[0], nv = s_misc[1];
+    const bool top1 = (p.topk == 1);
+    float bestd = INFINITY;
+    uint32_t bestp = 0xffffffffu;
+    int32_t bestid = -1;
+    for (int pos = tid; pos < ncand; pos += blockDim.x) {
+        int lo = 0, hi = nv;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+        }
+        const int no = (int) (s_sel[lo] & 0xffffffffu);
+        const int32_t id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo])];
+        const uint8_t *code = p.codes + (size_t) id * p.M;
+        float dist = 0.f;
+        if ((p.M & 3) == 0) {
+            const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
+            for (int i = 0; i < p.M / 4; ++i) {
+                const uint32_t wd = cw[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dist = __fadd_rn(dist, lds[(i * 4 + j) * p.Ks + ((wd >> (8 * j)) & 0xffu)]);
+            }
+        } else {
+            for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+        }
+        if (top1) {
+            if (dist < bestd) { bestd = dist; bestp = (uint32_t) pos; bestid = id; }
+        } else {
+            p.cand_id[bl * p.cand_stride + pos] = id;
+            p.cand_dist[bl * p.cand_stride + pos] = dist;
+        }
+    }
+    if (top1) {
+        unsigned long long key =
+            bestp == 0xffffffffu ? ~0ull
+                                 : (((unsigned long long) f32_orderable(__float_as_uint(bestd)) << 32) | bestp);
+        const unsigned long long mine = key;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off);
+            key = o < key ? o : key;
+        }
+        if ((tid & 63) == 0 && key != ~0ull) atomicMin(&s_red[1], key);
+        __syncthreads();
+        if (mine != ~0ull && mine == s_red[1]) {
+            p.out_ids[bl] = bestid;
+            p.out_dists[bl] = bestd;
+            p.out_counts[bl] = 1;
+        }
+    }
+}
+
+bool ivf_fused_supported(int nlist, int64_t w)
+{
+    return nlist <= kFusedMaxNlist && w <= kFusedMaxW;
+}
+
+hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st)
+{
+    if (p.B == 0) return hipSuccess;
+    const size_t smem = (((size_t) p.M * p.Ks * sizeof(float) + 15) & ~(size_t) 15) + (kFusedMaxW + 2) * 8 + 16 +
+                        (kFusedMaxW + 2) * 4 + 16 + (size_t) p.nlist * 4 + 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_fused_kernel, dim3((unsigned) p.B), dim3(256), smem, st, p);
     return hipGetLastError();
 }
 

@@ -1,0 +1,109 @@
+// rii_device.h -- device-side helpers shared by the HIP translation units (exact reference arithmetic).
+#pragma once
+#include "rii_internal.h"
+
+namespace riiamd {
+
+#define RII_SIMD_SSE 0
+#define RII_SIMD_AVX 1
+#define RII_SIMD_AVX512 2
+
+// ===================================================================================================
+// exact arithmetic helpers
+// ===================================================================================================
+__device__ __forceinline__ float sq_acc(float acc, float d, bool fused)
+{
+    return fused ? __fmaf_rn(d, d, acc) : __fadd_rn(acc, __fmul_rn(d, d));
+}
+
+// fvec_L2sqr, src/distance.h:117-252, all three compile-time variants (see oracle/rii_oracle.c for the
+// derivation of the lane order and FMA contraction).
+__device__ inline float fvec_l2sqr_dev(const float *__restrict__ x, const float *__restrict__ y, int d, int arch)
+{
+    const bool fused = (arch != RII_SIMD_SSE);
+    float l16[16], l8[8], l4[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) l16[i] = 0.f;
+    if (arch == RII_SIMD_AVX512) {
+        while (d >= 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) l16[i] = sq_acc(l16[i], __fsub_rn(x[i], y[i]), fused);
+            x += 16; y += 16; d -= 16;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l8[i] = __fadd_rn(l16[8 + i], l16[i]);
+    if (arch == RII_SIMD_AVX512 || arch == RII_SIMD_AVX) {
+        while (d >= 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) l8[i] = sq_acc(l8[i], __fsub_rn(x[i], y[i]), fused);
+            x += 8; y += 8; d -= 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l4[i] = __fadd_rn(l8[4 + i], l8[i]);
+    if (arch == RII_SIMD_SSE) {
+        while (d >= 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l4[i] = sq_acc(l4[i], __fsub_rn(x[i], y[i]), fused);
+            x += 4; y += 4; d -= 4;
+        }
+    } else if (d >= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l4[i] = sq_acc(l4[i], __fsub_rn(x[i], y[i]), fused);
+        x += 4; y += 4; d -= 4;
+    }
+    if (d > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = (i < d) ? __fsub_rn(x[i], y[i]) : 0.f;
+            l4[i] = sq_acc(l4[i], t, fused);
+        }
+    }
+    return __fadd_rn(__fadd_rn(l4[0], l4[1]), __fadd_rn(l4[2], l4[3]));
+}
+
+// L2SquaredDistance of src/pqkmeans.cpp:164-173 as auto-vectorised by GCC -Ofast ([objcode] in the oracle).
+__device__ __forceinline__ float hsum_tree(float *t, int w)
+{
+    while (w > 4) {
+        w >>= 1;
+        for (int i = 0; i < w; ++i) t[i] = __fadd_rn(t[w + i], t[i]);
+    }
+    float a = __fadd_rn(t[2], t[0]), b = __fadd_rn(t[3], t[1]);
+    return __fadd_rn(b, a);
+}
+
+__device__ inline float l2sq_pqk_dev(const float *__restrict__ a, const float *__restrict__ b, int n, int arch)
+{
+    const int W = (arch == RII_SIMD_AVX512) ? 16 : (arch == RII_SIMD_AVX ? 8 : 4);
+    const bool fused = (arch != RII_SIMD_SSE);
+    int i = 0;
+    float acc = 0.f;
+    float lanes[16];
+    if (n >= W) {
+        for (int l = 0; l < W; ++l) lanes[l] = 0.f;
+        for (; i + W <= n; i += W)
+            for (int l = 0; l < W; ++l) lanes[l] = sq_acc(lanes[l], __fsub_rn(a[i + l], b[i + l]), fused);
+        acc = hsum_tree(lanes, W);
+    }
+    const int H = W / 2;
+    if (H >= 4 && n - i >= H) {
+        for (int l = 0; l < H; ++l) {
+            float d = __fsub_rn(a[i + l], b[i + l]);
+            lanes[l] = __fmul_rn(d, d);
+        }
+        acc = __fadd_rn(acc, hsum_tree(lanes, H));
+        i += H;
+    }
+    for (; i < n; ++i) acc = sq_acc(acc, __fsub_rn(a[i], b[i]), fused);
+    return acc;
+}
+
+__device__ __forceinline__ size_t lut_index(int64_t b, int i, int MK, int QT)
+{
+    return ((size_t) (b / QT) * MK + i) * QT + (size_t) (b % QT);
+}
+
+
+}  // namespace riiamd

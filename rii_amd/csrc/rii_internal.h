@@ -83,8 +83,11 @@ struct IvfParams {
     float *cand_dist;             // [B][cand_stride]
     int64_t cand_stride;
     int64_t *out_ids; float *out_dists; int64_t *out_counts;   // rows b0.. of the caller's outputs
+    int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
+bool ivf_fused_supported(int nlist, int64_t w);
+hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_select(const IvfParams &p, hipStream_t st);
@@ -112,6 +115,8 @@ int lut_tile_for(int M, int Ks);
 bool fastscan_supported(int M, int Ks);
 hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qlut,
                                int32_t *d_slack, hipStream_t st);
+hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
+                                  int arch, int QT, float *d_lut, uint8_t *d_qlut, int32_t *d_slack, hipStream_t st);
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, hipStream_t st);

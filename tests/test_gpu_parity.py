@@ -251,3 +251,28 @@ def test_gpu_filter_rerank_overflow_falls_back_exactly():
     g.set_option("scan_mode", 0)
     i0, d0 = g.query_linear_batch(Q, 1, None)
     assert i0[0, 0] == 4999 and np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
+
+
+def test_gpu_ivf_fused_equals_emulation_path():
+    """ivf_fused=1 (default: one launch, flag-gated exact fallback) vs ivf_fused=0 (always the emulation kernels)."""
+    from rii_amd import RiiGpu
+    cw, codes, qs = make_problem(31, 16, 256, 6, 30000, "unit", dup=3000)
+    g = RiiGpu(cw, False)
+    g.add_codes(codes, False)
+    g.reconfigure(150, 3)
+    cen = g.coarse_centers_array()
+    cen[5] = cen[3]; cen[77] = cen[3]                    # duplicated centres => exactly tied coarse distances
+    g.set_coarse_centers(cen)
+    rng = np.random.default_rng(4)
+    sub = np.sort(rng.choice(30000, 2500, replace=False)).astype(np.int64)
+    Q = np.concatenate([qs, qs[::-1] * 0.7], 0)
+    for topk, L in ((1, 200), (1, 3000), (4, 200), (10, 17), (1, 1)):
+        for tids in (None, sub):
+            g.set_option("ivf_fused", 1)
+            a = g.query_ivf_batch(Q, topk, tids, L)
+            g.set_option("ivf_fused", 0)
+            b = g.query_ivf_batch(Q, topk, tids, L)
+            assert np.array_equal(a[2], b[2])
+            for r in range(Q.shape[0]):
+                n = int(a[2][r])
+                assert np.array_equal(a[0][r, :n], b[0][r, :n]) and np.array_equal(a[1][r, :n].view(np.uint32), b[1][r, :n].view(np.uint32))
