@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--n-base", type=int, default=1_000_000)
     ap.add_argument("--M", type=int, default=32)
     ap.add_argument("--workload", default="linear", choices=["linear", "ivf", "subset"])
+    ap.add_argument("--topk", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lut-mode", default="exact", choices=["exact", "mfma"])
     ap.add_argument("--scan-mode", type=int, default=1, choices=[0, 1],
@@ -78,6 +79,8 @@ def measured_traffic(args):
     except Exception:
         return None
     key = "%s/scan_mode=%d/M=%d/N=%d/B=%d" % (args.workload, args.scan_mode, args.M, args.n_base, args.batch)
+    if args.topk != 1:
+        key += "/topk=%d" % args.topk
     return tab.get(key, {}).get("hbm_bytes_per_launch")
 
 
@@ -131,7 +134,7 @@ def main():
     eng.add_codes(codes, False)
     eng.set_option("lut_mode", args.lut_mode)
     eng.set_option("scan_mode", args.scan_mode)
-    topk = 1
+    topk = args.topk
     S, L = 0, 0
     d_tids = 0
     if args.workload != "linear":
@@ -185,7 +188,7 @@ def main():
     k_ms, k_n = eng.timing_read(kernel)
     lut_ms, lut_n = eng.timing_read("lut")
     extra = {}
-    for kn in ("quant", "rerank", "gather", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select"):
+    for kn in ("quant", "rerank", "kth", "select", "gather", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select"):
         ms_, n_ = eng.timing_read(kn)
         if n_:
             extra[kn + "_avg_launch_ms"] = ms_ / n_
@@ -209,8 +212,8 @@ def main():
             "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SIFT1M-shaped %s ADC scan, D=128 M=%d Ks=256, N=%d, batch=%d per GPU, topk=1%s"
-                                   % (args.workload, M, N, B, (", nlist=1024 L=%d" % L) if L else ""),
+            "config": {"workload": "SIFT1M-shaped %s ADC scan, D=128 M=%d Ks=256, N=%d, batch=%d per GPU, topk=%d%s"
+                                   % (args.workload, M, N, B, topk, (", nlist=1024 L=%d" % L) if L else ""),
                        "global_batch": B * world, "parallelism": "query-sharded x%d, index replicated" % world,
                        "lut_mode": args.lut_mode, "simd_order": arch,
                        "scan_mode": "8-bit filter + exact fp32 re-rank" if args.scan_mode else "exact fp32 scan"},
@@ -220,7 +223,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": k_n,
                          "lut_avg_launch_ms": lut_ms / max(lut_n, 1), **extra},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "linear":
+        if world == 1 and not args.no_cpu_baseline and args.workload == "linear" and topk == 1:
             cb, cpu_ids = cpu_baseline(cw, codes, my_q.cpu().numpy(), arch)
             gpu_ids = out_ids.cpu().numpy()[:len(cpu_ids), 0]
             cb["ids_match_gpu"] = bool(np.array_equal(cpu_ids, gpu_ids))

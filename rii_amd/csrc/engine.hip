@@ -113,7 +113,7 @@ struct rii_engine {
     // scratch
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
-        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag;
+        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
 
@@ -296,20 +296,9 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
     ScanParams sp;
     sp.codes = d_codes; sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks; sp.lut = e->s_lut.as<float>();
     sp.B = (int) B; sp.QT = e->QT; sp.best = nullptr; sp.keys = nullptr; sp.b0 = 0; sp.bc = 0;
-    if (topk == 1 && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
-        // stage 0: quantise the tables; stage 1: 8-bit scan -> candidates; stage 2: exact re-rank
+    if (e->scan_mode == 1 && fastscan_supported(e->M, e->Ks) && topk <= rerank_topk_max_k()) {
+        // stage 0: quantise the tables; stage 1: byte-table scan -> candidates; stage 2: exact re-rank
         const int64_t tiles = (B + 15) / 16;
-        RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * 16));
-        RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
-        RII_TRY(e->s_cand.ensure((size_t) B * e->cand_cap * sizeof(unsigned long long)));
-        RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
-        if (!e->qlut_ready) {
-            ScopedTimer t(e, "quant", st);
-            HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_qlut.as<uint8_t>(),
-                                        e->s_slack.as<int32_t>(), st));
-        }
-        HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
-        e->last_fs_B = B;
         int64_t c = e->scan_chunks;
         if (c <= 0) {
             c = std::max<int64_t>(1, (e->n_cu + tiles - 1) / tiles);
@@ -318,19 +307,60 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
         c = std::max<int64_t>(1, std::min<int64_t>(c, 65535));
         const int64_t len = std::max<int64_t>(1, (n_codes + c - 1) / c);
         const int chunks = (int) ((n_codes + len - 1) / len);
-        {
-            ScopedTimer t(e, "scan", st);
-            HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
-                                 chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(),
-                                 e->cand_cap, st));
-        }
-        {
+        const int64_t G = (int64_t) chunks * 1024;                        // lane segments per query (top-k passes)
+        const bool topk_ok = topk == 1 || (int64_t) topk * 2 <= std::min<int64_t>(n_codes, G);
+        if (topk_ok) {
+            const int cap = topk == 1 ? e->cand_cap : std::max(e->cand_cap, 16 * topk);
+            RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * 16));
+            RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
+            RII_TRY(e->s_cand.ensure((size_t) B * cap * sizeof(unsigned long long)));
+            RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
+            if (!e->qlut_ready) {
+                ScopedTimer t(e, "quant", st);
+                HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_qlut.as<uint8_t>(),
+                                            e->s_slack.as<int32_t>(), st));
+            }
+            HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
+            e->last_fs_B = B;
+            if (topk == 1) {
+                {
+                    ScopedTimer t(e, "scan", st);
+                    HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
+                                         (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
+                                         e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr, st));
+                }
+                ScopedTimer t(e, "rerank", st);
+                HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT,
+                                           e->s_slack.as<int32_t>(), e->s_cand.as<unsigned long long>(),
+                                           e->s_cand_cnt.as<unsigned int>(), cap, d_remap, B, d_out_ids, d_out_dists, topk, st));
+                return RII_OK;
+            }
+            // top-k: pass 1 = per-lane-segment minima of the quantised sums, k-th smallest of them bounds the k-th
+            // smallest sum from above; pass 2 = keep every code within the proven slack of that bound; exact re-rank.
+            RII_TRY(e->s_segmin.ensure((size_t) B * G * sizeof(uint16_t)));
+            RII_TRY(e->s_thr16.ensure((size_t) B * sizeof(uint32_t)));
+            {
+                ScopedTimer t(e, "scan", st);
+                HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
+                                     chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, st));
+            }
+            {
+                ScopedTimer t(e, "kth", st);
+                HIP_TRY(launch_kth_threshold(e->s_segmin.as<uint16_t>(), G, B, topk, fastscan_max_sum(e->M),
+                                             e->s_slack.as<int32_t>(), e->s_thr16.as<uint32_t>(), st));
+            }
+            {
+                ScopedTimer t(e, "scan", st);
+                HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
+                                     chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), st));
+            }
             ScopedTimer t(e, "rerank", st);
-            HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT, e->s_slack.as<int32_t>(),
-                                       e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), e->cand_cap,
-                                       d_remap, B, d_out_ids, d_out_dists, topk, st));
+            HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT,
+                                       e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap, d_remap, B,
+                                       d_out_ids, d_out_dists, topk, st));
+            return RII_OK;
         }
-        return RII_OK;
     }
     if (topk == 1) {
         pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len);
@@ -392,7 +422,7 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
                      int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
     if (B == 0) return RII_OK;
-    RII_TRY(build_lut(e, d_queries, B, st, topk == 1));
+    RII_TRY(build_lut(e, d_queries, B, st, true));
     if (S == 0)
         return scan_topk(e, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
     // subset search: gather the S target codes once for the whole batch, scan them, map ids back
@@ -512,7 +542,7 @@ void free_all(rii_engine *e)
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
-                      &e->s_cand, &e->s_cand_cnt, &e->s_flag};
+                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;

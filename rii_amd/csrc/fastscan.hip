@@ -180,8 +180,13 @@ struct FsArgs {
     unsigned long long *cand;      // [B][cap] (a << 32 | local index)
     unsigned int *cand_count;      // [B]
     int cap;
+    uint16_t *segmin;              // MODE 1: [B][G] per-lane-segment minima of a(), G = gridDim.x * 1024
+    const uint32_t *thr16;         // MODE 2: [B] fixed thresholds (candidate <=> a < thr16[b])
 };
 
+// MODE 0: top-1, thresholds adapt to the block's running minimum.  MODE 1 / 2: the two passes of top-k (k > 1):
+// pass 1 records, per lane, the minimum a() over the codes that lane saw (a partition of the codes into G segments);
+// the k-th smallest segment minimum v_k is >= the k-th smallest a() overall, so pass 2 keeps a() <= v_k + slack.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // widen the four byte-packed partial sums of a row into 8 registers of two u16 fields each:
@@ -225,7 +230,7 @@ __device__ __forceinline__ uint32_t fs_thr_of(uint32_t a, uint32_t slack)
     return t > 0xffffu ? 0xffffu : t;
 }
 
-template <int MW, int KST>
+template <int MW, int KST, int MODE>
 __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -239,10 +244,21 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
         const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
         uint4 *d4 = reinterpret_cast<uint4 *>(smem);
         for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
-        if (tid < 8) s_thr[tid] = 0xffffffffu;
+        if (tid < 8) {
+            uint32_t word = 0xffffffffu;
+            if constexpr (MODE == 2) {          // word i = 2w + parity: low = query 4w+parity, high = query 4w+parity+2
+                const int q0 = 4 * (tid >> 1) + (tid & 1), b0 = tile * kFsQ + q0, b1 = b0 + 2;
+                const uint32_t lo = b0 < p.B ? p.thr16[b0] : 0u, hi = b1 < p.B ? p.thr16[b1] : 0u;
+                word = (lo & 0xffffu) | (hi << 16);
+            }
+            s_thr[tid] = word;
+        }
     }
     __syncthreads();
     const uint4 *lut = reinterpret_cast<const uint4 *>(smem);
+    uint32_t smin[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) smin[i] = 0xffffffffu;
 
     const int64_t c_begin = (int64_t) blockIdx.x * p.chunk_len;
     int64_t c_end = c_begin + p.chunk_len;
@@ -291,7 +307,16 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                 fs_flush(acc, pb);
             }
         }
-        if (it == 0) {
+        if constexpr (MODE == 1) {
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    smin[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, smin[i]),
+                                                                                    __builtin_bit_cast(u16x2, acc[i])));
+            }
+            continue;
+        }
+        if (MODE == 0 && it == 0) {
             // warm-up: publish thresholds from the first <=1024 codes before anybody tests candidacy
 #pragma unroll
             for (int q = 0; q < kFsQ; ++q) {
@@ -326,8 +351,10 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                     const uint32_t a = fs_get(acc, q);
                     const uint32_t t = high ? (thr[reg] >> 16) : (thr[reg] & 0xffffu);
                     if (a < t && b < p.B) {
-                        const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
-                        if (nt < t) fs_thr_lower(&s_thr[reg], high, nt);
+                        if constexpr (MODE == 0) {
+                            const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
+                            if (nt < t) fs_thr_lower(&s_thr[reg], high, nt);
+                        }
                         const unsigned int pos = atomicAdd(&p.cand_count[b], 1u);
                         if (pos < (unsigned int) p.cap)
                             p.cand[(size_t) b * p.cap + pos] = ((unsigned long long) a << 32) | (uint32_t) n;
@@ -336,13 +363,22 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
             }
         }
     }
+    if constexpr (MODE == 1) {
+        const size_t G = (size_t) gridDim.x * kFsThreads;
+        const size_t seg = (size_t) blockIdx.x * kFsThreads + tid;
+#pragma unroll
+        for (int q = 0; q < kFsQ; ++q) {
+            const int b = tile * kFsQ + q;
+            if (b < p.B) p.segmin[(size_t) b * G + seg] = (uint16_t) fs_get(smin, q);
+        }
+    }
 }
 
-template <int MW, int KST>
+template <int MW, int KST, int MODE>
 static hipError_t launch_fscan_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
     const size_t smem = (size_t) a.M * a.Ks * kFsQ + 64;
-    auto kern = fscan_kernel<MW, KST>;
+    auto kern = fscan_kernel<MW, KST, MODE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
@@ -354,20 +390,100 @@ bool fastscan_supported(int M, int Ks)
 {
     return (size_t) M * Ks * kFsQ + 64 <= (size_t) kMaxLutLdsBytes && M <= 256;
 }
+int fastscan_max_sum(int M) { return M * kFsLevels; }
+
+template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chunks, hipStream_t st)
+{
+    const int tiles = (a.B + kFsQ - 1) / kFsQ;
+    if (a.Ks == 256 && a.M == 8) return launch_fscan_t<2, 256, MODE>(a, chunks, tiles, st);
+    if (a.Ks == 256 && a.M == 16) return launch_fscan_t<4, 256, MODE>(a, chunks, tiles, st);
+    if (a.Ks == 256 && a.M == 32) return launch_fscan_t<8, 256, MODE>(a, chunks, tiles, st);
+    return launch_fscan_t<0, 0, MODE>(a, chunks, tiles, st);
+}
 
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
-                        unsigned int *d_cand_count, int cap, hipStream_t st)
+                        unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
+                        hipStream_t st)
 {
     if (B == 0 || n_codes == 0) return hipSuccess;
     FsArgs a;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
-    a.chunk_len = chunk_len; a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap;
-    const int tiles = (B + kFsQ - 1) / kFsQ;
-    if (Ks == 256 && M == 8) return launch_fscan_t<2, 256>(a, chunks, tiles, st);
-    if (Ks == 256 && M == 16) return launch_fscan_t<4, 256>(a, chunks, tiles, st);
-    if (Ks == 256 && M == 32) return launch_fscan_t<8, 256>(a, chunks, tiles, st);
-    return launch_fscan_t<0, 0>(a, chunks, tiles, st);
+    a.chunk_len = chunk_len; a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.segmin = d_segmin;
+    a.thr16 = d_thr16;
+    if (mode == 1) return launch_fscan_mode<1>(a, chunks, st);
+    if (mode == 2) return launch_fscan_mode<2>(a, chunks, st);
+    return launch_fscan_mode<0>(a, chunks, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// top-k, between the passes: v_k = k-th smallest of the G segment minima of query b  ->  thr16[b] = v_k + slack + 1.
+// One block per query; counting select over the value range [0, M*63].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kth_threshold_kernel(const uint16_t *__restrict__ segmin, int64_t G, int k,
+                                                            int maxv, const int32_t *__restrict__ slack,
+                                                            uint32_t *__restrict__ thr16)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *hist = reinterpret_cast<int *>(smem);                 // [maxv + 1]
+    __shared__ int s_part[256];
+    __shared__ int s_res;
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nb = maxv + 1;
+    for (int i = tid; i < nb; i += 256) hist[i] = 0;
+    if (tid == 0) s_res = -1;
+    __syncthreads();
+    const uint16_t *row = segmin + (size_t) b * G;
+    for (int64_t i = tid; i < G; i += 256) {
+        const int v = row[i];
+        if (v <= maxv) atomicAdd(&hist[v], 1);
+    }
+    __syncthreads();
+    const int per = (nb + 255) / 256;
+    const int lo = tid * per, hi = (lo + per < nb) ? lo + per : nb;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += hist[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, owner = -1;
+        for (int t = 0; t < 256; ++t) {
+            if (acc + s_part[t] >= k) { owner = t; break; }
+            acc += s_part[t];
+        }
+        s_part[0] = acc;                 // count before the owner's range (reuse slot 0 after reading all)
+        s_res = owner;
+    }
+    __syncthreads();
+    const int owner = s_res;
+    if (owner < 0) {
+        if (tid == 0) thr16[b] = 0xffffu;                       // fewer than k non-empty segments: keep everything
+        return;
+    }
+    if (tid == owner) {
+        int acc = s_part[0];
+        int v = hi - 1;
+        for (int i = lo; i < hi; ++i) {
+            acc += hist[i];
+            if (acc >= k) { v = i; break; }
+        }
+        const uint32_t t = (uint32_t) v + (uint32_t) slack[b] + 1u;
+        thr16[b] = t > 0xffffu ? 0xffffu : t;
+    }
+}
+
+hipError_t launch_kth_threshold(const uint16_t *d_segmin, int64_t G, int64_t B, int k, int maxv, const int32_t *d_slack,
+                                uint32_t *d_thr16, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    const size_t smem = (size_t) (maxv + 1) * sizeof(int);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kth_threshold_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kth_threshold_kernel, dim3((unsigned) B), dim3(256), smem, st, d_segmin, G, k, maxv, d_slack,
+                       d_thr16);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -484,6 +600,99 @@ hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, in
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rerank_top1_kernel, dim3((unsigned) B), dim3(256), smem, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 2 for top-k (k > 1): exact distances of every candidate (or of every code if the candidate buffer overflowed)
+// streamed through a block-local top-k: keys (orderable dist << 32 | index) below the current k-th best are appended
+// to an LDS buffer, which is bitonic-sorted and cut back to k whenever it could overflow.  Output in (dist, id) order.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRrBuf = 2048;             // LDS key buffer; supports topk <= kRrBuf / 2
+
+__device__ void rr_bitonic_sort(unsigned long long *buf, int tid)      // sorts kRrBuf keys ascending, 256 threads
+{
+    for (int size = 2; size <= kRrBuf; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < kRrBuf / 2; t += 256) {
+                const int i = 2 * t - (t & (stride - 1));           // lower index of the pair
+                const int j = i + stride;
+                const bool up = ((i & size) == 0);
+                const unsigned long long x = buf[i], y = buf[j];
+                if ((x > y) == up) { buf[i] = y; buf[j] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    const int MK = p.M * p.Ks;
+    unsigned long long *buf = reinterpret_cast<unsigned long long *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));
+    unsigned long long &s_thr = buf[kRrBuf];                                   // all LDS in the dynamic region
+    unsigned int &s_cnt = *reinterpret_cast<unsigned int *>(&buf[kRrBuf + 1]);
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int k = p.topk;
+    {
+        const float *src = p.lut + (size_t) (b / p.QT) * MK * p.QT + (b % p.QT);
+        for (int i = tid; i < MK; i += 256) lds[i] = src[(size_t) i * p.QT];
+        if (tid == 0) { s_cnt = 0u; s_thr = ~0ull; }
+    }
+    __syncthreads();
+    const unsigned int ncand = p.cand_count[b];
+    const bool overflow = ncand > (unsigned int) p.cap;
+    const int64_t total = overflow ? p.n_codes : (int64_t) ncand;
+    const unsigned long long *cand = p.cand + (size_t) b * p.cap;
+    for (int64_t base = 0; base < total; base += 256) {
+        if (s_cnt + 256u > (unsigned int) kRrBuf) {               // uniform: make room
+            for (int i = tid; i < kRrBuf; i += 256)
+                if ((unsigned int) i >= s_cnt) buf[i] = ~0ull;
+            rr_bitonic_sort(buf, tid);
+            if (tid == 0) { s_cnt = (unsigned int) k; s_thr = buf[k - 1]; }
+            __syncthreads();
+        }
+        const int64_t i = base + tid;
+        if (i < total) {
+            const uint32_t n = overflow ? (uint32_t) i : (uint32_t) (cand[i] & 0xffffffffu);
+            const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | n;
+            if (key < s_thr) buf[atomicAdd(&s_cnt, 1u)] = key;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < kRrBuf; i += 256)
+        if ((unsigned int) i >= s_cnt) buf[i] = ~0ull;
+    rr_bitonic_sort(buf, tid);
+    for (int j = tid; j < k; j += 256) {
+        const unsigned long long key = buf[j];
+        const uint32_t idx = (uint32_t) (key & 0xffffffffu);
+        p.out_ids[b * k + j] = (key == ~0ull) ? -1 : (p.remap ? p.remap[idx] : (int64_t) idx);
+        p.out_dists[b * k + j] = (key == ~0ull) ? INFINITY : __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
+    }
+}
+
+int rerank_topk_max_k() { return kRrBuf / 2; }
+
+hipError_t launch_rerank_topk(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
+                              const unsigned long long *d_cand, const unsigned int *d_cand_count, int cap,
+                              const int64_t *d_remap, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
+                              hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    RrArgs a;
+    a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.slack = nullptr;
+    a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.remap = d_remap; a.out_ids = d_out_ids;
+    a.out_dists = d_out_dists; a.topk = topk;
+    const size_t smem = (((size_t) M * Ks * sizeof(float) + 15) & ~(size_t) 15) + (size_t) (kRrBuf + 2) * 8;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rerank_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rerank_topk_kernel, dim3((unsigned) B), dim3(256), smem, st, a);
     return hipGetLastError();
 }
 

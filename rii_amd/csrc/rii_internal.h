@@ -119,7 +119,16 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
                                   int arch, int QT, float *d_lut, uint8_t *d_qlut, int32_t *d_slack, hipStream_t st);
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
-                        unsigned int *d_cand_count, int cap, hipStream_t st);
+                        unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
+                        hipStream_t st);
+int fastscan_max_sum(int M);
+int rerank_topk_max_k();
+hipError_t launch_kth_threshold(const uint16_t *d_segmin, int64_t G, int64_t B, int k, int maxv, const int32_t *d_slack,
+                                uint32_t *d_thr16, hipStream_t st);
+hipError_t launch_rerank_topk(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
+                              const unsigned long long *d_cand, const unsigned int *d_cand_count, int cap,
+                              const int64_t *d_remap, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
+                              hipStream_t st);
 hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const int32_t *d_slack, const unsigned long long *d_cand,
                               const unsigned int *d_cand_count, int cap, const int64_t *d_remap, int64_t B,

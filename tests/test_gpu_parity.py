@@ -276,3 +276,29 @@ def test_gpu_ivf_fused_equals_emulation_path():
             for r in range(Q.shape[0]):
                 n = int(a[2][r])
                 assert np.array_equal(a[0][r, :n], b[0][r, :n]) and np.array_equal(a[1][r, :n].view(np.uint32), b[1][r, :n].view(np.uint32))
+
+
+@pytest.mark.parametrize("shape", [(32, 256, 4, 60000, "sift", 0), (32, 256, 4, 30000, "unit", 9000),
+                                   (16, 256, 6, 40000, "unit", 0), (4, 20, 10, 5000, "unit", 0),
+                                   (3, 7, 37, 3000, "unit", 500), (20, 256, 2, 2000, "unit", 0)])
+def test_gpu_topk_filter_rerank_equals_sort_path(shape):
+    """topk > 1: the two-pass filter (segment minima -> k-th bound -> candidates) + exact streaming top-k must equal
+    the exhaustive path (all exact keys, full segmented sort) bit for bit, both being in canonical (dist, id) order."""
+    from rii_amd import RiiGpu
+    M, Ks, Ds, N, scale, dup = shape
+    cw, codes, qs = make_problem(321, M, Ks, Ds, N, scale, dup=dup)
+    g = RiiGpu(cw, False)
+    g.add_codes(codes, False)
+    rng = np.random.default_rng(8)
+    sub = np.sort(rng.choice(N, N // 4, replace=False)).astype(np.int64)
+    Q = np.concatenate([qs, qs[:7] * 0.3], 0)
+    for topk in (2, 10, 100, 400):
+        for tids in (None, sub):
+            if tids is not None and topk > len(tids):
+                continue
+            g.set_option("scan_mode", 1)
+            i1, d1 = g.query_linear_batch(Q, topk, tids)
+            g.set_option("scan_mode", 0)
+            i0, d0 = g.query_linear_batch(Q, topk, tids)
+            assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32)), (shape, topk)
+            assert np.array_equal(i1, i0), (shape, topk)
