@@ -239,10 +239,13 @@ int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
     return RII_OK;
 }
 
-int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, bool want_quant = false)
+int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, bool want_quant = false, int qt = 0,
+              bool alloc_only = false)
 {
-    const size_t tiles = (size_t) ((B + e->QT - 1) / e->QT);
-    RII_TRY(e->s_lut.ensure(tiles * (size_t) e->M * e->Ks * e->QT * sizeof(float)));
+    if (qt <= 0) qt = e->QT;
+    const size_t tiles = (size_t) ((B + qt - 1) / qt);
+    RII_TRY(e->s_lut.ensure(tiles * (size_t) e->M * e->Ks * qt * sizeof(float)));
+    if (alloc_only) return RII_OK;
     e->qlut_ready = false;
     if (want_quant && e->lut_mode == RII_LUT_EXACT && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
         RII_TRY(e->s_qlut.ensure((size_t) ((B + 15) / 16) * e->M * e->Ks * 16));
@@ -261,9 +264,9 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
             e->have_cnorm = true;
         }
         HIP_TRY(launch_lut_build_mfma(d_queries, B, e->d_codewords.as<float>(), e->d_cnorm.as<float>(), e->M, e->Ks,
-                                      e->Ds, e->QT, e->s_lut.as<float>(), st));
+                                      e->Ds, qt, e->s_lut.as<float>(), st));
     } else {
-        HIP_TRY(launch_lut_build(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch, e->QT,
+        HIP_TRY(launch_lut_build(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch, qt,
                                  e->s_lut.as<float>(), st));
     }
     return RII_OK;
@@ -440,11 +443,11 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     if (B == 0) return RII_OK;
     const int64_t nlist = nlist_of(e);
     RII_TRY(sync_lists(e));
-    RII_TRY(build_lut(e, d_queries, B, st));
 
     IvfParams p;
     p.codes = e->d_codes.as<uint8_t>(); p.N = e->N; p.M = e->M; p.Ks = e->Ks;
-    p.lut = e->s_lut.as<float>(); p.QT = e->QT;
+    p.QT = 1;                     // inverted-index kernels stage ONE query's table per block: plain [b][M*Ks] layout
+    p.queries = nullptr; p.codewords = e->d_codewords.as<float>(); p.Ds = e->Ds; p.arch = e->arch;
     p.centers = e->d_centers.as<uint8_t>(); p.nlist = (int) nlist;
     p.pl_off = e->d_pl_off.as<int64_t>();
     p.pl_ids = e->d_pl_ids.as<int32_t>();
@@ -487,6 +490,13 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     const bool fused = e->ivf_fused && ivf_fused_supported((int) nlist, w);
     RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
     p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
+    if (fused && e->lut_mode == RII_LUT_EXACT) {
+        RII_TRY(build_lut(e, d_queries, B, st, false, 1, /*alloc_only=*/true));   // tables are built inside the fused kernel
+        p.queries = d_queries;
+    } else {
+        RII_TRY(build_lut(e, d_queries, B, st, false, 1));
+    }
+    p.lut = e->s_lut.as<float>();
 
     for (int64_t b0 = 0; b0 < B; b0 += bc) {
         p.B = std::min<int64_t>(bc, B - b0);

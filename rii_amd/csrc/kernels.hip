@@ -686,7 +686,14 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     const int nlist = p.nlist;
     const int w = (int) p.w;
 
-    stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
+    if (p.queries) {
+        // table built in place (exact fvec_L2sqr order): no global round trip for the common case
+        const float *q = p.queries + (p.b0 + bl) * (int64_t) (p.M * p.Ds);
+        for (int i = tid; i < MK; i += blockDim.x)
+            lds[i] = fvec_l2sqr_dev(q + (size_t) (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
+    } else {
+        stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
+    }
     __syncthreads();
     for (int c = tid; c < nlist; c += blockDim.x) {
         const uint8_t *code = p.centers + (size_t) c * p.M;
@@ -744,7 +751,13 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         s_red[1] = ~0ull;
     }
     __syncthreads();
-    if (s_misc[2]) return;
+    if (s_misc[2]) {
+        if (p.queries) {         // hand the table to the exact-emulation kernels (layout [b][M*Ks], QT == 1)
+            float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
+            for (int i = tid; i < MK; i += blockDim.x) dst[i] = lds[i];
+        }
+        return;
+    }
     const int ncand = s_misc[0], nv = s_misc[1];
     const bool top1 = (p.topk == 1);
     float bestd = INFINITY;

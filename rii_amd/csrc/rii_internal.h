@@ -83,6 +83,8 @@ struct IvfParams {
     float *cand_dist;             // [B][cand_stride]
     int64_t cand_stride;
     int64_t *out_ids; float *out_dists; int64_t *out_counts;   // rows b0.. of the caller's outputs
+    const float *queries;         // non-null: ivf_fused_kernel builds the table itself from (queries, codewords)
+    const float *codewords; int Ds; int arch;
     int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
