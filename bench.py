@@ -117,8 +117,10 @@ def main_deep(args, world, rank, local, dev, arch):
         eng.query_linear_dev(q.data_ptr(), B, topk, 0, 0, out_ids.data_ptr(), out_d.data_ptr(), stream)
         merged[0] = rd.allgather_merge_topk(out_ids, out_d, topk, id_offset=offset)
 
+    use_dist = dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +134,7 @@ def main_deep(args, world, rank, local, dev, arch):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -153,7 +155,7 @@ def main_deep(args, world, rank, local, dev, arch):
             "roofline": {"bound": "hbm", "kernel": "fscan_kernel" if args.scan_mode else "scan_kernel",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": k_n}}))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -167,8 +169,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ           # launched by torch.distributed.run (any world size, incl. 1)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (got WORLD_SIZE=%d)" % (args.gpus, world)
     torch.cuda.set_device(local)
@@ -195,7 +200,7 @@ def main():
         t_codes = torch.empty((N, M), dtype=torch.uint8, device=dev)
         t_q = torch.empty((B * world, D), dtype=torch.float32, device=dev)
         t_gt = torch.empty((B * world,), dtype=torch.int64, device=dev)
-    if world > 1:
+    if use_dist:
         for t in (t_cw, t_codes, t_q, t_gt):
             dist.broadcast(t, 0)
     cw = t_cw.cpu().numpy()
@@ -222,8 +227,8 @@ def main():
     out_ids = torch.empty((B, topk), dtype=torch.int64, device=dev)
     out_d = torch.empty((B, topk), dtype=torch.float32, device=dev)
     out_cnt = torch.empty((B,), dtype=torch.int64, device=dev)
-    gather_ids = [torch.empty_like(out_ids) for _ in range(world)] if world > 1 else None
-    gather_d = [torch.empty_like(out_d) for _ in range(world)] if world > 1 else None
+    gather_ids = [torch.empty_like(out_ids) for _ in range(world)] if use_dist else None
+    gather_d = [torch.empty_like(out_d) for _ in range(world)] if use_dist else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -232,12 +237,12 @@ def main():
                               out_cnt.data_ptr(), stream)
         else:
             eng.query_linear_dev(my_q.data_ptr(), B, topk, d_tids, S, out_ids.data_ptr(), out_d.data_ptr(), stream)
-        if world > 1:      # top-k gather over xGMI (12 KB per rank: latency-bound)
+        if use_dist:       # top-k gather over xGMI (12 KB per rank: latency-bound)
             dist.all_gather(gather_ids, out_ids)
             dist.all_gather(gather_d, out_d)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -252,7 +257,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     eng.set_option("timing", 0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -268,10 +273,12 @@ def main():
         if n_:
             extra[kn + "_avg_launch_ms"] = ms_ / n_
     recall = bd.recall_at_r(out_ids.cpu().numpy(), my_gt, 1)
-    if world > 1:
+    if use_dist:
         r = torch.tensor([recall], dtype=torch.float64, device=dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         recall = float(r.item()) / world
+        allq = torch.cat(gather_ids, dim=0)          # the gathered batch really is every rank's rows, in rank order
+        assert allq.shape[0] == B * world and torch.equal(allq[rank * B:(rank + 1) * B], out_ids)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -304,7 +311,7 @@ def main():
             cb["ids_match_gpu"] = bool(np.array_equal(cpu_ids, gpu_ids))
             line["cpu_baseline"] = cb
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
