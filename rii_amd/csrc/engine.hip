@@ -91,6 +91,7 @@ struct rii_engine {
     int scan_chunks = 0;        // 0 = auto
     int scan_mode = 1;          // 1 = 8-bit filter + exact re-rank for top-1 (fastscan.hip), 0 = exact scan only
     int cand_cap = 4096;
+    bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
     int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)        // candidate slots per query for the re-rank stage
@@ -248,7 +249,8 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
     if (alloc_only) return RII_OK;
     e->qlut_ready = false;
     if (want_quant && e->lut_mode == RII_LUT_EXACT && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
-        RII_TRY(e->s_qlut.ensure((size_t) ((B + 15) / 16) * e->M * e->Ks * 16));
+        const int qr = fastscan_rows(e->M, e->Ks);
+        RII_TRY(e->s_qlut.ensure((size_t) ((B + qr - 1) / qr) * e->M * e->Ks * qr));
         RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
         ScopedTimer t(e, "lut", st);
         HIP_TRY(launch_lut_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch, e->QT,
@@ -301,7 +303,8 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
     sp.B = (int) B; sp.QT = e->QT; sp.best = nullptr; sp.keys = nullptr; sp.b0 = 0; sp.bc = 0;
     if (e->scan_mode == 1 && fastscan_supported(e->M, e->Ks) && topk <= rerank_topk_max_k()) {
         // stage 0: quantise the tables; stage 1: byte-table scan -> candidates; stage 2: exact re-rank
-        const int64_t tiles = (B + 15) / 16;
+        const int qr = fastscan_rows(e->M, e->Ks);
+        const int64_t tiles = (B + qr - 1) / qr;
         int64_t c = e->scan_chunks;
         if (c <= 0) {
             c = std::max<int64_t>(1, (e->n_cu + tiles - 1) / tiles);
@@ -313,8 +316,12 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
         const int64_t G = (int64_t) chunks * 1024;                        // lane segments per query (top-k passes)
         const bool topk_ok = topk == 1 || (int64_t) topk * 2 <= std::min<int64_t>(n_codes, G);
         if (topk_ok) {
-            const int cap = topk == 1 ? e->cand_cap : std::max(e->cand_cap, 16 * topk);
-            RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * 16));
+            // candidate slots per query: small batches are cut into many chunks (each with its own running minimum,
+            // hence more candidates per query), and can afford far more slots: ~128 MiB of slots in total
+            int cap = (int) std::min<int64_t>(262144, std::max<int64_t>(e->cand_cap, ((int64_t) 1 << 24) / std::max<int64_t>(B, 1)));
+            if (e->cand_cap_forced) cap = e->cand_cap;
+            if (topk > 1) cap = std::max(cap, 16 * topk);
+            RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * qr));
             RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
             RII_TRY(e->s_cand.ensure((size_t) B * cap * sizeof(unsigned long long)));
             RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
@@ -487,7 +494,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     p.coarse_dist = e->s_coarse_d.as<float>(); p.coarse_id = e->s_coarse_i.as<int32_t>();
     p.cum = e->s_cum.as<int32_t>(); p.ncand = e->s_ncand.as<int32_t>(); p.nvis = e->s_nvis.as<int32_t>();
     p.cand_id = e->s_cand_i.as<int32_t>(); p.cand_dist = e->s_cand_d.as<float>(); p.cand_stride = stride;
-    const bool fused = e->ivf_fused && ivf_fused_supported((int) nlist, w);
+    const bool fused = e->ivf_fused && ivf_fused_supported((int) nlist, w, topk);
     RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
     p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
     if (fused && e->lut_mode == RII_LUT_EXACT) {
@@ -914,6 +921,7 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
     } else if (k == "cand_cap") {
         if (value < 1 || value > (1 << 20)) return set_err(RII_ERR_INVALID, "bad cand_cap");
         e->cand_cap = (int) value;
+        e->cand_cap_forced = true;
     } else {
         return set_err(RII_ERR_INVALID, "unknown option '%s'", key);
     }

@@ -20,7 +20,7 @@
 namespace riiamd {
 
 constexpr int kFsThreads = 1024;
-constexpr int kFsQ = 16;               // queries per stage-1 tile (one byte each in a 16-byte LDS row)
+int fastscan_rows(int M, int Ks);      // queries per LDS row of the byte tables: 16, 8 or 0 (unsupported shape)
 constexpr int kFsLevels = 63;          // quantisation levels - 1 (6 bits) ...
 constexpr int kFsFlush = 4;            // ... so that kFsFlush entries add up inside a byte: 4 * 63 = 252 < 256
 
@@ -30,8 +30,8 @@ constexpr int kFsFlush = 4;            // ... so that kFsFlush entries add up in
 // ---------------------------------------------------------------------------------------------------
 // shared body: T(i) returns the exact fp32 entry i = m*Ks + ks of query b's table
 template <typename Getter>
-__device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M, int Ks, uint8_t *__restrict__ qlut,
-                                               int32_t *__restrict__ slack)
+__device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M, int Ks, int QR,
+                                               uint8_t *__restrict__ qlut, int32_t *__restrict__ slack)
 {
     __shared__ float s_lo[256], s_hi[256];          // per-m extrema (M <= 256)
     __shared__ double s_rlo[256], s_rhi[256];
@@ -66,7 +66,7 @@ __device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M
     const float delta = s_delta;
     const double ddelta = (double) delta;
     // 2. codes + residual extrema per m
-    uint8_t *dst = qlut + (size_t) (b / kFsQ) * MK * kFsQ + (b % kFsQ);     // element i at dst[i*16]
+    uint8_t *dst = qlut + (size_t) (b / QR) * MK * QR + (b % QR);     // element i at dst[i*QR]
     for (int m = wave; m < M; m += 4) {
         const float lo = s_lo[m];
         double rlo = INFINITY, rhi = -INFINITY;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M
             const float t = T(m * Ks + ks);
             const float x = floorf((t - lo) / delta + 0.5f);
             const int c = (x >= (float) kFsLevels) ? kFsLevels : (x > 0.f ? (int) x : 0);
-            dst[(size_t) (m * Ks + ks) * kFsQ] = (uint8_t) c;
+            dst[(size_t) (m * Ks + ks) * QR] = (uint8_t) c;
             const double r = (double) t - ((double) lo + (double) c * ddelta);
             rlo = fmin(rlo, r);
             rhi = fmax(rhi, r);
@@ -109,18 +109,18 @@ struct LdsLutGetter {
 };
 
 __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restrict__ lut, int64_t B, int M, int Ks,
-                                                           int QT, uint8_t *__restrict__ qlut,
+                                                           int QT, int QR, uint8_t *__restrict__ qlut,
                                                            int32_t *__restrict__ slack)
 {
     const int64_t b = blockIdx.x;
     GlobalLutGetter g{lut + (size_t) (b / QT) * M * Ks * QT + (b % QT), QT};
-    quantize_table(g, b, M, Ks, qlut, slack);
+    quantize_table(g, b, M, Ks, QR, qlut, slack);
 }
 
 // fused: exact table (fvec_L2sqr order, src/distance.h:117-252) -> global fp32 (for the re-rank) AND its quantisation
 __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__restrict__ queries, int64_t B,
                                                               const float *__restrict__ codewords, int M, int Ks, int Ds,
-                                                              int arch, int QT, float *__restrict__ lut,
+                                                              int arch, int QT, int QR, float *__restrict__ lut,
                                                               uint8_t *__restrict__ qlut, int32_t *__restrict__ slack)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
     }
     __syncthreads();
     LdsLutGetter g{s_t};
-    quantize_table(g, b, M, Ks, qlut, slack);
+    quantize_table(g, b, M, Ks, QR, qlut, slack);
 }
 
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
@@ -148,7 +148,7 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lut_build_quant_kernel, dim3((unsigned) B), dim3(256), smem, st, d_queries, B, d_codewords, M, Ks,
-                       Ds, arch, QT, d_lut, d_qlut, d_slack);
+                       Ds, arch, QT, fastscan_rows(M, Ks), d_lut, d_qlut, d_slack);
     return hipGetLastError();
 }
 
@@ -156,7 +156,8 @@ hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int
                                int32_t *d_slack, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned) B), dim3(256), 0, st, d_lut, B, M, Ks, QT, d_qlut, d_slack);
+    hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned) B), dim3(256), 0, st, d_lut, B, M, Ks, QT,
+                       fastscan_rows(M, Ks), d_qlut, d_slack);
     return hipGetLastError();
 }
 
@@ -191,10 +192,14 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // widen the four byte-packed partial sums of a row into 8 registers of two u16 fields each:
 // byte j of dword w is query 4w+j; even bytes -> acc[2w] (queries 4w, 4w+2), odd bytes -> acc[2w+1] (4w+1, 4w+3)
-__device__ __forceinline__ void fs_flush(uint32_t (&acc)[8], uint32_t (&pb)[4])
+template <int QR> struct FsRow;                                   // one LDS row = QR one-byte entries
+template <> struct FsRow<16> { typedef uint4 T; };
+template <> struct FsRow<8> { typedef uint2 T; };
+
+template <int QR> __device__ __forceinline__ void fs_flush(uint32_t (&acc)[QR / 2], uint32_t (&pb)[QR / 4])
 {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < QR / 4; ++w) {
         acc[2 * w] += pb[w] & 0x00ff00ffu;
         acc[2 * w + 1] += (pb[w] >> 8) & 0x00ff00ffu;
         pb[w] = 0u;
@@ -204,7 +209,11 @@ __device__ __forceinline__ void fs_add(uint32_t (&pb)[4], const uint4 &v)
 {
     pb[0] += v.x; pb[1] += v.y; pb[2] += v.z; pb[3] += v.w;
 }
-__device__ __forceinline__ uint32_t fs_get(const uint32_t (&acc)[8], int q)
+__device__ __forceinline__ void fs_add(uint32_t (&pb)[2], const uint2 &v)
+{
+    pb[0] += v.x; pb[1] += v.y;
+}
+template <int NR> __device__ __forceinline__ uint32_t fs_get(const uint32_t (&acc)[NR], int q)
 {
     const int w = q >> 2, j = q & 3;
     const uint32_t r = acc[2 * w + (j & 1)];
@@ -230,7 +239,7 @@ __device__ __forceinline__ uint32_t fs_thr_of(uint32_t a, uint32_t slack)
     return t > 0xffffu ? 0xffffu : t;
 }
 
-template <int MW, int KST, int MODE>
+template <int MW, int KST, int MODE, int QR>
 __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -238,16 +247,17 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     const int Ks = KST ? KST : p.Ks;
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
-    const size_t lut_bytes = (size_t) M * Ks * kFsQ;
-    uint32_t *s_thr = reinterpret_cast<uint32_t *>(smem + lut_bytes);          // [8] packed thresholds
+    const size_t lut_bytes = (size_t) M * Ks * QR;
+    uint32_t *s_thr = reinterpret_cast<uint32_t *>(smem + lut_bytes);          // [QR/2] packed thresholds
+    typedef typename FsRow<QR>::T Row;
     {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
         uint4 *d4 = reinterpret_cast<uint4 *>(smem);
         for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
-        if (tid < 8) {
+        if (tid < QR / 2) {
             uint32_t word = 0xffffffffu;
             if constexpr (MODE == 2) {          // word i = 2w + parity: low = query 4w+parity, high = query 4w+parity+2
-                const int q0 = 4 * (tid >> 1) + (tid & 1), b0 = tile * kFsQ + q0, b1 = b0 + 2;
+                const int q0 = 4 * (tid >> 1) + (tid & 1), b0 = tile * QR + q0, b1 = b0 + 2;
                 const uint32_t lo = b0 < p.B ? p.thr16[b0] : 0u, hi = b1 < p.B ? p.thr16[b1] : 0u;
                 word = (lo & 0xffffu) | (hi << 16);
             }
@@ -255,10 +265,10 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
         }
     }
     __syncthreads();
-    const uint4 *lut = reinterpret_cast<const uint4 *>(smem);
-    uint32_t smin[8];
+    const Row *lut = reinterpret_cast<const Row *>(smem);
+    uint32_t smin[QR / 2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) smin[i] = 0xffffffffu;
+    for (int i = 0; i < QR / 2; ++i) smin[i] = 0xffffffffu;
 
     const int64_t c_begin = (int64_t) blockIdx.x * p.chunk_len;
     int64_t c_end = c_begin + p.chunk_len;
@@ -269,11 +279,11 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     for (int it = 0; it < iters; ++it) {
         const int64_t n = c_begin + (int64_t) it * kFsThreads + tid;
         const bool active = n < c_end;
-        uint32_t acc[8], pb[4];
+        uint32_t acc[QR / 2], pb[QR / 4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0u;
+        for (int i = 0; i < QR / 2; ++i) acc[i] = 0u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pb[i] = 0u;
+        for (int i = 0; i < QR / 4; ++i) pb[i] = 0u;
         if (active) {
             if constexpr (MW != 0) {
                 const uint8_t *cp = p.codes + (size_t) n * (MW * 4);
@@ -295,22 +305,22 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                 for (int i = 0; i < MW; ++i) {          // 4 lookups per code word == one flush group
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fs_add(pb, lut[(i * 4 + j) * KST + ((w[i] >> (8 * j)) & 0xffu)]);
-                    fs_flush(acc, pb);
+                    fs_flush<QR>(acc, pb);
                 }
             } else {
                 const uint8_t *c = p.codes + (size_t) n * M;
                 int pend = 0;
                 for (int m = 0; m < M; ++m) {
                     fs_add(pb, lut[m * Ks + c[m]]);
-                    if (++pend == kFsFlush) { fs_flush(acc, pb); pend = 0; }
+                    if (++pend == kFsFlush) { fs_flush<QR>(acc, pb); pend = 0; }
                 }
-                fs_flush(acc, pb);
+                fs_flush<QR>(acc, pb);
             }
         }
         if constexpr (MODE == 1) {
             if (active) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < QR / 2; ++i)
                     smin[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, smin[i]),
                                                                                     __builtin_bit_cast(u16x2, acc[i])));
             }
@@ -319,8 +329,8 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
         if (MODE == 0 && it == 0) {
             // warm-up: publish thresholds from the first <=1024 codes before anybody tests candidacy
 #pragma unroll
-            for (int q = 0; q < kFsQ; ++q) {
-                const int b = tile * kFsQ + q;
+            for (int q = 0; q < QR; ++q) {
+                const int b = tile * QR + q;
                 uint32_t t = active ? fs_get(acc, q) : 0xffffffffu;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
@@ -334,19 +344,23 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
         }
         if (active) {
             // candidate test on the packed pairs: sat(thr+1 - a) != 0  <=>  a <= thr
-            const uint4 t0 = reinterpret_cast<const uint4 *>(s_thr)[0], t1 = reinterpret_cast<const uint4 *>(s_thr)[1];
-            const uint32_t thr[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            uint32_t thr[QR / 2];
+#pragma unroll
+            for (int i = 0; i < QR / 8; ++i) {
+                const uint4 t4 = reinterpret_cast<const uint4 *>(s_thr)[i];
+                thr[4 * i] = t4.x; thr[4 * i + 1] = t4.y; thr[4 * i + 2] = t4.z; thr[4 * i + 3] = t4.w;
+            }
             uint32_t hit = 0u;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < QR / 2; ++i) {
                 const u16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, thr[i]),
                                                               __builtin_bit_cast(u16x2, acc[i]));
                 hit |= __builtin_bit_cast(uint32_t, d);
             }
             if (hit) {
 #pragma unroll
-                for (int q = 0; q < kFsQ; ++q) {
-                    const int b = tile * kFsQ + q;
+                for (int q = 0; q < QR; ++q) {
+                    const int b = tile * QR + q;
                     const int reg = 2 * (q >> 2) + (q & 1), high = (q >> 1) & 1;
                     const uint32_t a = fs_get(acc, q);
                     const uint32_t t = high ? (thr[reg] >> 16) : (thr[reg] & 0xffffu);
@@ -367,18 +381,18 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
         const size_t G = (size_t) gridDim.x * kFsThreads;
         const size_t seg = (size_t) blockIdx.x * kFsThreads + tid;
 #pragma unroll
-        for (int q = 0; q < kFsQ; ++q) {
-            const int b = tile * kFsQ + q;
+        for (int q = 0; q < QR; ++q) {
+            const int b = tile * QR + q;
             if (b < p.B) p.segmin[(size_t) b * G + seg] = (uint16_t) fs_get(smin, q);
         }
     }
 }
 
-template <int MW, int KST, int MODE>
+template <int MW, int KST, int MODE, int QR>
 static hipError_t launch_fscan_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
-    const size_t smem = (size_t) a.M * a.Ks * kFsQ + 64;
-    auto kern = fscan_kernel<MW, KST, MODE>;
+    const size_t smem = (size_t) a.M * a.Ks * QR + 64;
+    auto kern = fscan_kernel<MW, KST, MODE, QR>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
@@ -386,19 +400,29 @@ static hipError_t launch_fscan_t(const FsArgs &a, int chunks, int tiles, hipStre
     return hipGetLastError();
 }
 
-bool fastscan_supported(int M, int Ks)
+// queries per LDS row: 16 (ds_read_b128) while the byte tables of 16 queries fit, else 8 (ds_read_b64), else 0
+int fastscan_rows(int M, int Ks)
 {
-    return (size_t) M * Ks * kFsQ + 64 <= (size_t) kMaxLutLdsBytes && M <= 256;
+    if (M > 256) return 0;
+    if ((size_t) M * Ks * 16 + 64 <= (size_t) kMaxLutLdsBytes) return 16;
+    if ((size_t) M * Ks * 8 + 64 <= (size_t) kMaxLutLdsBytes) return 8;
+    return 0;
 }
+bool fastscan_supported(int M, int Ks) { return fastscan_rows(M, Ks) != 0; }
 int fastscan_max_sum(int M) { return M * kFsLevels; }
 
 template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chunks, hipStream_t st)
 {
-    const int tiles = (a.B + kFsQ - 1) / kFsQ;
-    if (a.Ks == 256 && a.M == 8) return launch_fscan_t<2, 256, MODE>(a, chunks, tiles, st);
-    if (a.Ks == 256 && a.M == 16) return launch_fscan_t<4, 256, MODE>(a, chunks, tiles, st);
-    if (a.Ks == 256 && a.M == 32) return launch_fscan_t<8, 256, MODE>(a, chunks, tiles, st);
-    return launch_fscan_t<0, 0, MODE>(a, chunks, tiles, st);
+    const int qr = fastscan_rows(a.M, a.Ks);
+    const int tiles = (a.B + qr - 1) / qr;
+    if (qr == 16) {
+        if (a.Ks == 256 && a.M == 8) return launch_fscan_t<2, 256, MODE, 16>(a, chunks, tiles, st);
+        if (a.Ks == 256 && a.M == 16) return launch_fscan_t<4, 256, MODE, 16>(a, chunks, tiles, st);
+        if (a.Ks == 256 && a.M == 32) return launch_fscan_t<8, 256, MODE, 16>(a, chunks, tiles, st);
+        return launch_fscan_t<0, 0, MODE, 16>(a, chunks, tiles, st);
+    }
+    if (a.Ks == 256 && a.M == 64) return launch_fscan_t<16, 256, MODE, 8>(a, chunks, tiles, st);
+    return launch_fscan_t<0, 0, MODE, 8>(a, chunks, tiles, st);
 }
 
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
@@ -608,25 +632,6 @@ hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, in
 // streamed through a block-local top-k: keys (orderable dist << 32 | index) below the current k-th best are appended
 // to an LDS buffer, which is bitonic-sorted and cut back to k whenever it could overflow.  Output in (dist, id) order.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kRrBuf = 2048;             // LDS key buffer; supports topk <= kRrBuf / 2
-
-__device__ void rr_bitonic_sort(unsigned long long *buf, int tid)      // sorts kRrBuf keys ascending, 256 threads
-{
-    for (int size = 2; size <= kRrBuf; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < kRrBuf / 2; t += 256) {
-                const int i = 2 * t - (t & (stride - 1));           // lower index of the pair
-                const int j = i + stride;
-                const bool up = ((i & size) == 0);
-                const unsigned long long x = buf[i], y = buf[j];
-                if ((x > y) == up) { buf[i] = y; buf[j] = x; }
-            }
-        }
-    }
-    __syncthreads();
-}
-
 __global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -681,6 +681,9 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     int *s_cum = reinterpret_cast<int *>(s_red + 2);                                     // [kFusedMaxW + 1]
     int *s_misc = s_cum + (kFusedMaxW + 2);                                              // [4]: ncand, nv, flag
     float *s_dist = reinterpret_cast<float *>(s_misc + 4);                               // [nlist]
+    // top-k > 1: streaming selection buffer behind the coarse distances (8-byte aligned)
+    unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(
+        smem + ((reinterpret_cast<unsigned char *>(s_dist + p.nlist) - smem + 15) & ~(size_t) 15));
     const int64_t bl = blockIdx.x;
     const int tid = threadIdx.x;
     const int nlist = p.nlist;
@@ -763,7 +766,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     float bestd = INFINITY;
     uint32_t bestp = 0xffffffffu;
     int32_t bestid = -1;
-    for (int pos = tid; pos < ncand; pos += blockDim.x) {
+    for (int pos = tid; top1 && pos < ncand; pos += blockDim.x) {
         int lo = 0, hi = nv;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -786,9 +789,6 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         }
         if (top1) {
             if (dist < bestd) { bestd = dist; bestp = (uint32_t) pos; bestid = id; }
-        } else {
-            p.cand_id[bl * p.cand_stride + pos] = id;
-            p.cand_dist[bl * p.cand_stride + pos] = dist;
         }
     }
     if (top1) {
@@ -808,19 +808,86 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             p.out_dists[bl] = bestd;
             p.out_counts[bl] = 1;
         }
+        return;
+    }
+    // ---- top-k > 1: stream (dist, traversal position) keys through a block-local top-(k+1); if no two of those k+1
+    // distances are equal the answer is independent of std::partial_sort's internals, else hand over to the emulation ----
+    {
+        const int k1 = (p.topk + 1 < ncand) ? p.topk + 1 : ncand;
+        unsigned long long &s_kthr = s_buf[kRrBuf];
+        unsigned int &s_cnt = *reinterpret_cast<unsigned int *>(&s_buf[kRrBuf + 1]);
+        if (tid == 0) { s_cnt = 0u; s_kthr = ~0ull; }
+        __syncthreads();
+        for (int base = 0; base < ncand; base += 256) {
+            if (s_cnt + 256u > (unsigned int) kRrBuf) {
+                for (int i = tid; i < kRrBuf; i += 256)
+                    if ((unsigned int) i >= s_cnt) s_buf[i] = ~0ull;
+                rr_bitonic_sort(s_buf, tid);
+                if (tid == 0) { s_cnt = (unsigned int) k1; s_kthr = s_buf[k1 - 1]; }
+                __syncthreads();
+            }
+            const int pos = base + tid;
+            if (pos < ncand) {
+                int lo = 0, hi = nv;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+                }
+                const int no = (int) (s_sel[lo] & 0xffffffffu);
+                const int32_t id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo])];
+                const uint8_t *code = p.codes + (size_t) id * p.M;
+                float dist = 0.f;
+                for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+                const unsigned long long key =
+                    ((unsigned long long) f32_orderable(__float_as_uint(dist)) << 32) | (uint32_t) pos;
+                if (key < s_kthr) s_buf[atomicAdd(&s_cnt, 1u)] = key;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < kRrBuf; i += 256)
+            if ((unsigned int) i >= s_cnt) s_buf[i] = ~0ull;
+        rr_bitonic_sort(s_buf, tid);
+        if (tid == 0) {
+            int tie = 0;
+            for (int j = 0; j + 1 < k1; ++j)
+                if ((s_buf[j] >> 32) == (s_buf[j + 1] >> 32)) tie = 1;
+            s_misc[2] = tie;
+            if (tie) p.flag[bl] = 1;
+        }
+        __syncthreads();
+        if (s_misc[2]) {
+            if (p.queries) {
+                float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
+                for (int i = tid; i < MK; i += blockDim.x) dst[i] = lds[i];
+            }
+            return;
+        }
+        for (int j = tid; j < p.topk; j += 256) {
+            const unsigned long long key = s_buf[j];
+            const int pos = (int) (key & 0xffffffffu);
+            int lo = 0, hi = nv;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+            }
+            const int no = (int) (s_sel[lo] & 0xffffffffu);
+            p.out_ids[bl * p.topk + j] = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo])];
+            p.out_dists[bl * p.topk + j] = __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
+        }
+        if (tid == 0) p.out_counts[bl] = p.topk;
     }
 }
 
-bool ivf_fused_supported(int nlist, int64_t w)
+bool ivf_fused_supported(int nlist, int64_t w, int topk)
 {
-    return nlist <= kFusedMaxNlist && w <= kFusedMaxW;
+    return nlist <= kFusedMaxNlist && w <= kFusedMaxW && topk + 1 <= kRrBuf / 2;
 }
 
 hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st)
 {
     if (p.B == 0) return hipSuccess;
     const size_t smem = (((size_t) p.M * p.Ks * sizeof(float) + 15) & ~(size_t) 15) + (kFusedMaxW + 2) * 8 + 16 +
-                        (kFusedMaxW + 2) * 4 + 16 + (size_t) p.nlist * 4 + 16;
+                        (kFusedMaxW + 2) * 4 + 16 + (size_t) p.nlist * 4 + 32 + (p.topk > 1 ? (size_t) (kRrBuf + 2) * 8 : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
@@ -833,6 +900,7 @@ __global__ __launch_bounds__(64) void ivf_select_kernel(IvfParams p)
 {
     const int64_t bl = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (bl >= p.B) return;
+    if (p.flag && !p.flag[bl]) return;          // already answered by ivf_fused_kernel
     const int n = p.ncand[bl];
     if (n == 0) { p.out_counts[bl] = 0; return; }
     int32_t *ids = p.cand_id + bl * p.cand_stride;

@@ -88,7 +88,7 @@ struct IvfParams {
     int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
-bool ivf_fused_supported(int nlist, int64_t w);
+bool ivf_fused_supported(int nlist, int64_t w, int topk);
 hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st);
@@ -115,6 +115,7 @@ int lut_tile_for(int M, int Ks);
 
 // fast scan (fastscan.hip): 8-bit filter + exact re-rank, top-1
 bool fastscan_supported(int M, int Ks);
+int fastscan_rows(int M, int Ks);
 hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qlut,
                                int32_t *d_slack, hipStream_t st);
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,

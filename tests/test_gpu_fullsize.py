@@ -93,10 +93,10 @@ def test_full_ivf_with_L_equal_N_is_the_linear_scan(world):
     ii, idd, cnt = g.query_ivf_batch(Q[:32], 1, np.arange(N, dtype=np.int64), N)
     assert (cnt == 1).all()
     assert np.array_equal(idd.view(np.uint32), ld.view(np.uint32))
-    # ids may differ only where the minimum distance is attained by several codes (ivf walks lists, linear walks ids)
-    diff = np.nonzero(ii[:, 0] != li[:, 0])[0]
-    for b in diff:
-        assert np.array_equal(codes[ii[b, 0]], codes[li[b, 0]]) or True
+    # ids may differ only where the minimum distance is attained by several codes (ivf walks lists, linear walks ids):
+    # then both ids must carry the very same code
+    for b in np.nonzero(ii[:, 0] != li[:, 0])[0]:
+        assert np.array_equal(codes[ii[b, 0]], codes[li[b, 0]])
     # the bench configuration itself: L = L0, top-1, all 1024 queries answered, results inside the visited lists
     L0 = int(np.round(N / 1024))
     bi, bd, bc = g.query_ivf_batch(Q, 1, None, L0)

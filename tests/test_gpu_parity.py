@@ -215,7 +215,9 @@ def test_gpu_mfma_lut_within_tolerance():
 
 @pytest.mark.parametrize("shape", [(32, 256, 4, 50000, "sift", 0), (32, 256, 4, 30000, "unit", 6000),
                                    (16, 256, 6, 40000, "unit", 0), (8, 256, 16, 20000, "sift", 2000),
-                                   (4, 20, 10, 5000, "unit", 0), (20, 256, 2, 9000, "unit", 0), (3, 7, 37, 3000, "unit", 500)])
+                                   (4, 20, 10, 5000, "unit", 0), (20, 256, 2, 9000, "unit", 0), (3, 7, 37, 3000, "unit", 500),
+                                   (64, 256, 2, 30000, "unit", 3000), (48, 200, 3, 20000, "sift", 0), (72, 256, 1, 8000, "unit", 0),
+                                   (100, 256, 1, 4000, "unit", 0)])
 def test_gpu_filter_rerank_equals_exact_scan(shape):
     """scan_mode=1 (8-bit filter + exact re-rank, the default) must return exactly what scan_mode=0 (exact scan of
     every code) returns -- ids and distance bits -- incl. with heavy duplication (tied minima) and for subsets."""
@@ -266,8 +268,10 @@ def test_gpu_ivf_fused_equals_emulation_path():
     rng = np.random.default_rng(4)
     sub = np.sort(rng.choice(30000, 2500, replace=False)).astype(np.int64)
     Q = np.concatenate([qs, qs[::-1] * 0.7], 0)
-    for topk, L in ((1, 200), (1, 3000), (4, 200), (10, 17), (1, 1)):
+    for topk, L in ((1, 200), (1, 3000), (4, 200), (10, 17), (1, 1), (50, 3000), (200, 250), (7, 30000)):
         for tids in (None, sub):
+            if tids is not None and topk > len(tids):
+                continue
             g.set_option("ivf_fused", 1)
             a = g.query_ivf_batch(Q, topk, tids, L)
             g.set_option("ivf_fused", 0)
@@ -280,7 +284,8 @@ def test_gpu_ivf_fused_equals_emulation_path():
 
 @pytest.mark.parametrize("shape", [(32, 256, 4, 60000, "sift", 0), (32, 256, 4, 30000, "unit", 9000),
                                    (16, 256, 6, 40000, "unit", 0), (4, 20, 10, 5000, "unit", 0),
-                                   (3, 7, 37, 3000, "unit", 500), (20, 256, 2, 2000, "unit", 0)])
+                                   (3, 7, 37, 3000, "unit", 500), (20, 256, 2, 2000, "unit", 0),
+                                   (64, 256, 2, 20000, "unit", 2000)])
 def test_gpu_topk_filter_rerank_equals_sort_path(shape):
     """topk > 1: the two-pass filter (segment minima -> k-th bound -> candidates) + exact streaming top-k must equal
     the exhaustive path (all exact keys, full segmented sort) bit for bit, both being in canonical (dist, id) order."""
