@@ -109,7 +109,6 @@ struct rii_engine {
     // device state
     DevBuf d_codewords, d_cnorm, d_codes, d_centers, d_symtab, d_pl_off, d_pl_ids, d_list_len;
     bool have_symtab = false, have_cnorm = false, lists_dirty = true;
-    int64_t d_codes_n = 0;                           // codes resident on the device
 
     // scratch
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
@@ -236,7 +235,6 @@ int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
     HIP_TRY(hipMemcpyAsync(e->d_codes.as<uint8_t>() + old_bytes, codes, add, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->N += n;
-    e->d_codes_n = e->N;
     return RII_OK;
 }
 
@@ -428,10 +426,21 @@ int check_query_args(const rii_engine *e, int64_t B, int topk, int64_t S)
     return RII_OK;
 }
 
+constexpr int64_t kMaxBatch = 8192;       // queries per internal pass: bounds the table scratch (32 KiB fp32 per query)
+
 int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
                      int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
     if (B == 0) return RII_OK;
+    if (B > kMaxBatch) {
+        const int64_t D = (int64_t) e->M * e->Ds;
+        for (int64_t b0 = 0; b0 < B; b0 += kMaxBatch) {
+            const int64_t cur = std::min<int64_t>(kMaxBatch, B - b0);
+            RII_TRY(query_linear_dev(e, d_queries + b0 * D, cur, topk, d_tids, S, d_out_ids + b0 * topk,
+                                     d_out_dists + b0 * topk, st));
+        }
+        return RII_OK;
+    }
     RII_TRY(build_lut(e, d_queries, B, st, true));
     if (S == 0)
         return scan_topk(e, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
@@ -448,6 +457,15 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
                   int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st)
 {
     if (B == 0) return RII_OK;
+    if (B > kMaxBatch) {
+        const int64_t D = (int64_t) e->M * e->Ds;
+        for (int64_t b0 = 0; b0 < B; b0 += kMaxBatch) {
+            const int64_t cur = std::min<int64_t>(kMaxBatch, B - b0);
+            RII_TRY(query_ivf_dev(e, d_queries + b0 * D, cur, topk, d_tids, S, L, d_out_ids + b0 * topk,
+                                  d_out_dists + b0 * topk, d_out_counts + b0, st));
+        }
+        return RII_OK;
+    }
     const int64_t nlist = nlist_of(e);
     RII_TRY(sync_lists(e));
 
@@ -670,7 +688,7 @@ RII_API int rii_set_state(rii_engine *e, const uint8_t *centers, int64_t nlist, 
 {
     if (!e || nlist < 0 || N < 0) return set_err(RII_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(e->device));
-    e->codes.clear(); e->N = 0; e->d_codes_n = 0;
+    e->codes.clear(); e->N = 0;
     RII_TRY(append_codes(e, codes, N));
     e->centers.assign(centers, centers + (size_t) nlist * e->M);
     RII_TRY(upload_centers(e));
@@ -760,7 +778,6 @@ RII_API int rii_clear(rii_engine *e)
     e->codes.clear();
     e->lists.clear();
     e->N = 0;
-    e->d_codes_n = 0;
     e->lists_dirty = true;
     return RII_OK;
 }

@@ -307,3 +307,20 @@ def test_gpu_topk_filter_rerank_equals_sort_path(shape):
             i0, d0 = g.query_linear_batch(Q, topk, tids)
             assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32)), (shape, topk)
             assert np.array_equal(i1, i0), (shape, topk)
+
+
+def test_gpu_large_batch_is_chunked_transparently():
+    """B above the internal pass size (8192 queries) is processed in slices with identical per-row results."""
+    from rii_amd import RiiGpu
+    cw, codes, qs = make_problem(17, 8, 256, 4, 3000, "unit")
+    g = RiiGpu(cw, False)
+    g.add_codes(codes, False)
+    g.reconfigure(30, 2)
+    rng = np.random.default_rng(0)
+    Q = rng.random((20000, 32)).astype(np.float32)
+    ids, d = g.query_linear_batch(Q, 3, None)
+    i2, d2 = g.query_linear_batch(Q[15000:15040], 3, None)
+    assert np.array_equal(ids[15000:15040], i2) and np.array_equal(d[15000:15040], d2)
+    a = g.query_ivf_batch(Q, 2, None, 200)
+    b = g.query_ivf_batch(Q[9000:9050], 2, None, 200)
+    assert all(np.array_equal(x[9000:9050], y) for x, y in zip(a, b))
