@@ -48,3 +48,34 @@ def test_product_never_imports_the_oracle():
                 if "oracle" in low and any(tok in low for tok in ("import", "#include", "cdll", "dlopen", "-l", "librii_oracle")):
                     offenders.append("%s:%d: %s" % (os.path.join(dirpath, f), ln, line.strip()))
     assert not offenders, offenders
+
+
+def _build_c_client(tmp_path):
+    import subprocess
+    from rii_amd import core
+    so = core.build_library()
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-O1", "-std=c99", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke.c"), "-o", exe,
+                           "-L", os.path.dirname(so), "-lrii_amd", "-Wl,-rpath," + os.path.dirname(so),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_plain_c_client_links_and_fails_loudly_without_gpu(tmp_path):
+    """The boundary really is C: a gcc-compiled C99 program includes the header and links the library."""
+    import subprocess
+    from rii_amd import core
+    if core._lib().rii_device_count() > 0:
+        pytest.skip("a GPU is present (covered by the gpu-marked variant)")
+    exe = _build_c_client(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "failed loudly" in out.stdout, (out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_plain_c_client_on_gpu(tmp_path):
+    import subprocess
+    exe = _build_c_client(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "C ABI smoke OK" in out.stdout, (out.stdout, out.stderr)
