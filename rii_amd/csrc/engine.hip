@@ -113,7 +113,7 @@ struct rii_engine {
     // scratch
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
-        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16;
+        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
 
@@ -331,11 +331,14 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
             HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
             e->last_fs_B = B;
             if (topk == 1) {
+                RII_TRY(e->s_gthr.ensure((size_t) B * sizeof(uint32_t)));
+                HIP_TRY(hipMemsetAsync(e->s_gthr.p, 0xff, (size_t) B * sizeof(uint32_t), st));   // > any 16-bit threshold
                 {
                     ScopedTimer t(e, "scan", st);
                     HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
-                                         e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr, st));
+                                         e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
+                                         e->s_gthr.as<uint32_t>(), st));
                 }
                 ScopedTimer t(e, "rerank", st);
                 HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT,
@@ -350,7 +353,7 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
             {
                 ScopedTimer t(e, "scan", st);
                 HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
-                                     chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, st));
+                                     chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, st));
             }
             {
                 ScopedTimer t(e, "kth", st);
@@ -361,7 +364,7 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
                 ScopedTimer t(e, "scan", st);
                 HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
-                                     2, nullptr, e->s_thr16.as<uint32_t>(), st));
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, st));
             }
             ScopedTimer t(e, "rerank", st);
             HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT,
@@ -577,7 +580,7 @@ void free_all(rii_engine *e)
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
-                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16};
+                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;

@@ -183,6 +183,7 @@ struct FsArgs {
     int cap;
     uint16_t *segmin;              // MODE 1: [B][G] per-lane-segment minima of a(), G = gridDim.x * 1024
     const uint32_t *thr16;         // MODE 2: [B] fixed thresholds (candidate <=> a < thr16[b])
+    uint32_t *gthr;                // MODE 0: [B] thresholds shared by all chunk-blocks of a tile (pre-set to 0xffff)
 };
 
 // MODE 0: top-1, thresholds adapt to the block's running minimum.  MODE 1 / 2: the two passes of top-k (k > 1):
@@ -337,10 +338,22 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                     const uint32_t o = __shfl_xor(t, off);
                     t = o < t ? o : t;
                 }
-                if ((tid & 63) == 0 && t != 0xffffffffu && b < p.B)
-                    fs_thr_lower(&s_thr[2 * (q >> 2) + (q & 1)], (q >> 1) & 1, fs_thr_of(t, (uint32_t) p.slack[b]));
+                if ((tid & 63) == 0 && t != 0xffffffffu && b < p.B) {
+                    const uint32_t nt = fs_thr_of(t, (uint32_t) p.slack[b]);
+                    fs_thr_lower(&s_thr[2 * (q >> 2) + (q & 1)], (q >> 1) & 1, nt);
+                    atomicMin(&p.gthr[b], nt);
+                }
             }
             __syncthreads();
+        }
+        if (MODE == 0 && tid < QR) {
+            // adopt thresholds published by the blocks scanning the other chunks for the same queries.  A stale value
+            // only means a few more candidates: thresholds are upper bounds on (global minimum + slack + 1) at all times.
+            const int b = tile * QR + tid;
+            if (b < p.B) {
+                const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fs_thr_lower(&s_thr[2 * (tid >> 2) + (tid & 1)], (tid >> 1) & 1, g);
+            }
         }
         if (active) {
             // candidate test on the packed pairs: sat(thr+1 - a) != 0  <=>  a <= thr
@@ -367,7 +380,10 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                     if (a < t && b < p.B) {
                         if constexpr (MODE == 0) {
                             const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
-                            if (nt < t) fs_thr_lower(&s_thr[reg], high, nt);
+                            if (nt < t) {
+                                fs_thr_lower(&s_thr[reg], high, nt);
+                                atomicMin(&p.gthr[b], nt);       // let the other chunks of this tile prune with it too
+                            }
                         }
                         const unsigned int pos = atomicAdd(&p.cand_count[b], 1u);
                         if (pos < (unsigned int) p.cap)
@@ -428,10 +444,11 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        hipStream_t st)
+                        uint32_t *d_gthr, hipStream_t st)
 {
     if (B == 0 || n_codes == 0) return hipSuccess;
     FsArgs a;
+    a.gthr = d_gthr;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
     a.chunk_len = chunk_len; a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.segmin = d_segmin;
     a.thr16 = d_thr16;
