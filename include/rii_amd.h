@@ -111,7 +111,8 @@ int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *assign);
 
 /* Options: "lut_mode" (RII_LUT_*), "scan_mode" (1 = 8-bit filter + exact re-rank for top-1 [default], 0 = exact scan
  * only; results are identical), "ivf_fused" (1 = one fused launch for the common inverted-index case with per-query
- * exact fallback [default], 0 = always the std::partial_sort emulation kernels; results are identical), "cand_cap",
+ * exact fallback [default], 0 = always the std::partial_sort emulation kernels; results are identical),
+ * "fast_min_batch" (top-1 batches smaller than this use the exact scan; default 128), "cand_cap",
  * "scan_chunks" (0 = auto), "timing" (0/1). */
 int rii_set_option(rii_engine *e, const char *key, int64_t value);
 int64_t rii_get_option(const rii_engine *e, const char *key);

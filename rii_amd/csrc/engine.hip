@@ -90,6 +90,7 @@ struct rii_engine {
     int lut_mode = RII_LUT_EXACT;
     int scan_chunks = 0;        // 0 = auto
     int scan_mode = 1;          // 1 = 8-bit filter + exact re-rank for top-1 (fastscan.hip), 0 = exact scan only
+    int fast_min_batch = 128;   // top-1 batches below this take the exact scan (option "fast_min_batch")
     int cand_cap = 4096;
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
@@ -299,7 +300,9 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
     ScanParams sp;
     sp.codes = d_codes; sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks; sp.lut = e->s_lut.as<float>();
     sp.B = (int) B; sp.QT = e->QT; sp.best = nullptr; sp.keys = nullptr; sp.b0 = 0; sp.bc = 0;
-    if (e->scan_mode == 1 && fastscan_supported(e->M, e->Ks) && topk <= rerank_topk_max_k()) {
+    // small top-1 batches: the exact scan needs no candidate machinery and wins below ~128 queries (tools/sweep_batch.py)
+    const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
+    if (e->scan_mode == 1 && !small_top1 && fastscan_supported(e->M, e->Ks) && topk <= rerank_topk_max_k()) {
         // stage 0: quantise the tables; stage 1: byte-table scan -> candidates; stage 2: exact re-rank
         const int qr = fastscan_rows(e->M, e->Ks);
         const int64_t tiles = (B + qr - 1) / qr;
@@ -444,7 +447,7 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
         }
         return RII_OK;
     }
-    RII_TRY(build_lut(e, d_queries, B, st, true));
+    RII_TRY(build_lut(e, d_queries, B, st, !(topk == 1 && B < e->fast_min_batch)));
     if (S == 0)
         return scan_topk(e, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
     // subset search: gather the S target codes once for the whole batch, scan them, map ids back
@@ -938,6 +941,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->scan_mode = (int) value;
     } else if (k == "ivf_fused") {
         e->ivf_fused = value ? 1 : 0;
+    } else if (k == "fast_min_batch") {
+        e->fast_min_batch = (int) std::max<int64_t>(0, value);
     } else if (k == "cand_cap") {
         if (value < 1 || value > (1 << 20)) return set_err(RII_ERR_INVALID, "bad cand_cap");
         e->cand_cap = (int) value;
@@ -957,6 +962,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "scan_mode") return e->scan_mode;
     if (k == "cand_cap") return e->cand_cap;
     if (k == "ivf_fused") return e->ivf_fused;
+    if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;
         std::vector<unsigned int> h((size_t) e->last_fs_B);

@@ -228,6 +228,7 @@ def test_gpu_filter_rerank_equals_exact_scan(shape):
     Q = np.concatenate([qs, rng.permutation(qs.reshape(-1)).reshape(qs.shape), qs * 0.5, qs[:5] * 0.0 + 1e3], 0)
     g = RiiGpu(cw, False)
     g.add_codes(codes, False)
+    g.set_option("fast_min_batch", 0)                  # force the filter path also for this small batch
     sub = np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int64)
     for tids in (None, sub):
         g.set_option("scan_mode", 1)
@@ -249,6 +250,7 @@ def test_gpu_filter_rerank_overflow_falls_back_exactly():
     q = O.OracleRii(cw).codewords[:, codes[4999], :][np.arange(32), np.arange(32)].reshape(-1)   # the code's own centroid
     Q = np.stack([q, qs[0], qs[1]]).astype(np.float32)
     g.set_option("cand_cap", 64)
+    g.set_option("fast_min_batch", 0)
     i1, d1 = g.query_linear_batch(Q, 1, None)
     g.set_option("scan_mode", 0)
     i0, d0 = g.query_linear_batch(Q, 1, None)
