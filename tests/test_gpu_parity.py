@@ -326,3 +326,32 @@ def test_gpu_large_batch_is_chunked_transparently():
     a = g.query_ivf_batch(Q, 2, None, 200)
     b = g.query_ivf_batch(Q[9000:9050], 2, None, 200)
     assert all(np.array_equal(x[9000:9050], y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("M,Ks,Ds,N", [(1, 1, 1, 1), (1, 2, 3, 2), (2, 256, 1, 3), (32, 256, 4, 1), (5, 3, 2, 64), (1, 256, 128, 300)])
+def test_gpu_degenerate_shapes_vs_oracle(M, Ks, Ds, N):
+    """Smallest possible everything: one code, one subspace, one codeword, nlist == 1 and nlist == N, L == topk == 1."""
+    from rii_amd import RiiGpu
+    cw, codes, qs = make_problem(M * 1000 + N, M, Ks, Ds, N, "unit")
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False); o.add_codes(codes, False)
+    assert g.query_linear_batch(np.zeros((0, M * Ds), np.float32), 1, None)[0].shape == (0, 1)     # empty batch
+    for topk in sorted({1, N}):
+        ids, d = g.query_linear_batch(qs[:3], topk, None)
+        for b in range(3):
+            want = o.query_linear(qs[b], topk, E)
+            assert np.array_equal(np.asarray(want[1], np.float32).view(np.uint32), d[b].view(np.uint32))
+            if topk == 1:
+                assert list(ids[b]) == list(want[0])
+    for nlist in sorted({1, N}):
+        g.reconfigure(nlist, 2); o.reconfigure(nlist, 2)
+        assert g.coarse_centers == o.coarse_centers and g.posting_lists == o.posting_lists
+        for topk, L in {(1, 1), (1, N), (N, N)}:
+            ids, d, cnt = g.query_ivf_batch(qs[:3], topk, None, L)
+            for b in range(3):
+                n = int(cnt[b])
+                assert_same_result((ids[b, :n], d[b, :n]), o.query_ivf(qs[b], topk, E, L), "nlist=%d k=%d L=%d" % (nlist, topk, L))
+    one = np.array([N - 1], np.int64)
+    ids, d = g.query_linear_batch(qs[:2], 1, one)
+    assert (ids == N - 1).all()
