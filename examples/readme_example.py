@@ -1,8 +1,12 @@
 """The reference README's usage (README.md:80-140 there), unchanged except for the import line and the codec
 (nanopq is replaced by the stand-in of rii_amd.codec when it is not installed).  Needs an MI355X."""
+import os
+import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # run from a checkout
 
 try:
     import nanopq
