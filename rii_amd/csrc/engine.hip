@@ -521,6 +521,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     const bool fused = e->ivf_fused && ivf_fused_supported((int) nlist, w, topk);
     RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
     p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
+    p.sel_cap = ivf_fused_sel_cap((int) nlist, w);
     if (fused && e->lut_mode == RII_LUT_EXACT) {
         RII_TRY(build_lut(e, d_queries, B, st, false, 1, /*alloc_only=*/true));   // tables are built inside the fused kernel
         p.queries = d_queries;

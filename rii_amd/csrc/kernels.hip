@@ -676,10 +676,11 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     const int MK = p.M * p.Ks;
     float *lds = reinterpret_cast<float *>(smem);
     unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
-    unsigned long long *s_sel = reinterpret_cast<unsigned long long *>(base);            // [kFusedMaxW + 2]
-    unsigned long long *s_red = s_sel + (kFusedMaxW + 2);                                // [2]
-    int *s_cum = reinterpret_cast<int *>(s_red + 2);                                     // [kFusedMaxW + 1]
-    int *s_misc = s_cum + (kFusedMaxW + 2);                                              // [4]: ncand, nv, flag
+    const int SC = p.sel_cap;                                                            // kFusedMaxW + 2, or pow2 >= nlist
+    unsigned long long *s_sel = reinterpret_cast<unsigned long long *>(base);            // [SC]
+    unsigned long long *s_red = s_sel + SC;                                              // [2]
+    int *s_cum = reinterpret_cast<int *>(s_red + 2);                                     // [SC + 2]
+    int *s_misc = s_cum + (SC + 2);                                                      // [4]: ncand, nv, flag
     float *s_dist = reinterpret_cast<float *>(s_misc + 4);                               // [nlist]
     // top-k > 1: streaming selection buffer behind the coarse distances (8-byte aligned)
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(
@@ -707,10 +708,16 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         p.coarse_id[bl * nlist + c] = c;
     }
     __syncthreads();
-    // ---- w+1 rounds of block arg-min over keys strictly greater than the previous pick ----
+    // ---- the w+1 smallest (dist, list id) keys, ascending: few -> rounds of block arg-min over keys strictly greater
+    // than the previous pick; many -> bitonic sort of all list keys ----
     const int rounds = (w + 1 < nlist) ? w + 1 : nlist;
     unsigned long long last = 0ull;
-    for (int r = 0; r < rounds; ++r) {
+    if (rounds > kFusedMaxW + 1) {
+        for (int c = tid; c < SC; c += blockDim.x)
+            s_sel[c] = c < nlist ? (((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c) : ~0ull;
+        rr_bitonic_sort(s_sel, tid, SC);
+    }
+    for (int r = 0; r < rounds && rounds <= kFusedMaxW + 1; ++r) {
         if (tid == 0) s_red[0] = ~0ull;
         __syncthreads();
         unsigned long long best = ~0ull;
@@ -880,14 +887,23 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
 
 bool ivf_fused_supported(int nlist, int64_t w, int topk)
 {
-    return nlist <= kFusedMaxNlist && w <= kFusedMaxW && topk + 1 <= kRrBuf / 2;
+    (void) w;
+    return nlist <= kFusedMaxNlist && topk + 1 <= kRrBuf / 2;
+}
+int ivf_fused_sel_cap(int nlist, int64_t w)
+{
+    if (w <= kFusedMaxW) return kFusedMaxW + 2;
+    int c = 64;
+    while (c < nlist) c <<= 1;
+    return c;
 }
 
 hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st)
 {
     if (p.B == 0) return hipSuccess;
-    const size_t smem = (((size_t) p.M * p.Ks * sizeof(float) + 15) & ~(size_t) 15) + (kFusedMaxW + 2) * 8 + 16 +
-                        (kFusedMaxW + 2) * 4 + 16 + (size_t) p.nlist * 4 + 32 + (p.topk > 1 ? (size_t) (kRrBuf + 2) * 8 : 0);
+    const size_t smem = (((size_t) p.M * p.Ks * sizeof(float) + 15) & ~(size_t) 15) + (size_t) p.sel_cap * 8 + 16 +
+                        (size_t) (p.sel_cap + 2) * 4 + 16 + (size_t) p.nlist * 4 + 32 +
+                        (p.topk > 1 ? (size_t) (kRrBuf + 2) * 8 : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;

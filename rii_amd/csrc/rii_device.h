@@ -109,12 +109,13 @@ __device__ __forceinline__ size_t lut_index(int64_t b, int i, int MK, int QT)
 // ---- block-local streaming top-k support (256 threads): LDS key buffer + bitonic sort ----
 constexpr int kRrBuf = 2048;             // LDS key buffer; supports topk <= kRrBuf / 2
 
-__device__ inline void rr_bitonic_sort(unsigned long long *buf, int tid)      // sorts kRrBuf keys ascending, 256 threads
+// sorts n keys (n a power of two) ascending in LDS with 256 threads
+__device__ inline void rr_bitonic_sort(unsigned long long *buf, int tid, int n = kRrBuf)
 {
-    for (int size = 2; size <= kRrBuf; size <<= 1) {
+    for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int t = tid; t < kRrBuf / 2; t += 256) {
+            for (int t = tid; t < n / 2; t += 256) {
                 const int i = 2 * t - (t & (stride - 1));           // lower index of the pair
                 const int j = i + stride;
                 const bool up = ((i & size) == 0);

@@ -85,10 +85,12 @@ struct IvfParams {
     int64_t *out_ids; float *out_dists; int64_t *out_counts;   // rows b0.. of the caller's outputs
     const float *queries;         // non-null: ivf_fused_kernel builds the table itself from (queries, codewords)
     const float *codewords; int Ds; int arch;
+    int sel_cap;                  // ivf_fused_kernel: capacity of its list-selection array (ivf_fused_sel_cap)
     int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
 bool ivf_fused_supported(int nlist, int64_t w, int topk);
+int ivf_fused_sel_cap(int nlist, int64_t w);
 hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st);
