@@ -65,8 +65,9 @@ ref, arch, flav = O.load_reference(%(flavour)r)
 assert flav == %(flavour)r, (flav, %(flavour)r)
 for case in CASES:
     run_case(ref, arch, case)
-from tests.gen_golden import run_neartie
+from tests.gen_golden import run_neartie, run_stale
 run_neartie(ref, arch)
+run_stale(ref, arch)
 """
 
 
@@ -125,6 +126,30 @@ def run_neartie(ref, arch):
         np.savez_compressed(os.path.join(GOLD, "neartie_ds%d.%s.out.npz" % (Ds, arch)), pl_off=off, pl_ids=ids)
         np.savez_compressed(os.path.join(GOLD, "neartie_ds%d.in.npz" % Ds), codewords=cw, centers=centers,
                             new_codes=newc)
+
+
+STALE_CALLS = ((20, 100), (20, 40), (3, 30), (12, 50), (1, 51), (6, 49))
+
+
+def run_stale(ref, arch):
+    """the `vectors not found` return (src/rii.h:324-325) and the walk over the unsorted tail of the
+    coarse order: codes appended with update_flag=False after a reconfigure, so the lists cover only 50 of 5050 ids."""
+    cw, codes, qs = make_problem(13, 8, 64, 4, 5050, "unit")
+    e = ref.RiiCpp(cw, False)
+    e.add_codes(codes[:50], False)
+    e.reconfigure(10, 3)
+    e.add_codes(codes[50:], False)
+    out = {}
+    n_empty = 0
+    for ci, (topk, L) in enumerate(STALE_CALLS):
+        for b in range(8):
+            ids, d = e.query_ivf(qs[b], topk, E, L)
+            out["c%d_q%d_ids" % (ci, b)] = np.array(ids, np.int64)
+            out["c%d_q%d_d" % (ci, b)] = np.array(d, np.float32)
+            n_empty += (len(ids) == 0)
+    assert n_empty > 0
+    np.savez_compressed(os.path.join(GOLD, "stale_lists.%s.out.npz" % arch), **out)
+    np.savez_compressed(os.path.join(GOLD, "stale_lists.in.npz"), codewords=cw, codes=codes, queries=qs[:8])
 
 
 def hash_name(name):

@@ -73,3 +73,26 @@ def replay_neartie(make_engine, Ds, arch):
     e.set_coarse_centers(inp["centers"])
     e.add_codes(inp["new_codes"], True)
     assert [list(l) for l in e.posting_lists] == csr_to_lists(out["pl_off"], out["pl_ids"])
+
+
+STALE_CALLS = ((20, 100), (20, 40), (3, 30), (12, 50), (1, 51), (6, 49))
+
+
+def replay_stale(make_engine, arch):
+    """Empty-return / unsorted-tail branches of QueryIvf (src/rii.h:283-326) with stale posting lists."""
+    inp = np.load(os.path.join(GOLD, "stale_lists.in.npz"))
+    out = np.load(os.path.join(GOLD, "stale_lists.%s.out.npz" % arch))
+    cw, codes, qs = inp["codewords"], inp["codes"], inp["queries"]
+    e = make_engine(cw)
+    e.add_codes(codes[:50], False)
+    e.reconfigure(10, 3)
+    e.add_codes(codes[50:], False)
+    empty = np.array([], np.int64)
+    n_empty = 0
+    for ci, (topk, L) in enumerate(STALE_CALLS):
+        for b in range(8):
+            got = e.query_ivf(qs[b], topk, empty, L)
+            want = (out["c%d_q%d_ids" % (ci, b)], out["c%d_q%d_d" % (ci, b)])
+            assert_same_result(got, want, "stale k=%d L=%d q=%d" % (topk, L, b))
+            n_empty += (len(want[0]) == 0)
+    assert n_empty > 0

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie
+from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie, replay_stale
 from tests.util import make_problem, assert_same_result, assert_same_result_modulo_ties
 
 pytestmark = pytest.mark.gpu
@@ -355,3 +355,8 @@ def test_gpu_degenerate_shapes_vs_oracle(M, Ks, Ds, N):
     one = np.array([N - 1], np.int64)
     ids, d = g.query_linear_batch(qs[:2], 1, one)
     assert (ids == N - 1).all()
+
+
+@pytest.mark.parametrize("arch", ["avx512", "avx"])
+def test_gpu_stale_lists_golden(arch):
+    replay_stale(gpu_engine(arch), arch)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie, load_case, GOLD
+from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie, replay_stale, load_case, GOLD
 
 
 @pytest.mark.parametrize("arch", ["avx512", "avx"])
@@ -34,3 +34,8 @@ def test_neartie_flavours_differ():
     a = np.load(os.path.join(GOLD, "neartie_ds4.avx512.out.npz"))
     b = np.load(os.path.join(GOLD, "neartie_ds4.avx.out.npz"))
     assert not (np.array_equal(a["pl_off"], b["pl_off"]) and np.array_equal(a["pl_ids"], b["pl_ids"]))
+
+
+@pytest.mark.parametrize("arch", ["avx512", "avx"])
+def test_oracle_stale_lists_golden(arch):
+    replay_stale(lambda cw: O.OracleRii(cw, False, simd_arch=arch), arch)
