@@ -251,10 +251,13 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
         const int qr = fastscan_rows(e->M, e->Ks);
         RII_TRY(e->s_qlut.ensure((size_t) ((B + qr - 1) / qr) * e->M * e->Ks * qr));
         RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
+        RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
+        RII_TRY(e->s_gthr.ensure((size_t) B * sizeof(uint32_t)));
         ScopedTimer t(e, "lut", st);
         HIP_TRY(launch_lut_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch, e->QT,
-                                       e->s_lut.as<float>(), e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), st));
-        e->qlut_ready = true;
+                                       e->s_lut.as<float>(), e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
+                                       e->s_cand_cnt.as<unsigned int>(), e->s_gthr.as<uint32_t>(), st));
+        e->qlut_ready = true;            // ... and the candidate counters / shared thresholds are already reset
         return RII_OK;
     }
     ScopedTimer t(e, "lut", st);
@@ -331,11 +334,12 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
                 HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_qlut.as<uint8_t>(),
                                             e->s_slack.as<int32_t>(), st));
             }
-            HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
+            if (!e->qlut_ready) HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
             e->last_fs_B = B;
             if (topk == 1) {
                 RII_TRY(e->s_gthr.ensure((size_t) B * sizeof(uint32_t)));
-                HIP_TRY(hipMemsetAsync(e->s_gthr.p, 0xff, (size_t) B * sizeof(uint32_t), st));   // > any 16-bit threshold
+                if (!e->qlut_ready)
+                    HIP_TRY(hipMemsetAsync(e->s_gthr.p, 0xff, (size_t) B * sizeof(uint32_t), st));   // > any 16-bit threshold
                 {
                     ScopedTimer t(e, "scan", st);
                     HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),

@@ -121,12 +121,18 @@ __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restri
 __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__restrict__ queries, int64_t B,
                                                               const float *__restrict__ codewords, int M, int Ks, int Ds,
                                                               int arch, int QT, int QR, float *__restrict__ lut,
-                                                              uint8_t *__restrict__ qlut, int32_t *__restrict__ slack)
+                                                              uint8_t *__restrict__ qlut, int32_t *__restrict__ slack,
+                                                              unsigned int *__restrict__ cand_cnt,
+                                                              uint32_t *__restrict__ gthr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_t = reinterpret_cast<float *>(smem);
     const int64_t b = blockIdx.x;
     const int MK = M * Ks;
+    if (threadIdx.x == 0) {            // per-query state of the filter stage, reset here instead of by two memset launches
+        if (cand_cnt) cand_cnt[b] = 0u;
+        if (gthr) gthr[b] = 0xffffffffu;
+    }
     const float *q = queries + b * (int64_t) (M * Ds);
     for (int i = threadIdx.x; i < MK; i += blockDim.x) {
         const int m = i / Ks;
@@ -140,7 +146,8 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
 }
 
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
-                                  int arch, int QT, float *d_lut, uint8_t *d_qlut, int32_t *d_slack, hipStream_t st)
+                                  int arch, int QT, float *d_lut, uint8_t *d_qlut, int32_t *d_slack,
+                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     const size_t smem = (size_t) M * Ks * sizeof(float);
@@ -148,7 +155,7 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lut_build_quant_kernel, dim3((unsigned) B), dim3(256), smem, st, d_queries, B, d_codewords, M, Ks,
-                       Ds, arch, QT, fastscan_rows(M, Ks), d_lut, d_qlut, d_slack);
+                       Ds, arch, QT, fastscan_rows(M, Ks), d_lut, d_qlut, d_slack, d_cand_cnt, d_gthr);
     return hipGetLastError();
 }
 
