@@ -43,7 +43,11 @@ def parse():
 
 
 def cpu_baseline(cw, codes, queries, arch_hint):
-    """The reference's own path (per-query loop, OpenMP over N: src/rii.h:195-242) on the host cores."""
+    """The reference's own path (per-query loop, OpenMP over N: src/rii.h:195-242) on the host cores.  The reference
+    runs with OpenMP's default thread count (= all hardware threads); on a many-core host that is not its best setting
+    (the serial std::partial_sort + 16 MB resize dominate and fork/join over 256 threads costs), so a few thread counts
+    are timed on a bounded sample and the BEST one is reported, with `cores` = the threads it used."""
+    import ctypes
     from oracle import oracle as O
     ref, arch, flav = O.load_reference()
     E = np.array([], np.int64)
@@ -54,19 +58,35 @@ def cpu_baseline(cw, codes, queries, arch_hint):
         eng = O.OracleRii(cw, False, simd_arch=arch_hint)
         kind = "port"
     eng.add_codes(codes, False)
-    eng.query_linear(queries[0], 1, E)                        # warm-up
-    t0 = time.perf_counter()
-    for q in queries[:4]:
-        eng.query_linear(q, 1, E)
-    per = (time.perf_counter() - t0) / 4
-    n = int(min(len(queries), max(8, 15.0 / max(per, 1e-6))))    # ~15 s of CPU work
-    t0 = time.perf_counter()
-    ids = [eng.query_linear(q, 1, E)[0][0] for q in queries[:n]]
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "queries/s", "cores": os.cpu_count(), "kind": kind,
-            "sample": "%d of the batch's queries, one query per call (the reference has no batch entry point), "
-                      "full %d-code linear scan, top-1, OpenMP default threads%s" %
-                      (n, codes.shape[0], (", build flavour " + flav) if ref is not None else "")}, np.array(ids)
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+    ncpu = os.cpu_count() or 1
+    settings = sorted({ncpu, min(ncpu, 64), min(ncpu, 16), min(ncpu, 8)}, reverse=True) if gomp else [ncpu]
+    tried, best = [], None
+    ids_full = None
+    for nthr in settings:
+        if gomp:
+            gomp.omp_set_num_threads(int(nthr))
+        eng.query_linear(queries[0], 1, E)                        # warm-up
+        t0 = time.perf_counter()
+        for q in queries[:4]:
+            eng.query_linear(q, 1, E)
+        per = (time.perf_counter() - t0) / 4
+        n = int(min(len(queries), max(8, 6.0 / max(per, 1e-6))))  # ~6 s of CPU work per setting
+        t0 = time.perf_counter()
+        ids = [eng.query_linear(q, 1, E)[0][0] for q in queries[:n]]
+        dt = time.perf_counter() - t0
+        tried.append("%d threads: %.1f q/s over %d queries" % (nthr, n / dt, n))
+        if ids_full is None or len(ids) > len(ids_full):
+            ids_full = ids
+        if best is None or n / dt > best[0]:
+            best = (n / dt, nthr, n)
+    return {"value": best[0], "unit": "queries/s", "cores": best[1], "kind": kind,
+            "sample": "one query per call (the reference has no batch entry point), full %d-code linear scan, top-1%s; "
+                      "thread counts tried: %s" % (codes.shape[0], (", build flavour " + flav) if ref is not None else "",
+                                                    "; ".join(tried))}, np.array(ids_full)
 
 
 def measured_traffic(args):
@@ -303,7 +323,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": ("fscan" if (args.scan_mode and kernel == "scan") else kernel) + "_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": k_n,
-                         "lut_avg_launch_ms": lut_ms / max(lut_n, 1), **extra},
+                         "lut_avg_launch_ms": lut_ms / max(lut_n, 1), **extra,
+                         "note": "codes are shared by the whole batch through LDS/L2, so algorithmic bytes exceed HBM "
+                                 "traffic by design; the measured limiter of the scan is LDS bank conflicts "
+                                 "(profiles/r01_fscan_pmc_counters.txt: SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT)"},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "linear" and topk == 1:
             cb, cpu_ids = cpu_baseline(cw, codes, my_q.cpu().numpy(), arch)
