@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
     const float *q = queries + b * (int64_t) (M * Ds);
     for (int i = threadIdx.x; i < MK; i += blockDim.x) {
         const int m = i / Ks;
-        const float t = fvec_l2sqr_dev(q + (size_t) m * Ds, codewords + (size_t) i * Ds, Ds, arch);
+        const float t = fvec_l2sqr_any(q + (size_t) m * Ds, codewords + (size_t) i * Ds, Ds, arch);
         s_t[i] = t;
         lut[lut_index(b, i, MK, QT)] = t;
     }

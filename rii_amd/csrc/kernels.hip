@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void lut_build_kernel(const float *__restrict_
         const int m = i / Ks;
         const float *q = queries + b * (int64_t) (M * Ds) + (int64_t) m * Ds;
         const float *c = codewords + (size_t) i * Ds;
-        lut[lut_index(b, i, MK, QT)] = fvec_l2sqr_dev(q, c, Ds, arch);
+        lut[lut_index(b, i, MK, QT)] = fvec_l2sqr_any(q, c, Ds, arch);
     }
 }
 
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         // table built in place (exact fvec_L2sqr order): no global round trip for the common case
         const float *q = p.queries + (p.b0 + bl) * (int64_t) (p.M * p.Ds);
         for (int i = tid; i < MK; i += blockDim.x)
-            lds[i] = fvec_l2sqr_dev(q + (size_t) (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
+            lds[i] = fvec_l2sqr_any(q + (size_t) (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
     } else {
         stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
     }

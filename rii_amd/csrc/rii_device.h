@@ -63,6 +63,35 @@ __device__ inline float fvec_l2sqr_dev(const float *__restrict__ x, const float 
     return __fadd_rn(__fadd_rn(l4[0], l4[1]), __fadd_rn(l4[2], l4[3]));
 }
 
+// Straight-line form of fvec_L2sqr for d < 8 under the AVX / AVX512 variants (identical for both: the 16- and 8-wide
+// loops do not run; distance.h:144-169): lanes 0..3 take elements 0..3 (fma with 0 == rounded square), then the
+// zero-padded tail elements 4..7 are fma'd on top, then (l0+l1)+(l2+l3).  No loops: the loads of many table entries can
+// be in flight at once, which is what bounds the table kernels (one block builds 8192 entries).
+__device__ __forceinline__ float fvec_l2sqr_lt8_fused(const float *__restrict__ x, const float *__restrict__ y, int d)
+{
+    float l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t = (i < d) ? __fsub_rn(x[i], y[i]) : 0.f;
+        l[i] = __fmul_rn(t, t);                       // == fma(t, t, 0)
+    }
+    if (d > 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = (4 + i < d) ? __fsub_rn(x[4 + i], y[4 + i]) : 0.f;
+            l[i] = __fmaf_rn(t, t, l[i]);
+        }
+    }
+    return __fadd_rn(__fadd_rn(l[0], l[1]), __fadd_rn(l[2], l[3]));
+}
+
+// dispatcher used by the table kernels
+__device__ __forceinline__ float fvec_l2sqr_any(const float *__restrict__ x, const float *__restrict__ y, int d, int arch)
+{
+    if (d < 8 && arch != RII_SIMD_SSE) return fvec_l2sqr_lt8_fused(x, y, d);
+    return fvec_l2sqr_dev(x, y, d, arch);
+}
+
 // L2SquaredDistance of src/pqkmeans.cpp:164-173 as auto-vectorised by GCC -Ofast ([objcode] in the oracle).
 __device__ __forceinline__ float hsum_tree(float *t, int w)
 {
