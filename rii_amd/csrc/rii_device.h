@@ -63,32 +63,22 @@ __device__ inline float fvec_l2sqr_dev(const float *__restrict__ x, const float 
     return __fadd_rn(__fadd_rn(l4[0], l4[1]), __fadd_rn(l4[2], l4[3]));
 }
 
-// Straight-line form of fvec_L2sqr for d < 8 under the AVX / AVX512 variants (identical for both: the 16- and 8-wide
-// loops do not run; distance.h:144-169): lanes 0..3 take elements 0..3 (fma with 0 == rounded square), then the
-// zero-padded tail elements 4..7 are fma'd on top, then (l0+l1)+(l2+l3).  No loops: the loads of many table entries can
-// be in flight at once, which is what bounds the table kernels (one block builds 8192 entries).
-__device__ __forceinline__ float fvec_l2sqr_lt8_fused(const float *__restrict__ x, const float *__restrict__ y, int d)
+// Ds == 4 (the SIFT shape: D=128, M=32) in straight-line form with two 16-byte loads.  Identical for all three SIMD
+// variants: one 4-wide chunk into zeroed lanes (fma(t,t,+0) == the rounded square == SSE's mul-then-add-to-zero), no
+// tail, then (l0+l1)+(l2+l3) (distance.h:148-169 / :194-216 / :229-251).  Callers guarantee 16-byte alignment.
+__device__ __forceinline__ float fvec_l2sqr_ds4(const float *__restrict__ x, const float *__restrict__ y)
 {
-    float l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float t = (i < d) ? __fsub_rn(x[i], y[i]) : 0.f;
-        l[i] = __fmul_rn(t, t);                       // == fma(t, t, 0)
-    }
-    if (d > 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float t = (4 + i < d) ? __fsub_rn(x[4 + i], y[4 + i]) : 0.f;
-            l[i] = __fmaf_rn(t, t, l[i]);
-        }
-    }
-    return __fadd_rn(__fadd_rn(l[0], l[1]), __fadd_rn(l[2], l[3]));
+    const float4 a = *reinterpret_cast<const float4 *>(x);
+    const float4 c = *reinterpret_cast<const float4 *>(y);
+    const float t0 = __fsub_rn(a.x, c.x), t1 = __fsub_rn(a.y, c.y), t2 = __fsub_rn(a.z, c.z), t3 = __fsub_rn(a.w, c.w);
+    return __fadd_rn(__fadd_rn(__fmul_rn(t0, t0), __fmul_rn(t1, t1)), __fadd_rn(__fmul_rn(t2, t2), __fmul_rn(t3, t3)));
 }
 
-// dispatcher used by the table kernels
+// dispatcher used by the table kernels (x = query sub-vector at m*Ds floats, y = codeword at i*Ds floats: both 16-byte
+// aligned when Ds == 4 because the query rows and the codeword array are)
 __device__ __forceinline__ float fvec_l2sqr_any(const float *__restrict__ x, const float *__restrict__ y, int d, int arch)
 {
-    if (d < 8 && arch != RII_SIMD_SSE) return fvec_l2sqr_lt8_fused(x, y, d);
+    if (d == 4) return fvec_l2sqr_ds4(x, y);
     return fvec_l2sqr_dev(x, y, d, arch);
 }
 
