@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
         if (gthr) gthr[b] = 0xffffffffu;
     }
     const float *q = queries + b * (int64_t) (M * Ds);
-    for (int i = threadIdx.x; i < MK; i += blockDim.x) {
+#pragma unroll 8
+    for (int i = threadIdx.x; i < MK; i += 256) {        // independent entries: keep several pairs of loads in flight
         const int m = i / Ks;
         const float t = fvec_l2sqr_any(q + (size_t) m * Ds, codewords + (size_t) i * Ds, Ds, arch);
         s_t[i] = t;
@@ -694,9 +695,11 @@ __global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
         }
         __syncthreads();
     }
-    for (int i = tid; i < kRrBuf; i += 256)
+    int nsort = 64;                               // smallest power of two covering the keys actually collected
+    while (nsort < (int) s_cnt || nsort < k) nsort <<= 1;
+    for (int i = tid; i < nsort; i += 256)
         if ((unsigned int) i >= s_cnt) buf[i] = ~0ull;
-    rr_bitonic_sort(buf, tid);
+    rr_bitonic_sort(buf, tid, nsort);
     for (int j = tid; j < k; j += 256) {
         const unsigned long long key = buf[j];
         const uint32_t idx = (uint32_t) (key & 0xffffffffu);

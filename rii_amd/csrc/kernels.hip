@@ -693,7 +693,8 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     if (p.queries) {
         // table built in place (exact fvec_L2sqr order): no global round trip for the common case
         const float *q = p.queries + (p.b0 + bl) * (int64_t) (p.M * p.Ds);
-        for (int i = tid; i < MK; i += blockDim.x)
+#pragma unroll 8
+        for (int i = tid; i < MK; i += 256)      // independent entries: keep several pairs of loads in flight
             lds[i] = fvec_l2sqr_any(q + (size_t) (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
     } else {
         stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
@@ -702,7 +703,17 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     for (int c = tid; c < nlist; c += blockDim.x) {
         const uint8_t *code = p.centers + (size_t) c * p.M;
         float dist = 0.f;
-        for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+        if ((p.M & 3) == 0) {
+            const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
+            for (int i = 0; i < p.M / 4; ++i) {
+                const uint32_t wd = cw[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dist = __fadd_rn(dist, lds[(i * 4 + j) * p.Ks + ((wd >> (8 * j)) & 0xffu)]);
+            }
+        } else {
+            for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+        }
         s_dist[c] = dist;
         p.coarse_dist[bl * nlist + c] = dist;          // kept for the exact-emulation fallback
         p.coarse_id[bl * nlist + c] = c;
@@ -851,9 +862,11 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             }
             __syncthreads();
         }
-        for (int i = tid; i < kRrBuf; i += 256)
+        int nsort = 64;                           // smallest power of two covering the keys actually collected
+        while (nsort < (int) s_cnt) nsort <<= 1;
+        for (int i = tid; i < nsort; i += 256)
             if ((unsigned int) i >= s_cnt) s_buf[i] = ~0ull;
-        rr_bitonic_sort(s_buf, tid);
+        rr_bitonic_sort(s_buf, tid, nsort);
         if (tid == 0) {
             int tie = 0;
             for (int j = 0; j + 1 < k1; ++j)
