@@ -134,12 +134,15 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
         if (gthr) gthr[b] = 0xffffffffu;
     }
     const float *q = queries + b * (int64_t) (M * Ds);
-#pragma unroll 8
-    for (int i = threadIdx.x; i < MK; i += 256) {        // independent entries: keep several pairs of loads in flight
-        const int m = i / Ks;
-        const float t = fvec_l2sqr_any(q + (size_t) m * Ds, codewords + (size_t) i * Ds, Ds, arch);
-        s_t[i] = t;
-        lut[lut_index(b, i, MK, QT)] = t;
+    for (int m = 0; m < M; ++m) {                    // query sub-vector address is wave-uniform inside this loop
+        const float *qm = q + (size_t) m * Ds;
+        const float *cm = codewords + (size_t) m * Ks * Ds;
+        for (int ks = threadIdx.x; ks < Ks; ks += 256) {
+            const int i = m * Ks + ks;
+            const float t = fvec_l2sqr_any(qm, cm + (size_t) ks * Ds, Ds, arch);
+            s_t[i] = t;
+            lut[lut_index(b, i, MK, QT)] = t;
+        }
     }
     __syncthreads();
     LdsLutGetter g{s_t};

@@ -693,9 +693,12 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     if (p.queries) {
         // table built in place (exact fvec_L2sqr order): no global round trip for the common case
         const float *q = p.queries + (p.b0 + bl) * (int64_t) (p.M * p.Ds);
-#pragma unroll 8
-        for (int i = tid; i < MK; i += 256)      // independent entries: keep several pairs of loads in flight
-            lds[i] = fvec_l2sqr_any(q + (size_t) (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
+        for (int m = 0; m < p.M; ++m) {           // query sub-vector address is wave-uniform inside this loop
+            const float *qm = q + (size_t) m * p.Ds;
+            const float *cm = p.codewords + (size_t) m * p.Ks * p.Ds;
+            for (int ks = tid; ks < p.Ks; ks += 256)
+                lds[m * p.Ks + ks] = fvec_l2sqr_any(qm, cm + (size_t) ks * p.Ds, p.Ds, p.arch);
+        }
     } else {
         stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
     }
