@@ -21,8 +21,12 @@ namespace riiamd {
 
 constexpr int kFsThreads = 1024;
 int fastscan_rows(int M, int Ks);      // queries per LDS row of the byte tables: 16, 8 or 0 (unsupported shape)
-constexpr int kFsLevels = 63;          // quantisation levels - 1 (6 bits) ...
-constexpr int kFsFlush = 4;            // ... so that kFsFlush entries add up inside a byte: 4 * 63 = 252 < 256
+#ifndef RII_FS_LEVELS
+#define RII_FS_LEVELS 63
+#endif
+constexpr int kFsLevels = RII_FS_LEVELS;            // quantisation levels - 1 (63: 6 bits, 31: 5 bits) ...
+constexpr int kFsFlush = 255 / kFsLevels;            // ... so that kFsFlush entries add up inside a byte (4 x 63, 8 x 31)
+static_assert(kFsFlush * kFsLevels <= 255 && (kFsFlush == 4 || kFsFlush == 8), "byte-packed partial sums must not carry");
 
 // ---------------------------------------------------------------------------------------------------
 // per-query quantisation of the exact table to kFsLevels+1 levels (one byte per entry) + slack.  One block (256 threads) per query.
@@ -314,10 +318,10 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < MW; ++i) {          // 4 lookups per code word == one flush group
+                for (int i = 0; i < MW; ++i) {          // 4 lookups per code word; flush every kFsFlush lookups
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fs_add(pb, lut[(i * 4 + j) * KST + ((w[i] >> (8 * j)) & 0xffu)]);
-                    fs_flush<QR>(acc, pb);
+                    if ((i * 4 + 4) % kFsFlush == 0 || i == MW - 1) fs_flush<QR>(acc, pb);
                 }
             } else {
                 const uint8_t *c = p.codes + (size_t) n * M;
