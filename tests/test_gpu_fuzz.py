@@ -1,0 +1,80 @@
+"""GPU: seeded differential fuzzing of the whole C-ABI surface against the CPU oracle over random shapes
+(M, Ks, Ds, N, duplicates, nlist, iterations, topk, L, target sets).  Bit-exact; linear topk>1 under the tie contract."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import make_problem, assert_same_result, assert_same_result_modulo_ties
+
+pytestmark = pytest.mark.gpu
+E = np.array([], np.int64)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_against_oracle(seed):
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(1000 + seed)
+    M = int(rng.integers(1, 41))
+    Ks = int(rng.choice([2, 3, 16, 20, 64, 100, 255, 256]))
+    Ds = int(rng.integers(1, 10))
+    N = int(rng.choice([1, 2, 7, 63, 64, 65, 500, 1025, 3000, 6000]))
+    arch = str(rng.choice(["avx512", "avx", "sse"]))
+    scale = str(rng.choice(["unit", "sift"]))
+    dup = int(N * rng.choice([0.0, 0.0, 0.2, 0.9]))
+    cw, codes, qs = make_problem(seed, M, Ks, Ds, N, scale, dup=dup)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    n1 = int(rng.integers(0, N + 1))
+    for part in (codes[:n1], codes[n1:]):
+        if len(part):
+            g.add_codes(part, False); o.add_codes(part, False)
+    g.set_option("fast_min_batch", int(rng.choice([0, 128])))
+    Q = qs[:5]
+    all_codes = [codes]
+
+    def true_dist(q):
+        c = np.concatenate(all_codes, 0)
+        d = O.dtable(cw, q, arch)
+        acc = np.zeros(c.shape[0], np.float32)
+        for m in range(M):
+            acc = (acc + d[m, c[:, m]]).astype(np.float32)
+        return acc
+
+    # --- linear ---
+    for _ in range(3):
+        S = int(rng.integers(0, N + 1)) if rng.random() < 0.6 else 0
+        tids = np.sort(rng.choice(N, S, replace=False)).astype(np.int64) if S else E
+        pool = S if S else N
+        topk = int(rng.integers(1, min(pool, 60) + 1))
+        ids, d = g.query_linear_batch(Q, topk, tids)
+        for b in range(len(Q)):
+            want = o.query_linear(Q[b], topk, tids)
+            if topk == 1:
+                assert_same_result((ids[b], d[b]), want, "lin seed=%d b=%d" % (seed, b))
+            else:
+                assert_same_result_modulo_ties((ids[b], d[b]), want, true_dist(Q[b]), "lin k=%d seed=%d b=%d" % (topk, seed, b))
+    # --- inverted index ---
+    nlist = int(rng.integers(1, min(N, 200) + 1))
+    it = int(rng.integers(0, 4))
+    g.reconfigure(nlist, it); o.reconfigure(nlist, it)
+    assert g.coarse_centers == o.coarse_centers, "centres seed=%d" % seed
+    assert g.posting_lists == o.posting_lists, "lists seed=%d" % seed
+    if rng.random() < 0.5:                                    # append more codes, with or without list update
+        extra = make_problem(seed + 7, M, Ks, Ds, 50, scale)[1]
+        upd = bool(rng.random() < 0.5)
+        g.add_codes(extra, upd); o.add_codes(extra, upd)
+        all_codes.append(extra)
+        assert g.posting_lists == o.posting_lists
+    Nn = g.N
+    for _ in range(4):
+        S = int(rng.integers(1, Nn + 1)) if rng.random() < 0.5 else 0
+        tids = np.sort(rng.choice(Nn, S, replace=False)).astype(np.int64) if S else E
+        pool = S if S else Nn
+        topk = int(rng.integers(1, min(pool, 40) + 1))
+        L = int(rng.integers(topk, Nn + 1))
+        g.set_option("ivf_fused", int(rng.random() < 0.8))
+        ids, d, cnt = g.query_ivf_batch(Q, topk, tids, L)
+        for b in range(len(Q)):
+            want = o.query_ivf(Q[b], topk, tids, L)
+            n = int(cnt[b])
+            assert_same_result((ids[b, :n], d[b, :n]), want, "ivf seed=%d k=%d L=%d S=%d b=%d" % (seed, topk, L, S, b))
