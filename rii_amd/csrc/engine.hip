@@ -318,13 +318,19 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
         const int64_t len = std::max<int64_t>(1, (n_codes + c - 1) / c);
         const int chunks = (int) ((n_codes + len - 1) / len);
         const int64_t G = (int64_t) chunks * 1024;                        // lane segments per query (top-k passes)
-        const bool topk_ok = topk == 1 || (int64_t) topk * 2 <= std::min<int64_t>(n_codes, G);
+        // pass 1 of top-k only has to bound the k-th smallest quantised sum from above: a 1-in-`stride` sample of the
+        // 1024-code slabs does (its k-th smallest is the ~(stride*k)-th smallest overall: a few more candidates, 1/stride
+        // of the pass).  Needs enough sampled codes per lane segment for the bound to be tight and k distinct winners.
+        const int64_t slabs = (len + 1023) / 1024;
+        int stride = 1;
+        while (stride < 8 && slabs / (stride * 2) >= 8 && (n_codes / (stride * 2)) >= (int64_t) 64 * topk) stride *= 2;
+        const bool topk_ok = topk == 1 || (int64_t) topk * 2 <= std::min<int64_t>(n_codes / stride, G);
         if (topk_ok) {
             // candidate slots per query: small batches are cut into many chunks (each with its own running minimum,
             // hence more candidates per query), and can afford far more slots: ~128 MiB of slots in total
             int cap = (int) std::min<int64_t>(262144, std::max<int64_t>(e->cand_cap, ((int64_t) 1 << 24) / std::max<int64_t>(B, 1)));
             if (e->cand_cap_forced) cap = e->cand_cap;
-            if (topk > 1) cap = std::max(cap, 16 * topk);
+            if (topk > 1) cap = std::max(cap, 16 * topk * stride);
             RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * qr));
             RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
             RII_TRY(e->s_cand.ensure((size_t) B * cap * sizeof(unsigned long long)));
@@ -345,7 +351,7 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
                     HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
-                                         e->s_gthr.as<uint32_t>(), st));
+                                         e->s_gthr.as<uint32_t>(), 1, st));
                 }
                 ScopedTimer t(e, "rerank", st);
                 HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT,
@@ -360,7 +366,7 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
             {
                 ScopedTimer t(e, "scan", st);
                 HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
-                                     chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, st));
+                                     chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride, st));
             }
             {
                 ScopedTimer t(e, "kth", st);
@@ -371,7 +377,7 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
                 ScopedTimer t(e, "scan", st);
                 HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
-                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, st));
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, st));
             }
             ScopedTimer t(e, "rerank", st);
             HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT,

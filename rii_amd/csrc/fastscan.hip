@@ -199,6 +199,7 @@ struct FsArgs {
     uint16_t *segmin;              // MODE 1: [B][G] per-lane-segment minima of a(), G = gridDim.x * 1024
     const uint32_t *thr16;         // MODE 2: [B] fixed thresholds (candidate <=> a < thr16[b])
     uint32_t *gthr;                // MODE 0: [B] thresholds shared by all chunk-blocks of a tile (pre-set to 0xffff)
+    int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
 };
 
 // MODE 0: top-1, thresholds adapt to the block's running minimum.  MODE 1 / 2: the two passes of top-k (k > 1):
@@ -292,7 +293,9 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     const int64_t span = c_end > c_begin ? c_end - c_begin : 0;
     const int iters = (int) ((span + kFsThreads - 1) / kFsThreads);
 
-    for (int it = 0; it < iters; ++it) {
+    // MODE 1 only needs an UPPER bound on the k-th smallest sum, so it may look at a strided sample of the codes
+    const int it_step = (MODE == 1) ? p.sample_stride : 1;
+    for (int it = 0; it < iters; it += it_step) {
         const int64_t n = c_begin + (int64_t) it * kFsThreads + tid;
         const bool active = n < c_end;
         uint32_t acc[QR / 2], pb[QR / 4];
@@ -459,11 +462,12 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, hipStream_t st)
+                        uint32_t *d_gthr, int sample_stride, hipStream_t st)
 {
     if (B == 0 || n_codes == 0) return hipSuccess;
     FsArgs a;
     a.gthr = d_gthr;
+    a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
     a.chunk_len = chunk_len; a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.segmin = d_segmin;
     a.thr16 = d_thr16;

@@ -126,7 +126,7 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, hipStream_t st);
+                        uint32_t *d_gthr, int sample_stride, hipStream_t st);
 int fastscan_max_sum(int M);
 int rerank_topk_max_k();
 hipError_t launch_kth_threshold(const uint16_t *d_segmin, int64_t G, int64_t B, int k, int maxv, const int32_t *d_slack,
