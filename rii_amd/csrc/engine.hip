@@ -323,7 +323,11 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
         // of the pass).  Needs enough sampled codes per lane segment for the bound to be tight and k distinct winners.
         const int64_t slabs = (len + 1023) / 1024;
         int stride = 1;
-        while (stride < 8 && slabs / (stride * 2) >= 8 && (n_codes / (stride * 2)) >= (int64_t) 64 * topk) stride *= 2;
+        // the looser bound costs candidates (~stride * k per query), and once most waves meet a candidate in every slab the
+        // divergent emission path dominates pass 2: keep stride * k around a few hundred
+        while (stride < 8 && slabs / (stride * 2) >= 8 && (int64_t) stride * 2 * topk <= 256 &&
+               (n_codes / (stride * 2)) >= (int64_t) 64 * topk)
+            stride *= 2;
         const bool topk_ok = topk == 1 || (int64_t) topk * 2 <= std::min<int64_t>(n_codes / stride, G);
         if (topk_ok) {
             // candidate slots per query: small batches are cut into many chunks (each with its own running minimum,
