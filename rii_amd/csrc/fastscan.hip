@@ -381,20 +381,34 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                 const uint4 t4 = reinterpret_cast<const uint4 *>(s_thr)[i];
                 thr[4 * i] = t4.x; thr[4 * i + 1] = t4.y; thr[4 * i + 2] = t4.z; thr[4 * i + 3] = t4.w;
             }
-            uint32_t hit = 0u;
+            uint32_t hit = 0u, dsat[QR / 2];
 #pragma unroll
             for (int i = 0; i < QR / 2; ++i) {
                 const u16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, thr[i]),
                                                               __builtin_bit_cast(u16x2, acc[i]));
-                hit |= __builtin_bit_cast(uint32_t, d);
+                dsat[i] = __builtin_bit_cast(uint32_t, d);
+                hit |= dsat[i];
             }
             if (hit) {
+                // rare path: walk only the queries whose field is non-zero (usually exactly one)
+                uint32_t mask = 0u;
 #pragma unroll
-                for (int q = 0; q < QR; ++q) {
+                for (int i = 0; i < QR / 2; ++i) {        // register i: low field = query 4(i/2)+(i&1), high field = +2
+                    const int ql = 4 * (i >> 1) + (i & 1);
+                    mask |= ((dsat[i] & 0xffffu) ? 1u : 0u) << ql;
+                    mask |= ((dsat[i] >> 16) ? 1u : 0u) << (ql + 2);
+                }
+                while (mask) {
+                    const int q = __ffs((int) mask) - 1;
+                    mask &= mask - 1u;
                     const int b = tile * QR + q;
                     const int reg = 2 * (q >> 2) + (q & 1), high = (q >> 1) & 1;
-                    const uint32_t a = fs_get(acc, q);
-                    const uint32_t t = high ? (thr[reg] >> 16) : (thr[reg] & 0xffffu);
+                    uint32_t av = 0u, tv = 0u;
+#pragma unroll
+                    for (int i = 0; i < QR / 2; ++i)          // register select without dynamic indexing
+                        if (i == reg) { av = acc[i]; tv = thr[i]; }
+                    const uint32_t a = high ? (av >> 16) : (av & 0xffffu);
+                    const uint32_t t = high ? (tv >> 16) : (tv & 0xffffu);
                     if (a < t && b < p.B) {
                         if constexpr (MODE == 0) {
                             const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
