@@ -94,6 +94,7 @@ struct rii_engine {
     int cand_cap = 4096;
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
+    int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
     int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)        // candidate slots per query for the re-rank stage
     int timing = 0;
@@ -114,7 +115,7 @@ struct rii_engine {
     // scratch
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
-        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr;
+        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
 
@@ -245,17 +246,21 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
     if (qt <= 0) qt = e->QT;
     const size_t tiles = (size_t) ((B + qt - 1) / qt);
     RII_TRY(e->s_lut.ensure(tiles * (size_t) e->M * e->Ks * qt * sizeof(float)));
+    e->lut_qt = qt;
     if (alloc_only) return RII_OK;
     e->qlut_ready = false;
     if (want_quant && e->lut_mode == RII_LUT_EXACT && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
         const int qr = fastscan_rows(e->M, e->Ks);
         RII_TRY(e->s_qlut.ensure((size_t) ((B + qr - 1) / qr) * e->M * e->Ks * qr));
+        RII_TRY(e->s_qc.ensure((size_t) B * e->M * e->Ks));
+        e->lut_qt = 1;                    // the fused kernel writes the plain [b][M*Ks] layout (coalesced; re-rank reads it)
         RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
         RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
         RII_TRY(e->s_gthr.ensure((size_t) B * sizeof(uint32_t)));
         ScopedTimer t(e, "lut", st);
-        HIP_TRY(launch_lut_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch, e->QT,
-                                       e->s_lut.as<float>(), e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
+        HIP_TRY(launch_lut_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch,
+                                       e->s_lut.as<float>(), e->s_qc.as<uint8_t>(), e->s_qlut.as<uint8_t>(),
+                                       e->s_slack.as<int32_t>(),
                                        e->s_cand_cnt.as<unsigned int>(), e->s_gthr.as<uint32_t>(), st));
         e->qlut_ready = true;            // ... and the candidate counters / shared thresholds are already reset
         return RII_OK;
@@ -297,11 +302,11 @@ void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, i
 
 // the scan over `n_codes` codes at d_codes for B queries whose tables are in s_lut; ids are local indices
 // translated through d_remap (subset search) when given.
-int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B, int topk, const int64_t *d_remap,
-              int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int64_t n_codes, int64_t B, int topk,
+              const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
     ScanParams sp;
-    sp.codes = d_codes; sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks; sp.lut = e->s_lut.as<float>();
+    sp.codes = d_codes; sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks;
     sp.B = (int) B; sp.QT = e->QT; sp.best = nullptr; sp.keys = nullptr; sp.b0 = 0; sp.bc = 0;
     // small top-1 batches: the exact scan needs no candidate machinery and wins below ~128 queries (tools/sweep_batch.py)
     const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
@@ -341,8 +346,9 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
             RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
             if (!e->qlut_ready) {
                 ScopedTimer t(e, "quant", st);
-                HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_qlut.as<uint8_t>(),
-                                            e->s_slack.as<int32_t>(), st));
+                RII_TRY(e->s_qc.ensure((size_t) B * e->M * e->Ks));
+                HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->lut_qt, e->s_qc.as<uint8_t>(),
+                                            e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), st));
             }
             if (!e->qlut_ready) HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
             e->last_fs_B = B;
@@ -358,7 +364,7 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
                                          e->s_gthr.as<uint32_t>(), 1, st));
                 }
                 ScopedTimer t(e, "rerank", st);
-                HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT,
+                HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
                                            e->s_slack.as<int32_t>(), e->s_cand.as<unsigned long long>(),
                                            e->s_cand_cnt.as<unsigned int>(), cap, d_remap, B, d_out_ids, d_out_dists, topk, st));
                 return RII_OK;
@@ -384,12 +390,15 @@ int scan_topk(rii_engine *e, const uint8_t *d_codes, int64_t n_codes, int64_t B,
                                      2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, st));
             }
             ScopedTimer t(e, "rerank", st);
-            HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->QT,
+            HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
                                        e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap, d_remap, B,
                                        d_out_ids, d_out_dists, topk, st));
             return RII_OK;
         }
     }
+    // the exhaustive kernels read the tile-interleaved layout: re-lay the tables out if the fused kernel wrote plain ones
+    if (e->lut_qt != e->QT) RII_TRY(build_lut(e, d_queries, B, st, false));
+    sp.lut = e->s_lut.as<float>();
     if (topk == 1) {
         pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len);
         RII_TRY(e->s_best.ensure((size_t) B * sizeof(unsigned long long)));
@@ -463,14 +472,14 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
     }
     RII_TRY(build_lut(e, d_queries, B, st, !(topk == 1 && B < e->fast_min_batch)));
     if (S == 0)
-        return scan_topk(e, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
+        return scan_topk(e, d_queries, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
     // subset search: gather the S target codes once for the whole batch, scan them, map ids back
     RII_TRY(e->s_sub_codes.ensure((size_t) S * e->M));
     {
         ScopedTimer t(e, "gather", st);
         HIP_TRY(launch_gather_codes(e->d_codes.as<uint8_t>(), e->M, d_tids, S, e->s_sub_codes.as<uint8_t>(), st));
     }
-    return scan_topk(e, e->s_sub_codes.as<uint8_t>(), S, B, topk, d_tids, d_out_ids, d_out_dists, st);
+    return scan_topk(e, d_queries, e->s_sub_codes.as<uint8_t>(), S, B, topk, d_tids, d_out_ids, d_out_dists, st);
 }
 
 int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
@@ -598,7 +607,7 @@ void free_all(rii_engine *e)
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
-                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr};
+                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr, &e->s_qc};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;
@@ -917,7 +926,7 @@ RII_API int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *ou
     if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
     if (B == 0) return RII_OK;
     RII_TRY(stage_inputs(e, queries, B, nullptr, 0, 1));
-    RII_TRY(build_lut(e, e->s_queries.as<float>(), B, e->stream));
+    RII_TRY(build_lut(e, e->s_queries.as<float>(), B, e->stream));          // tile-interleaved (QT) layout
     const size_t bytes = (size_t) B * e->M * e->Ks * sizeof(float);
     RII_TRY(e->s_keys_a.ensure(bytes));
     HIP_TRY(launch_lut_untile(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_keys_a.as<float>(), e->stream));

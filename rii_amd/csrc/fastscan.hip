@@ -16,6 +16,7 @@
 #include "rii_internal.h"
 #include "rii_device.h"
 #include <float.h>
+#include <algorithm>
 
 namespace riiamd {
 
@@ -34,8 +35,8 @@ static_assert(kFsFlush * kFsLevels <= 255 && (kFsFlush == 4 || kFsFlush == 8), "
 // ---------------------------------------------------------------------------------------------------
 // shared body: T(i) returns the exact fp32 entry i = m*Ks + ks of query b's table
 template <typename Getter>
-__device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M, int Ks, int QR,
-                                               uint8_t *__restrict__ qlut, int32_t *__restrict__ slack)
+__device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M, int Ks,
+                                               uint8_t *__restrict__ qc, int32_t *__restrict__ slack)
 {
     __shared__ float s_lo[256], s_hi[256];          // per-m extrema (M <= 256)
     __shared__ double s_rlo[256], s_rhi[256];
@@ -70,7 +71,8 @@ __device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M
     const float delta = s_delta;
     const double ddelta = (double) delta;
     // 2. codes + residual extrema per m
-    uint8_t *dst = qlut + (size_t) (b / QR) * MK * QR + (b % QR);     // element i at dst[i*QR]
+    uint8_t *dst = qc + (size_t) b * MK;          // compact [b][M*Ks]: coalesced byte stores; qlut_interleave_kernel
+                                                  // then builds the [tile][M*Ks][QR] rows the scan reads
     for (int m = wave; m < M; m += 4) {
         const float lo = s_lo[m];
         double rlo = INFINITY, rhi = -INFINITY;
@@ -78,7 +80,7 @@ __device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M
             const float t = T(m * Ks + ks);
             const float x = floorf((t - lo) / delta + 0.5f);
             const int c = (x >= (float) kFsLevels) ? kFsLevels : (x > 0.f ? (int) x : 0);
-            dst[(size_t) (m * Ks + ks) * QR] = (uint8_t) c;
+            dst[m * Ks + ks] = (uint8_t) c;
             const double r = (double) t - ((double) lo + (double) c * ddelta);
             rlo = fmin(rlo, r);
             rhi = fmax(rhi, r);
@@ -113,19 +115,19 @@ struct LdsLutGetter {
 };
 
 __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restrict__ lut, int64_t B, int M, int Ks,
-                                                           int QT, int QR, uint8_t *__restrict__ qlut,
+                                                           int QT, uint8_t *__restrict__ qc,
                                                            int32_t *__restrict__ slack)
 {
     const int64_t b = blockIdx.x;
     GlobalLutGetter g{lut + (size_t) (b / QT) * M * Ks * QT + (b % QT), QT};
-    quantize_table(g, b, M, Ks, QR, qlut, slack);
+    quantize_table(g, b, M, Ks, qc, slack);
 }
 
 // fused: exact table (fvec_L2sqr order, src/distance.h:117-252) -> global fp32 (for the re-rank) AND its quantisation
 __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__restrict__ queries, int64_t B,
                                                               const float *__restrict__ codewords, int M, int Ks, int Ds,
-                                                              int arch, int QT, int QR, float *__restrict__ lut,
-                                                              uint8_t *__restrict__ qlut, int32_t *__restrict__ slack,
+                                                              int arch, float *__restrict__ lut,
+                                                              uint8_t *__restrict__ qc, int32_t *__restrict__ slack,
                                                               unsigned int *__restrict__ cand_cnt,
                                                               uint32_t *__restrict__ gthr)
 {
@@ -145,16 +147,63 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
             const int i = m * Ks + ks;
             const float t = fvec_l2sqr_any(qm, cm + (size_t) ks * Ds, Ds, arch);
             s_t[i] = t;
-            lut[lut_index(b, i, MK, QT)] = t;
+            lut[(size_t) b * MK + i] = t;          // plain [b][M*Ks] layout: coalesced, and what the re-rank stages
         }
     }
     __syncthreads();
     LdsLutGetter g{s_t};
-    quantize_table(g, b, M, Ks, QR, qlut, slack);
+    quantize_table(g, b, M, Ks, qc, slack);
 }
 
+// compact [b][M*Ks] bytes -> [tile][M*Ks][QR]: one 16-byte (QR=16) or 8-byte (QR=8) row per thread, coalesced both ways
+template <int QR>
+__global__ __launch_bounds__(256) void qlut_interleave_kernel(const uint8_t *__restrict__ qc, int64_t B, int MK,
+                                                              uint8_t *__restrict__ qlut)
+{
+    const int64_t tiles = (B + QR - 1) / QR;
+    const int64_t total = tiles * MK;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t tile = t / MK;
+        const int i = (int) (t - tile * MK);
+        uint32_t w[QR / 4];
+#pragma unroll
+        for (int k = 0; k < QR / 4; ++k) w[k] = 0u;
+#pragma unroll
+        for (int q = 0; q < QR; ++q) {
+            const int64_t b = tile * QR + q;
+            const uint32_t v = b < B ? qc[(size_t) b * MK + i] : 0u;
+            w[q >> 2] |= v << (8 * (q & 3));
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(qlut + (size_t) t * QR);
+#pragma unroll
+        for (int k = 0; k < QR / 4; ++k) dst[k] = w[k];
+    }
+}
+
+static hipError_t launch_qlut_interleave(const uint8_t *d_qc, int64_t B, int M, int Ks, uint8_t *d_qlut, hipStream_t st)
+{
+    const int qr = fastscan_rows(M, Ks);
+    const int MK = M * Ks;
+    const int64_t total = ((B + qr - 1) / qr) * MK;
+    int blocks = (int) std::min<int64_t>((total + 255) / 256, 8192);
+    if (qr == 16) hipLaunchKernelGGL(qlut_interleave_kernel<16>, dim3(blocks), dim3(256), 0, st, d_qc, B, MK, d_qlut);
+    else hipLaunchKernelGGL(qlut_interleave_kernel<8>, dim3(blocks), dim3(256), 0, st, d_qc, B, MK, d_qlut);
+    return hipGetLastError();
+}
+
+hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qc, uint8_t *d_qlut,
+                               int32_t *d_slack, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned) B), dim3(256), 0, st, d_lut, B, M, Ks, QT, d_qc, d_slack);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, st);
+}
+
+// fused: exact table in the plain [b][M*Ks] layout + quantisation
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
-                                  int arch, int QT, float *d_lut, uint8_t *d_qlut, int32_t *d_slack,
+                                  int arch, float *d_lut, uint8_t *d_qc, uint8_t *d_qlut, int32_t *d_slack,
                                   unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
@@ -163,17 +212,10 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lut_build_quant_kernel, dim3((unsigned) B), dim3(256), smem, st, d_queries, B, d_codewords, M, Ks,
-                       Ds, arch, QT, fastscan_rows(M, Ks), d_lut, d_qlut, d_slack, d_cand_cnt, d_gthr);
-    return hipGetLastError();
-}
-
-hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qlut,
-                               int32_t *d_slack, hipStream_t st)
-{
-    if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned) B), dim3(256), 0, st, d_lut, B, M, Ks, QT,
-                       fastscan_rows(M, Ks), d_qlut, d_slack);
-    return hipGetLastError();
+                       Ds, arch, d_lut, d_qc, d_slack, d_cand_cnt, d_gthr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, st);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -118,10 +118,10 @@ int lut_tile_for(int M, int Ks);
 // fast scan (fastscan.hip): 8-bit filter + exact re-rank, top-1
 bool fastscan_supported(int M, int Ks);
 int fastscan_rows(int M, int Ks);
-hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qlut,
+hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qc, uint8_t *d_qlut,
                                int32_t *d_slack, hipStream_t st);
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
-                                  int arch, int QT, float *d_lut, uint8_t *d_qlut, int32_t *d_slack,
+                                  int arch, float *d_lut, uint8_t *d_qc, uint8_t *d_qlut, int32_t *d_slack,
                                   unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st);
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
