@@ -172,7 +172,7 @@ def main_deep(args, world, rank, local, dev, arch):
                        "global_batch": B, "parallelism": "database-sharded x%d, all-gather + (dist,id) merge" % world,
                        "scan_mode": "byte-table filter + exact fp32 re-rank" if args.scan_mode else "exact fp32 scan"},
             "recall_at_1": None,
-            "roofline": {"bound": "hbm", "kernel": "fscan_kernel" if args.scan_mode else "scan_kernel",
+            "roofline": {"bound": "hbm", "kernel": "fscan_kernel" if (args.scan_mode and (topk > 1 or B >= 128)) else "scan_kernel",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": k_n}}))
     if use_dist:

@@ -281,9 +281,13 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
     return RII_OK;
 }
 
-void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, int64_t *chunk_len)
+// queries per table tile of the exhaustive scan for a batch of B: 1 for one or two queries (see launch_scan_wk)
+int exact_tile_for(const rii_engine *e, int64_t B, int topk) { return (topk == 1 && B <= 2) ? 1 : e->QT; }
+
+void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, int64_t *chunk_len, int qt = 0)
 {
-    const int64_t tiles = (B + e->QT - 1) / e->QT;
+    if (qt <= 0) qt = e->QT;
+    const int64_t tiles = (B + qt - 1) / qt;
     int64_t c = e->scan_chunks;
     if (c <= 0) {
         // ~2 workgroups' worth of tiles per CU, but never chunks shorter than 8K codes (table staging cost)
@@ -396,11 +400,13 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             return RII_OK;
         }
     }
-    // the exhaustive kernels read the tile-interleaved layout: re-lay the tables out if the fused kernel wrote plain ones
-    if (e->lut_qt != e->QT) RII_TRY(build_lut(e, d_queries, B, st, false));
+    // the exhaustive kernels read the tile-interleaved layout: re-lay the tables out if they are in another one
+    const int qt = exact_tile_for(e, B, topk);
+    if (e->lut_qt != qt) RII_TRY(build_lut(e, d_queries, B, st, false, qt));
     sp.lut = e->s_lut.as<float>();
+    sp.QT = qt;
     if (topk == 1) {
-        pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len);
+        pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len, qt);
         RII_TRY(e->s_best.ensure((size_t) B * sizeof(unsigned long long)));
         sp.best = e->s_best.as<unsigned long long>();
         HIP_TRY(hipMemsetAsync(sp.best, 0xff, (size_t) B * sizeof(unsigned long long), st));
@@ -470,7 +476,10 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
         }
         return RII_OK;
     }
-    RII_TRY(build_lut(e, d_queries, B, st, !(topk == 1 && B < e->fast_min_batch)));
+    {
+        const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
+        RII_TRY(build_lut(e, d_queries, B, st, !small_top1, small_top1 ? exact_tile_for(e, B, topk) : 0));
+    }
     if (S == 0)
         return scan_topk(e, d_queries, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
     // subset search: gather the S target codes once for the whole batch, scan them, map ids back

@@ -356,6 +356,13 @@ template <bool WK> static hipError_t launch_scan_wk(const ScanParams &sp, hipStr
     if (fast && sp.QT == 4 && sp.M == 16) return launch_scan_t<4, 4, 256, WK>(sp, tile0, ntiles, st);
     if (fast && sp.QT == 4 && sp.M == 32) return launch_scan_t<4, 8, 256, WK>(sp, tile0, ntiles, st);
     if (fast && sp.QT == 2 && sp.M == 64) return launch_scan_t<2, 16, 256, WK>(sp, tile0, ntiles, st);
+    if constexpr (!WK) {      // one or two queries: 4-byte table rows (ds_read_b32: 7 LDS cycles per 64 lookups instead of 11.7),
+                              // which is what lets a single query stream codes at the HBM rate
+        if (fast && sp.QT == 1 && sp.M == 8) return launch_scan_t<1, 2, 256, false>(sp, tile0, ntiles, st);
+        if (fast && sp.QT == 1 && sp.M == 16) return launch_scan_t<1, 4, 256, false>(sp, tile0, ntiles, st);
+        if (fast && sp.QT == 1 && sp.M == 32) return launch_scan_t<1, 8, 256, false>(sp, tile0, ntiles, st);
+        if (fast && sp.QT == 1 && sp.M == 64) return launch_scan_t<1, 16, 256, false>(sp, tile0, ntiles, st);
+    }
     if (sp.QT == 4) return launch_scan_t<4, 0, 0, WK>(sp, tile0, ntiles, st);
     if (sp.QT == 2) return launch_scan_t<2, 0, 0, WK>(sp, tile0, ntiles, st);
     return launch_scan_t<1, 0, 0, WK>(sp, tile0, ntiles, st);
