@@ -281,8 +281,9 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
     return RII_OK;
 }
 
-// queries per table tile of the exhaustive scan for a batch of B: 1 for one or two queries (see launch_scan_wk)
-int exact_tile_for(const rii_engine *e, int64_t B, int topk) { return (topk == 1 && B <= 2) ? 1 : e->QT; }
+// queries per table tile of the exhaustive scan for a batch of B: 1 for a single query (see launch_scan_wk; two
+// queries would walk the codes twice, which loses to one 4-query tile)
+int exact_tile_for(const rii_engine *e, int64_t B, int topk) { return (topk == 1 && B == 1) ? 1 : e->QT; }
 
 void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, int64_t *chunk_len, int qt = 0)
 {
