@@ -89,6 +89,14 @@ def cpu_baseline(cw, codes, queries, arch_hint):
                                                     "; ".join(tried))}, np.array(ids_full)
 
 
+def measured_traffic_key(key):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def measured_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/*_traffic.json:
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per the MI355X guide's gfx950 correction), or None if not measured for this
@@ -173,7 +181,8 @@ def main_deep(args, world, rank, local, dev, arch):
                        "scan_mode": "byte-table filter + exact fp32 re-rank" if args.scan_mode else "exact fp32 scan"},
             "recall_at_1": None,
             "roofline": {"bound": "hbm", "kernel": "fscan_kernel" if (args.scan_mode and (topk > 1 or B >= 128)) else "scan_kernel",
-                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": measured_traffic_key("deep/scan_mode=%d/M=16/N=%d/B=%d" % (args.scan_mode, n_shard, B)),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": k_n}}))
     if use_dist:
         dist.destroy_process_group()
