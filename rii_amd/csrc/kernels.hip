@@ -277,28 +277,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
 #pragma unroll
     for (int q = 0; q < QT; ++q) { bestd[q] = INFINITY; besti[q] = 0xffffffffu; }
 
-    // single-query streaming (QT == 1): four codes per lane per trip, loads issued before any table lookup, so that
-    // enough bytes are in flight per CU to cover the HBM latency (this is the HBM-bound regime of the scan)
-    if constexpr (QT == 1 && MW != 0 && !WRITE_KEYS) {
-        constexpr int U = 4;
-        for (int64_t n0 = c_begin + tid; n0 < c_end; n0 += (int64_t) U * kScanThreads) {
-            uint32_t w[U][MW];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t n = n0 + (int64_t) u * kScanThreads;
-                if (n < c_end) load_code_words<MW>(p.codes + (size_t) n * (MW * 4), w[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t n = n0 + (int64_t) u * kScanThreads;
-                if (n < c_end) {
-                    float acc[1];
-                    adc_words<1, MW, KST>(w[u], lut, acc);
-                    if (acc[0] < bestd[0]) { bestd[0] = acc[0]; besti[0] = (uint32_t) n; }
-                }
-            }
-        }
-    } else
     for (int64_t n = c_begin + tid; n < c_end; n += kScanThreads) {
         float acc[QT];
         if constexpr (MW != 0) {
