@@ -118,6 +118,9 @@ struct rii_engine {
         s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
+    void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
+    size_t h_pin_cap = 0;
+    DevBuf s_out_pack;              // [ids | dists | counts] of a small batch, copied back in one transfer
 
     std::map<std::string, KernelTimer> timers;
 };
@@ -621,6 +624,9 @@ void free_all(rii_engine *e)
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;
+    if (e->h_pin) (void) hipHostFree(e->h_pin);
+    e->h_pin = nullptr;
+    e->s_out_pack.release();
     for (auto &kv : e->timers)
         for (auto &pr : kv.second.pending) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     e->timers.clear();
@@ -863,6 +869,74 @@ RII_API int rii_get_posting_lists(const rii_engine *e, int64_t *off, int32_t *id
     return RII_OK;
 }
 
+// Host-pointer calls.  Small batches (the reference's one-query-per-call pattern above all) go through ONE pinned
+// staging buffer: queries in with a single async H2D, [ids | dists | counts] back with a single D2H -- the pageable
+// copies of the generic path cost more than the kernels at that size.
+namespace {
+constexpr size_t kPinLimit = 1 << 20;
+
+int ensure_pin(rii_engine *e, size_t bytes)
+{
+    if (bytes <= e->h_pin_cap) return RII_OK;
+    if (e->h_pin) HIP_TRY(hipHostFree(e->h_pin));
+    e->h_pin = nullptr; e->h_pin_cap = 0;
+    const size_t cap = std::max<size_t>(bytes, 64 << 10);
+    HIP_TRY(hipHostMalloc(&e->h_pin, cap, hipHostMallocDefault));
+    e->h_pin_cap = cap;
+    return RII_OK;
+}
+
+// runs one host-pointer query call; ivf == false: linear (out_counts unused)
+int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int topk, const int64_t *tids, int64_t S, int64_t L,
+               int64_t *out_ids, float *out_dists, int64_t *out_counts)
+{
+    const size_t D = (size_t) e->M * e->Ds;
+    const size_t q_bytes = (size_t) B * D * sizeof(float);
+    const size_t ids_bytes = (size_t) B * topk * sizeof(int64_t), d_bytes = (size_t) B * topk * sizeof(float);
+    const size_t c_bytes = ivf ? (size_t) B * sizeof(int64_t) : 0;
+    const size_t out_bytes = ids_bytes + c_bytes + d_bytes;           // 8-byte fields first: keeps every field aligned
+    const bool small = q_bytes + out_bytes <= kPinLimit;
+    hipStream_t st = e->stream;
+    if (!small) {
+        RII_TRY(stage_inputs(e, queries, B, tids, S, topk));
+        if (ivf)
+            RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, L, e->s_out_ids.as<int64_t>(),
+                                  e->s_out_dists.as<float>(), e->s_out_counts.as<int64_t>(), st));
+        else
+            RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S,
+                                     e->s_out_ids.as<int64_t>(), e->s_out_dists.as<float>(), st));
+        HIP_TRY(hipMemcpyAsync(out_ids, e->s_out_ids.p, ids_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_dists, e->s_out_dists.p, d_bytes, hipMemcpyDeviceToHost, st));
+        if (ivf) HIP_TRY(hipMemcpyAsync(out_counts, e->s_out_counts.p, c_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return RII_OK;
+    }
+    RII_TRY(ensure_pin(e, q_bytes + out_bytes));
+    RII_TRY(e->s_queries.ensure(std::max<size_t>(q_bytes, 16)));
+    RII_TRY(e->s_out_pack.ensure(std::max<size_t>(out_bytes, 16)));
+    RII_TRY(e->s_tids.ensure(std::max<size_t>((size_t) S * sizeof(int64_t), 16)));
+    unsigned char *pin = static_cast<unsigned char *>(e->h_pin);
+    memcpy(pin, queries, q_bytes);
+    HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, q_bytes, hipMemcpyHostToDevice, st));
+    if (S) HIP_TRY(hipMemcpyAsync(e->s_tids.p, tids, (size_t) S * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    unsigned char *dp = e->s_out_pack.as<unsigned char>();
+    int64_t *d_ids = reinterpret_cast<int64_t *>(dp);
+    int64_t *d_cnt = reinterpret_cast<int64_t *>(dp + ids_bytes);
+    float *d_d = reinterpret_cast<float *>(dp + ids_bytes + c_bytes);
+    if (ivf)
+        RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, L, d_ids, d_d, d_cnt, st));
+    else
+        RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, d_ids, d_d, st));
+    unsigned char *pout = pin + q_bytes;
+    HIP_TRY(hipMemcpyAsync(pout, dp, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(out_ids, pout, ids_bytes);
+    if (ivf) memcpy(out_counts, pout + ids_bytes, c_bytes);
+    memcpy(out_dists, pout + ids_bytes + c_bytes, d_bytes);
+    return RII_OK;
+}
+}  // namespace
+
 RII_API int rii_query_linear(rii_engine *e, const float *queries, int64_t B, int topk, const int64_t *tids, int64_t S,
                              int64_t *out_ids, float *out_dists)
 {
@@ -871,13 +945,7 @@ RII_API int rii_query_linear(rii_engine *e, const float *queries, int64_t B, int
     RII_TRY(check_query_args(e, B, topk, S));
     RII_TRY(check_tids_host(e, tids, S));
     if (B == 0) return RII_OK;
-    RII_TRY(stage_inputs(e, queries, B, tids, S, topk));
-    RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, e->s_out_ids.as<int64_t>(),
-                             e->s_out_dists.as<float>(), e->stream));
-    HIP_TRY(hipMemcpyAsync(out_ids, e->s_out_ids.p, (size_t) B * topk * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(out_dists, e->s_out_dists.p, (size_t) B * topk * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return RII_OK;
+    return host_query(e, false, queries, B, topk, tids, S, 0, out_ids, out_dists, nullptr);
 }
 
 static int check_ivf_args(const rii_engine *e, int topk, int64_t L)
@@ -897,14 +965,7 @@ RII_API int rii_query_ivf(rii_engine *e, const float *queries, int64_t B, int to
     RII_TRY(check_ivf_args(e, topk, L));
     RII_TRY(check_tids_host(e, tids, S));
     if (B == 0) return RII_OK;
-    RII_TRY(stage_inputs(e, queries, B, tids, S, topk));
-    RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, L, e->s_out_ids.as<int64_t>(),
-                          e->s_out_dists.as<float>(), e->s_out_counts.as<int64_t>(), e->stream));
-    HIP_TRY(hipMemcpyAsync(out_ids, e->s_out_ids.p, (size_t) B * topk * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(out_dists, e->s_out_dists.p, (size_t) B * topk * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(out_counts, e->s_out_counts.p, (size_t) B * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return RII_OK;
+    return host_query(e, true, queries, B, topk, tids, S, L, out_ids, out_dists, out_counts);
 }
 
 RII_API int rii_query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
