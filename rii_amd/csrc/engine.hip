@@ -120,7 +120,9 @@ struct rii_engine {
     size_t sort_temp_bytes = 0;
     void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
     size_t h_pin_cap = 0;
-    DevBuf s_out_pack;              // [ids | dists | counts] of a small batch, copied back in one transfer
+    DevBuf s_out_pack;              // [ids | counts | flags | dists] of a small batch, copied back in one transfer
+    riiamd::IvfParams ivf_deferred; // host-pointer small batches: fallback kernels are launched only if a flag came back set
+    bool ivf_has_deferred = false;
 
     std::map<std::string, KernelTimer> timers;
 };
@@ -496,8 +498,10 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
 }
 
 int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
-                  int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st)
+                  int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st,
+                  int32_t *d_flag_defer = nullptr)
 {
+    e->ivf_has_deferred = false;
     if (B == 0) return RII_OK;
     if (B > kMaxBatch) {
         const int64_t D = (int64_t) e->M * e->Ds;
@@ -557,6 +561,8 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     const bool fused = e->ivf_fused && ivf_fused_supported((int) nlist, w, topk);
     RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
     p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
+    const bool defer = fused && d_flag_defer && bc >= B;       // one launch group: the caller inspects the flags itself
+    if (defer) p.flag = d_flag_defer;
     p.sel_cap = ivf_fused_sel_cap((int) nlist, w);
     if (fused && e->lut_mode == RII_LUT_EXACT) {
         RII_TRY(build_lut(e, d_queries, B, st, false, 1, /*alloc_only=*/true));   // tables are built inside the fused kernel
@@ -577,6 +583,11 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             // order raise flag[b] and are redone by the exact emulation kernels below (which skip the others)
             ScopedTimer t(e, "ivf_fused", st);
             HIP_TRY(launch_ivf_fused(p, st));
+            if (defer) {
+                e->ivf_deferred = p;
+                e->ivf_has_deferred = true;
+                return RII_OK;
+            }
         } else {
             ScopedTimer t(e, "ivf_coarse", st);
             HIP_TRY(launch_ivf_coarse(p, st));
@@ -585,6 +596,18 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
         { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
         if (topk != 1) { ScopedTimer t(e, "ivf_select", st); HIP_TRY(launch_ivf_select(p, st)); }
     }
+    return RII_OK;
+}
+
+// the exact-emulation kernels for the queries ivf_fused_kernel flagged (deferred form, see host_query)
+int ivf_run_deferred_fallback(rii_engine *e, hipStream_t st)
+{
+    if (!e->ivf_has_deferred) return RII_OK;
+    const IvfParams &p = e->ivf_deferred;
+    { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
+    { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
+    if (p.topk != 1) { ScopedTimer t(e, "ivf_select", st); HIP_TRY(launch_ivf_select(p, st)); }
+    e->ivf_has_deferred = false;
     return RII_OK;
 }
 
@@ -894,7 +917,8 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     const size_t q_bytes = (size_t) B * D * sizeof(float);
     const size_t ids_bytes = (size_t) B * topk * sizeof(int64_t), d_bytes = (size_t) B * topk * sizeof(float);
     const size_t c_bytes = ivf ? (size_t) B * sizeof(int64_t) : 0;
-    const size_t out_bytes = ids_bytes + c_bytes + d_bytes;           // 8-byte fields first: keeps every field aligned
+    const size_t f_bytes = ivf ? (size_t) B * sizeof(int32_t) : 0;    // flags of ivf_fused_kernel (deferred fallback)
+    const size_t out_bytes = ids_bytes + c_bytes + f_bytes + d_bytes; // 8-byte fields first: keeps every field aligned
     const bool small = q_bytes + out_bytes <= kPinLimit;
     hipStream_t st = e->stream;
     if (!small) {
@@ -922,17 +946,31 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     unsigned char *dp = e->s_out_pack.as<unsigned char>();
     int64_t *d_ids = reinterpret_cast<int64_t *>(dp);
     int64_t *d_cnt = reinterpret_cast<int64_t *>(dp + ids_bytes);
-    float *d_d = reinterpret_cast<float *>(dp + ids_bytes + c_bytes);
+    int32_t *d_flag = reinterpret_cast<int32_t *>(dp + ids_bytes + c_bytes);
+    float *d_d = reinterpret_cast<float *>(dp + ids_bytes + c_bytes + f_bytes);
     if (ivf)
-        RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, L, d_ids, d_d, d_cnt, st));
+        RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, L, d_ids, d_d, d_cnt, st, d_flag));
     else
         RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, d_ids, d_d, st));
     unsigned char *pout = pin + q_bytes;
     HIP_TRY(hipMemcpyAsync(pout, dp, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (ivf && e->ivf_has_deferred) {
+        // the fused kernel answered every query unless it raised a flag (exact tie / walk past list w): only then are
+        // the emulation kernels launched -- three launches saved on the common path
+        const int32_t *flags = reinterpret_cast<const int32_t *>(pout + ids_bytes + c_bytes);
+        bool any = false;
+        for (int64_t b = 0; b < B; ++b) any |= (flags[b] != 0);
+        if (any) {
+            RII_TRY(ivf_run_deferred_fallback(e, st));
+            HIP_TRY(hipMemcpyAsync(pout, dp, out_bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        e->ivf_has_deferred = false;
+    }
     memcpy(out_ids, pout, ids_bytes);
     if (ivf) memcpy(out_counts, pout + ids_bytes, c_bytes);
-    memcpy(out_dists, pout + ids_bytes + c_bytes, d_bytes);
+    memcpy(out_dists, pout + ids_bytes + c_bytes + f_bytes, d_bytes);
     return RII_OK;
 }
 }  // namespace
