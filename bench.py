@@ -89,6 +89,18 @@ def cpu_baseline(cw, codes, queries, arch_hint):
                                                     "; ".join(tried))}, np.array(ids_full)
 
 
+def lds_gather(args, alg_bytes, avg_s, kernel):
+    """The roofline that actually binds the linear scan: table-entry bytes gathered from LDS per second against the
+    ds_read_b128 peak (256 B/clk/CU x 256 CUs x 2.4 GHz = 157.3 TB/s; MI355X guide, LDS table).  One (query, code, m)
+    lookup moves 1 byte with the byte-table filter and 4 bytes with the exact fp32 scan; random code bytes cost ~2.8x the
+    conflict-free cycles (SQ_LDS_BANK_CONFLICT), so ~0.36 is the practical ceiling of this formulation."""
+    if kernel != "scan" or avg_s <= 0:
+        return None
+    entry_bytes = 1 if (args.scan_mode and (args.topk > 1 or args.batch >= 128)) else 4
+    achieved = alg_bytes * entry_bytes / avg_s / 1e12
+    return {"achieved": achieved, "peak": 157.3, "unit": "TB/s", "frac": achieved / 157.3, "entry_bytes": entry_bytes}
+
+
 def measured_traffic_key(key):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
@@ -333,6 +345,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": k_n,
                          "lut_avg_launch_ms": lut_ms / max(lut_n, 1), **extra,
+                         "lds_gather": lds_gather(args, alg_bytes, avg_s, kernel),
                          "note": "codes are shared by the whole batch through LDS/L2, so algorithmic bytes exceed HBM "
                                  "traffic by design; the measured limiter of the scan is LDS bank conflicts "
                                  "(profiles/r01_fscan_pmc_counters.txt: SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT)"},
