@@ -592,9 +592,15 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             ScopedTimer t(e, "ivf_coarse", st);
             HIP_TRY(launch_ivf_coarse(p, st));
         }
-        { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
-        { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
-        if (topk != 1) { ScopedTimer t(e, "ivf_select", st); HIP_TRY(launch_ivf_select(p, st)); }
+        if (fused && ivf_exact_lds_supported(e->M, e->Ks, (int) nlist, L)) {
+            // flagged queries: exact std::partial_sort emulation with every working set in LDS
+            ScopedTimer t(e, "ivf_exact", st);
+            HIP_TRY(launch_ivf_exact_lds(p, st));
+        } else {
+            { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
+            { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
+            if (topk != 1) { ScopedTimer t(e, "ivf_select", st); HIP_TRY(launch_ivf_select(p, st)); }
+        }
     }
     return RII_OK;
 }
@@ -604,9 +610,14 @@ int ivf_run_deferred_fallback(rii_engine *e, hipStream_t st)
 {
     if (!e->ivf_has_deferred) return RII_OK;
     const IvfParams &p = e->ivf_deferred;
-    { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
-    { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
-    if (p.topk != 1) { ScopedTimer t(e, "ivf_select", st); HIP_TRY(launch_ivf_select(p, st)); }
+    if (ivf_exact_lds_supported(p.M, p.Ks, p.nlist, p.L)) {
+        ScopedTimer t(e, "ivf_exact", st);
+        HIP_TRY(launch_ivf_exact_lds(p, st));
+    } else {
+        { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
+        { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
+        if (p.topk != 1) { ScopedTimer t(e, "ivf_select", st); HIP_TRY(launch_ivf_select(p, st)); }
+    }
     e->ivf_has_deferred = false;
     return RII_OK;
 }

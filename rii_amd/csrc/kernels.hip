@@ -958,6 +958,111 @@ hipError_t launch_ivf_select(const IvfParams &p, hipStream_t st)
     return hipGetLastError();
 }
 
+// ===================================================================================================
+// Exact emulation for the flagged queries, entirely in LDS (block per query, early exit unless flag[b]):
+// the coarse (list, dist) pairs and the candidate (id, dist) pairs live in LDS, ONE lane re-runs libstdc++'s
+// std::partial_sort on them (64-cycle LDS accesses instead of dependent global loads: ~50 us instead of ~1 ms for a
+// query), the candidate scan in between is parallel.  Covers nlist <= kExactLdsMax and L <= kExactLdsMax; larger shapes
+// use the global-memory kernels above.
+// ===================================================================================================
+constexpr int kExactLdsMax = 4096;
+
+__global__ __launch_bounds__(256) void ivf_exact_lds_kernel(IvfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t bl = blockIdx.x;
+    if (p.flag && !p.flag[bl]) return;
+    const int MK = p.M * p.Ks;
+    const int nlist = p.nlist;
+    const int tid = threadIdx.x;
+    float *lds = reinterpret_cast<float *>(smem);
+    unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
+    float *s_cdist = reinterpret_cast<float *>(base);                 // [nlist]   coarse distances (sorted in place)
+    int32_t *s_cid = reinterpret_cast<int32_t *>(s_cdist + nlist);    // [nlist]   list ids
+    int32_t *s_cum = s_cid + nlist;                                   // [nlist+1] cumulative candidate counts
+    int32_t *s_misc = s_cum + (nlist + 1);                            // [4]
+    const int lcap = (int) (p.L < kExactLdsMax ? p.L : kExactLdsMax);
+    float *s_dd = reinterpret_cast<float *>(s_misc + 4);              // [lcap] candidate distances
+    int32_t *s_di = reinterpret_cast<int32_t *>(s_dd + lcap);         // [lcap] candidate ids
+
+    stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);               // handed over by ivf_fused_kernel (or built before)
+    __syncthreads();
+    for (int c = tid; c < nlist; c += blockDim.x) {
+        const uint8_t *code = p.centers + (size_t) c * p.M;
+        float dist = 0.f;
+        for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+        s_cdist[c] = dist;
+        s_cid[c] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        pq_partial_sort(s_cid, s_cdist, (long) p.w, (long) nlist);                  // src/rii.h:279-280
+        long long cnt = 0;
+        int nv = 0;
+        bool finished = false;
+        for (int c = 0; c < nlist; ++c) {                                           // src/rii.h:286-321
+            const long long len = p.list_len[s_cid[c]];
+            s_cum[c] = (int) cnt;
+            if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+            cnt += len;
+            if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+        }
+        if (!finished) { cnt = 0; nv = 0; }
+        s_cum[nv] = (int) cnt;
+        s_misc[0] = (int) cnt; s_misc[1] = nv;
+    }
+    __syncthreads();
+    const int ncand = s_misc[0], nv = s_misc[1];
+    if (ncand == 0) {
+        if (tid == 0) p.out_counts[bl] = 0;                                          // src/rii.h:324-325
+        return;
+    }
+    for (int pos = tid; pos < ncand; pos += blockDim.x) {
+        int lo = 0, hi = nv;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+        }
+        const int no = s_cid[lo];
+        const int32_t id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo])];
+        const uint8_t *code = p.codes + (size_t) id * p.M;
+        float dist = 0.f;
+        for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+        s_dd[pos] = dist;
+        s_di[pos] = id;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        pq_partial_sort(s_di, s_dd, (long) p.topk, (long) ncand);                    // src/rii.h:312-313
+        p.out_counts[bl] = p.topk;
+    }
+    __syncthreads();
+    for (int j = tid; j < p.topk; j += blockDim.x) {
+        p.out_ids[bl * p.topk + j] = s_di[j];
+        p.out_dists[bl * p.topk + j] = s_dd[j];
+    }
+}
+
+bool ivf_exact_lds_supported(int M, int Ks, int nlist, int64_t L)
+{
+    const size_t lcap = (size_t) (L < kExactLdsMax ? L : kExactLdsMax);
+    const size_t need = (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 + 16 + lcap * 8 + 64;
+    return nlist <= kExactLdsMax && L <= kExactLdsMax && need <= 160 * 1024;
+}
+
+hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st)
+{
+    if (p.B == 0) return hipSuccess;
+    const size_t lcap = (size_t) (p.L < kExactLdsMax ? p.L : kExactLdsMax);
+    const size_t smem = (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15) + (size_t) p.nlist * 8 + (size_t) (p.nlist + 1) * 4 + 16 +
+                        lcap * 8 + 64;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_exact_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_exact_lds_kernel, dim3((unsigned) p.B), dim3(256), smem, st, p);
+    return hipGetLastError();
+}
+
 // ---- target-id filtering (src/rii.h:294-296 does a binary search per posting; here: one bitmap per batch
 // and an order-preserving compaction of every list, so the traversal above is oblivious to S) ----
 __global__ void bitmap_set_kernel(const int64_t *__restrict__ tids, int64_t S, uint32_t *__restrict__ bitmap)

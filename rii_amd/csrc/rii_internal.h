@@ -95,6 +95,8 @@ hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_select(const IvfParams &p, hipStream_t st);
+bool ivf_exact_lds_supported(int M, int Ks, int nlist, int64_t L);
+hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st);
 hipError_t launch_bitmap_set(const int64_t *d_tids, int64_t S, uint32_t *d_bitmap, hipStream_t st);
 hipError_t launch_filter_lists(const int64_t *d_pl_off, const int32_t *d_pl_ids, int nlist,
                                const uint32_t *d_bitmap, int32_t *d_fids, int32_t *d_flen, hipStream_t st);
