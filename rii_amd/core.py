@@ -1,6 +1,6 @@
 """ctypes binding of librii_amd.so -- the thin shim that takes the place of the reference's pybind11 module
 `main` (src/main.cpp:11-61).  `RiiGpu` exposes the same attribute names as `main.RiiCpp` so that the Python
-class `Rii` (rii_amd/rii.py, mirroring rii/rii.py) is written against an identical surface, plus the batched
+class `Rii` (rii_amd/api.py, the counterpart of the reference's rii/rii.py) is written against an identical surface, plus the batched
 entry points the reference does not have.
 
 The product path never falls back to a CPU implementation: if the HIP library is missing it is built with
