@@ -103,3 +103,29 @@ def test_full_ivf_with_L_equal_N_is_the_linear_scan(world):
     assert (bc == 1).all() and (bd[:, 0] >= ld.min() * 0).all()
     lin_i, lin_d = g.query_linear_batch(Q, 1, None)
     assert (bd[:, 0] >= lin_d[:, 0]).all()           # an inverted-index answer can never beat the exhaustive one
+
+
+def test_large_index_beyond_2_pow_24_codes():
+    """20M codes (M=16): code indices above 2^24 (fp32-exact integer range) and several chunks per tile; the filter path
+    must agree with the exhaustive scan, and top-k with the full-sort path."""
+    from rii_amd import RiiGpu
+    Nbig, Mb = 20_000_000, 16
+    cw, _, qs = make_problem(77, Mb, 256, 6, 8, "unit")
+    rng = np.random.default_rng(123)
+    codes = rng.integers(0, 256, size=(Nbig, Mb), dtype=np.uint8)
+    plant = rng.integers(1 << 24, Nbig, size=8)
+    Q = rng.random((160, Mb * 6)).astype(np.float32)
+    for j, pos in enumerate(plant):                      # make query j's nearest code sit at a large index
+        codes[pos] = np.argmin(((cw - Q[j].reshape(Mb, 1, 6)) ** 2).sum(-1), axis=1)
+    g = RiiGpu(cw, False)
+    g.add_codes(codes, False)
+    g.set_option("scan_mode", 1)
+    i1, d1 = g.query_linear_batch(Q, 1, None)
+    i5, d5 = g.query_linear_batch(Q[:16], 5, None)
+    g.set_option("scan_mode", 0)
+    i0, d0 = g.query_linear_batch(Q, 1, None)
+    j5, e5 = g.query_linear_batch(Q[:16], 5, None)
+    assert np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
+    assert np.array_equal(i5, j5) and np.array_equal(d5.view(np.uint32), e5.view(np.uint32))
+    assert (i1[:8, 0] == plant).all()
+    assert (i1 >= (1 << 24)).any()
