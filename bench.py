@@ -214,8 +214,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("RII_BENCH_BACKEND", "nccl")     # "gloo": debugging the N>1 logic on a box with one GPU
+        if backend != "nccl":
+            local = int(os.environ.get("RII_BENCH_DEVICE", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (got WORLD_SIZE=%d)" % (args.gpus, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -241,9 +244,28 @@ def main():
         t_codes = torch.empty((N, M), dtype=torch.uint8, device=dev)
         t_q = torch.empty((B * world, D), dtype=torch.float32, device=dev)
         t_gt = torch.empty((B * world,), dtype=torch.int64, device=dev)
+    host_coll = use_dist and dist.get_backend() != "nccl"         # gloo: run the collectives on host copies
+
+    def bcast(t):
+        if host_coll:
+            c = t.cpu()
+            dist.broadcast(c, 0)
+            t.copy_(c)
+        else:
+            dist.broadcast(t, 0)
+
+    def all_gather(outs, t):
+        if host_coll:
+            hs = [torch.empty_like(t, device="cpu") for _ in outs]
+            dist.all_gather(hs, t.cpu())
+            for o, h in zip(outs, hs):
+                o.copy_(h)
+        else:
+            dist.all_gather(outs, t)
+
     if use_dist:
         for t in (t_cw, t_codes, t_q, t_gt):
-            dist.broadcast(t, 0)
+            bcast(t)
     cw = t_cw.cpu().numpy()
     codes = t_codes.cpu().numpy()
     del t_codes
@@ -279,8 +301,8 @@ def main():
         else:
             eng.query_linear_dev(my_q.data_ptr(), B, topk, d_tids, S, out_ids.data_ptr(), out_d.data_ptr(), stream)
         if use_dist:       # top-k gather over xGMI (12 KB per rank: latency-bound)
-            dist.all_gather(gather_ids, out_ids)
-            dist.all_gather(gather_d, out_d)
+            all_gather(gather_ids, out_ids)
+            all_gather(gather_d, out_d)
 
     def barrier():
         if use_dist:
@@ -299,7 +321,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.set_option("timing", 0)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_coll else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -315,7 +337,7 @@ def main():
             extra[kn + "_avg_launch_ms"] = ms_ / n_
     recall = bd.recall_at_r(out_ids.cpu().numpy(), my_gt, 1)
     if use_dist:
-        r = torch.tensor([recall], dtype=torch.float64, device=dev)
+        r = torch.tensor([recall], dtype=torch.float64, device="cpu" if host_coll else dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         recall = float(r.item()) / world
         allq = torch.cat(gather_ids, dim=0)          # the gathered batch really is every rank's rows, in rank order
