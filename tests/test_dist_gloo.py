@@ -39,7 +39,19 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+class _GpuBatch(object):
+    """The real engine (both ranks share GPU 0 in this test; the collective is gloo on host tensors)."""
+
+    def __init__(self, cw, codes):
+        from rii_amd import RiiGpu
+        self.g = RiiGpu(cw, False, simd_arch="avx512", device=0)
+        self.g.add_codes(codes, False)
+
+    def query_linear_batch(self, Q, topk, tids=None):
+        return self.g.query_linear_batch(Q, topk, tids)
+
+
+def _worker(rank, world, port, q, use_gpu=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -51,7 +63,7 @@ def _worker(rank, world, port, q):
         Q = qs[:8]
         # --- database sharding ---
         s, e = rd.shard_range(N, rank, world)
-        local = _OracleBatch(cw, codes[s:e])
+        local = (_GpuBatch if use_gpu else _OracleBatch)(cw, codes[s:e])
         idx = rd.DbShardedIndex(local, s, e)
         for topk in (1, 5, 50):
             gi, gd = idx.query_linear_batch(Q, topk)
@@ -68,7 +80,7 @@ def _worker(rank, world, port, q):
         wi, wd = full.query_linear_batch(Q, 3, few)
         assert np.array_equal(gi.numpy(), wi)
         # --- query sharding ---
-        qidx = rd.QueryShardedIndex(full)
+        qidx = rd.QueryShardedIndex(_GpuBatch(cw, codes) if use_gpu else full)
         gi, gd = qidx.query_linear_batch(Q, 4)
         wi, wd = full.query_linear_batch(Q, 4)
         assert np.array_equal(gi.numpy(), wi) and np.array_equal(gd.numpy().view(np.uint32), wd.view(np.uint32))
@@ -80,17 +92,28 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world2_gloo_db_and_query_sharding():
+def _run_world2(use_gpu):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_gpu)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_world2_gloo_db_and_query_sharding():
+    _run_world2(use_gpu=False)
+
+
+@pytest.mark.gpu
+def test_world2_sharded_real_engines_match_single_index():
+    """The same two-rank decomposition with the HIP engine on each rank (database shards / query shards), checked
+    against the oracle's answer on the concatenated database."""
+    _run_world2(use_gpu=True)
 
 
 def test_merge_topk_canonical_rule():
