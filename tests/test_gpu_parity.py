@@ -360,3 +360,37 @@ def test_gpu_degenerate_shapes_vs_oracle(M, Ks, Ds, N):
 @pytest.mark.parametrize("arch", ["avx512", "avx"])
 def test_gpu_stale_lists_golden(arch):
     replay_stale(gpu_engine(arch), arch)
+
+
+def test_gpu_input_layouts_and_bad_inputs():
+    """Strided / Fortran-ordered arrays are accepted like pybind11's array_t accepts them; NaN queries and unsorted
+    target ids must not crash or hang the engine."""
+    from rii_amd import RiiGpu
+    cw, codes, qs = make_problem(9, 8, 256, 4, 4000, "unit")
+    g = RiiGpu(np.asfortranarray(cw), False)
+    g.add_codes(np.asfortranarray(codes), False)
+    g.reconfigure(40, 2)
+    big = np.zeros((32, 64), np.float32)
+    big[::2, ::2] = qs
+    strided = big[::2, ::2]                                  # non-contiguous view of the 16 queries
+    a = g.query_linear_batch(strided, 3, None)
+    b = g.query_linear_batch(np.ascontiguousarray(strided), 3, None)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert g.query_linear(strided[5], 1, E) == g.query_linear(qs[5].copy(), 1, E)
+    bad = qs[:4].copy()
+    bad[1, 3] = np.nan
+    bad[2, 0] = np.inf
+    ids, d = g.query_linear_batch(bad, 2, None)             # must return; rows 0 and 3 are ordinary queries
+    ok = g.query_linear_batch(qs[:4], 2, None)
+    assert np.array_equal(ids[[0, 3]], ok[0][[0, 3]]) and np.array_equal(d[[0, 3]], ok[1][[0, 3]])
+    g.query_ivf_batch(bad, 2, None, 300)
+    with pytest.raises(ValueError):
+        g.query_linear(qs[0], 1, np.array([5, 3, 9], np.int64))       # unsorted target ids
+    with pytest.raises(ValueError):
+        g.query_linear(qs[0], 1, np.array([3, 3, 9], np.int64))       # duplicates
+    with pytest.raises(ValueError):
+        g.query_linear(qs[0], 1, np.array([3, 4000], np.int64))       # out of range
+    with pytest.raises(TypeError):
+        g.query_linear(qs[0], 1, np.array([3, 9], np.int32))          # noconvert (src/main.cpp:20)
+    with pytest.raises(TypeError):
+        g.add_codes(codes.astype(np.int32), False)
