@@ -115,7 +115,7 @@ struct rii_engine {
     // scratch
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
-        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc;
+        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
@@ -564,6 +564,12 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     const bool defer = fused && d_flag_defer && bc >= B;       // one launch group: the caller inspects the flags itself
     if (defer) p.flag = d_flag_defer;
     p.sel_cap = ivf_fused_sel_cap((int) nlist, w);
+    p.flag_list = nullptr; p.nflag = nullptr;
+    if (fused) {                      // [0] = count, [1..] = flagged query indices of the current launch group
+        RII_TRY(e->s_flag_list.ensure((size_t) (bc + 1) * sizeof(int32_t)));
+        p.nflag = e->s_flag_list.as<int>();
+        p.flag_list = e->s_flag_list.as<int32_t>() + 1;
+    }
     if (fused && e->lut_mode == RII_LUT_EXACT) {
         RII_TRY(build_lut(e, d_queries, B, st, false, 1, /*alloc_only=*/true));   // tables are built inside the fused kernel
         p.queries = d_queries;
@@ -579,6 +585,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
         p.out_dists = d_out_dists + b0 * topk;
         p.out_counts = d_out_counts + b0;
         if (fused) {
+            HIP_TRY(hipMemsetAsync(p.nflag, 0, sizeof(int), st));
             // common case answered in one launch; queries whose answer could hinge on std::partial_sort's internal
             // order raise flag[b] and are redone by the exact emulation kernels below (which skip the others)
             ScopedTimer t(e, "ivf_fused", st);
@@ -654,7 +661,7 @@ void free_all(rii_engine *e)
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
-                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr, &e->s_qc};
+                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr, &e->s_qc, &e->s_flag_list};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;

@@ -18,6 +18,7 @@
 #include "rii_internal.h"
 #include "rii_device.h"
 #include <float.h>
+#include <algorithm>
 
 namespace riiamd {
 
@@ -778,6 +779,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         s_cum[nv] = (int) cnt;
         s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = flag;
         p.flag[bl] = flag;
+        if (flag && p.flag_list) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
         if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
         s_red[1] = ~0ull;
     }
@@ -882,7 +884,10 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             for (int j = 0; j + 1 < k1; ++j)
                 if ((s_buf[j] >> 32) == (s_buf[j + 1] >> 32)) tie = 1;
             s_misc[2] = tie;
-            if (tie) p.flag[bl] = 1;
+            if (tie) {
+                p.flag[bl] = 1;
+                if (p.flag_list) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
+            }
         }
         __syncthreads();
         if (s_misc[2]) {
@@ -970,8 +975,13 @@ constexpr int kExactLdsMax = 4096;
 __global__ __launch_bounds__(256) void ivf_exact_lds_kernel(IvfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int64_t bl = blockIdx.x;
-    if (p.flag && !p.flag[bl]) return;
+    // a small persistent grid walks the compact list of flagged queries (the kernel needs ~100 KiB of LDS per block:
+    // launching one block per query of the batch would serialise thousands of empty blocks behind that footprint)
+    const int nflag = p.flag_list ? *p.nflag : (int) p.B;
+    for (int fi = blockIdx.x; fi < nflag; fi += gridDim.x) {
+    const int64_t bl = p.flag_list ? p.flag_list[fi] : fi;
+    if (!p.flag_list && p.flag && !p.flag[bl]) continue;
+    __syncthreads();                                   // previous query's LDS contents are dead from here on
     const int MK = p.M * p.Ks;
     const int nlist = p.nlist;
     const int tid = threadIdx.x;
@@ -1015,7 +1025,7 @@ __global__ __launch_bounds__(256) void ivf_exact_lds_kernel(IvfParams p)
     const int ncand = s_misc[0], nv = s_misc[1];
     if (ncand == 0) {
         if (tid == 0) p.out_counts[bl] = 0;                                          // src/rii.h:324-325
-        return;
+        continue;
     }
     for (int pos = tid; pos < ncand; pos += blockDim.x) {
         int lo = 0, hi = nv;
@@ -1041,6 +1051,7 @@ __global__ __launch_bounds__(256) void ivf_exact_lds_kernel(IvfParams p)
         p.out_ids[bl * p.topk + j] = s_di[j];
         p.out_dists[bl * p.topk + j] = s_dd[j];
     }
+    }   // flagged-query loop
 }
 
 bool ivf_exact_lds_supported(int M, int Ks, int nlist, int64_t L)
@@ -1059,7 +1070,8 @@ hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_exact_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ivf_exact_lds_kernel, dim3((unsigned) p.B), dim3(256), smem, st, p);
+    const unsigned grid = p.flag_list ? (unsigned) std::min<int64_t>(p.B, 256) : (unsigned) p.B;
+    hipLaunchKernelGGL(ivf_exact_lds_kernel, dim3(grid), dim3(256), smem, st, p);
     return hipGetLastError();
 }
 

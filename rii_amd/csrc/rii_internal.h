@@ -86,6 +86,7 @@ struct IvfParams {
     const float *queries;         // non-null: ivf_fused_kernel builds the table itself from (queries, codewords)
     const float *codewords; int Ds; int arch;
     int sel_cap;                  // ivf_fused_kernel: capacity of its list-selection array (ivf_fused_sel_cap)
+    int32_t *flag_list; int *nflag;  // compact list of flagged queries + its length (filled by ivf_fused_kernel)
     int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
