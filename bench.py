@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--topk", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lut-mode", default="exact", choices=["exact", "mfma"])
+    ap.add_argument("--scan-order", type=int, default=1, choices=[0, 1],
+                    help="1: scan the LDS-friendly permutation of the codes (default), 0: id order")
     ap.add_argument("--scan-mode", type=int, default=1, choices=[0, 1],
                     help="1: 8-bit filter + exact re-rank (default), 0: exact scan of every code; identical results")
     return ap.parse_args()
@@ -144,6 +146,7 @@ def main_deep(args, world, rank, local, dev, arch):
     eng = RiiGpu(cw, False, simd_arch=arch, device=local)
     eng.add_codes(codes, False)
     eng.set_option("scan_mode", args.scan_mode)
+    eng.set_option("scan_order", args.scan_order)
     del codes
     topk = args.topk
     q = torch.from_numpy(np.ascontiguousarray(query[:B])).to(dev)
@@ -277,6 +280,7 @@ def main():
     eng.add_codes(codes, False)
     eng.set_option("lut_mode", args.lut_mode)
     eng.set_option("scan_mode", args.scan_mode)
+    eng.set_option("scan_order", args.scan_order)
     topk = args.topk
     S, L = 0, 0
     d_tids = 0

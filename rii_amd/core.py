@@ -7,8 +7,10 @@ The product path never falls back to a CPU implementation: if the HIP library is
 hipcc; if there is no GPU, constructing an engine raises RiiAmdError.
 """
 import ctypes
+import importlib.util
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -63,6 +65,24 @@ def build_library(force=False):
     return so
 
 
+def _bind_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels ship their own libamdhip64 and load it by file name
+    (torch/lib, RPATH $ORIGIN); librii_amd.so asks for the soname.  If this library came first, a later `import torch`
+    would bring a second runtime into the process, and that one finds no GPU.  So when torch is installed and not loaded
+    yet, bind to ITS runtime: the loader then resolves both requests to the same object.  RII_SYSTEM_HIP=1 opts out."""
+    if "torch" in sys.modules or os.environ.get("RII_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def _lib():
     global _LIB
     if _LIB is not None:
@@ -70,6 +90,7 @@ def _lib():
     so = library_path()
     if not os.path.exists(so):
         build_library()
+    _bind_hip_runtime()
     L = ctypes.CDLL(so)
     c_int, c_i64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
     f32p = ctypes.POINTER(ctypes.c_float)

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <random>
 #include <string>
@@ -110,6 +111,12 @@ struct rii_engine {
 
     // device state
     DevBuf d_codewords, d_cnorm, d_codes, d_centers, d_symtab, d_pl_off, d_pl_ids, d_list_len;
+    // LDS-friendly scan order of the filter stage (scanorder.hip): codes gathered in scan order + position -> id.
+    // Windows of 1024 codes are independent, so appends only (re)order the windows past `scan_cov`.
+    DevBuf d_scan_codes, d_scan_perm;
+    int scan_order = 1;         // option "scan_order"
+    int64_t scan_cov = 0;       // codes [0, scan_cov) are final (whole windows)
+    int64_t scan_N = -1;        // N the order was last completed for
     bool have_symtab = false, have_cnorm = false, lists_dirty = true;
 
     // scratch
@@ -125,6 +132,13 @@ struct rii_engine {
     bool ivf_has_deferred = false;
 
     std::map<std::string, KernelTimer> timers;
+
+    // every C-ABI entry point holds `mu` while it touches engine state or enqueues work (one caller at a time);
+    // `last_stream`/`order_ev` chain the scratch buffers' users when callers alternate between streams
+    mutable std::mutex mu;
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t order_ev = nullptr;
 };
 
 namespace {
@@ -237,6 +251,8 @@ int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
     if (n == 0) return RII_OK;
     const size_t M = (size_t) e->M;
     const size_t old_bytes = (size_t) e->N * M, add = (size_t) n * M;
+    if (e->N < e->scan_cov) e->scan_cov = 0;         // the code array was restarted (clear / set_state)
+    e->scan_N = -1;
     e->codes.insert(e->codes.end(), codes, codes + add);
     RII_TRY(e->d_codes.ensure(old_bytes + add, old_bytes, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_codes.as<uint8_t>() + old_bytes, codes, add, hipMemcpyHostToDevice, e->stream));
@@ -310,6 +326,25 @@ void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, i
     *chunk_len = len;
 }
 
+constexpr int64_t kScanOrderMinN = 1 << 16;     // below this the scan is too short for the order to matter
+
+int ensure_scan_order(rii_engine *e, hipStream_t st)
+{
+    if (e->scan_N == e->N) return RII_OK;
+    const size_t M = (size_t) e->M;
+    const int64_t cov = std::min(e->scan_cov, e->N);
+    RII_TRY(e->d_scan_codes.ensure((size_t) e->N * M, (size_t) cov * M, st));
+    RII_TRY(e->d_scan_perm.ensure((size_t) e->N * sizeof(int32_t), (size_t) cov * sizeof(int32_t), st));
+    {
+        ScopedTimer t(e, "scan_order", st);
+        HIP_TRY(launch_scan_order(e->d_codes.as<uint8_t>(), e->N, e->M, e->Ks, cov / 1024, e->d_scan_perm.as<int32_t>(),
+                                  e->d_scan_codes.as<uint8_t>(), st));
+    }
+    e->scan_cov = (e->N / 1024) * 1024;
+    e->scan_N = e->N;
+    return RII_OK;
+}
+
 // the scan over `n_codes` codes at d_codes for B queries whose tables are in s_lut; ids are local indices
 // translated through d_remap (subset search) when given.
 int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int64_t n_codes, int64_t B, int topk,
@@ -330,7 +365,8 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             c = std::min<int64_t>(c, std::max<int64_t>(1, n_codes / 4096));
         }
         c = std::max<int64_t>(1, std::min<int64_t>(c, 65535));
-        const int64_t len = std::max<int64_t>(1, (n_codes + c - 1) / c);
+        int64_t len = std::max<int64_t>(1, (n_codes + c - 1) / c);
+        len = (len + 1023) / 1024 * 1024;                                 // chunks start on a block-iteration boundary
         const int chunks = (int) ((n_codes + len - 1) / len);
         const int64_t G = (int64_t) chunks * 1024;                        // lane segments per query (top-k passes)
         // pass 1 of top-k only has to bound the k-th smallest quantised sum from above: a 1-in-`stride` sample of the
@@ -350,6 +386,14 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             int cap = (int) std::min<int64_t>(262144, std::max<int64_t>(e->cand_cap, ((int64_t) 1 << 24) / std::max<int64_t>(B, 1)));
             if (e->cand_cap_forced) cap = e->cand_cap;
             if (topk > 1) cap = std::max(cap, 16 * topk * stride);
+            // whole-database scans run over the LDS-friendly copy of the codes; the re-rank maps positions back to ids
+            const int32_t *d_perm = nullptr;
+            if (e->scan_order && !d_remap && d_codes == e->d_codes.as<uint8_t>() && n_codes == e->N && qr == 16 &&
+                n_codes >= kScanOrderMinN && scan_order_supported(e->M, e->Ks)) {
+                RII_TRY(ensure_scan_order(e, st));
+                d_codes = e->d_scan_codes.as<uint8_t>();
+                d_perm = e->d_scan_perm.as<int32_t>();
+            }
             RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * qr));
             RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
             RII_TRY(e->s_cand.ensure((size_t) B * cap * sizeof(unsigned long long)));
@@ -376,7 +420,7 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
                 ScopedTimer t(e, "rerank", st);
                 HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
                                            e->s_slack.as<int32_t>(), e->s_cand.as<unsigned long long>(),
-                                           e->s_cand_cnt.as<unsigned int>(), cap, d_remap, B, d_out_ids, d_out_dists, topk, st));
+                                           e->s_cand_cnt.as<unsigned int>(), cap, d_remap, d_perm, B, d_out_ids, d_out_dists, topk, st));
                 return RII_OK;
             }
             // top-k: pass 1 = per-lane-segment minima of the quantised sums, k-th smallest of them bounds the k-th
@@ -401,8 +445,8 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             }
             ScopedTimer t(e, "rerank", st);
             HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
-                                       e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap, d_remap, B,
-                                       d_out_ids, d_out_dists, topk, st));
+                                       e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap, d_remap,
+                                       d_perm, B, d_out_ids, d_out_dists, topk, st));
             return RII_OK;
         }
     }
@@ -654,10 +698,31 @@ int check_tids_host(const rii_engine *e, const int64_t *tids, int64_t S)
     return RII_OK;
 }
 
+// Scratch buffers are shared by all calls of an engine, so work enqueued on a different stream than the previous
+// call's must wait for it.  User streams are only touched while the caller vouches for them (inside a call).
+int begin_on(rii_engine *e, hipStream_t st)
+{
+    if (e->last_stream_valid && e->last_stream != st) {
+        if (!e->order_ev) HIP_TRY(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
+        if (e->last_stream == e->stream) HIP_TRY(hipEventRecord(e->order_ev, e->stream));
+        HIP_TRY(hipStreamWaitEvent(st, e->order_ev, 0));
+    }
+    e->last_stream = st;
+    e->last_stream_valid = true;
+    return RII_OK;
+}
+int end_on(rii_engine *e, hipStream_t st)
+{
+    if (st == e->stream) return RII_OK;
+    if (!e->order_ev) HIP_TRY(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->order_ev, st));
+    return RII_OK;
+}
+
 void free_all(rii_engine *e)
 {
     DevBuf *bufs[] = {&e->d_codewords, &e->d_cnorm, &e->d_codes, &e->d_centers, &e->d_symtab, &e->d_pl_off,
-                      &e->d_pl_ids, &e->d_list_len, &e->s_queries, &e->s_tids, &e->s_lut, &e->s_best, &e->s_out_ids,
+                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->s_queries, &e->s_tids, &e->s_lut, &e->s_best, &e->s_out_ids,
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
@@ -671,6 +736,8 @@ void free_all(rii_engine *e)
     for (auto &kv : e->timers)
         for (auto &pr : kv.second.pending) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     e->timers.clear();
+    if (e->order_ev) (void) hipEventDestroy(e->order_ev);
+    e->order_ev = nullptr;
     if (e->stream) (void) hipStreamDestroy(e->stream);
     e->stream = nullptr;
 }
@@ -740,7 +807,9 @@ RII_API void rii_destroy(rii_engine *e)
 RII_API int rii_add_codes(rii_engine *e, const uint8_t *codes, int64_t n, int update_flag)
 {
     if (!e || (n > 0 && !codes) || n < 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     if (update_flag && e->centers.empty())
         return set_err(RII_ERR_STATE,
                        "reconfigure() must be called before add(vecs=X, update_posting_lists=True). If this is the "
@@ -761,7 +830,9 @@ RII_API int rii_add_codes(rii_engine *e, const uint8_t *codes, int64_t n, int up
 RII_API int rii_set_coarse_centers(rii_engine *e, const uint8_t *centers, int64_t nlist)
 {
     if (!e || !centers || nlist <= 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     e->centers.assign(centers, centers + (size_t) nlist * e->M);
     RII_TRY(upload_centers(e));
     e->lists.assign((size_t) nlist, std::vector<int32_t>());
@@ -774,7 +845,9 @@ RII_API int rii_set_state(rii_engine *e, const uint8_t *centers, int64_t nlist, 
                           const int64_t *pl_off, const int32_t *pl_ids)
 {
     if (!e || nlist < 0 || N < 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     e->codes.clear(); e->N = 0;
     RII_TRY(append_codes(e, codes, N));
     e->centers.assign(centers, centers + (size_t) nlist * e->M);
@@ -791,7 +864,9 @@ RII_API int rii_set_state(rii_engine *e, const uint8_t *centers, int64_t nlist, 
 RII_API int rii_reconfigure(rii_engine *e, int nlist, int iter)
 {
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     if (nlist <= 0 || (int64_t) nlist > e->N)
         return set_err(RII_ERR_INVALID, "reconfigure: need 0 < nlist=%d <= N=%lld (src/rii.h:110-111)", nlist, (long long) e->N);
     if (iter < 0) return set_err(RII_ERR_INVALID, "iter must be >= 0");
@@ -861,6 +936,7 @@ RII_API int rii_reconfigure(rii_engine *e, int nlist, int iter)
 RII_API int rii_clear(rii_engine *e)
 {
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> guard(e->mu);
     e->centers.clear();
     e->codes.clear();
     e->lists.clear();
@@ -878,30 +954,35 @@ RII_API int rii_get_verbose(const rii_engine *e) { return e ? e->verbose : 0; }
 RII_API int rii_set_verbose(rii_engine *e, int verbose)
 {
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> guard(e->mu);
     e->verbose = verbose;
     return RII_OK;
 }
 RII_API int rii_get_codewords(const rii_engine *e, float *out)
 {
     if (!e || !out) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     memcpy(out, e->codewords.data(), e->codewords.size() * sizeof(float));
     return RII_OK;
 }
 RII_API int rii_get_codes(const rii_engine *e, uint8_t *out)
 {
     if (!e || (!out && e->N)) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     if (e->N) memcpy(out, e->codes.data(), e->codes.size());
     return RII_OK;
 }
 RII_API int rii_get_coarse_centers(const rii_engine *e, uint8_t *out)
 {
     if (!e || (!out && !e->centers.empty())) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     if (!e->centers.empty()) memcpy(out, e->centers.data(), e->centers.size());
     return RII_OK;
 }
 RII_API int rii_get_posting_lists(const rii_engine *e, int64_t *off, int32_t *ids)
 {
     if (!e || !off) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     off[0] = 0;
     for (size_t i = 0; i < e->lists.size(); ++i) {
         if (ids && !e->lists[i].empty()) memcpy(ids + off[i], e->lists[i].data(), e->lists[i].size() * sizeof(int32_t));
@@ -997,7 +1078,9 @@ RII_API int rii_query_linear(rii_engine *e, const float *queries, int64_t B, int
                              int64_t *out_ids, float *out_dists)
 {
     if (!e || (B > 0 && (!queries || !out_ids || !out_dists)) || (S > 0 && !tids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     RII_TRY(check_query_args(e, B, topk, S));
     RII_TRY(check_tids_host(e, tids, S));
     if (B == 0) return RII_OK;
@@ -1016,7 +1099,9 @@ RII_API int rii_query_ivf(rii_engine *e, const float *queries, int64_t B, int to
                           int64_t L, int64_t *out_ids, float *out_dists, int64_t *out_counts)
 {
     if (!e || (B > 0 && (!queries || !out_ids || !out_dists || !out_counts)) || (S > 0 && !tids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     RII_TRY(check_query_args(e, B, topk, S));
     RII_TRY(check_ivf_args(e, topk, L));
     RII_TRY(check_tids_host(e, tids, S));
@@ -1028,10 +1113,13 @@ RII_API int rii_query_linear_dev(rii_engine *e, const float *d_queries, int64_t 
                                  int64_t S, int64_t *d_out_ids, float *d_out_dists, void *stream)
 {
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
     RII_TRY(check_query_args(e, B, topk, S));
-    return query_linear_dev(e, d_queries, B, topk, d_tids, S, d_out_ids, d_out_dists,
-                            stream ? (hipStream_t) stream : e->stream);
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    RII_TRY(begin_on(e, st));
+    RII_TRY(query_linear_dev(e, d_queries, B, topk, d_tids, S, d_out_ids, d_out_dists, st));
+    return end_on(e, st);
 }
 
 RII_API int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
@@ -1039,17 +1127,22 @@ RII_API int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, 
                               void *stream)
 {
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
     RII_TRY(check_query_args(e, B, topk, S));
     RII_TRY(check_ivf_args(e, topk, L));
-    return query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts,
-                         stream ? (hipStream_t) stream : e->stream);
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    RII_TRY(begin_on(e, st));
+    RII_TRY(query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts, st));
+    return end_on(e, st);
 }
 
 RII_API int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out)
 {
     if (!e || !queries || !out || B < 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
     if (B == 0) return RII_OK;
     RII_TRY(stage_inputs(e, queries, B, nullptr, 0, 1));
@@ -1065,7 +1158,9 @@ RII_API int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *ou
 RII_API int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *assign)
 {
     if (!e || n < 0 || (n > 0 && (!codes || !assign))) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     if (e->centers.empty()) return set_err(RII_ERR_STATE, "no coarse centres");
     if (n == 0) return RII_OK;
     RII_TRY(e->s_sub_codes.ensure((size_t) n * e->M));
@@ -1079,6 +1174,7 @@ RII_API int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *
 RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
 {
     if (!e || !key) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     const std::string k(key);
     if (k == "lut_mode") {
         if (value != RII_LUT_EXACT && value != RII_LUT_MFMA) return set_err(RII_ERR_INVALID, "bad lut_mode");
@@ -1092,6 +1188,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->scan_mode = (int) value;
     } else if (k == "ivf_fused") {
         e->ivf_fused = value ? 1 : 0;
+    } else if (k == "scan_order") {
+        e->scan_order = value ? 1 : 0;
     } else if (k == "fast_min_batch") {
         e->fast_min_batch = (int) std::max<int64_t>(0, value);
     } else if (k == "cand_cap") {
@@ -1106,6 +1204,7 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
 RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
 {
     if (!e || !key) return -1;
+    std::lock_guard<std::mutex> guard(e->mu);
     const std::string k(key);
     if (k == "lut_mode") return e->lut_mode;
     if (k == "scan_chunks") return e->scan_chunks;
@@ -1113,6 +1212,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "scan_mode") return e->scan_mode;
     if (k == "cand_cap") return e->cand_cap;
     if (k == "ivf_fused") return e->ivf_fused;
+    if (k == "scan_order") return e->scan_order;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;
@@ -1131,7 +1231,9 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
 RII_API int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms, int64_t *launches)
 {
     if (!e || !kernel) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     KernelTimer &t = e->timers[kernel];
     for (auto &pr : t.pending) {
         HIP_TRY(hipEventSynchronize(pr.second));
@@ -1150,6 +1252,7 @@ RII_API int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms,
 RII_API int rii_timing_reset(rii_engine *e)
 {
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> guard(e->mu);
     for (auto &kv : e->timers) {
         for (auto &pr : kv.second.pending) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
         kv.second.pending.clear();
@@ -1161,7 +1264,9 @@ RII_API int rii_timing_reset(rii_engine *e)
 RII_API int rii_synchronize(rii_engine *e)
 {
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_on(e, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return RII_OK;
 }

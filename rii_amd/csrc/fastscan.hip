@@ -618,6 +618,7 @@ struct RrArgs {
     const unsigned int *cand_count;
     int cap;
     const int64_t *remap;
+    const int32_t *perm;          // scan position -> code id (scanorder.hip), or NULL when the codes are in id order
     int64_t *out_ids;
     float *out_dists;
     int topk;
@@ -676,13 +677,15 @@ __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
             if ((c >> 32) > lim) continue;
             const uint32_t n = (uint32_t) (c & 0xffffffffu);
             const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
-            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | n;
+            const uint32_t id = p.perm ? (uint32_t) p.perm[n] : n;
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | id;
             best = key < best ? key : best;
         }
     } else {
         for (int64_t n = tid; n < p.n_codes; n += blockDim.x) {
             const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
-            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | (uint32_t) n;
+            const uint32_t id = p.perm ? (uint32_t) p.perm[n] : (uint32_t) n;
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | id;
             best = key < best ? key : best;
         }
     }
@@ -703,11 +706,13 @@ __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
 
 hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const int32_t *d_slack, const unsigned long long *d_cand,
-                              const unsigned int *d_cand_count, int cap, const int64_t *d_remap, int64_t B,
-                              int64_t *d_out_ids, float *d_out_dists, int topk, hipStream_t st)
+                              const unsigned int *d_cand_count, int cap, const int64_t *d_remap,
+                              const int32_t *d_perm, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
+                              hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     RrArgs a;
+    a.perm = d_perm;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.slack = d_slack;
     a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.remap = d_remap; a.out_ids = d_out_ids;
     a.out_dists = d_out_dists; a.topk = topk;
@@ -757,7 +762,8 @@ __global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
         if (i < total) {
             const uint32_t n = overflow ? (uint32_t) i : (uint32_t) (cand[i] & 0xffffffffu);
             const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
-            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | n;
+            const uint32_t id = p.perm ? (uint32_t) p.perm[n] : n;
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | id;
             if (key < s_thr) buf[atomicAdd(&s_cnt, 1u)] = key;
         }
         __syncthreads();
@@ -779,11 +785,12 @@ int rerank_topk_max_k() { return kRrBuf / 2; }
 
 hipError_t launch_rerank_topk(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const unsigned long long *d_cand, const unsigned int *d_cand_count, int cap,
-                              const int64_t *d_remap, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
-                              hipStream_t st)
+                              const int64_t *d_remap, const int32_t *d_perm, int64_t B, int64_t *d_out_ids,
+                              float *d_out_dists, int topk, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     RrArgs a;
+    a.perm = d_perm;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.slack = nullptr;
     a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.remap = d_remap; a.out_ids = d_out_ids;
     a.out_dists = d_out_dists; a.topk = topk;

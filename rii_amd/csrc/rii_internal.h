@@ -136,11 +136,17 @@ hipError_t launch_kth_threshold(const uint16_t *d_segmin, int64_t G, int64_t B, 
                                 uint32_t *d_thr16, hipStream_t st);
 hipError_t launch_rerank_topk(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const unsigned long long *d_cand, const unsigned int *d_cand_count, int cap,
-                              const int64_t *d_remap, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
-                              hipStream_t st);
+                              const int64_t *d_remap, const int32_t *d_perm, int64_t B, int64_t *d_out_ids,
+                              float *d_out_dists, int topk, hipStream_t st);
 hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const int32_t *d_slack, const unsigned long long *d_cand,
-                              const unsigned int *d_cand_count, int cap, const int64_t *d_remap, int64_t B,
-                              int64_t *d_out_ids, float *d_out_dists, int topk, hipStream_t st);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
+                              const unsigned int *d_cand_count, int cap, const int64_t *d_remap,
+                              const int32_t *d_perm, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
+                              hipStream_t st);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
+
+// scanorder.hip: LDS-friendly scan order for the filter stage (perm[pos] = code id, codes gathered in that order)
+bool scan_order_supported(int M, int Ks);
+hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, int64_t win0, int32_t *d_perm,
+                             uint8_t *d_out_codes, hipStream_t st);
 
 }  // namespace riiamd

@@ -394,3 +394,116 @@ def test_gpu_input_layouts_and_bad_inputs():
         g.query_linear(qs[0], 1, np.array([3, 9], np.int32))          # noconvert (src/main.cpp:20)
     with pytest.raises(TypeError):
         g.add_codes(codes.astype(np.int32), False)
+
+
+def test_concurrent_callers_one_engine():
+    """Several host threads hammer ONE engine (ctypes drops the GIL during the call): the engine serialises them, every
+    call still returns exactly what a lone caller gets."""
+    import threading
+    from rii_amd import RiiGpu
+    cw, codes, _ = make_problem(77, 16, 256, 4, 20000, "unit")
+    qs = np.random.default_rng(77).random((64, 64)).astype(np.float32)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.reconfigure(40, 3)
+    want_lin = g.query_linear_batch(qs, 3, None)
+    want_ivf = g.query_ivf_batch(qs, 3, None, 400)
+    errors = []
+
+    def worker(kind):
+        try:
+            for it in range(20):
+                if kind == 0:
+                    ids, d = g.query_linear_batch(qs, 3, None)
+                    assert np.array_equal(ids, want_lin[0]) and np.array_equal(d, want_lin[1])
+                elif kind == 1:
+                    ids, d, c = g.query_ivf_batch(qs, 3, None, 400)
+                    assert np.array_equal(ids, want_ivf[0]) and np.array_equal(d, want_ivf[1])
+                else:
+                    i1, d1 = g.query_linear(qs[it % 64], 3, E)
+                    assert list(i1) == list(want_lin[0][it % 64])
+        except Exception as ex:          # noqa: BLE001 -- reported to the main thread
+            errors.append(repr(ex))
+
+    ts = [threading.Thread(target=worker, args=(k % 3,)) for k in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:3]
+
+
+def test_alternating_streams_share_scratch_safely():
+    """Device-pointer calls on two different streams without host synchronisation in between: the engine chains
+    them (they share scratch buffers), so both result sets are right."""
+    import torch
+    from rii_amd import RiiGpu
+    cw, codes, _ = make_problem(78, 32, 256, 4, 60000, "unit")
+    qs = np.random.default_rng(78).random((256, 128)).astype(np.float32)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    want_a = g.query_linear_batch(qs[:128], 1, None)
+    want_b = g.query_linear_batch(qs[128:], 1, None)
+    dev = torch.device("cuda:0")
+    qa = torch.from_numpy(qs[:128]).to(dev)
+    qb = torch.from_numpy(qs[128:]).to(dev)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs = []
+    for rep in range(6):
+        ia = torch.empty((128, 1), dtype=torch.int64, device=dev); da = torch.empty((128, 1), dtype=torch.float32, device=dev)
+        ib = torch.empty((128, 1), dtype=torch.int64, device=dev); db = torch.empty((128, 1), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        g.query_linear_dev(qa.data_ptr(), 128, 1, 0, 0, ia.data_ptr(), da.data_ptr(), s1.cuda_stream)
+        g.query_linear_dev(qb.data_ptr(), 128, 1, 0, 0, ib.data_ptr(), db.data_ptr(), s2.cuda_stream)
+        outs.append((ia, da, ib, db))
+    torch.cuda.synchronize()
+    for ia, da, ib, db in outs:
+        assert np.array_equal(ia.cpu().numpy(), want_a[0]) and np.array_equal(da.cpu().numpy(), want_a[1])
+        assert np.array_equal(ib.cpu().numpy(), want_b[0]) and np.array_equal(db.cpu().numpy(), want_b[1])
+
+
+@pytest.mark.parametrize("M,N", [(32, 70000), (16, 66000), (8, 65536 + 1000), (12, 67000)])
+def test_scan_order_does_not_change_results(M, N):
+    """The filter stage scans an LDS-friendly permutation of the codes (scanorder.hip); ids, distances and tie-breaks must
+    be exactly those of the id-order scan and of the exhaustive scan -- including on a database with exact duplicates,
+    across appends (only the windows past the covered prefix are re-ordered) and after clear()."""
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(M * 1000 + 5)
+    cw = rng.random((M, 256, 4)).astype(np.float32)
+    codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
+    codes[rng.integers(0, N, 3000)] = codes[rng.integers(0, N, 3000)]          # exact ties
+    qs = rng.random((200, M * 4)).astype(np.float32)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+
+    def all_modes(topk):
+        out = []
+        for mode, order in ((1, 1), (1, 0), (0, 0)):
+            g.set_option("scan_mode", mode)
+            g.set_option("scan_order", order)
+            out.append(g.query_linear_batch(qs, topk, None))
+        g.set_option("scan_mode", 1)
+        g.set_option("scan_order", 1)
+        return out
+
+    def check(topk):
+        a, b, c = all_modes(topk)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[1], c[1])
+        if topk == 1:
+            assert np.array_equal(a[0], c[0])
+
+    first = N - 3000
+    g.add_codes(codes[:first], False)
+    check(1)
+    check(10)
+    g.add_codes(codes[first:first + 1500], False)          # grows the last, partial window and adds new ones
+    check(1)
+    g.add_codes(codes[first + 1500:], False)
+    check(1)
+    check(33)
+    want = g.query_linear_batch(qs, 1, None)
+    g.clear()
+    g.add_codes(codes[::-1].copy(), False)                 # same N, other codes: the stale order must not survive
+    got = g.query_linear_batch(qs, 1, None)
+    g.set_option("scan_mode", 0)
+    ref = g.query_linear_batch(qs, 1, None)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[1], want[1])                 # the same multiset of codes: the same best distances
