@@ -255,15 +255,134 @@ template <int QR> struct FsRow;                                   // one LDS row
 template <> struct FsRow<16> { typedef uint4 T; };
 template <> struct FsRow<8> { typedef uint2 T; };
 
+// odd bytes of a dword as two u16 fields, [b1, 0, b3, 0]: one v_perm_b32 (both sources are x, so the selector only
+// ever names bytes of x; 0x0c selects the constant 0x00)
+__device__ __forceinline__ uint32_t fs_odd_bytes(uint32_t x) { return __builtin_amdgcn_perm(x, x, 0x0c030c01u); }
+
 template <int QR> __device__ __forceinline__ void fs_flush(uint32_t (&acc)[QR / 2], uint32_t (&pb)[QR / 4])
 {
 #pragma unroll
     for (int w = 0; w < QR / 4; ++w) {
         acc[2 * w] += pb[w] & 0x00ff00ffu;
-        acc[2 * w + 1] += (pb[w] >> 8) & 0x00ff00ffu;
+        acc[2 * w + 1] += fs_odd_bytes(pb[w]);
         pb[w] = 0u;
     }
 }
+
+// byte J of a code word times the row size (1 << SH), i.e. the LDS offset of the row inside its subspace table, in ONE
+// VALU instruction: the SDWA form of v_lshlrev_b32 selects and zero-extends the byte on the way in.
+template <int J, int SH> __device__ __forceinline__ uint32_t fs_row_off(uint32_t w)
+{
+    static_assert(SH == 4 || SH == 3, "row size is 16 or 8 bytes");
+    uint32_t r;
+    if constexpr (SH == 4) {
+        if constexpr (J == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(w));
+        if constexpr (J == 1) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(w));
+        if constexpr (J == 2) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(w));
+        if constexpr (J == 3) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(w));
+    } else {
+        if constexpr (J == 0) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(w));
+        if constexpr (J == 1) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(w));
+        if constexpr (J == 2) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(w));
+        if constexpr (J == 3) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(w));
+    }
+    return r;
+}
+
+// The rows are fetched with hand-placed ds_read instructions: dynamic LDS starts at address 0 in this kernel (it has no
+// static __shared__), so the row offset IS the address and the subspace table base rides in the instruction's 16-bit
+// offset field; tables past 64 KiB need the upper part of their base added to the address (one more VALU instruction).
+// The compiler does not count outstanding LDS operations issued from asm, so fs_wait4 names the registers that become
+// valid: every use of a row is data-dependent on its wait.  (The compiler's own waits stay correct: LDS returns in
+// order, extra outstanding operations only make its lgkmcnt conditions stricter.)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int QR> struct FsVec;
+template <> struct FsVec<16> { typedef u32x4 T; };
+template <> struct FsVec<8> { typedef u32x2 T; };
+
+template <int QR, int KST, int M_, int J> __device__ __forceinline__ typename FsVec<QR>::T fs_row_issue(uint32_t w)
+{
+    constexpr int SH = QR == 16 ? 4 : 3;
+    constexpr uint32_t tab = (uint32_t) M_ * KST * QR;
+    constexpr uint32_t hi = tab & 0xffff0000u, lo = tab & 0xffffu;
+    uint32_t addr = fs_row_off<J, SH>(w);
+    if constexpr (hi != 0) addr += hi;
+    typename FsVec<QR>::T r;
+    if constexpr (QR == 16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(lo));
+    else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(lo));
+    return r;
+}
+// the four rows one code word selects (subspaces 4*I .. 4*I+3), in flight after this returns
+template <int QR, int KST, int I> __device__ __forceinline__ void fs_word_issue(uint32_t w, typename FsVec<QR>::T (&r)[4])
+{
+    r[0] = fs_row_issue<QR, KST, 4 * I, 0>(w);
+    r[1] = fs_row_issue<QR, KST, 4 * I + 1, 1>(w);
+    r[2] = fs_row_issue<QR, KST, 4 * I + 2, 2>(w);
+    r[3] = fs_row_issue<QR, KST, 4 * I + 3, 3>(w);
+}
+// wait until at most PENDING younger LDS operations are outstanding: the four rows named become valid
+template <int PENDING, typename V> __device__ __forceinline__ void fs_wait4(V (&r)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(PENDING));
+}
+
+// a + b + c in one instruction.  Written as asm because the optimiser otherwise re-balances the integer sums below into
+// pairwise adds (one more instruction per three-operand sum; the kernel is VALU-bound).
+__device__ __forceinline__ uint32_t fs_add3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// byte-packed sum of four rows, <= 4 * kFsLevels per byte
+template <int QR> __device__ __forceinline__ void fs_word_sum(const typename FsVec<QR>::T (&r)[4], uint32_t (&s)[QR / 4])
+{
+#pragma unroll
+    for (int d = 0; d < QR / 4; ++d) s[d] = fs_add3(r[0][d], r[1][d], r[2][d]) + r[3][d];
+}
+
+// all MW code words of one code against the byte tables: acc[] = 16-bit sums per query (packing: see fs_flush).
+// Two words (8 rows) are consumed per step while the next two are already in flight.
+template <int QR, int KST, int MW, int I> __device__ __forceinline__ void fs_code_steps(const uint32_t (&w)[MW], uint32_t (&acc)[QR / 2],
+                                                                                        typename FsVec<QR>::T (&ra)[4],
+                                                                                        typename FsVec<QR>::T (&rb)[4])
+{
+    if constexpr (I < MW) {
+        typename FsVec<QR>::T na[4], nb[4];
+        constexpr bool more = I + 2 < MW;
+        if constexpr (more) {
+            fs_word_issue<QR, KST, I + 2>(w[I + 2], na);
+            fs_word_issue<QR, KST, I + 3>(w[I + 3], nb);
+        }
+        uint32_t sa[QR / 4], sb[QR / 4];
+        fs_wait4<more ? 12 : 4>(ra);
+        fs_word_sum<QR>(ra, sa);
+        fs_wait4<more ? 8 : 0>(rb);
+        fs_word_sum<QR>(rb, sb);
+#pragma unroll
+        for (int d = 0; d < QR / 4; ++d) {
+            if constexpr (I == 0) {
+                acc[2 * d] = (sa[d] & 0x00ff00ffu) + (sb[d] & 0x00ff00ffu);
+                acc[2 * d + 1] = fs_odd_bytes(sa[d]) + fs_odd_bytes(sb[d]);
+            } else {
+                acc[2 * d] = fs_add3(acc[2 * d], sa[d] & 0x00ff00ffu, sb[d] & 0x00ff00ffu);
+                acc[2 * d + 1] = fs_add3(acc[2 * d + 1], fs_odd_bytes(sa[d]), fs_odd_bytes(sb[d]));
+            }
+        }
+        if constexpr (more) fs_code_steps<QR, KST, MW, I + 2>(w, acc, na, nb);
+    }
+}
+template <int QR, int KST, int MW> __device__ __forceinline__ void fs_code(const uint32_t (&w)[MW], uint32_t (&acc)[QR / 2])
+{
+    static_assert(MW % 2 == 0 && kFsFlush == 4, "pairs of code words, 4 lookups per byte-packed sum");
+    typename FsVec<QR>::T ra[4], rb[4];
+    fs_word_issue<QR, KST, 0>(w[0], ra);
+    fs_word_issue<QR, KST, 1>(w[1], rb);
+    fs_code_steps<QR, KST, MW, 0>(w, acc, ra, rb);
+}
+
 __device__ __forceinline__ void fs_add(uint32_t (&pb)[4], const uint4 &v)
 {
     pb[0] += v.x; pb[1] += v.y; pb[2] += v.z; pb[3] += v.w;
@@ -362,11 +481,15 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                         w[2 * i] = v.x; w[2 * i + 1] = v.y;
                     }
                 }
+                if constexpr (kFsFlush == 4 && MW % 2 == 0) {
+                    fs_code<QR, KST, MW>(w, acc);
+                } else {
 #pragma unroll
-                for (int i = 0; i < MW; ++i) {          // 4 lookups per code word; flush every kFsFlush lookups
+                    for (int i = 0; i < MW; ++i) {          // 4 lookups per code word; flush every kFsFlush lookups
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fs_add(pb, lut[(i * 4 + j) * KST + ((w[i] >> (8 * j)) & 0xffu)]);
-                    if ((i * 4 + 4) % kFsFlush == 0 || i == MW - 1) fs_flush<QR>(acc, pb);
+                        for (int j = 0; j < 4; ++j) fs_add(pb, lut[(i * 4 + j) * KST + ((w[i] >> (8 * j)) & 0xffu)]);
+                        if ((i * 4 + 4) % kFsFlush == 0 || i == MW - 1) fs_flush<QR>(acc, pb);
+                    }
                 }
             } else {
                 const uint8_t *c = p.codes + (size_t) n * M;
