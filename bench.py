@@ -376,8 +376,9 @@ def main():
                          "lut_avg_launch_ms": lut_ms / max(lut_n, 1), **extra,
                          "lds_gather": lds_gather(args, alg_bytes, avg_s, kernel),
                          "note": "codes are shared by the whole batch through LDS/L2, so algorithmic bytes exceed HBM "
-                                 "traffic by design; the measured limiter of the scan is LDS bank conflicts "
-                                 "(profiles/r01_fscan_pmc_counters.txt: SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT)"},
+                                 "traffic by design; the scan's limiters are the LDS gather rate (bank conflicts) and VALU issue, "
+                                 "both ~70-80% busy (profiles/r01_fscan_pmc_counters.txt: SQ_LDS_IDX_ACTIVE, "
+                                 "SQ_LDS_BANK_CONFLICT, SQ_INSTS_VALU)"},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "linear" and topk == 1:
             cb, cpu_ids = cpu_baseline(cw, codes, my_q.cpu().numpy(), arch)

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
 OUT=gpurun_out/prof_summary; RAW=/tmp/rii_prof_raw
 mkdir -p $OUT; rm -rf $RAW; mkdir -p $RAW
-KREGEX='scan_kernel|lut_build|ivf_|assign_kernel|finalize|fscan|rerank|lut_quant|gather_codes'
+KREGEX='scan_order|scan_kernel|lut_build|ivf_|assign_kernel|finalize|fscan|rerank|lut_quant|gather_codes'
 BENCH="python bench.py --no-cpu-baseline $*"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/kt -o kt -- $BENCH --steps 10 --warmup 2 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $RAW/kt.err
