@@ -91,7 +91,7 @@ struct rii_engine {
     int lut_mode = RII_LUT_EXACT;
     int scan_chunks = 0;        // 0 = auto
     int scan_mode = 1;          // 1 = 8-bit filter + exact re-rank for top-1 (fastscan.hip), 0 = exact scan only
-    int fast_min_batch = 128;   // top-1 batches below this take the exact scan (option "fast_min_batch")
+    int fast_min_batch = 33;    // top-1 batches below this take the exact scan (option "fast_min_batch"; tools/sweep_fast_min.py)
     int cand_cap = 4096;
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
@@ -361,8 +361,11 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
         const int64_t tiles = (B + qr - 1) / qr;
         int64_t c = e->scan_chunks;
         if (c <= 0) {
+            // one block per CU; chunks shorter than 8 slabs or more than 128 of them cost more in candidates (every chunk
+            // starts from its own thresholds) than they win in parallelism (tools/chunk_sweep.py)
             c = std::max<int64_t>(1, (e->n_cu + tiles - 1) / tiles);
-            c = std::min<int64_t>(c, std::max<int64_t>(1, n_codes / 4096));
+            c = std::min<int64_t>(c, std::max<int64_t>(1, n_codes / 8192));
+            c = std::min<int64_t>(c, 128);
         }
         c = std::max<int64_t>(1, std::min<int64_t>(c, 65535));
         int64_t len = std::max<int64_t>(1, (n_codes + c - 1) / c);

@@ -21,6 +21,7 @@
 namespace riiamd {
 
 constexpr int kFsThreads = 1024;
+constexpr size_t kFsLdsBytes = 160 * 1024 - 512;    // LDS one scan block may use (tables + thresholds + staged candidates)
 int fastscan_rows(int M, int Ks);      // queries per LDS row of the byte tables: 16, 8 or 0 (unsupported shape)
 #ifndef RII_FS_LEVELS
 #define RII_FS_LEVELS 63
@@ -140,6 +141,29 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
         if (gthr) gthr[b] = 0xffffffffu;
     }
     const float *q = queries + b * (int64_t) (M * Ds);
+    if (Ds == 4) {
+        // 8 independent 16-byte codeword loads in flight per thread: a block per query has nothing else to hide the
+        // load latency behind, and the one-entry-per-trip loop below was the ~30 us floor of small batches
+        const float4 *cw4 = reinterpret_cast<const float4 *>(codewords);
+        const float4 *q4 = reinterpret_cast<const float4 *>(q);
+        for (int i0 = threadIdx.x; i0 < MK; i0 += 256 * 8) {
+            float4 c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                c[u] = i < MK ? cw4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                if (i < MK) {
+                    const float t = fvec_l2sqr_ds4v(q4[i / Ks], c[u]);
+                    s_t[i] = t;
+                    lut[(size_t) b * MK + i] = t;
+                }
+            }
+        }
+    } else
     for (int m = 0; m < M; ++m) {                    // query sub-vector address is wave-uniform inside this loop
         const float *qm = q + (size_t) m * Ds;
         const float *cm = codewords + (size_t) m * Ks * Ds;
@@ -238,6 +262,7 @@ struct FsArgs {
     unsigned long long *cand;      // [B][cap] (a << 32 | local index)
     unsigned int *cand_count;      // [B]
     int cap;
+    int lcap;                      // candidate slots per query staged in LDS by each block (0 = emit straight to global)
     uint16_t *segmin;              // MODE 1: [B][G] per-lane-segment minima of a(), G = gridDim.x * 1024
     const uint32_t *thr16;         // MODE 2: [B] fixed thresholds (candidate <=> a < thr16[b])
     uint32_t *gthr;                // MODE 0: [B] thresholds shared by all chunk-blocks of a tile (pre-set to 0xffff)
@@ -427,6 +452,11 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     const int tile = blockIdx.y;
     const size_t lut_bytes = (size_t) M * Ks * QR;
     uint32_t *s_thr = reinterpret_cast<uint32_t *>(smem + lut_bytes);          // [QR/2] packed thresholds
+    // candidates are staged per block: LDS counter + list per query, appended to the global lists with ONE atomicAdd per
+    // (block, query) at the end -- hundreds of chunk-blocks bumping the same global counter once per candidate was the
+    // floor of the small-batch scan.  A full local list spills straight to the global one.
+    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(smem + lut_bytes + 64);     // [QR] staged candidates, then [QR] global bases
+    unsigned long long *s_lcand = reinterpret_cast<unsigned long long *>(smem + lut_bytes + 64 + QR * 8);   // [QR][lcap]
     typedef typename FsRow<QR>::T Row;
     {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
@@ -441,6 +471,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
             }
             s_thr[tid] = word;
         }
+        if (tid < 2 * QR) s_lcnt[tid] = 0u;
     }
     __syncthreads();
     const Row *lut = reinterpret_cast<const Row *>(smem);
@@ -454,6 +485,68 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     const int64_t span = c_end > c_begin ? c_end - c_begin : 0;
     const int iters = (int) ((span + kFsThreads - 1) / kFsThreads);
 
+    uint32_t acc0[QR / 2] = {};
+    int64_t n0 = 0;
+    bool active0 = false;
+    // candidate test of one code (its 16-bit sums in a[], scan position n) against the thresholds in LDS
+    auto test_and_emit = [&](const uint32_t (&acc)[QR / 2], int64_t n) {
+        // candidate test on the packed pairs: sat(thr+1 - a) != 0  <=>  a <= thr
+        uint32_t thr[QR / 2];
+#pragma unroll
+        for (int i = 0; i < QR / 8; ++i) {
+            const uint4 t4 = reinterpret_cast<const uint4 *>(s_thr)[i];
+            thr[4 * i] = t4.x; thr[4 * i + 1] = t4.y; thr[4 * i + 2] = t4.z; thr[4 * i + 3] = t4.w;
+        }
+        uint32_t hit = 0u, dsat[QR / 2];
+#pragma unroll
+        for (int i = 0; i < QR / 2; ++i) {
+            const u16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, thr[i]),
+                                                          __builtin_bit_cast(u16x2, acc[i]));
+            dsat[i] = __builtin_bit_cast(uint32_t, d);
+            hit |= dsat[i];
+        }
+        if (hit) {
+            // rare path: walk only the queries whose field is non-zero (usually exactly one)
+            uint32_t mask = 0u;
+#pragma unroll
+            for (int i = 0; i < QR / 2; ++i) {        // register i: low field = query 4(i/2)+(i&1), high field = +2
+                const int ql = 4 * (i >> 1) + (i & 1);
+                mask |= ((dsat[i] & 0xffffu) ? 1u : 0u) << ql;
+                mask |= ((dsat[i] >> 16) ? 1u : 0u) << (ql + 2);
+            }
+            while (mask) {
+                const int q = __ffs((int) mask) - 1;
+                mask &= mask - 1u;
+                const int b = tile * QR + q;
+                const int reg = 2 * (q >> 2) + (q & 1), high = (q >> 1) & 1;
+                uint32_t av = 0u, tv = 0u;
+#pragma unroll
+                for (int i = 0; i < QR / 2; ++i)          // register select without dynamic indexing
+                    if (i == reg) { av = acc[i]; tv = thr[i]; }
+                const uint32_t a = high ? (av >> 16) : (av & 0xffffu);
+                const uint32_t t = high ? (tv >> 16) : (tv & 0xffffu);
+                if (a < t && b < p.B) {
+                    if constexpr (MODE == 0) {
+                        const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
+                        if (nt < t) {
+                            fs_thr_lower(&s_thr[reg], high, nt);
+                            atomicMin(&p.gthr[b], nt);       // let the other chunks of this tile prune with it too
+                        }
+                    }
+                    const unsigned long long rec = ((unsigned long long) a << 32) | (uint32_t) n;
+                    bool staged = false;
+                    if (p.lcap > 0) {
+                        const unsigned int lp = atomicAdd(&s_lcnt[q], 1u);
+                        if (lp < (unsigned int) p.lcap) { s_lcand[(size_t) q * p.lcap + lp] = rec; staged = true; }
+                    }
+                    if (!staged) {
+                        const unsigned int pos = atomicAdd(&p.cand_count[b], 1u);
+                        if (pos < (unsigned int) p.cap) p.cand[(size_t) b * p.cap + pos] = rec;
+                    }
+                }
+            }
+        }
+    };
     // MODE 1 only needs an UPPER bound on the k-th smallest sum, so it may look at a strided sample of the codes
     const int it_step = (MODE == 1) ? p.sample_stride : 1;
     for (int it = 0; it < iters; it += it_step) {
@@ -524,7 +617,6 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                 if ((tid & 63) == 0 && t != 0xffffffffu && b < p.B) {
                     const uint32_t nt = fs_thr_of(t, (uint32_t) p.slack[b]);
                     fs_thr_lower(&s_thr[2 * (q >> 2) + (q & 1)], (q >> 1) & 1, nt);
-                    atomicMin(&p.gthr[b], nt);
                 }
             }
             __syncthreads();
@@ -535,59 +627,42 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
             const int b = tile * QR + tid;
             if (b < p.B) {
                 const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (it == 0) {
+                    // publish the block's warm-up minimum ONCE (per-wave atomics from hundreds of chunk-blocks on the same
+                    // 16 words used to cost more than the scan itself at small batches)
+                    const uint32_t word = s_thr[2 * (tid >> 2) + (tid & 1)];
+                    const uint32_t mine = ((tid >> 1) & 1) ? (word >> 16) : (word & 0xffffu);
+                    if (mine < g) atomicMin(&p.gthr[b], mine);
+                }
                 fs_thr_lower(&s_thr[2 * (tid >> 2) + (tid & 1)], (tid >> 1) & 1, g);
             }
         }
-        if (active) {
-            // candidate test on the packed pairs: sat(thr+1 - a) != 0  <=>  a <= thr
-            uint32_t thr[QR / 2];
+        if (MODE == 0 && it == 0) {
+            // the first slab is judged LAST: right now the thresholds only know this block's first 1024 codes, at the end
+            // they know the whole chunk and what the other chunks published (short chunks used to emit most of their
+            // candidates here)
 #pragma unroll
-            for (int i = 0; i < QR / 8; ++i) {
-                const uint4 t4 = reinterpret_cast<const uint4 *>(s_thr)[i];
-                thr[4 * i] = t4.x; thr[4 * i + 1] = t4.y; thr[4 * i + 2] = t4.z; thr[4 * i + 3] = t4.w;
-            }
-            uint32_t hit = 0u, dsat[QR / 2];
-#pragma unroll
-            for (int i = 0; i < QR / 2; ++i) {
-                const u16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, thr[i]),
-                                                              __builtin_bit_cast(u16x2, acc[i]));
-                dsat[i] = __builtin_bit_cast(uint32_t, d);
-                hit |= dsat[i];
-            }
-            if (hit) {
-                // rare path: walk only the queries whose field is non-zero (usually exactly one)
-                uint32_t mask = 0u;
-#pragma unroll
-                for (int i = 0; i < QR / 2; ++i) {        // register i: low field = query 4(i/2)+(i&1), high field = +2
-                    const int ql = 4 * (i >> 1) + (i & 1);
-                    mask |= ((dsat[i] & 0xffffu) ? 1u : 0u) << ql;
-                    mask |= ((dsat[i] >> 16) ? 1u : 0u) << (ql + 2);
-                }
-                while (mask) {
-                    const int q = __ffs((int) mask) - 1;
-                    mask &= mask - 1u;
-                    const int b = tile * QR + q;
-                    const int reg = 2 * (q >> 2) + (q & 1), high = (q >> 1) & 1;
-                    uint32_t av = 0u, tv = 0u;
-#pragma unroll
-                    for (int i = 0; i < QR / 2; ++i)          // register select without dynamic indexing
-                        if (i == reg) { av = acc[i]; tv = thr[i]; }
-                    const uint32_t a = high ? (av >> 16) : (av & 0xffffu);
-                    const uint32_t t = high ? (tv >> 16) : (tv & 0xffffu);
-                    if (a < t && b < p.B) {
-                        if constexpr (MODE == 0) {
-                            const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
-                            if (nt < t) {
-                                fs_thr_lower(&s_thr[reg], high, nt);
-                                atomicMin(&p.gthr[b], nt);       // let the other chunks of this tile prune with it too
-                            }
-                        }
-                        const unsigned int pos = atomicAdd(&p.cand_count[b], 1u);
-                        if (pos < (unsigned int) p.cap)
-                            p.cand[(size_t) b * p.cap + pos] = ((unsigned long long) a << 32) | (uint32_t) n;
-                    }
-                }
-            }
+            for (int i = 0; i < QR / 2; ++i) acc0[i] = acc[i];
+            n0 = n;
+            active0 = active;
+        } else if (active) {
+            test_and_emit(acc, n);
+        }
+    }
+    if (MODE == 0 && active0) test_and_emit(acc0, n0);
+    if (MODE == 0 && p.lcap > 0) {
+        __syncthreads();
+        if (tid < QR) {
+            const int b = tile * QR + tid;
+            const unsigned int c = min(s_lcnt[tid], (unsigned int) p.lcap);
+            s_lcnt[QR + tid] = (c && b < p.B) ? atomicAdd(&p.cand_count[b], c) : 0u;
+        }
+        __syncthreads();
+        for (int q = tid >> 6; q < QR; q += kFsThreads >> 6) {        // one wave per query
+            const int b = tile * QR + q;
+            const unsigned int c = min(s_lcnt[q], (unsigned int) p.lcap), base = s_lcnt[QR + q];
+            for (unsigned int i = tid & 63; i < c; i += 64)
+                if (base + i < (unsigned int) p.cap) p.cand[(size_t) b * p.cap + base + i] = s_lcand[(size_t) q * p.lcap + i];
         }
     }
     if constexpr (MODE == 1) {
@@ -604,12 +679,17 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
 template <int MW, int KST, int MODE, int QR>
 static hipError_t launch_fscan_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
-    const size_t smem = (size_t) a.M * a.Ks * QR + 64;
+    const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8;
+    FsArgs b = a;
+    // top-1 only: the fixed-threshold pass of top-k emits so often that LDS atomics queueing behind the table reads cost
+    // more than the global ones they save (measured)
+    b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) QR * 8));
+    const size_t smem = tab + (size_t) QR * 8 * b.lcap;
     auto kern = fscan_kernel<MW, KST, MODE, QR>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
     return hipGetLastError();
 }
 

@@ -66,6 +66,11 @@ __device__ inline float fvec_l2sqr_dev(const float *__restrict__ x, const float 
 // Ds == 4 (the SIFT shape: D=128, M=32) in straight-line form with two 16-byte loads.  Identical for all three SIMD
 // variants: one 4-wide chunk into zeroed lanes (fma(t,t,+0) == the rounded square == SSE's mul-then-add-to-zero), no
 // tail, then (l0+l1)+(l2+l3) (distance.h:148-169 / :194-216 / :229-251).  Callers guarantee 16-byte alignment.
+__device__ __forceinline__ float fvec_l2sqr_ds4v(const float4 &a, const float4 &c)
+{
+    const float t0 = __fsub_rn(a.x, c.x), t1 = __fsub_rn(a.y, c.y), t2 = __fsub_rn(a.z, c.z), t3 = __fsub_rn(a.w, c.w);
+    return __fadd_rn(__fadd_rn(__fmul_rn(t0, t0), __fmul_rn(t1, t1)), __fadd_rn(__fmul_rn(t2, t2), __fmul_rn(t3, t3)));
+}
 __device__ __forceinline__ float fvec_l2sqr_ds4(const float *__restrict__ x, const float *__restrict__ y)
 {
     const float4 a = *reinterpret_cast<const float4 *>(x);
