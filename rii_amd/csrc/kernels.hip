@@ -701,6 +701,24 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     if (p.queries) {
         // table built in place (exact fvec_L2sqr order): no global round trip for the common case
         const float *q = p.queries + (p.b0 + bl) * (int64_t) (p.M * p.Ds);
+        if (p.Ds == 4) {
+            // 8 independent 16-byte codeword loads in flight per thread (the block has nothing else to hide them behind)
+            const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
+            const float4 *q4 = reinterpret_cast<const float4 *>(q);
+            for (int i0 = tid; i0 < MK; i0 += 256 * 8) {
+                float4 cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 256;
+                    cv[u] = i < MK ? cw4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 256;
+                    if (i < MK) lds[i] = fvec_l2sqr_ds4v(q4[i / p.Ks], cv[u]);
+                }
+            }
+        } else
         for (int m = 0; m < p.M; ++m) {           // query sub-vector address is wave-uniform inside this loop
             const float *qm = q + (size_t) m * p.Ds;
             const float *cm = p.codewords + (size_t) m * p.Ks * p.Ds;
@@ -726,8 +744,6 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
         }
         s_dist[c] = dist;
-        p.coarse_dist[bl * nlist + c] = dist;          // kept for the exact-emulation fallback
-        p.coarse_id[bl * nlist + c] = c;
     }
     __syncthreads();
     // ---- the w+1 smallest (dist, list id) keys, ascending: few -> rounds of block arg-min over keys strictly greater
@@ -785,7 +801,12 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     }
     __syncthreads();
     if (s_misc[2]) {
-        if (p.queries) {         // hand the table to the exact-emulation kernels (layout [b][M*Ks], QT == 1)
+        // flagged: hand the coarse scores and the table (layout [b][M*Ks], QT == 1) to the exact-emulation kernels
+        for (int c = tid; c < nlist; c += blockDim.x) {
+            p.coarse_dist[bl * nlist + c] = s_dist[c];
+            p.coarse_id[bl * nlist + c] = c;
+        }
+        if (p.queries) {
             float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
             for (int i = tid; i < MK; i += blockDim.x) dst[i] = lds[i];
         }
@@ -890,7 +911,11 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             }
         }
         __syncthreads();
-        if (s_misc[2]) {
+        if (s_misc[2]) {          // ties at the cut, found only now: same hand-over as above
+            for (int c = tid; c < nlist; c += blockDim.x) {
+                p.coarse_dist[bl * nlist + c] = s_dist[c];
+                p.coarse_id[bl * nlist + c] = c;
+            }
             if (p.queries) {
                 float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
                 for (int i = tid; i < MK; i += blockDim.x) dst[i] = lds[i];
