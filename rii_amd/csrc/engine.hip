@@ -605,7 +605,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     p.coarse_dist = e->s_coarse_d.as<float>(); p.coarse_id = e->s_coarse_i.as<int32_t>();
     p.cum = e->s_cum.as<int32_t>(); p.ncand = e->s_ncand.as<int32_t>(); p.nvis = e->s_nvis.as<int32_t>();
     p.cand_id = e->s_cand_i.as<int32_t>(); p.cand_dist = e->s_cand_d.as<float>(); p.cand_stride = stride;
-    const bool fused = e->ivf_fused && ivf_fused_supported((int) nlist, w, topk);
+    const bool fused = e->ivf_fused && ivf_fused_supported(e->M, e->Ks, (int) nlist, w, topk);
     RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
     p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
     const bool defer = fused && d_flag_defer && bc >= B;       // one launch group: the caller inspects the flags itself

@@ -678,6 +678,40 @@ hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st)
 constexpr int kFusedMaxW = 32;
 constexpr int kFusedMaxNlist = 4096;
 
+// sequential fp32 ADC (RiiCpp::ADist, src/rii.h:375-394) of one code against a table in LDS
+__device__ __forceinline__ float adc_lds(const float *lds, const uint8_t *code, int M, int Ks)
+{
+    float dist = 0.f;
+    if ((M & 3) == 0) {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
+        for (int i = 0; i < M / 4; ++i) {
+            const uint32_t wd = cw[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dist = __fadd_rn(dist, lds[(i * 4 + j) * Ks + ((wd >> (8 * j)) & 0xffu)]);
+        }
+    } else {
+        for (int m = 0; m < M; ++m) dist = __fadd_rn(dist, lds[m * Ks + code[m]]);
+    }
+    return dist;
+}
+// the same for a code already in registers as MQ (<= 4) 16-byte pieces
+__device__ __forceinline__ float adc_lds_wide(const float *lds, const uint4 (&cv)[4], int MQ, int Ks)
+{
+    float dist = 0.f;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        if (qd < MQ) {
+            const uint32_t wds[4] = {cv[qd].x, cv[qd].y, cv[qd].z, cv[qd].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dist = __fadd_rn(dist, lds[((qd * 4 + i) * 4 + j) * Ks + ((wds[i] >> (8 * j)) & 0xffu)]);
+        }
+    }
+    return dist;
+}
+
 __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -690,9 +724,11 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     int *s_cum = reinterpret_cast<int *>(s_red + 2);                                     // [SC + 2]
     int *s_misc = s_cum + (SC + 2);                                                      // [4]: ncand, nv, flag
     float *s_dist = reinterpret_cast<float *>(s_misc + 4);                               // [nlist]
-    // top-k > 1: streaming selection buffer behind the coarse distances (8-byte aligned)
+    int *s_len = reinterpret_cast<int *>(s_dist + p.nlist);                              // [SC + 2] lengths of the selected lists ...
+    int *s_poff = s_len + (SC + 2);                                                      // [SC + 2] ... and their offsets, in visiting order
+    // top-k > 1: streaming selection buffer behind them (8-byte aligned)
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(
-        smem + ((reinterpret_cast<unsigned char *>(s_dist + p.nlist) - smem + 15) & ~(size_t) 15));
+        smem + ((reinterpret_cast<unsigned char *>(s_poff + (SC + 2)) - smem + 15) & ~(size_t) 15));
     const int64_t bl = blockIdx.x;
     const int tid = threadIdx.x;
     const int nlist = p.nlist;
@@ -729,21 +765,32 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
     }
     __syncthreads();
-    for (int c = tid; c < nlist; c += blockDim.x) {
-        const uint8_t *code = p.centers + (size_t) c * p.M;
-        float dist = 0.f;
-        if ((p.M & 3) == 0) {
-            const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
-            for (int i = 0; i < p.M / 4; ++i) {
-                const uint32_t wd = cw[i];
+    // every global load of this block is latency-exposed (one block per query, a few blocks per CU), so the gathers below
+    // are issued in batches: up to four codes per thread, whole codes in registers before the first table lookup
+    const bool wide = (p.M & 15) == 0 && p.M <= 64;
+    for (int c0 = tid; c0 < nlist; c0 += 4 * 256) {
+        if (wide) {
+            uint4 cv[4][4];
+            const int MQ = p.M >> 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    dist = __fadd_rn(dist, lds[(i * 4 + j) * p.Ks + ((wd >> (8 * j)) & 0xffu)]);
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 256;
+                const uint4 *cp = reinterpret_cast<const uint4 *>(p.centers + (size_t) (c < nlist ? c : 0) * p.M);
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    if (qd < MQ) cv[u][qd] = cp[qd];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 256;
+                if (c < nlist) s_dist[c] = adc_lds_wide(lds, cv[u], MQ, p.Ks);
             }
         } else {
-            for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 256;
+                if (c < nlist) s_dist[c] = adc_lds(lds, p.centers + (size_t) c * p.M, p.M, p.Ks);
+            }
         }
-        s_dist[c] = dist;
     }
     __syncthreads();
     // ---- the w+1 smallest (dist, list id) keys, ascending: few -> rounds of block arg-min over keys strictly greater
@@ -775,6 +822,12 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         if (tid == 0) s_sel[r] = last;
         __syncthreads();
     }
+    for (int c = tid; c < (w < nlist ? w : nlist); c += blockDim.x) {      // lengths / offsets of the lists the walk may visit
+        const int no = (int) (s_sel[c] & 0xffffffffu);
+        s_len[c] = p.list_len[no];
+        s_poff[c] = (int) p.pl_off[no];                                    // N < 2^31
+    }
+    __syncthreads();
     if (tid == 0) {
         int flag = 0;
         for (int r = 0; r + 1 < rounds; ++r)
@@ -784,8 +837,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         bool finished = false;
         const int wl = w < nlist ? w : nlist;
         for (int c = 0; c < wl && !flag; ++c) {
-            const int no = (int) (s_sel[c] & 0xffffffffu);
-            const long long len = p.list_len[no];
+            const long long len = s_len[c];
             s_cum[c] = (int) cnt;
             if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
             cnt += len;
@@ -817,30 +869,41 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     float bestd = INFINITY;
     uint32_t bestp = 0xffffffffu;
     int32_t bestid = -1;
-    for (int pos = tid; top1 && pos < ncand; pos += blockDim.x) {
-        int lo = 0, hi = nv;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_cum[mid] <= pos) lo = mid; else hi = mid;
-        }
-        const int no = (int) (s_sel[lo] & 0xffffffffu);
-        const int32_t id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo])];
-        const uint8_t *code = p.codes + (size_t) id * p.M;
-        float dist = 0.f;
-        if ((p.M & 3) == 0) {
-            const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
-            for (int i = 0; i < p.M / 4; ++i) {
-                const uint32_t wd = cw[i];
+    for (int p0 = tid; top1 && p0 < ncand; p0 += 4 * 256) {
+        int32_t id[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    dist = __fadd_rn(dist, lds[(i * 4 + j) * p.Ks + ((wd >> (8 * j)) & 0xffu)]);
+        for (int u = 0; u < 4; ++u) {                 // posting ids of up to four traversal positions: loads in flight together
+            const int pos = p0 + u * 256;
+            id[u] = -1;
+            if (pos < ncand) {
+                int lo = 0, hi = nv;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+                }
+                id[u] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
             }
+        }
+        float dist[4];
+        if (wide) {
+            uint4 cv[4][4];
+            const int MQ = p.M >> 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint4 *cp = reinterpret_cast<const uint4 *>(p.codes + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    if (qd < MQ) cv[u][qd] = cp[qd];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dist[u] = adc_lds_wide(lds, cv[u], MQ, p.Ks);
         } else {
-            for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+            for (int u = 0; u < 4; ++u)
+                dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, p.codes + (size_t) id[u] * p.M, p.M, p.Ks);
         }
-        if (top1) {
-            if (dist < bestd) { bestd = dist; bestp = (uint32_t) pos; bestid = id; }
-        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                   // ascending traversal position: strict < keeps the first minimum
+            if (id[u] >= 0 && dist[u] < bestd) { bestd = dist[u]; bestp = (uint32_t) (p0 + u * 256); bestid = id[u]; }
     }
     if (top1) {
         unsigned long long key =
@@ -884,11 +947,8 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                     const int mid = (lo + hi) >> 1;
                     if (s_cum[mid] <= pos) lo = mid; else hi = mid;
                 }
-                const int no = (int) (s_sel[lo] & 0xffffffffu);
-                const int32_t id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo])];
-                const uint8_t *code = p.codes + (size_t) id * p.M;
-                float dist = 0.f;
-                for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
+                const int32_t id = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
+                const float dist = adc_lds(lds, p.codes + (size_t) id * p.M, p.M, p.Ks);
                 const unsigned long long key =
                     ((unsigned long long) f32_orderable(__float_as_uint(dist)) << 32) | (uint32_t) pos;
                 if (key < s_kthr) s_buf[atomicAdd(&s_cnt, 1u)] = key;
@@ -930,18 +990,23 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 const int mid = (lo + hi) >> 1;
                 if (s_cum[mid] <= pos) lo = mid; else hi = mid;
             }
-            const int no = (int) (s_sel[lo] & 0xffffffffu);
-            p.out_ids[bl * p.topk + j] = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo])];
+            p.out_ids[bl * p.topk + j] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
             p.out_dists[bl * p.topk + j] = __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
         }
         if (tid == 0) p.out_counts[bl] = p.topk;
     }
 }
 
-bool ivf_fused_supported(int nlist, int64_t w, int topk)
+static size_t ivf_fused_smem(int M, int Ks, int nlist, int sel_cap, int topk)
 {
-    (void) w;
-    return nlist <= kFusedMaxNlist && topk + 1 <= kRrBuf / 2;
+    return (((size_t) M * Ks * sizeof(float) + 15) & ~(size_t) 15) + (size_t) sel_cap * 8 + 16 + (size_t) (sel_cap + 2) * 4 + 16 +
+           (size_t) nlist * 4 + (size_t) (sel_cap + 2) * 8 + 32 + (topk > 1 ? (size_t) (kRrBuf + 2) * 8 : 0);
+}
+int ivf_fused_sel_cap(int nlist, int64_t w);
+bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk)
+{
+    return nlist <= kFusedMaxNlist && topk + 1 <= kRrBuf / 2 &&
+           ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk) <= (size_t) 160 * 1024;
 }
 int ivf_fused_sel_cap(int nlist, int64_t w)
 {
@@ -954,9 +1019,7 @@ int ivf_fused_sel_cap(int nlist, int64_t w)
 hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st)
 {
     if (p.B == 0) return hipSuccess;
-    const size_t smem = (((size_t) p.M * p.Ks * sizeof(float) + 15) & ~(size_t) 15) + (size_t) p.sel_cap * 8 + 16 +
-                        (size_t) (p.sel_cap + 2) * 4 + 16 + (size_t) p.nlist * 4 + 32 +
-                        (p.topk > 1 ? (size_t) (kRrBuf + 2) * 8 : 0);
+    const size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;

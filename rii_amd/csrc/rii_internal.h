@@ -90,7 +90,7 @@ struct IvfParams {
     int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
-bool ivf_fused_supported(int nlist, int64_t w, int topk);
+bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk);
 int ivf_fused_sel_cap(int nlist, int64_t w);
 hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st);
