@@ -112,15 +112,19 @@ int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *assign);
 /* Options: "lut_mode" (RII_LUT_*), "scan_mode" (1 = 8-bit filter + exact re-rank for top-1 [default], 0 = exact scan
  * only; results are identical), "ivf_fused" (1 = one fused launch for the common inverted-index case with per-query
  * exact fallback [default], 0 = always the std::partial_sort emulation kernels; results are identical),
- * "fast_min_batch" (top-1 batches smaller than this use the exact scan; default 128), "cand_cap",
- * "scan_chunks" (0 = auto), "timing" (0/1). */
+ * "fast_min_batch" (top-1 batches smaller than this use the exact scan; default 33), "scan_order" (1 = the filter
+ * scans an LDS-friendly permutation of the codes [default], 0 = id order; results are identical), "cand_cap",
+ * "scan_chunks" (0 = auto), "timing" (0/1).
+ *
+ * Threading: every entry point locks the engine, concurrent callers are serialised.  The *_dev calls return after
+ * enqueueing; calls on different streams are ordered with an event (they share the engine's scratch buffers). */
 int rii_set_option(rii_engine *e, const char *key, int64_t value);
 int64_t rii_get_option(const rii_engine *e, const char *key);
 
 /* Per-kernel HIP-event timing (enabled by option "timing"=1): events are recorded on the launch stream
  * around every launch of the named kernel; reading synchronises the stream.
  * names: "lut", "scan", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select", "assign", "gather", "select", "quant", "rerank",
- * "ivf_fused", "ivf_exact", "kth". */
+ * "ivf_fused", "ivf_exact", "kth", "scan_order". */
 int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms, int64_t *launches);
 int rii_timing_reset(rii_engine *e);
 int rii_synchronize(rii_engine *e);
