@@ -460,6 +460,16 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
     sp.QT = qt;
     if (topk == 1) {
         pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len, qt);
+        // 16-byte table rows (4 queries per row) meet the same ds_read_b128 service groups as the filter's byte tables:
+        // whole-database scans walk the LDS-friendly copy of the codes
+        if (e->scan_order && qt == 4 && !d_remap && d_codes == e->d_codes.as<uint8_t>() && n_codes == e->N &&
+            n_codes >= kScanOrderMinN && scan_order_supported(e->M, e->Ks)) {
+            RII_TRY(ensure_scan_order(e, st));
+            sp.codes = e->d_scan_codes.as<uint8_t>();
+            sp.perm = e->d_scan_perm.as<int32_t>();
+            sp.chunk_len = (sp.chunk_len + 1023) / 1024 * 1024;          // chunks start on a 64-lane slab boundary
+            sp.chunks = (int) ((n_codes + sp.chunk_len - 1) / sp.chunk_len);
+        }
         RII_TRY(e->s_best.ensure((size_t) B * sizeof(unsigned long long)));
         sp.best = e->s_best.as<unsigned long long>();
         HIP_TRY(hipMemsetAsync(sp.best, 0xff, (size_t) B * sizeof(unsigned long long), st));

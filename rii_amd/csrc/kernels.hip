@@ -238,9 +238,10 @@ struct ScanArgs {
     unsigned long long *best;
     unsigned long long *keys;
     int b0;
+    const int32_t *perm;           // scan position -> code id (scanorder.hip) or NULL when the codes are in id order
 };
 
-template <int QT, int MW, int KST, bool WRITE_KEYS>
+template <int QT, int MW, int KST, bool WRITE_KEYS, bool PERM = false>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -304,7 +305,24 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
                 // strict '<' + ascending n per lane => the first minimum wins, like a size-1 heap-select
                 if (acc[q] < bestd[q]) { bestd[q] = acc[q]; besti[q] = (uint32_t) n; }
             }
+            if constexpr (PERM) {
+                // in the permuted scan order a lane's ids are not ascending: an exact tie (rare) goes to the smaller id
+                bool tie = false;
+#pragma unroll
+                for (int q = 0; q < QT; ++q) tie |= (acc[q] == bestd[q]) & (besti[q] != (uint32_t) n);
+                if (__builtin_expect(tie, 0)) {
+                    const int32_t idn = p.perm[n];
+#pragma unroll
+                    for (int q = 0; q < QT; ++q)
+                        if (acc[q] == bestd[q] && besti[q] != (uint32_t) n && idn < p.perm[besti[q]]) besti[q] = (uint32_t) n;
+                }
+            }
         }
+    }
+    if constexpr (PERM) {            // positions -> ids
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+            if (besti[q] != 0xffffffffu) besti[q] = (uint32_t) p.perm[besti[q]];
     }
 
     if constexpr (!WRITE_KEYS) {
@@ -331,18 +349,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
     }
 }
 
-template <int QT, int MW, int KST, bool WK>
+template <int QT, int MW, int KST, bool WK, bool PERM = false>
 static hipError_t launch_scan_t(const ScanParams &sp, int tile0, int ntiles, hipStream_t st)
 {
+    if constexpr (!WK && !PERM && QT == 4) {          // the scan-order variant exists for the 4-query tiles only
+        if (sp.perm) return launch_scan_t<QT, MW, KST, WK, true>(sp, tile0, ntiles, st);
+    }
     const size_t lut_bytes = (size_t) sp.M * sp.Ks * QT * sizeof(float);
     const size_t smem = ((lut_bytes + 15) & ~(size_t) 15) + 64;
-    auto kern = scan_kernel<QT, MW, KST, WK>;
+    auto kern = scan_kernel<QT, MW, KST, WK, PERM>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     ScanArgs a;
     a.codes = sp.codes; a.n_codes = sp.n_codes; a.M = sp.M; a.Ks = sp.Ks; a.lut = sp.lut; a.B = sp.B;
     a.tile0 = tile0; a.chunk_len = sp.chunk_len; a.best = sp.best; a.keys = sp.keys; a.b0 = sp.b0;
+    a.perm = PERM ? sp.perm : nullptr;
     hipLaunchKernelGGL(kern, dim3(sp.chunks, ntiles), dim3(kScanThreads), smem, st, a);
     return hipGetLastError();
 }

@@ -34,6 +34,7 @@ struct ScanParams {
     unsigned long long *best;    // [B] packed (orderable dist bits << 32 | local index), pre-set to ~0
     unsigned long long *keys;    // optional [Bc][n_codes] packed keys (general top-k path), else nullptr
     int b0, bc;                  // query range written to `keys`
+    const int32_t *perm = nullptr;   // top-1 only: codes are in the LDS-friendly scan order, perm[pos] = id
 };
 
 // orderable mapping of an fp32 to u32 (monotone for all finite values incl. negatives)

@@ -475,7 +475,7 @@ def test_scan_order_does_not_change_results(M, N):
 
     def all_modes(topk):
         out = []
-        for mode, order in ((1, 1), (1, 0), (0, 0)):
+        for mode, order in ((1, 1), (1, 0), (0, 0), (0, 1)):
             g.set_option("scan_mode", mode)
             g.set_option("scan_order", order)
             out.append(g.query_linear_batch(qs, topk, None))
@@ -484,9 +484,10 @@ def test_scan_order_does_not_change_results(M, N):
         return out
 
     def check(topk):
-        a, b, c = all_modes(topk)
+        a, b, c, d = all_modes(topk)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
         assert np.array_equal(a[1], c[1])
+        assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1])      # exhaustive scan, id order vs scan order
         if topk == 1:
             assert np.array_equal(a[0], c[0])
 
