@@ -337,7 +337,8 @@ int ensure_scan_order(rii_engine *e, hipStream_t st)
     RII_TRY(e->d_scan_perm.ensure((size_t) e->N * sizeof(int32_t), (size_t) cov * sizeof(int32_t), st));
     {
         ScopedTimer t(e, "scan_order", st);
-        HIP_TRY(launch_scan_order(e->d_codes.as<uint8_t>(), e->N, e->M, e->Ks, cov / 1024, e->d_scan_perm.as<int32_t>(),
+        HIP_TRY(launch_scan_order(e->d_codes.as<uint8_t>(), e->N, e->M, e->Ks, fastscan_rows(e->M, e->Ks), cov / 1024,
+                                  e->d_scan_perm.as<int32_t>(),
                                   e->d_scan_codes.as<uint8_t>(), st));
     }
     e->scan_cov = (e->N / 1024) * 1024;
@@ -391,7 +392,7 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             if (topk > 1) cap = std::max(cap, 16 * topk * stride);
             // whole-database scans run over the LDS-friendly copy of the codes; the re-rank maps positions back to ids
             const int32_t *d_perm = nullptr;
-            if (e->scan_order && !d_remap && d_codes == e->d_codes.as<uint8_t>() && n_codes == e->N && qr == 16 &&
+            if (e->scan_order && !d_remap && d_codes == e->d_codes.as<uint8_t>() && n_codes == e->N &&
                 n_codes >= kScanOrderMinN && scan_order_supported(e->M, e->Ks)) {
                 RII_TRY(ensure_scan_order(e, st));
                 d_codes = e->d_scan_codes.as<uint8_t>();
@@ -462,8 +463,8 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
         pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len, qt);
         // 16-byte table rows (4 queries per row) meet the same ds_read_b128 service groups as the filter's byte tables:
         // whole-database scans walk the LDS-friendly copy of the codes
-        if (e->scan_order && qt == 4 && !d_remap && d_codes == e->d_codes.as<uint8_t>() && n_codes == e->N &&
-            n_codes >= kScanOrderMinN && scan_order_supported(e->M, e->Ks)) {
+        if (e->scan_order && qt == 4 && fastscan_rows(e->M, e->Ks) == 16 && !d_remap && d_codes == e->d_codes.as<uint8_t>() &&
+            n_codes == e->N && n_codes >= kScanOrderMinN && scan_order_supported(e->M, e->Ks)) {
             RII_TRY(ensure_scan_order(e, st));
             sp.codes = e->d_scan_codes.as<uint8_t>();
             sp.perm = e->d_scan_perm.as<int32_t>();

@@ -147,7 +147,7 @@ hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, in
 
 // scanorder.hip: LDS-friendly scan order for the filter stage (perm[pos] = code id, codes gathered in that order)
 bool scan_order_supported(int M, int Ks);
-hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, int64_t win0, int32_t *d_perm,
+hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, int rows, int64_t win0, int32_t *d_perm,
                              uint8_t *d_out_codes, hipStream_t st);
 
 }  // namespace riiamd

@@ -25,7 +25,7 @@ namespace riiamd {
 constexpr int kSoWindow = 1024;
 constexpr int kSoThreads = 256;
 constexpr int kSoStripe = kSoWindow / kSoThreads;     // candidates owned by one thread, offered one at a time
-constexpr int kSoMaxM = 40;
+constexpr int kSoMaxM = 64;
 
 // lane of the i-th member of service group j (j = 0..3) of a wave -- MI355X_MICROARCH.md "LDS", ds_read_b128 row
 __device__ __forceinline__ int so_group_lane(int j, int i)
@@ -40,9 +40,12 @@ __device__ __forceinline__ int so_group_lane(int j, int i)
 // One block per window.  LDS: codes of the window (padded to an odd word stride), the group under construction
 // (seen[m][Ks bits], quad load cnt[m][16], max load mx[m]) and the placement order.
 __global__ __launch_bounds__(kSoThreads) void scan_order_kernel(const uint8_t *__restrict__ codes, int64_t N, int M, int Ks,
-                                                                int64_t win0, int32_t *__restrict__ perm,
+                                                                int64_t win0, int gs, int32_t *__restrict__ perm,
                                                                 uint8_t *__restrict__ out_codes)
 {
+    // gs = lanes per LDS service group = bank slots per row size: 16 for 16-byte rows (ds_read_b128), 32 for 8-byte rows
+    // (ds_read_b64: lanes 0-31 / 32-63, slot = row & 31)
+    const int smask = gs - 1, gshift = gs == 16 ? 4 : 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int64_t base = (win0 + blockIdx.x) * (int64_t) kSoWindow;
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(kSoThreads) void scan_order_kernel(const uint8_t *_
     const int cw = ((M + 3) >> 2) | 1;                                           // words per staged code (odd: no bank pile-up)
     uint32_t *s_code = reinterpret_cast<uint32_t *>(smem);                       // [kSoWindow][cw]
     uint32_t *s_seen = s_code + (size_t) kSoWindow * cw;                         // [M][8]
-    uint8_t *s_cnt = reinterpret_cast<uint8_t *>(s_seen + (size_t) M * 8);       // [M][16]
-    uint8_t *s_mx = s_cnt + (size_t) M * 16;                                     // [M] (+pad)
+    uint8_t *s_cnt = reinterpret_cast<uint8_t *>(s_seen + (size_t) M * 8);       // [M][32] (gs used)
+    uint8_t *s_mx = s_cnt + (size_t) M * 32;                                     // [M] (+pad)
     uint32_t *s_red = reinterpret_cast<uint32_t *>(s_mx + ((M + 3) & ~3));       // [2][4]
     uint16_t *s_order = reinterpret_cast<uint16_t *>(s_red + 8);                 // [kSoWindow]
 
@@ -68,13 +71,13 @@ __global__ __launch_bounds__(kSoThreads) void scan_order_kernel(const uint8_t *_
     __syncthreads();
 
     int k = 0;                                  // this thread's next candidate is tid + k*kSoThreads
-    const int ngroups = nplace >> 4;
+    const int ngroups = nplace >> gshift;
     for (int g = 0; g < ngroups; ++g) {
         for (int i = tid; i < M * 8; i += kSoThreads) s_seen[i] = 0u;
-        for (int i = tid; i < M * 4; i += kSoThreads) reinterpret_cast<uint32_t *>(s_cnt)[i] = 0u;
+        for (int i = tid; i < M * 8; i += kSoThreads) reinterpret_cast<uint32_t *>(s_cnt)[i] = 0u;
         if (tid < M) s_mx[tid] = 0;
         __syncthreads();
-        for (int pick = 0; pick < 16; ++pick) {
+        for (int pick = 0; pick < gs; ++pick) {
             const int cand = tid + k * kSoThreads;
             uint32_t key = 0xffffffffu;
             if (k < kSoStripe && cand < nplace) {
@@ -83,8 +86,8 @@ __global__ __launch_bounds__(kSoThreads) void scan_order_kernel(const uint8_t *_
                 for (int m = 0; m < M; ++m) {
                     const int ks = (cp[m >> 2] >> (8 * (m & 3))) & 0xff;
                     const bool seen = (s_seen[m * 8 + (ks >> 5)] >> (ks & 31)) & 1u;
-                    const int load = s_cnt[m * 16 + ((m * Ks + ks) & 15)];
-                    if (!seen) cost += (load + 1 > (int) s_mx[m] ? 16u : 0u) + (uint32_t) load;
+                    const int load = s_cnt[m * 32 + ((m * Ks + ks) & smask)];
+                    if (!seen) cost += (load + 1 > (int) s_mx[m] ? 32u : 0u) + (uint32_t) load;
                 }
                 key = (cost << 10) | (uint32_t) cand;
             }
@@ -99,31 +102,35 @@ __global__ __launch_bounds__(kSoThreads) void scan_order_kernel(const uint8_t *_
             uint32_t best = red[0];
 #pragma unroll
             for (int i = 1; i < kSoThreads / 64; ++i) best = red[i] < best ? red[i] : best;
-            const int win = (int) (best & 1023u);              // always valid: nplace is a multiple of 16
+            const int win = (int) (best & 1023u);              // always valid: nplace is a multiple of 64
             if ((win & (kSoThreads - 1)) == tid) ++k;
-            if (tid == 0) s_order[g * 16 + pick] = (uint16_t) win;
+            if (tid == 0) s_order[g * gs + pick] = (uint16_t) win;
             if (tid < M) {
                 const int m = tid;
                 const int ks = (s_code[(size_t) win * cw + (m >> 2)] >> (8 * (m & 3))) & 0xff;
                 const uint32_t bit = 1u << (ks & 31);
                 if (!(s_seen[m * 8 + (ks >> 5)] & bit)) {
                     s_seen[m * 8 + (ks >> 5)] |= bit;
-                    const int q = (m * Ks + ks) & 15;
-                    const uint8_t c = (uint8_t) (s_cnt[m * 16 + q] + 1);
-                    s_cnt[m * 16 + q] = c;
+                    const int q = (m * Ks + ks) & smask;
+                    const uint8_t c = (uint8_t) (s_cnt[m * 32 + q] + 1);
+                    s_cnt[m * 32 + q] = c;
                     if (c > s_mx[m]) s_mx[m] = c;
                 }
             }
             __syncthreads();
         }
     }
-    // placement: group g = 4*slab + j, member i -> lane so_group_lane(j, i) of slab
+    // placement (gs = 16): group g = 4*slab + j, member i -> lane so_group_lane(j, i) of slab
     for (int i = tid; i < nw; i += kSoThreads) {
         int src = i, pos = i;
         if (i < nplace) {
-            const int g = i >> 4, mem = i & 15;
             src = s_order[i];
-            pos = ((g >> 2) << 6) + so_group_lane(g & 3, mem);
+            if (gs == 16) {
+                const int g = i >> 4, mem = i & 15;
+                pos = ((g >> 2) << 6) + so_group_lane(g & 3, mem);
+            } else {
+                pos = i;                                       // groups of 32 are the contiguous halves of a wave
+            }
         }
         perm[base + pos] = (int32_t) (base + src);
         uint8_t *dst = out_codes + (size_t) (base + pos) * M;
@@ -139,13 +146,14 @@ __global__ __launch_bounds__(kSoThreads) void scan_order_kernel(const uint8_t *_
 bool scan_order_supported(int M, int Ks) { return M >= 1 && M <= kSoMaxM && Ks <= 256; }
 
 // windows [win0, ceil(N/1024)) of the code array are (re)ordered; perm / out_codes must hold N entries
-hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, int64_t win0, int32_t *d_perm,
+hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, int rows, int64_t win0, int32_t *d_perm,
                              uint8_t *d_out_codes, hipStream_t st)
 {
+    const int gs = rows == 16 ? 16 : 32;          // queries per byte-table row 16 -> ds_read_b128 groups, 8 -> ds_read_b64
     const int64_t nwin = (N + kSoWindow - 1) / kSoWindow - win0;
     if (nwin <= 0) return hipSuccess;
     const int cw = ((M + 3) >> 2) | 1;
-    const size_t smem = (size_t) kSoWindow * cw * 4 + (size_t) M * 32 + (size_t) M * 16 + ((M + 3) & ~3) + 32 +
+    const size_t smem = (size_t) kSoWindow * cw * 4 + (size_t) M * 32 + (size_t) M * 32 + ((M + 3) & ~3) + 32 +
                         (size_t) kSoWindow * 2;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_order_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
@@ -153,7 +161,7 @@ hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, i
     for (int64_t w = 0; w < nwin; w += 65535 * 16) {          // grid.x limit is far away; keep launches bounded anyway
         const int64_t n = std::min<int64_t>(nwin - w, 65535 * 16);
         hipLaunchKernelGGL(scan_order_kernel, dim3((unsigned) n), dim3(kSoThreads), smem, st, d_codes, N, M, Ks, win0 + w,
-                           d_perm, d_out_codes);
+                           gs, d_perm, d_out_codes);
     }
     return hipGetLastError();
 }

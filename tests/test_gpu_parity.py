@@ -460,7 +460,7 @@ def test_alternating_streams_share_scratch_safely():
         assert np.array_equal(ib.cpu().numpy(), want_b[0]) and np.array_equal(db.cpu().numpy(), want_b[1])
 
 
-@pytest.mark.parametrize("M,N", [(32, 70000), (16, 66000), (8, 65536 + 1000), (12, 67000)])
+@pytest.mark.parametrize("M,N", [(32, 70000), (16, 66000), (8, 65536 + 1000), (12, 67000), (64, 66500)])
 def test_scan_order_does_not_change_results(M, N):
     """The filter stage scans an LDS-friendly permutation of the codes (scanorder.hip); ids, distances and tie-breaks must
     be exactly those of the id-order scan and of the exhaustive scan -- including on a database with exact duplicates,
