@@ -79,3 +79,12 @@ def test_plain_c_client_on_gpu(tmp_path):
     exe = _build_c_client(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "C ABI smoke OK" in out.stdout, (out.stdout, out.stderr)
+
+
+def test_main_module_shim_exposes_riicpp():
+    """`rii_amd.main.RiiCpp` is what `import main` resolves to after the one-line swap of INTEGRATION.md §2: it must carry
+    every member the reference's `rii/rii.py` touches on `main.RiiCpp` (src/main.cpp:12-54)."""
+    from rii_amd import main
+    for name in ("reconfigure", "add_codes", "query_linear", "query_ivf", "clear", "verbose", "coarse_centers",
+                 "flattened_codes", "posting_lists", "N", "nlist", "__getstate__", "__setstate__"):
+        assert hasattr(main.RiiCpp, name), name
