@@ -123,3 +123,16 @@ class QueryShardedIndex(object):
         s, e = shard_range(Q.shape[0], rank, w)
         ids, d = self.engine.query_linear_batch(np.ascontiguousarray(Q[s:e]), topk, target_ids)
         return allgather_query_shards(ids, d, self.group)
+
+    def query_ivf_batch(self, Q, topk, target_ids, L):
+        """Inverted-index search, query-sharded (the reference's "stop at exactly L candidates in list order" rule is a
+        per-query sequential rule, so the index is replicated and the queries are split).
+        Returns (ids [B,topk], dists [B,topk], counts [B]) on every rank."""
+        rank, w = world()
+        assert Q.shape[0] % w == 0, "batch must divide evenly over the ranks (all-gather of equal shapes)"
+        s, e = shard_range(Q.shape[0], rank, w)
+        ids, d, cnt = self.engine.query_ivf_batch(np.ascontiguousarray(Q[s:e]), topk, target_ids, L)
+        gi, gd = allgather_query_shards(ids, d, self.group)
+        gc, _ = allgather_query_shards(np.asarray(cnt, np.int64).reshape(-1, 1),
+                                       np.zeros((len(cnt), 1), np.float32), self.group)
+        return gi, gd, gc.reshape(-1)

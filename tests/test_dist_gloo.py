@@ -30,6 +30,20 @@ class _OracleBatch(object):
             ids[b], d[b] = i, dd
         return ids, d
 
+    def reconfigure(self, nlist, it):
+        self.o.reconfigure(nlist, it)
+
+    def query_ivf_batch(self, Q, topk, tids, L):
+        t = np.array([], np.int64) if tids is None else np.asarray(tids, np.int64)
+        ids = np.full((Q.shape[0], topk), -1, np.int64)
+        d = np.full((Q.shape[0], topk), np.inf, np.float32)
+        cnt = np.zeros(Q.shape[0], np.int64)
+        for b in range(Q.shape[0]):
+            i, dd = self.o.query_ivf(Q[b], topk, t, L)
+            cnt[b] = len(i)
+            ids[b, :len(i)], d[b, :len(i)] = i, dd
+        return ids, d, cnt
+
 
 def _free_port():
     s = socket.socket()
@@ -49,6 +63,12 @@ class _GpuBatch(object):
 
     def query_linear_batch(self, Q, topk, tids=None):
         return self.g.query_linear_batch(Q, topk, tids)
+
+    def reconfigure(self, nlist, it):
+        self.g.reconfigure(nlist, it)
+
+    def query_ivf_batch(self, Q, topk, tids, L):
+        return self.g.query_ivf_batch(Q, topk, tids, L)
 
 
 def _worker(rank, world, port, q, use_gpu=False):
@@ -80,10 +100,23 @@ def _worker(rank, world, port, q, use_gpu=False):
         wi, wd = full.query_linear_batch(Q, 3, few)
         assert np.array_equal(gi.numpy(), wi)
         # --- query sharding ---
-        qidx = rd.QueryShardedIndex(_GpuBatch(cw, codes) if use_gpu else full)
+        rep = _GpuBatch(cw, codes) if use_gpu else full
+        qidx = rd.QueryShardedIndex(rep)
         gi, gd = qidx.query_linear_batch(Q, 4)
         wi, wd = full.query_linear_batch(Q, 4)
         assert np.array_equal(gi.numpy(), wi) and np.array_equal(gd.numpy().view(np.uint32), wd.view(np.uint32))
+        # inverted index, query-sharded (replicated index): identical to the single-index answer, counts included
+        full.reconfigure(40, 2)
+        if rep is not full:
+            rep.reconfigure(40, 2)
+        for topk, L, t in ((1, 200, None), (5, 600, tids)):
+            gi, gd, gc = qidx.query_ivf_batch(Q, topk, t, L)
+            wi, wd, wc = full.query_ivf_batch(Q, topk, t, L)
+            assert np.array_equal(gc.numpy(), wc)
+            for b in range(Q.shape[0]):
+                n = int(wc[b])
+                assert np.array_equal(gi.numpy()[b, :n], wi[b, :n]), "ivf ids k=%d" % topk
+                assert np.array_equal(gd.numpy()[b, :n].view(np.uint32), wd[b, :n].view(np.uint32))
         q.put((rank, "ok"))
     except Exception as ex:                                   # noqa: BLE001
         import traceback
