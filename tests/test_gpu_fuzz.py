@@ -78,3 +78,49 @@ def test_fuzz_against_oracle(seed):
             want = o.query_ivf(Q[b], topk, tids, L)
             n = int(cnt[b])
             assert_same_result((ids[b, :n], d[b, :n]), want, "ivf seed=%d k=%d L=%d S=%d b=%d" % (seed, topk, L, S, b))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_large_db_paths_agree(seed):
+    """Databases big enough for the scan-order copy (N >= 65536), random shapes: the filter over the scan order, the filter in
+    id order, the exhaustive scan over the scan order and the plain exhaustive scan must return identical top-1 results
+    (ids and distance bits) and identical top-k distance rows; checked again after an append."""
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(5000 + seed)
+    M = int(rng.choice([3, 8, 12, 16, 20, 32, 36, 40, 64]))
+    Ks = int(rng.choice([256, 256, 256, 64, 100]))
+    Ds = int(rng.choice([1, 2, 4, 6]))
+    N = int(rng.integers(65536, 140000))
+    B = int(rng.choice([5, 40, 130, 300]))
+    cw = rng.random((M, Ks, Ds)).astype(np.float32)
+    if rng.random() < 0.4:
+        cw = np.round(cw * 255)                      # integer-valued codebooks: exact ties are common
+    codes = rng.integers(0, Ks, size=(N, M), dtype=np.uint8)
+    ndup = int(N * rng.choice([0.0, 0.01, 0.3]))
+    if ndup:
+        codes[rng.integers(0, N, ndup)] = codes[rng.integers(0, N, ndup)]
+    Q = rng.random((B, M * Ds)).astype(np.float32) * (255 if cw.max() > 2 else 1)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    n1 = int(rng.integers(N // 2, N))
+    g.add_codes(codes[:n1], False)
+
+    def run(mode, order, topk):
+        g.set_option("scan_mode", mode)
+        g.set_option("scan_order", order)
+        g.set_option("fast_min_batch", int(rng.choice([0, 33])))
+        return g.query_linear_batch(Q, topk, None)
+
+    for stage in range(2):
+        ref = run(0, 0, 1)
+        for mode, order in ((1, 1), (1, 0), (0, 1)):
+            got = run(mode, order, 1)
+            assert np.array_equal(got[0], ref[0]), "ids seed=%d mode=%d order=%d stage=%d" % (seed, mode, order, stage)
+            assert np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32))
+        k = int(rng.integers(2, 50))
+        refk = run(0, 0, k)
+        for mode, order in ((1, 1), (1, 0)):
+            gotk = run(mode, order, k)
+            assert np.array_equal(gotk[1].view(np.uint32), refk[1].view(np.uint32)), "topk dists seed=%d" % seed
+            assert np.array_equal(gotk[0], refk[0]), "topk ids seed=%d" % seed       # both sides use the canonical (dist, id) order
+        if stage == 0:
+            g.add_codes(codes[n1:], False)
