@@ -309,12 +309,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
                 // in the permuted scan order a lane's ids are not ascending: an exact tie (rare) goes to the smaller id
                 bool tie = false;
 #pragma unroll
-                for (int q = 0; q < QT; ++q) tie |= (acc[q] == bestd[q]) & (besti[q] != (uint32_t) n);
+                for (int q = 0; q < QT; ++q)          // besti == ~0: nothing chosen yet (acc = +inf meets the initial bestd)
+                    tie |= (acc[q] == bestd[q]) & (besti[q] != (uint32_t) n) & (besti[q] != 0xffffffffu);
                 if (__builtin_expect(tie, 0)) {
                     const int32_t idn = p.perm[n];
 #pragma unroll
                     for (int q = 0; q < QT; ++q)
-                        if (acc[q] == bestd[q] && besti[q] != (uint32_t) n && idn < p.perm[besti[q]]) besti[q] = (uint32_t) n;
+                        if (acc[q] == bestd[q] && besti[q] != (uint32_t) n && besti[q] != 0xffffffffu &&
+                            idn < p.perm[besti[q]])
+                            besti[q] = (uint32_t) n;
                 }
             }
         }
@@ -954,26 +957,53 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         unsigned int &s_cnt = *reinterpret_cast<unsigned int *>(&s_buf[kRrBuf + 1]);
         if (tid == 0) { s_cnt = 0u; s_kthr = ~0ull; }
         __syncthreads();
-        for (int base = 0; base < ncand; base += 256) {
-            if (s_cnt + 256u > (unsigned int) kRrBuf) {
+        for (int base = 0; base < ncand; base += 4 * 256) {       // four traversal positions per thread and trip (batched gathers)
+            if (s_cnt + 4u * 256u > (unsigned int) kRrBuf) {
                 for (int i = tid; i < kRrBuf; i += 256)
                     if ((unsigned int) i >= s_cnt) s_buf[i] = ~0ull;
                 rr_bitonic_sort(s_buf, tid);
                 if (tid == 0) { s_cnt = (unsigned int) k1; s_kthr = s_buf[k1 - 1]; }
                 __syncthreads();
             }
-            const int pos = base + tid;
-            if (pos < ncand) {
-                int lo = 0, hi = nv;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+            int32_t id[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pos = base + u * 256 + tid;
+                id[u] = -1;
+                if (pos < ncand) {
+                    int lo = 0, hi = nv;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+                    }
+                    id[u] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
                 }
-                const int32_t id = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
-                const float dist = adc_lds(lds, p.codes + (size_t) id * p.M, p.M, p.Ks);
-                const unsigned long long key =
-                    ((unsigned long long) f32_orderable(__float_as_uint(dist)) << 32) | (uint32_t) pos;
-                if (key < s_kthr) s_buf[atomicAdd(&s_cnt, 1u)] = key;
+            }
+            float dist[4];
+            if (wide) {
+                uint4 cv[4][4];
+                const int MQ = p.M >> 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint4 *cp = reinterpret_cast<const uint4 *>(p.codes + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+                        if (qd < MQ) cv[u][qd] = cp[qd];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dist[u] = adc_lds_wide(lds, cv[u], MQ, p.Ks);
+            } else {
+                for (int u = 0; u < 4; ++u)
+                    dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, p.codes + (size_t) id[u] * p.M, p.M, p.Ks);
+            }
+            const unsigned long long thr = s_kthr;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (id[u] >= 0) {
+                    const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(dist[u])) << 32) |
+                                                   (uint32_t) (base + u * 256 + tid);
+                    if (key < thr) s_buf[atomicAdd(&s_cnt, 1u)] = key;
+                }
             }
             __syncthreads();
         }

@@ -508,3 +508,33 @@ def test_scan_order_does_not_change_results(M, N):
     ref = g.query_linear_batch(qs, 1, None)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     assert np.array_equal(got[1], want[1])                 # the same multiset of codes: the same best distances
+
+
+@pytest.mark.parametrize("B", [3, 6, 40, 200])
+def test_degenerate_queries_on_a_large_db_do_not_fault(B):
+    """Inf / NaN queries over a database big enough for the scan-order paths: every distance is +inf or NaN, nothing is ever
+    'better' than the initial +inf, and the tie logic of the permuted exhaustive scan must not chase the 'nothing chosen yet'
+    sentinel (it did: out-of-bounds read).  Ordinary rows of the same batch keep their results in every mode."""
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(B)
+    M, N = 16, 70000
+    cw = rng.random((M, 256, 4)).astype(np.float32)
+    codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
+    Q = rng.random((B, M * 4)).astype(np.float32)
+    bad = Q.copy()
+    bad[0, :] = np.inf
+    bad[1, 5] = np.nan
+    if B > 4:
+        bad[4, :] = -np.inf
+    good = [b for b in range(B) if b not in (0, 1, 4)]
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.set_option("scan_mode", 0); g.set_option("scan_order", 0)
+    want = g.query_linear_batch(Q, 1, None)
+    for mode, order, fmb in ((0, 1, 33), (0, 0, 33), (1, 1, 0), (1, 0, 0), (1, 1, 33)):
+        g.set_option("scan_mode", mode); g.set_option("scan_order", order); g.set_option("fast_min_batch", fmb)
+        for rep in range(3):
+            ids, d = g.query_linear_batch(bad, 1, None)
+            assert np.array_equal(ids[good], want[0][good]) and np.array_equal(d[good], want[1][good]), (mode, order, fmb)
+        ids, d = g.query_linear_batch(bad, 7, None)
+        assert ids.shape == (B, 7)
