@@ -362,11 +362,20 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
         const int64_t tiles = (B + qr - 1) / qr;
         int64_t c = e->scan_chunks;
         if (c <= 0) {
-            // one block per CU; chunks shorter than 8 slabs or more than 128 of them cost more in candidates (every chunk
-            // starts from its own thresholds) than they win in parallelism (tools/chunk_sweep.py)
-            c = std::max<int64_t>(1, (e->n_cu + tiles - 1) / tiles);
-            c = std::min<int64_t>(c, std::max<int64_t>(1, n_codes / 8192));
-            c = std::min<int64_t>(c, 128);
+            // one block per CU at a time (LDS), all blocks equally long: the scan takes ceil(tiles * c / n_cu) rounds, each
+            // as long as n_codes / c codes plus a fixed cost per block (table staging, warm-up, candidate flush: worth
+            // ~13K codes, tools/chunk_sweep.py).  Pick the c that minimises the product (63 tiles: 4 chunks = 252 blocks in
+            // one round, not 5 = 315 in two; 188 tiles: 4 chunks = 3 rounds of a quarter, not one round of everything);
+            // never chunks shorter than 8 slabs or more than 128 of them (every chunk starts from its own thresholds)
+            const int64_t cmax = std::max<int64_t>(1, std::min<int64_t>(128, n_codes / 8192));
+            const double per_block = 13000.0;
+            double best_cost = 1e300;
+            c = 1;
+            for (int64_t cc = 1; cc <= cmax; ++cc) {
+                const double rounds = (double) ((tiles * cc + e->n_cu - 1) / e->n_cu);
+                const double cost = rounds * ((double) n_codes / (double) cc + per_block);
+                if (cost < best_cost) { best_cost = cost; c = cc; }
+            }
         }
         c = std::max<int64_t>(1, std::min<int64_t>(c, 65535));
         int64_t len = std::max<int64_t>(1, (n_codes + c - 1) / c);

@@ -463,13 +463,15 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
         uint4 *d4 = reinterpret_cast<uint4 *>(smem);
         for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
         if (tid < QR / 2) {
-            uint32_t word = 0xffffffffu;
-            if constexpr (MODE == 2) {          // word i = 2w + parity: low = query 4w+parity, high = query 4w+parity+2
-                const int q0 = 4 * (tid >> 1) + (tid & 1), b0 = tile * QR + q0, b1 = b0 + 2;
-                const uint32_t lo = b0 < p.B ? p.thr16[b0] : 0u, hi = b1 < p.B ? p.thr16[b1] : 0u;
-                word = (lo & 0xffffu) | (hi << 16);
+            // word i = 2w + parity: low = query 4w+parity, high = query 4w+parity+2.  Queries past the end of the batch
+            // (last tile) get threshold 0: they can never "hit", or every code of the chunk would take the slow path
+            const int q0 = 4 * (tid >> 1) + (tid & 1), b0 = tile * QR + q0, b1 = b0 + 2;
+            uint32_t lo = b0 < p.B ? 0xffffu : 0u, hi = b1 < p.B ? 0xffffu : 0u;
+            if constexpr (MODE == 2) {
+                lo = b0 < p.B ? p.thr16[b0] : 0u;
+                hi = b1 < p.B ? p.thr16[b1] : 0u;
             }
-            s_thr[tid] = word;
+            s_thr[tid] = (lo & 0xffffu) | (hi << 16);
         }
         if (tid < 2 * QR) s_lcnt[tid] = 0u;
     }
