@@ -124,6 +124,134 @@ __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restri
     quantize_table(g, b, M, Ks, qc, slack);
 }
 
+// The common shapes (Ds == 4, M <= 32, Ks <= 256) keep the whole table of a query in registers: wave w owns the subspaces
+// m = w, w+4, ... (8 of them), lane l the entries ks = l, l+64, ... (4 of them) -- 32 values per thread.  Building,
+// per-subspace extrema, quantisation and residual extrema all run on those registers (no LDS copy of the table, no second
+// and third pass over it), the eight per-subspace shuffle reductions of a wave are interleaved, and the division by the step
+// is a multiplication by its reciprocal (any rounding of the level is fine: the residuals are taken from the levels actually
+// stored).  One block used to take ~35 us whatever the batch size -- a fixed cost under every batch.
+__device__ __forceinline__ void build_quantize_regs(const float *__restrict__ q, const float *__restrict__ codewords, int64_t b,
+                                                    int M, int Ks, float *__restrict__ lut,
+                                                    uint8_t *__restrict__ qc, int32_t *__restrict__ slack)
+{
+    __shared__ float s_lo[32], s_hi[32];
+    __shared__ double s_rlo[32], s_rhi[32];
+    __shared__ float s_delta;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int MK = M * Ks;
+    float t[8][4];
+    {
+        const float4 *cw4 = reinterpret_cast<const float4 *>(codewords);
+        const float4 *q4 = reinterpret_cast<const float4 *>(q);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {               // two halves: 16 codeword loads in flight, 64 VGPRs of staging
+            float4 cv[4][4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = wave + 4 * (4 * h + mi), ks = lane + 64 * e;
+                    cv[mi][e] = (m < M && ks < Ks) ? cw4[m * Ks + ks] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = wave + 4 * (4 * h + mi);
+                const float4 qm = m < M ? q4[m] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[4 * h + mi][e] = fvec_l2sqr_ds4v(qm, cv[mi][e]);
+            }
+        }
+    }
+    float lo[8], hi[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = wave + 4 * mi;
+        lo[mi] = INFINITY; hi[mi] = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ks = lane + 64 * e;
+            if (m < M && ks < Ks) {
+                lut[(size_t) b * MK + m * Ks + ks] = t[mi][e];        // plain [b][M*Ks] layout: coalesced, what the re-rank stages
+                lo[mi] = fminf(lo[mi], t[mi][e]);
+                hi[mi] = fmaxf(hi[mi], t[mi][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            lo[mi] = fminf(lo[mi], __shfl_xor(lo[mi], off));
+            hi[mi] = fmaxf(hi[mi], __shfl_xor(hi[mi], off));
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = wave + 4 * mi;
+            if (m < M) { s_lo[m] = lo[mi]; s_hi[m] = hi[mi]; }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float range = (tid < M) ? s_hi[tid] - s_lo[tid] : 0.f;
+        // NaN ranges must poison the result like the serial fmaxf chain of quantize_table would not: keep its semantics
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) range = fmaxf(range, __shfl_xor(range, off));
+        if (tid == 0) {
+            float d = range / (float) kFsLevels;
+            if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
+            s_delta = d * 1.000001f;
+        }
+    }
+    __syncthreads();
+    const float delta = s_delta, inv = 1.0f / delta;
+    const double ddelta = (double) delta;
+    uint8_t *dst = qc + (size_t) b * MK;          // compact [b][M*Ks]; qlut_interleave_kernel builds the rows the scan reads
+    double rlo[8], rhi[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = wave + 4 * mi;
+        rlo[mi] = INFINITY; rhi[mi] = -INFINITY;
+        const float l = lo[mi];                    // every lane holds the reduced value after the xor-shuffles
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ks = lane + 64 * e;
+            if (m < M && ks < Ks) {
+                const float x = floorf((t[mi][e] - l) * inv + 0.5f);
+                const int c = (x >= (float) kFsLevels) ? kFsLevels : (x > 0.f ? (int) x : 0);
+                dst[m * Ks + ks] = (uint8_t) c;
+                const double res = (double) t[mi][e] - ((double) l + (double) c * ddelta);
+                rlo[mi] = fmin(rlo[mi], res);
+                rhi[mi] = fmax(rhi[mi], res);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            rlo[mi] = fmin(rlo[mi], __shfl_xor(rlo[mi], off));
+            rhi[mi] = fmax(rhi[mi], __shfl_xor(rhi[mi], off));
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = wave + 4 * mi;
+            if (m < M) { s_rlo[m] = rlo[mi]; s_rhi[m] = rhi[mi]; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double Rlo = 0.0, Rhi = 0.0, dmax = 0.0;
+        for (int m = 0; m < M; ++m) { Rlo += s_rlo[m]; Rhi += s_rhi[m]; dmax += fabs((double) s_hi[m]) + fabs((double) s_lo[m]); }
+        // |fp32 sequential sum - real sum| <= (M-1) * 2^-24 * sum|t| (standard bound); use M * 2^-23 * dmax
+        const double eps = (double) M * 1.1920928955078125e-07 * dmax;
+        double sl = (Rhi - Rlo + 2.0 * eps) / ddelta;
+        sl = sl * (1.0 + 1e-9) + 2.0;                      // margins for the roundings of this very computation
+        slack[b] = (sl >= 0.0 && sl < 60000.0) ? (int32_t) sl : 60000;      // >= 0xffff - max a(): everything is a candidate
+    }
+}
+
 // fused: exact table (fvec_L2sqr order, src/distance.h:117-252) -> global fp32 (for the re-rank) AND its quantisation
 __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__restrict__ queries, int64_t B,
                                                               const float *__restrict__ codewords, int M, int Ks, int Ds,
@@ -179,6 +307,22 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
     quantize_table(g, b, M, Ks, qc, slack);
 }
 
+// the register-resident variant as its own kernel (its register budget must not be set by the generic paths above)
+__global__ __launch_bounds__(256) void lut_build_quant_regs_kernel(const float *__restrict__ queries, int64_t B,
+                                                                   const float *__restrict__ codewords, int M, int Ks,
+                                                                   float *__restrict__ lut, uint8_t *__restrict__ qc,
+                                                                   int32_t *__restrict__ slack,
+                                                                   unsigned int *__restrict__ cand_cnt,
+                                                                   uint32_t *__restrict__ gthr)
+{
+    const int64_t b = blockIdx.x;
+    if (threadIdx.x == 0) {            // per-query state of the filter stage, reset here instead of by two memset launches
+        if (cand_cnt) cand_cnt[b] = 0u;
+        if (gthr) gthr[b] = 0xffffffffu;
+    }
+    build_quantize_regs(queries + b * (int64_t) (M * 4), codewords, b, M, Ks, lut, qc, slack);
+}
+
 // compact [b][M*Ks] bytes -> [tile][M*Ks][QR]: one 16-byte (QR=16) or 8-byte (QR=8) row per thread, coalesced both ways
 template <int QR>
 __global__ __launch_bounds__(256) void qlut_interleave_kernel(const uint8_t *__restrict__ qc, int64_t B, int MK,
@@ -231,6 +375,13 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
                                   unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
+    if (Ds == 4 && M <= 32 && Ks <= 256) {          // Ds == 4: all three fvec_L2sqr variants coincide (rii_device.h)
+        hipLaunchKernelGGL(lut_build_quant_regs_kernel, dim3((unsigned) B), dim3(256), 0, st, d_queries, B, d_codewords, M, Ks,
+                           d_lut, d_qc, d_slack, d_cand_cnt, d_gthr);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+        return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, st);
+    }
     const size_t smem = (size_t) M * Ks * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lut_build_quant_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
