@@ -1006,7 +1006,14 @@ __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
     const int tid = threadIdx.x;
     {
         const float *src = p.lut + (size_t) (b / p.QT) * MK * p.QT + (b % p.QT);
-        for (int i = tid; i < MK; i += blockDim.x) lds[i] = src[(size_t) i * p.QT];
+        if (p.QT == 1 && (MK & 3) == 0) {               // plain [b][M*Ks] layout (what the fused table kernel writes): 16-byte copies
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(lds);
+#pragma unroll 4
+            for (int i = tid; i < MK / 4; i += blockDim.x) d4[i] = s4[i];
+        } else {
+            for (int i = tid; i < MK; i += blockDim.x) lds[i] = src[(size_t) i * p.QT];
+        }
         if (tid == 0) { red[0] = ~0ull; red[1] = ~0ull; }
     }
     __syncthreads();
@@ -1098,7 +1105,14 @@ __global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
     const int k = p.topk;
     {
         const float *src = p.lut + (size_t) (b / p.QT) * MK * p.QT + (b % p.QT);
-        for (int i = tid; i < MK; i += 256) lds[i] = src[(size_t) i * p.QT];
+        if (p.QT == 1 && (MK & 3) == 0) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(lds);
+#pragma unroll 4
+            for (int i = tid; i < MK / 4; i += 256) d4[i] = s4[i];
+        } else {
+            for (int i = tid; i < MK; i += 256) lds[i] = src[(size_t) i * p.QT];
+        }
         if (tid == 0) { s_cnt = 0u; s_thr = ~0ull; }
     }
     __syncthreads();
