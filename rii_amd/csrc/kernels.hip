@@ -737,6 +737,9 @@ __device__ __forceinline__ float adc_lds_wide(const float *lds, const uint4 (&cv
     return dist;
 }
 
+// Instantiated per (top-1 / top-k, Ds == 4 / generic): the all-in-one kernel was 63 KB of code -- the size of the instruction
+// cache two CUs share -- of which a top-1, Ds = 4 query runs a fraction.
+template <bool TOP1, bool DS4>
 __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     if (p.queries) {
         // table built in place (exact fvec_L2sqr order): no global round trip for the common case
         const float *q = p.queries + (p.b0 + bl) * (int64_t) (p.M * p.Ds);
-        if (p.Ds == 4) {
+        if constexpr (DS4) {
             // 8 independent 16-byte codeword loads in flight per thread (the block has nothing else to hide them behind)
             const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
             const float4 *q4 = reinterpret_cast<const float4 *>(q);
@@ -890,7 +893,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         return;
     }
     const int ncand = s_misc[0], nv = s_misc[1];
-    const bool top1 = (p.topk == 1);
+    constexpr bool top1 = TOP1;
     float bestd = INFINITY;
     uint32_t bestp = 0xffffffffu;
     int32_t bestid = -1;
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         for (int u = 0; u < 4; ++u)                   // ascending traversal position: strict < keeps the first minimum
             if (id[u] >= 0 && dist[u] < bestd) { bestd = dist[u]; bestp = (uint32_t) (p0 + u * 256); bestid = id[u]; }
     }
-    if (top1) {
+    if constexpr (TOP1) {
         unsigned long long key =
             bestp == 0xffffffffu ? ~0ull
                                  : (((unsigned long long) f32_orderable(__float_as_uint(bestd)) << 32) | bestp);
@@ -949,6 +952,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         }
         return;
     }
+    if constexpr (!TOP1)
     // ---- top-k > 1: stream (dist, traversal position) keys through a block-local top-(k+1); if no two of those k+1
     // distances are equal the answer is independent of std::partial_sort's internals, else hand over to the emulation ----
     {
@@ -1072,10 +1076,13 @@ hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st)
 {
     if (p.B == 0) return hipSuccess;
     const size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    const bool top1 = p.topk == 1, ds4 = p.Ds == 4;
+    auto kern = top1 ? (ds4 ? ivf_fused_kernel<true, true> : ivf_fused_kernel<true, false>)
+                     : (ds4 ? ivf_fused_kernel<false, true> : ivf_fused_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ivf_fused_kernel, dim3((unsigned) p.B), dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned) p.B), dim3(256), smem, st, p);
     return hipGetLastError();
 }
 
