@@ -92,12 +92,12 @@ struct rii_engine {
     int scan_chunks = 0;        // 0 = auto
     int scan_mode = 1;          // 1 = 8-bit filter + exact re-rank for top-1 (fastscan.hip), 0 = exact scan only
     int fast_min_batch = 33;    // top-1 batches below this take the exact scan (option "fast_min_batch"; tools/sweep_fast_min.py)
-    int cand_cap = 4096;
+    int cand_cap = 4096;        // candidate slots per query for the re-rank stage (lower bound; grows for small batches)
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
     int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
-    int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)        // candidate slots per query for the re-rank stage
+    int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)
     int timing = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
