@@ -124,7 +124,7 @@ int64_t rii_get_option(const rii_engine *e, const char *key);
 /* Per-kernel HIP-event timing (enabled by option "timing"=1): events are recorded on the launch stream
  * around every launch of the named kernel; reading synchronises the stream.
  * names: "lut", "scan", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select", "assign", "gather", "select", "quant", "rerank",
- * "ivf_fused", "ivf_exact", "kth", "scan_order". */
+ * "ivf_fused", "ivf_exact", "kth", "scan_order", "tie". */
 int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms, int64_t *launches);
 int rii_timing_reset(rii_engine *e);
 int rii_synchronize(rii_engine *e);

@@ -122,7 +122,8 @@ struct rii_engine {
     // scratch
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
-        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list;
+        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
+        s_tie_list, s_tie_hid, s_tie_hd;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
@@ -346,11 +347,38 @@ int ensure_scan_order(rii_engine *e, hipStream_t st)
     return RII_OK;
 }
 
+// linear top-k (k > 1): the producers of the canonical (dist, id) result append the queries whose k+1 smallest distances
+// hold an exact tie to s_tie_list ([0] = count, [1..] = query indices relative to b0); linear_tie_kernel replays
+// std::partial_sort (src/rii.h:234-235) for them over the codes in the reference's index order.
+int tie_list_reset(rii_engine *e, int64_t bc, hipStream_t st)
+{
+    RII_TRY(e->s_tie_list.ensure((size_t) (bc + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(e->s_tie_list.p, 0, sizeof(int32_t), st));
+    return RII_OK;
+}
+int tie_fixup(rii_engine *e, const uint8_t *d_codes_idx, int64_t n_codes, int64_t b0, int64_t bc, int topk,
+              const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+{
+    if (!linear_tie_supported(e->M, e->Ks))
+        return set_err(RII_ERR_UNSUPPORTED, "M*Ks=%d tables do not fit LDS next to the tie-order work list", e->M * e->Ks);
+    const int grid = (int) std::min<int64_t>(bc, 2LL * e->n_cu);
+    if (!linear_tie_heap_in_lds(e->M, e->Ks, topk)) {
+        RII_TRY(e->s_tie_hid.ensure((size_t) grid * topk * sizeof(int32_t)));
+        RII_TRY(e->s_tie_hd.ensure((size_t) grid * topk * sizeof(float)));
+    }
+    ScopedTimer t(e, "tie", st);
+    HIP_TRY(launch_linear_tie(d_codes_idx, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, b0,
+                              e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), d_remap, d_out_ids, d_out_dists,
+                              topk, grid, e->s_tie_hid.as<int32_t>(), e->s_tie_hd.as<float>(), st));
+    return RII_OK;
+}
+
 // the scan over `n_codes` codes at d_codes for B queries whose tables are in s_lut; ids are local indices
 // translated through d_remap (subset search) when given.
 int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int64_t n_codes, int64_t B, int topk,
               const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
+    const uint8_t *const d_codes_idx = d_codes;     // the codes in the index order of the reference's `scores` array
     ScanParams sp;
     sp.codes = d_codes; sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks;
     sp.B = (int) B; sp.QT = e->QT; sp.best = nullptr; sp.keys = nullptr; sp.b0 = 0; sp.bc = 0;
@@ -456,11 +484,15 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
                                      2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, st));
             }
-            ScopedTimer t(e, "rerank", st);
-            HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
-                                       e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap, d_remap,
-                                       d_perm, B, d_out_ids, d_out_dists, topk, st));
-            return RII_OK;
+            RII_TRY(tie_list_reset(e, B, st));
+            {
+                ScopedTimer t(e, "rerank", st);
+                HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
+                                           e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap, d_remap,
+                                           d_perm, B, d_out_ids, d_out_dists, topk, e->s_tie_list.as<int32_t>() + 1,
+                                           e->s_tie_list.as<int>(), st));
+            }
+            return tie_fixup(e, d_codes_idx, n_codes, 0, B, topk, d_remap, d_out_ids, d_out_dists, st);
         }
     }
     // the exhaustive kernels read the tile-interleaved layout: re-lay the tables out if they are in another one
@@ -515,7 +547,11 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
                                         cur, n_codes, &e->sort_temp, &e->sort_temp_bytes, st));
             HIP_TRY(launch_gather_sorted_topk(e->s_keys_b.as<unsigned long long>(), cur, n_codes, topk, d_remap,
                                               d_out_ids + b0 * topk, d_out_dists + b0 * topk, st));
+            RII_TRY(tie_list_reset(e, cur, st));
+            HIP_TRY(launch_sorted_tie_flag(e->s_keys_b.as<unsigned long long>(), cur, n_codes, topk,
+                                           e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), st));
         }
+        RII_TRY(tie_fixup(e, d_codes_idx, n_codes, b0, cur, topk, d_remap, d_out_ids, d_out_dists, st));
     }
     return RII_OK;
 }
@@ -749,7 +785,8 @@ void free_all(rii_engine *e)
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
-                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr, &e->s_qc, &e->s_flag_list};
+                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr, &e->s_qc, &e->s_flag_list,
+                      &e->s_tie_list, &e->s_tie_hid, &e->s_tie_hd};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;

@@ -978,23 +978,9 @@ struct RrArgs {
     int64_t *out_ids;
     float *out_dists;
     int topk;
+    int32_t *flag_list = nullptr;    // top-k: queries whose k+1 smallest distances hold an exact tie (redone by tieorder.hip)
+    int *nflag = nullptr;
 };
-
-__device__ __forceinline__ float exact_adist(const float *lds, const uint8_t *code, int M, int Ks)
-{
-    float dist = 0.f;
-    if ((M & 3) == 0) {
-        const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
-        for (int i = 0; i < M / 4; ++i) {
-            const uint32_t w = cw[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dist = __fadd_rn(dist, lds[(i * 4 + j) * Ks + ((w >> (8 * j)) & 0xffu)]);
-        }
-    } else {
-        for (int m = 0; m < M; ++m) dist = __fadd_rn(dist, lds[m * Ks + code[m]]);
-    }
-    return dist;
-}
 
 __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
 {
@@ -1115,17 +1101,25 @@ __global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
         }
         if (tid == 0) { s_cnt = 0u; s_thr = ~0ull; }
     }
-    __syncthreads();
     const unsigned int ncand = p.cand_count[b];
     const bool overflow = ncand > (unsigned int) p.cap;
     const int64_t total = overflow ? p.n_codes : (int64_t) ncand;
+    // the k+1 smallest keys are tracked: two equal distances among them mean the reference's answer hinges on
+    // std::partial_sort's heap order (tieorder.hip redoes the query).  Every code tied with the k-th distance is a
+    // candidate (see the exactness proof above), so a tie across the cut cannot hide outside the candidate set.
+    const int k1 = (int64_t) k + 1 < total ? k + 1 : (int) total;
     const unsigned long long *cand = p.cand + (size_t) b * p.cap;
     for (int64_t base = 0; base < total; base += 256) {
-        if (s_cnt + 256u > (unsigned int) kRrBuf) {               // uniform: make room
+        // the make-room decision must be uniform (the branch holds barriers): snapshot the counter between two barriers,
+        // after every append of the previous trip and before any append of this one
+        __syncthreads();
+        const unsigned int cnt_now = s_cnt;
+        __syncthreads();
+        if (cnt_now + 256u > (unsigned int) kRrBuf) {
             for (int i = tid; i < kRrBuf; i += 256)
-                if ((unsigned int) i >= s_cnt) buf[i] = ~0ull;
+                if ((unsigned int) i >= cnt_now) buf[i] = ~0ull;
             rr_bitonic_sort(buf, tid);
-            if (tid == 0) { s_cnt = (unsigned int) k; s_thr = buf[k - 1]; }
+            if (tid == 0) { s_cnt = (unsigned int) k1; s_thr = buf[k1 - 1]; }
             __syncthreads();
         }
         const int64_t i = base + tid;
@@ -1136,13 +1130,20 @@ __global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
             const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | id;
             if (key < s_thr) buf[atomicAdd(&s_cnt, 1u)] = key;
         }
-        __syncthreads();
     }
+    __syncthreads();
     int nsort = 64;                               // smallest power of two covering the keys actually collected
     while (nsort < (int) s_cnt || nsort < k) nsort <<= 1;
     for (int i = tid; i < nsort; i += 256)
         if ((unsigned int) i >= s_cnt) buf[i] = ~0ull;
     rr_bitonic_sort(buf, tid, nsort);
+    int tie = 0;
+    for (int j = tid; j + 1 < k1; j += 256)
+        if ((buf[j] >> 32) == (buf[j + 1] >> 32)) tie = 1;
+    if (__syncthreads_or(tie) && p.flag_list) {
+        if (tid == 0) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) b;
+        return;                                    // linear_tie_kernel writes this row
+    }
     for (int j = tid; j < k; j += 256) {
         const unsigned long long key = buf[j];
         const uint32_t idx = (uint32_t) (key & 0xffffffffu);
@@ -1151,15 +1152,16 @@ __global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
     }
 }
 
-int rerank_topk_max_k() { return kRrBuf / 2; }
+int rerank_topk_max_k() { return kRrBuf / 2 - 1; }      // the k+1 smallest keys are tracked
 
 hipError_t launch_rerank_topk(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const unsigned long long *d_cand, const unsigned int *d_cand_count, int cap,
                               const int64_t *d_remap, const int32_t *d_perm, int64_t B, int64_t *d_out_ids,
-                              float *d_out_dists, int topk, hipStream_t st)
+                              float *d_out_dists, int topk, int32_t *d_flag_list, int *d_nflag, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     RrArgs a;
+    a.flag_list = d_flag_list; a.nflag = d_nflag;
     a.perm = d_perm;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.slack = nullptr;
     a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.remap = d_remap; a.out_ids = d_out_ids;

@@ -448,6 +448,29 @@ hipError_t launch_gather_sorted_topk(const unsigned long long *d_sorted, int64_t
     return hipGetLastError();
 }
 
+// sort path: flag the rows whose k+1 smallest distances hold an exact tie (the reference's order then depends on
+// std::partial_sort's heap; tieorder.hip redoes those queries).  One thread per row pair.
+__global__ void sorted_tie_flag_kernel(const unsigned long long *__restrict__ sorted, int64_t bc, int64_t n_codes, int topk,
+                                       int32_t *__restrict__ flag_list, int *__restrict__ nflag)
+{
+    const int64_t k1 = (int64_t) topk + 1 < n_codes ? topk + 1 : n_codes;      // keys compared: rows [0, k1)
+    const int64_t per = k1 - 1;
+    const int64_t b = blockIdx.x;
+    if (b >= bc || per <= 0) return;
+    int tie = 0;
+    for (int64_t j = threadIdx.x; j < per; j += blockDim.x)
+        if ((sorted[b * n_codes + j] >> 32) == (sorted[b * n_codes + j + 1] >> 32)) tie = 1;
+    if (__syncthreads_or(tie) && threadIdx.x == 0) flag_list[atomicAdd(nflag, 1)] = (int32_t) b;
+}
+hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
+                                  int32_t *d_flag_list, int *d_nflag, hipStream_t st)
+{
+    if (bc == 0 || topk < 2) return hipSuccess;
+    hipLaunchKernelGGL(sorted_tie_flag_kernel, dim3((unsigned) bc), dim3(256), 0, st, d_sorted, bc, n_codes, topk,
+                       d_flag_list, d_nflag);
+    return hipGetLastError();
+}
+
 // subset search: compact the target codes once per batch (src/rii.h:218-228 gathers per query)
 __global__ void gather_codes_kernel(const uint8_t *__restrict__ codes, int M, const int64_t *__restrict__ ids,
                                     int64_t S, uint8_t *__restrict__ out)
@@ -469,67 +492,6 @@ hipError_t launch_gather_codes(const uint8_t *d_codes, int M, const int64_t *d_i
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(gather_codes_kernel, dim3(blocks), dim3(256), 0, st, d_codes, M, d_ids, S, d_out);
     return hipGetLastError();
-}
-
-// ===================================================================================================
-// std::partial_sort (libstdc++: __heap_select + __sort_heap over __adjust_heap/__push_heap), run by ONE
-// lane per query on (id, dist) pairs compared on dist only -- the comparator of src/rii.h:234,279,312.
-// Re-running the library's exact sequence of moves reproduces (i) which of several exactly tied
-// candidates the reference returns and (ii) the order of the coarse lists *past* w, which QueryIvf walks
-// when the first w lists hold fewer than topk hits (src/rii.h:283-326).
-// ===================================================================================================
-__device__ void pq_adjust_heap(int32_t *ids, float *ds, long hole, long len, int32_t vid, float vd)
-{
-    const long top = hole;
-    long child = hole;
-    while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        if (ds[child] < ds[child - 1]) child--;
-        ids[hole] = ids[child]; ds[hole] = ds[child];
-        hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-        child = 2 * (child + 1);
-        ids[hole] = ids[child - 1]; ds[hole] = ds[child - 1];
-        hole = child - 1;
-    }
-    long parent = (hole - 1) / 2;
-    while (hole > top && ds[parent] < vd) {
-        ids[hole] = ids[parent]; ds[hole] = ds[parent];
-        hole = parent;
-        parent = (hole - 1) / 2;
-    }
-    ids[hole] = vid; ds[hole] = vd;
-}
-
-__device__ void pq_partial_sort(int32_t *ids, float *ds, long middle, long n)
-{
-    long len = middle;
-    if (len >= 2) {
-        long parent = (len - 2) / 2;
-        for (;;) {
-            pq_adjust_heap(ids, ds, parent, len, ids[parent], ds[parent]);
-            if (parent == 0) break;
-            parent--;
-        }
-    }
-    if (len > 0) {
-        for (long i = middle; i < n; ++i) {
-            if (ds[i] < ds[0]) {
-                const int32_t vid = ids[i];
-                const float vd = ds[i];
-                ids[i] = ids[0]; ds[i] = ds[0];
-                pq_adjust_heap(ids, ds, 0, len, vid, vd);
-            }
-        }
-    }
-    while (len > 1) {
-        --len;
-        const int32_t vid = ids[len];
-        const float vd = ds[len];
-        ids[len] = ids[0]; ds[len] = ds[0];
-        pq_adjust_heap(ids, ds, 0, len, vid, vd);
-    }
 }
 
 // ===================================================================================================
@@ -962,9 +924,14 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         if (tid == 0) { s_cnt = 0u; s_kthr = ~0ull; }
         __syncthreads();
         for (int base = 0; base < ncand; base += 4 * 256) {       // four traversal positions per thread and trip (batched gathers)
-            if (s_cnt + 4u * 256u > (unsigned int) kRrBuf) {
+            // the make-room decision must be uniform (the branch holds barriers): snapshot the counter between two barriers,
+            // after every append of the previous trip and before any append of this one
+            __syncthreads();
+            const unsigned int cnt_now = s_cnt;
+            __syncthreads();
+            if (cnt_now + 4u * 256u > (unsigned int) kRrBuf) {
                 for (int i = tid; i < kRrBuf; i += 256)
-                    if ((unsigned int) i >= s_cnt) s_buf[i] = ~0ull;
+                    if ((unsigned int) i >= cnt_now) s_buf[i] = ~0ull;
                 rr_bitonic_sort(s_buf, tid);
                 if (tid == 0) { s_cnt = (unsigned int) k1; s_kthr = s_buf[k1 - 1]; }
                 __syncthreads();
@@ -1009,8 +976,8 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                     if (key < thr) s_buf[atomicAdd(&s_cnt, 1u)] = key;
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
         int nsort = 64;                           // smallest power of two covering the keys actually collected
         while (nsort < (int) s_cnt) nsort <<= 1;
         for (int i = tid; i < nsort; i += 256)

@@ -152,4 +152,84 @@ __device__ inline void rr_bitonic_sort(unsigned long long *buf, int tid, int n =
 }
 
 
+// ===================================================================================================
+// std::partial_sort (libstdc++: __heap_select + __sort_heap over __adjust_heap/__push_heap), run by ONE
+// lane per query on (id, dist) pairs compared on dist only -- the comparator of src/rii.h:234,279,312.
+// Re-running the library's exact sequence of moves reproduces (i) which of several exactly tied
+// candidates the reference returns and (ii) the order of the coarse lists *past* w, which QueryIvf walks
+// when the first w lists hold fewer than topk hits (src/rii.h:283-326).
+// ===================================================================================================
+__device__ inline void pq_adjust_heap(int32_t *ids, float *ds, long hole, long len, int32_t vid, float vd)
+{
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (ds[child] < ds[child - 1]) child--;
+        ids[hole] = ids[child]; ds[hole] = ds[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        ids[hole] = ids[child - 1]; ds[hole] = ds[child - 1];
+        hole = child - 1;
+    }
+    long parent = (hole - 1) / 2;
+    while (hole > top && ds[parent] < vd) {
+        ids[hole] = ids[parent]; ds[hole] = ds[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    ids[hole] = vid; ds[hole] = vd;
+}
+
+__device__ inline void pq_partial_sort(int32_t *ids, float *ds, long middle, long n)
+{
+    long len = middle;
+    if (len >= 2) {
+        long parent = (len - 2) / 2;
+        for (;;) {
+            pq_adjust_heap(ids, ds, parent, len, ids[parent], ds[parent]);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    if (len > 0) {
+        for (long i = middle; i < n; ++i) {
+            if (ds[i] < ds[0]) {
+                const int32_t vid = ids[i];
+                const float vd = ds[i];
+                ids[i] = ids[0]; ds[i] = ds[0];
+                pq_adjust_heap(ids, ds, 0, len, vid, vd);
+            }
+        }
+    }
+    while (len > 1) {
+        --len;
+        const int32_t vid = ids[len];
+        const float vd = ds[len];
+        ids[len] = ids[0]; ds[len] = ds[0];
+        pq_adjust_heap(ids, ds, 0, len, vid, vd);
+    }
+}
+
+
+// sequential fp32 ADC (RiiCpp::ADist, src/rii.h:386-394) of one code against a plain [M][Ks] table in LDS
+__device__ __forceinline__ float exact_adist(const float *lds, const uint8_t *code, int M, int Ks)
+{
+    float dist = 0.f;
+    if ((M & 3) == 0) {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(code);
+        for (int i = 0; i < M / 4; ++i) {
+            const uint32_t w = cw[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dist = __fadd_rn(dist, lds[(i * 4 + j) * Ks + ((w >> (8 * j)) & 0xffu)]);
+        }
+    } else {
+        for (int m = 0; m < M; ++m) dist = __fadd_rn(dist, lds[m * Ks + code[m]]);
+    }
+    return dist;
+}
+
+
 }  // namespace riiamd

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from tests.util import assert_same_result, assert_same_result_modulo_ties
+from tests.util import assert_same_result
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASE_NAMES = ["readme_m32", "deep_m16", "test_m4_ks20", "test_m20", "wide_ds16", "dup_codes"]
@@ -21,10 +21,9 @@ def csr_to_lists(off, ids):
     return [ids[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
 
 
-def replay_case(make_engine, name, arch, exact_ties=True, true_dist_fn=None):
-    """exact_ties=True demands bit-identical ids even among exactly tied distances (what the oracle, which
-    restates std::partial_sort, achieves).  exact_ties=False applies the documented tie contract of the
-    HIP linear scan for topk>1 (canonical (dist,id) order): see DESIGN.md §Parity contract."""
+def replay_case(make_engine, name, arch):
+    """Every call must reproduce the reference's recorded ids and distances bit for bit, exactly tied distances
+    included (std::partial_sort's heap order: src/rii.h:234-235,279-280,312-313)."""
     inp, out = load_case(name, arch)
     cw, codes, qs = inp["codewords"], inp["codes"], inp["queries"]
     calls = json.loads(str(inp["calls"]))
@@ -49,11 +48,7 @@ def replay_case(make_engine, name, arch, exact_ties=True, true_dist_fn=None):
         else:
             got = e.query_ivf(qs[c["q"]], c["topk"], tsets[c["tids"]], c["L"])
         want = (out["c%d_ids" % i], out["c%d_d" % i])
-        if exact_ties or c["op"] == "ivf" or c["topk"] == 1:
-            assert_same_result(got, want, what)
-        else:
-            td = true_dist_fn(qs[c["q"]]) if true_dist_fn else None
-            assert_same_result_modulo_ties(got, want, td, what)
+        assert_same_result(got, want, what)
         n_checked += 1
     e.add_codes(out["extra_codes"], True)
     want = csr_to_lists(out["final_pl_off"], out["final_pl_ids"])

@@ -65,23 +65,28 @@ def test_full_shard_minimum_is_global_minimum(world):
     assert np.array_equal(best_i, gi[:, 0]) and np.array_equal(best_d.view(np.uint32), gd[:, 0].view(np.uint32))
 
 
-def test_full_topk_consistency(world):
+def test_full_topk_vs_oracle_and_consistency(world):
+    """Linear top-10 / top-100 at N = 1M: a sample of queries against the oracle (ids AND order, exact ties included -- the
+    database holds 5000 duplicated codes), and size-independent properties over the whole batch."""
     g, cw, codes, Q = world
     i1, d1 = g.query_linear_batch(Q, 1, None)
     i10, d10 = g.query_linear_batch(Q, 10, None)
     i100, d100 = g.query_linear_batch(Q[:128], 100, None)
-    assert np.array_equal(i10[:, 0], i1[:, 0]) and np.array_equal(d10[:, 0].view(np.uint32), d1[:, 0].view(np.uint32))
-    assert (np.diff(d10, axis=1) >= 0).all() and (np.diff(d100, axis=1) >= 0).all()
-    assert np.array_equal(i100[:, :10], i10[:128]) and np.array_equal(d100[:, :10], d10[:128])
-    assert all(len(set(r)) == 100 for r in i100)
-    # every returned id carries its true distance: recompute a sample exactly on the host
     o = O.OracleRii(cw, False, simd_arch="avx512")
-    for b in (0, 77):
-        dt = O.dtable(cw, Q[b], "avx512")
-        for j in (0, 5, 9):
-            assert np.float32(O.lib().oracle_adist(dt.ctypes.data_as(O.ctypes.POINTER(O.ctypes.c_float)), M, Ks,
-                                                   np.ascontiguousarray(codes[i10[b, j]]).ctypes.data_as(
-                                                       O.ctypes.POINTER(O.ctypes.c_uint8)))) == d10[b, j]
+    o.add_codes(codes, False)
+    E = np.array([], np.int64)
+    for b in list(range(12)) + [77, 500, 1023]:
+        assert_same_result((i10[b], d10[b]), o.query_linear(Q[b], 10, E), "N=1M top-10 b=%d" % b)
+    for b in (0, 5, 100, 127):
+        assert_same_result((i100[b], d100[b]), o.query_linear(Q[b], 100, E), "N=1M top-100 b=%d" % b)
+    assert np.array_equal(d10[:, 0].view(np.uint32), d1[:, 0].view(np.uint32))
+    assert (np.diff(d10, axis=1) >= 0).all() and (np.diff(d100, axis=1) >= 0).all()
+    assert np.array_equal(d100[:, :10], d10[:128])
+    untied = (np.diff(d100[:, :11], axis=1) > 0).all(axis=1)        # rows whose 11 smallest distances are all different
+    assert untied.sum() > 64
+    assert np.array_equal(i100[untied, :10], i10[:128][untied])
+    assert np.array_equal(i10[:128][untied, 0], i1[:128][untied, 0])
+    assert all(len(set(r)) == 100 for r in i100)
 
 
 def test_full_ivf_with_L_equal_N_is_the_linear_scan(world):
@@ -103,6 +108,58 @@ def test_full_ivf_with_L_equal_N_is_the_linear_scan(world):
     assert (bc == 1).all() and (bd[:, 0] >= ld.min() * 0).all()
     lin_i, lin_d = g.query_linear_batch(Q, 1, None)
     assert (bd[:, 0] >= lin_d[:, 0]).all()           # an inverted-index answer can never beat the exhaustive one
+
+
+@pytest.fixture(scope="module")
+def ivf_world(world):
+    """BASELINE configs 3 and 4 at their full size: reconfigure(1024, 5) on the GPU and in the oracle (PQk-means fit on
+    100k sampled codes + coarse assignment of all 1M codes: src/rii.h:108-156)."""
+    g, cw, codes, Q = world
+    g.reconfigure(1024, 5)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    o.reconfigure(1024, 5)
+    return g, o, Q
+
+
+def test_full_reconfigure_equals_oracle(ivf_world):
+    g, o, Q = ivf_world
+    assert g.coarse_centers == o.coarse_centers
+    assert g.posting_lists == o.posting_lists
+
+
+SAMPLE = list(range(16)) + [100, 333, 512, 777, 1000, 1023]
+
+
+def test_full_config3_ivf_known_answers(ivf_world):
+    """Config 3 (N=1M, nlist=1024, L=L0=977, batch 1024) against the oracle: strict ids, distances and counts."""
+    g, o, Q = ivf_world
+    E = np.array([], np.int64)
+    L0 = int(np.round(N / 1024))
+    for topk in (1, 10):
+        ids, d, cnt = g.query_ivf_batch(Q, topk, None, L0)
+        for b in SAMPLE:
+            n = int(cnt[b])
+            assert_same_result((ids[b, :n], d[b, :n]), o.query_ivf(Q[b], topk, E, L0), "config 3 k=%d b=%d" % (topk, b))
+        assert (cnt == topk).all()
+
+
+def test_full_config4_subset_known_answers(ivf_world):
+    """Config 4 (sorted random |S| = 100k target ids shared by the batch): linear and inverted-index search (w = 13)
+    against the oracle, strict."""
+    g, o, Q = ivf_world
+    rng = np.random.default_rng(1234)
+    S = np.sort(rng.choice(N, 100_000, replace=False)).astype(np.int64)
+    L0 = int(np.round(N / 1024))
+    for topk in (1, 10):
+        li, ld = g.query_linear_batch(Q, topk, S)
+        ii, idd, cnt = g.query_ivf_batch(Q, topk, S, L0)
+        assert np.isin(li, S).all()
+        for b in SAMPLE:
+            assert_same_result((li[b], ld[b]), o.query_linear(Q[b], topk, S), "config 4 linear k=%d b=%d" % (topk, b))
+            n = int(cnt[b])
+            assert_same_result((ii[b, :n], idd[b, :n]), o.query_ivf(Q[b], topk, S, L0), "config 4 ivf k=%d b=%d" % (topk, b))
+            assert np.isin(ii[b, :n], S).all()
 
 
 def test_large_index_beyond_2_pow_24_codes():

@@ -1,14 +1,13 @@
 """GPU parity tests proper: the HIP engine, called through the C ABI (rii_amd.core.RiiGpu -> librii_amd.so),
 against (1) the golden vectors recorded from the real reference and (2) the CPU oracle on seeded inputs.
-Bit-exact on ids and distances; the only relaxation is the documented tie contract of the linear scan for
-topk > 1 (canonical (dist, id) order instead of std::partial_sort's heap order) -- DESIGN.md §Parity contract.
+Bit-exact on ids and distances, exactly tied distances included (std::partial_sort's heap order is replayed on the GPU).
 """
 import numpy as np
 import pytest
 
 from oracle import oracle as O
 from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie, replay_stale
-from tests.util import make_problem, assert_same_result, assert_same_result_modulo_ties
+from tests.util import make_problem, assert_same_result
 
 pytestmark = pytest.mark.gpu
 E = np.array([], np.int64)
@@ -33,10 +32,7 @@ def true_dist_fn_for(cw, codes, arch):
 @pytest.mark.parametrize("arch", ["avx512", "avx"])
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_gpu_replays_golden(name, arch):
-    from tests.replay import load_case
-    inp, _ = load_case(name, arch)
-    td = true_dist_fn_for(inp["codewords"], inp["codes"], arch)
-    n = replay_case(gpu_engine(arch), name, arch, exact_ties=False, true_dist_fn=td)
+    n = replay_case(gpu_engine(arch), name, arch)
     assert n > 50
 
 
@@ -81,10 +77,7 @@ def test_gpu_vs_oracle_linear_ivf_batch(shape):
             ids, d = g.query_linear_batch(Q, topk, tids)
             for b in range(Q.shape[0]):
                 want = o.query_linear(Q[b], topk, tids)
-                if topk == 1:
-                    assert_same_result((ids[b], d[b]), want, "linear b=%d" % b)
-                else:
-                    assert_same_result_modulo_ties((ids[b], d[b]), want, td(Q[b]), "linear k=%d b=%d" % (topk, b))
+                assert_same_result((ids[b], d[b]), want, "linear k=%d S=%d b=%d" % (topk, len(tids), b))
     nlist = max(2, int(np.sqrt(N)) // 2)
     g.reconfigure(nlist, 3); o.reconfigure(nlist, 3)
     assert g.coarse_centers == o.coarse_centers
@@ -311,6 +304,40 @@ def test_gpu_topk_filter_rerank_equals_sort_path(shape):
             assert np.array_equal(i1, i0), (shape, topk)
 
 
+@pytest.mark.parametrize("case", [(8, 16, 2, 5000, 3.0), (4, 8, 3, 1200, 2.0), (32, 256, 4, 70000, 255.0), (16, 256, 6, 66000, 4.0)])
+def test_gpu_linear_topk_tie_order_vs_oracle(case):
+    """Exactly tied distances (integer-valued codebooks and queries, duplicated codes): the ids must come back in the order
+    std::partial_sort leaves them in (src/rii.h:234-235) -- filter + re-rank path, sort path (k > 1023, scan_mode 0),
+    subset search, k == N, and the LDS-friendly scan order (N >= 65536) included."""
+    from rii_amd import RiiGpu
+    M, Ks, Ds, N, vmax = case
+    rng = np.random.default_rng(M * 7 + N)
+    cw = np.round(rng.random((M, Ks, Ds)) * vmax).astype(np.float32)
+    qs = np.round(rng.random((9, M * Ds)) * vmax).astype(np.float32)
+    codes = rng.integers(0, Ks, size=(N, M), dtype=np.uint8)
+    codes[rng.integers(0, N, N // 4)] = codes[rng.integers(0, N, N // 4)]
+    arch = "avx512"
+    g = RiiGpu(cw, False, simd_arch=arch)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    g.add_codes(codes, False); o.add_codes(codes, False)
+    sub = np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int64)
+    ks = tuple(k for k in (2, 5, 50, 700, 1500) if k < N) + ((N,) if N <= 5000 else ())
+    n_tied = 0
+    for topk in ks:
+        for tids in (E, sub):
+            if len(tids) and topk > len(tids):
+                continue
+            for mode in ((1, 0) if topk <= 50 else (1,)):
+                g.set_option("scan_mode", mode)
+                ids, d = g.query_linear_batch(qs, topk, tids)
+                for b in range(len(qs)):
+                    want = o.query_linear(qs[b], topk, tids)
+                    assert_same_result((ids[b], d[b]), want, "tie order k=%d S=%d mode=%d b=%d" % (topk, len(tids), mode, b))
+                    n_tied += int(len(np.unique(np.asarray(want[1]))) < topk)
+    g.set_option("scan_mode", 1)
+    assert n_tied > 0, "the case was meant to produce exactly tied distances inside the top-k"
+
+
 def test_gpu_large_batch_is_chunked_transparently():
     """B above the internal pass size (8192 queries) is processed in slices with identical per-row results."""
     from rii_amd import RiiGpu
@@ -340,10 +367,7 @@ def test_gpu_degenerate_shapes_vs_oracle(M, Ks, Ds, N):
     for topk in sorted({1, N}):
         ids, d = g.query_linear_batch(qs[:3], topk, None)
         for b in range(3):
-            want = o.query_linear(qs[b], topk, E)
-            assert np.array_equal(np.asarray(want[1], np.float32).view(np.uint32), d[b].view(np.uint32))
-            if topk == 1:
-                assert list(ids[b]) == list(want[0])
+            assert_same_result((ids[b], d[b]), o.query_linear(qs[b], topk, E), "degenerate linear k=%d b=%d" % (topk, b))
     for nlist in sorted({1, N}):
         g.reconfigure(nlist, 2); o.reconfigure(nlist, 2)
         assert g.coarse_centers == o.coarse_centers and g.posting_lists == o.posting_lists
@@ -488,8 +512,7 @@ def test_scan_order_does_not_change_results(M, N):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
         assert np.array_equal(a[1], c[1])
         assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1])      # exhaustive scan, id order vs scan order
-        if topk == 1:
-            assert np.array_equal(a[0], c[0])
+        assert np.array_equal(a[0], c[0])                                     # ties included: both replay std::partial_sort
 
     first = N - 3000
     g.add_codes(codes[:first], False)

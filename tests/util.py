@@ -29,27 +29,6 @@ def assert_same_result(got, want, what=""):
     assert list(gi) == list(wi), "%s: ids differ" % what
 
 
-def assert_same_result_modulo_ties(got, want, true_dist=None, what=""):
-    """Parity contract when exactly-tied distances straddle the cut: identical distance multiset (bitwise),
-    identical ids wherever the distance is unique in want+1 context, and every id carries its true distance."""
-    gi, gd = got
-    wi, wd = want
-    assert len(gi) == len(wi), "%s: length" % what
-    gd = np.asarray(gd, np.float32)
-    wd = np.asarray(wd, np.float32)
-    assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32)), "%s: distance sequence differs" % what
-    gi = np.asarray(gi)
-    wi = np.asarray(wi)
-    uniq, cnt = np.unique(wd, return_counts=True)
-    single = np.isin(wd, uniq[cnt == 1])
-    if len(wd):
-        single &= (wd != wd[-1])         # the last distance may tie with an element just past the cut
-    assert np.array_equal(gi[single], wi[single]), "%s: ids differ at untied positions" % what
-    if true_dist is not None:
-        td = np.asarray(true_dist, np.float32)[gi]
-        assert np.array_equal(td.view(np.uint32), gd.view(np.uint32)), "%s: id/distance pairing" % what
-
-
 def ref_with_state(ref, cw, centers, codes, lists):
     """Build a reference engine with chosen coarse centres through its pickle hook (src/main.cpp:35-53)."""
     e = ref.RiiCpp.__new__(ref.RiiCpp)
