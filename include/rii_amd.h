@@ -86,8 +86,9 @@ int rii_get_coarse_centers(const rii_engine *e, uint8_t *out /* nlist*M */);    
 int rii_get_posting_lists(const rii_engine *e, int64_t *off /* nlist+1 */, int32_t *ids /* N */);
 
 /* RiiCpp::QueryLinear -- src/main.cpp:17-21, src/rii.h:195-242, for B queries.
- * queries: [B, M*Ks... D] row-major fp32 (D = M*Ds).  tids: S sorted, duplicate-free int64 ids shared by the
- * batch, S == 0 means "all".  out_ids [B,topk] int64, out_dists [B,topk] fp32, ascending distance.
+ * queries: [B, D] row-major fp32 (D = M*Ds).  tids: S int64 ids in [0, N) shared by the batch, S == 0 means "all";
+ * scored in the order given, duplicates included, like the reference (the inverted index treats them as a set, which
+ * is the reference's answer for the sorted ids it documents).  out_ids [B,topk] int64, out_dists [B,topk] fp32, ascending distance.
  * Requires topk <= N and (S == 0 || topk <= S <= N). */
 int rii_query_linear(rii_engine *e, const float *queries, int64_t B, int topk, const int64_t *tids, int64_t S,
                      int64_t *out_ids, float *out_dists);

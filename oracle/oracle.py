@@ -199,6 +199,19 @@ class OracleRii(object):
         self._lists = [[] for _ in range(self.nlist)]
         self.update_posting_lists(0, self.N)
 
+    # ----- py::pickle, src/main.cpp:35-53: the reference's 5-tuple -----
+    def __getstate__(self):
+        return (self.codewords.tolist(), bool(self.verbose), self.coarse_centers, self.flattened_codes, self.posting_lists)
+
+    def __setstate__(self, t):
+        if len(t) != 5:
+            raise RuntimeError("Invalid state when reading pickled item")
+        arch = getattr(self, "arch", None)
+        self.__init__(np.asarray(t[0], np.float32), bool(t[1]), arch)
+        self.centers = np.ascontiguousarray(np.asarray(t[2], np.uint8).reshape(-1, self.M))
+        self.codes = np.ascontiguousarray(np.asarray(t[3], np.uint8).reshape(-1, self.M))
+        self._lists = [list(l) for l in t[4]]
+
     def clear(self):                                    # src/rii.h:328-333
         self.codes = np.zeros((0, self.M), np.uint8)
         self.centers = np.zeros((0, self.M), np.uint8)

@@ -160,6 +160,14 @@ def _check(rc):
 _EMPTY_I64 = np.zeros(0, np.int64)
 
 
+def _rebuild_engine(cls, simd_arch):
+    """Unpickling helper: an empty engine (RiiCpp(), src/main.cpp:13) that remembers the SIMD order it emulates."""
+    e = cls.__new__(cls)
+    e._h = ctypes.c_void_p()
+    e._simd = simd_arch
+    return e
+
+
 class RiiGpu(object):
     """MI355X engine with the surface of `main.RiiCpp` (src/main.cpp:12-54)."""
 
@@ -384,28 +392,32 @@ class RiiGpu(object):
         off, ids = self.posting_lists_csr()
         return [ids[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
 
-    # ---- pickle: the same 5 logical fields as py::pickle in src/main.cpp:35-53 ----
+    # ---- pickle: exactly the 5-tuple of py::pickle in src/main.cpp:35-53 -- (codewords as nested lists [M][Ks][Ds],
+    # verbose, coarse_centers list[list[int]], flattened_codes list[int] of N*M, posting_lists list[list[int]]) -- so a
+    # state produced here loads into the reference's RiiCpp.__setstate__ and vice versa.  The fvec_L2sqr variant the
+    # engine emulates (`simd_arch`, a property of the reference *build*, not of its state) travels out of band: as a
+    # constructor argument of __reduce__ for our own pickles, and as the host default for states coming from a reference.
     def __getstate__(self):
-        off, ids = self.posting_lists_csr()
-        return (self.codewords, self.verbose, self.coarse_centers_array(), self.codes_array(), (off, ids),
-                self._simd)
+        return (self.codewords.tolist(), self.verbose, self.coarse_centers, self.flattened_codes, self.posting_lists)
+
+    def __reduce__(self):
+        return (_rebuild_engine, (self.__class__, self._simd), self.__getstate__())
 
     def __setstate__(self, t):
-        if len(t) not in (5, 6):
+        if len(t) != 5:                    # src/main.cpp:41-43
             raise RuntimeError("Invalid state when reading pickled item")
-        cw, verbose, centers, codes, lists = t[:5]
-        simd = t[5] if len(t) == 6 else None
+        cw, verbose, centers, codes, lists = t
+        simd = getattr(self, "_simd", None)
+        if getattr(self, "_h", None):      # __setstate__ on a live engine replaces it
+            _lib().rii_destroy(self._h)
         self._h = ctypes.c_void_p()
         cw = np.asarray(cw, np.float32)
         self._create(cw, bool(verbose), simd, None)
         M = cw.shape[0]
         centers = np.ascontiguousarray(np.asarray(centers, np.uint8).reshape(-1, M))
         codes = np.ascontiguousarray(np.asarray(codes, np.uint8).reshape(-1, M))
-        if isinstance(lists, tuple):
-            off, ids = lists
-        else:                              # reference layout: list of lists
-            off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
-            ids = np.concatenate([np.asarray(l, np.int32) for l in lists]) if len(lists) else np.zeros(0, np.int32)
+        off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+        ids = np.concatenate([np.asarray(l, np.int32) for l in lists]) if len(lists) else np.zeros(0, np.int32)
         off = np.ascontiguousarray(off, np.int64)
         ids = np.ascontiguousarray(ids, np.int32)
         if ids.size == 0:

@@ -162,7 +162,19 @@ struct ScopedTimer {
     {
         if (a && b) {
             (void) hipEventRecord(b, st);
-            e->timers[name].pending.emplace_back(a, b);
+            KernelTimer &t = e->timers[name];
+            t.pending.emplace_back(a, b);
+            // fold finished pairs into the totals so that an unread timer does not pile up events
+            while (t.pending.size() > 64 && hipEventQuery(t.pending.front().second) == hipSuccess) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, t.pending.front().first, t.pending.front().second) == hipSuccess) {
+                    t.total_ms += ms;
+                    t.launches += 1;
+                }
+                (void) hipEventDestroy(t.pending.front().first);
+                (void) hipEventDestroy(t.pending.front().second);
+                t.pending.erase(t.pending.begin());
+            }
         }
     }
 };
@@ -747,13 +759,14 @@ int stage_inputs(rii_engine *e, const float *queries, int64_t B, const int64_t *
 
 int check_tids_host(const rii_engine *e, const int64_t *tids, int64_t S)
 {
-    // the reference requires sorted, duplicate-free ids in range (docs tutorial.rst:190-204, rii.h:294)
-    for (int64_t s = 0; s < S; ++s) {
+    // The reference documents sorted, duplicate-free ids (docs tutorial.rst:190-204) but never checks: QueryLinear scores
+    // the ids in the order given, duplicates included (src/rii.h:218-228), and so does the engine.  QueryIvf's
+    // std::binary_search (rii.h:294) is only meaningful on sorted ids; there the engine treats the ids as a set, which
+    // is the reference's answer whenever its precondition holds.  Out-of-range ids (an out-of-bounds read in the
+    // reference) are the one thing rejected.
+    for (int64_t s = 0; s < S; ++s)
         if (tids[s] < 0 || tids[s] >= e->N)
             return set_err(RII_ERR_INVALID, "target id %lld out of range [0, %lld)", (long long) tids[s], (long long) e->N);
-        if (s && tids[s] <= tids[s - 1])
-            return set_err(RII_ERR_INVALID, "target_ids must be sorted ascending without duplicates");
-    }
     return RII_OK;
 }
 
@@ -1178,8 +1191,12 @@ RII_API int rii_query_linear_dev(rii_engine *e, const float *d_queries, int64_t 
     RII_TRY(check_query_args(e, B, topk, S));
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     RII_TRY(begin_on(e, st));
-    RII_TRY(query_linear_dev(e, d_queries, B, topk, d_tids, S, d_out_ids, d_out_dists, st));
-    return end_on(e, st);
+    // the ordering event is recorded on the error path too: work already enqueued on `st` still uses the shared scratch
+    const int r = query_linear_dev(e, d_queries, B, topk, d_tids, S, d_out_ids, d_out_dists, st);
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
 }
 
 RII_API int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
@@ -1193,8 +1210,11 @@ RII_API int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, 
     RII_TRY(check_ivf_args(e, topk, L));
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     RII_TRY(begin_on(e, st));
-    RII_TRY(query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts, st));
-    return end_on(e, st);
+    const int r = query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts, st);
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
 }
 
 RII_API int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out)

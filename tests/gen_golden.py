@@ -65,9 +65,10 @@ ref, arch, flav = O.load_reference(%(flavour)r)
 assert flav == %(flavour)r, (flav, %(flavour)r)
 for case in CASES:
     run_case(ref, arch, case)
-from tests.gen_golden import run_neartie, run_stale
+from tests.gen_golden import run_neartie, run_stale, run_state
 run_neartie(ref, arch)
 run_stale(ref, arch)
+run_state(ref, arch)
 """
 
 
@@ -150,6 +151,35 @@ def run_stale(ref, arch):
     assert n_empty > 0
     np.savez_compressed(os.path.join(GOLD, "stale_lists.%s.out.npz" % arch), **out)
     np.savez_compressed(os.path.join(GOLD, "stale_lists.in.npz"), codewords=cw, codes=codes, queries=qs[:8])
+
+
+STATE_CALLS = (("linear", 1, 0), ("linear", 7, 0), ("ivf", 1, 50), ("ivf", 5, 120), ("ivf", 3, 600))
+
+
+def run_state(ref, arch):
+    """f2 (src/main.cpp:35-53): the 5-tuple the reference's py::pickle get-state returns for a configured index, stored
+    verbatim (a pickle of plain Python lists / floats / bools: data, no reference objects), plus what a reference engine
+    re-created from that very state through set-state answers."""
+    import pickle
+    cw, codes, qs = make_problem(29, 8, 32, 4, 600, "unit", dup=60)
+    e = ref.RiiCpp(cw, False)
+    e.add_codes(codes[:500], False)
+    e.reconfigure(12, 4)
+    e.add_codes(codes[500:], True)
+    state = e.__getstate__()
+    assert isinstance(state, tuple) and len(state) == 5
+    with open(os.path.join(GOLD, "state_m8.%s.pkl" % arch), "wb") as f:
+        pickle.dump(state, f, protocol=2)
+    e2 = ref.RiiCpp.__new__(ref.RiiCpp)
+    e2.__setstate__(state)
+    out = {}
+    for ci, (op, topk, L) in enumerate(STATE_CALLS):
+        for b in range(6):
+            ids, d = e2.query_linear(qs[b], topk, E) if op == "linear" else e2.query_ivf(qs[b], topk, E, L)
+            assert (ids, d) == (e.query_linear(qs[b], topk, E) if op == "linear" else e.query_ivf(qs[b], topk, E, L))
+            out["c%d_q%d_ids" % (ci, b)] = np.array(ids, np.int64)
+            out["c%d_q%d_d" % (ci, b)] = np.array(d, np.float32)
+    np.savez_compressed(os.path.join(GOLD, "state_m8.%s.out.npz" % arch), queries=qs[:6], **out)
 
 
 def hash_name(name):

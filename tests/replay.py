@@ -91,3 +91,31 @@ def replay_stale(make_engine, arch):
             assert_same_result(got, want, "stale k=%d L=%d q=%d" % (topk, L, b))
             n_empty += (len(want[0]) == 0)
     assert n_empty > 0
+
+
+STATE_CALLS = (("linear", 1, 0), ("linear", 7, 0), ("ivf", 1, 50), ("ivf", 5, 120), ("ivf", 3, 600))
+
+
+def load_state_fixture(arch):
+    """The reference's pickle state (src/main.cpp:35-53) recorded by tests/gen_golden.py: a plain 5-tuple of lists."""
+    import pickle
+    with open(os.path.join(GOLD, "state_m8.%s.pkl" % arch), "rb") as f:
+        state = pickle.load(f)
+    return state, np.load(os.path.join(GOLD, "state_m8.%s.out.npz" % arch))
+
+
+def replay_state(engine_from_state, arch):
+    """engine_from_state(5-tuple) -> engine; its answers must equal those of the reference re-created from the state."""
+    state, out = load_state_fixture(arch)
+    assert isinstance(state, tuple) and len(state) == 5
+    e = engine_from_state(state)
+    assert e.N == len(state[3]) // len(state[0]) and e.nlist == len(state[2])
+    assert [list(l) for l in e.posting_lists] == [list(l) for l in state[4]]
+    empty = np.array([], np.int64)
+    qs = out["queries"]
+    for ci, (op, topk, L) in enumerate(STATE_CALLS):
+        for b in range(6):
+            got = e.query_linear(qs[b], topk, empty) if op == "linear" else e.query_ivf(qs[b], topk, empty, L)
+            assert_same_result(got, (out["c%d_q%d_ids" % (ci, b)], out["c%d_q%d_d" % (ci, b)]),
+                               "state %s k=%d L=%d q=%d" % (op, topk, L, b))
+    return e

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie, replay_stale
+from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie, replay_stale, replay_state
 from tests.util import make_problem, assert_same_result
 
 pytestmark = pytest.mark.gpu
@@ -179,14 +179,60 @@ def test_gpu_pickle_roundtrip():
     import pickle
     from rii_amd import RiiGpu
     cw, codes, qs = make_problem(5, 8, 256, 4, 3000, "unit")
-    g = RiiGpu(cw, False)
+    g = RiiGpu(cw, False, simd_arch="avx")
     g.add_codes(codes, False)
     g.reconfigure(30, 3)
     g2 = pickle.loads(pickle.dumps(g))
+    assert g2._simd == "avx"                                 # travels as a constructor argument, not in the state
     assert g2.N == g.N and g2.nlist == g.nlist and g2.posting_lists == g.posting_lists
     a = g.query_ivf_batch(qs[:4], 5, None, 300)
     b = g2.query_ivf_batch(qs[:4], 5, None, 300)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # the state is exactly the reference's 5-tuple of plain Python values (src/main.cpp:35-38)
+    st = g.__getstate__()
+    assert isinstance(st, tuple) and len(st) == 5
+    assert isinstance(st[0], list) and isinstance(st[0][0][0][0], float) and isinstance(st[1], bool)
+    assert isinstance(st[2][0][0], int) and isinstance(st[3][0], int) and len(st[3]) == 3000 * 8
+    assert isinstance(st[4], list) and isinstance(st[4][0], list) and sum(len(l) for l in st[4]) == 3000
+    with pytest.raises(RuntimeError):
+        RiiGpu.__new__(RiiGpu).__setstate__(st + ("extra",))   # "Invalid state when reading pickled item", main.cpp:41-43
+
+
+@pytest.mark.parametrize("arch", ["avx512", "avx"])
+def test_gpu_loads_reference_pickle_state(arch):
+    """f2: a state produced by the real reference (recorded by tests/gen_golden.py) loads into the engine through
+    __setstate__ and answers like the reference re-created from the same state."""
+    from rii_amd import RiiGpu
+
+    def make(state):
+        g = RiiGpu.__new__(RiiGpu)
+        g._simd = arch
+        g.__setstate__(state)
+        return g
+    replay_state(make, arch)
+
+
+def test_gpu_state_loads_into_the_real_reference():
+    """f2, other direction: an index built on the GPU, handed to the compiled reference (oracle/_ref) through its own
+    py::pickle set-state, answers identically there."""
+    from rii_amd import RiiGpu
+    ref, arch, _ = O.load_reference()
+    if ref is None:
+        pytest.skip("no runnable oracle/_ref build on this host")
+    cw, codes, qs = make_problem(31, 8, 64, 4, 4000, "unit", dup=300)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    g.add_codes(codes[:3500], False)
+    g.reconfigure(40, 4)
+    g.add_codes(codes[3500:], True)
+    r = ref.RiiCpp.__new__(ref.RiiCpp)
+    r.__setstate__(g.__getstate__())
+    assert r.N == g.N and r.nlist == g.nlist and r.posting_lists == g.posting_lists
+    sub = np.sort(np.random.default_rng(2).choice(4000, 700, replace=False)).astype(np.int64)
+    for b in range(8):
+        for tids in (E, sub):
+            for topk in (1, 6):
+                assert_same_result(g.query_linear(qs[b], topk, tids), r.query_linear(qs[b], topk, tids), "state->ref linear")
+                assert_same_result(g.query_ivf(qs[b], topk, tids, 150), r.query_ivf(qs[b], topk, tids, 150), "state->ref ivf")
 
 
 def test_gpu_mfma_lut_within_tolerance():
@@ -408,10 +454,18 @@ def test_gpu_input_layouts_and_bad_inputs():
     ok = g.query_linear_batch(qs[:4], 2, None)
     assert np.array_equal(ids[[0, 3]], ok[0][[0, 3]]) and np.array_equal(d[[0, 3]], ok[1][[0, 3]])
     g.query_ivf_batch(bad, 2, None, 300)
-    with pytest.raises(ValueError):
-        g.query_linear(qs[0], 1, np.array([5, 3, 9], np.int64))       # unsorted target ids
-    with pytest.raises(ValueError):
-        g.query_linear(qs[0], 1, np.array([3, 3, 9], np.int64))       # duplicates
+    o = O.OracleRii(cw, False)
+    o.add_codes(codes, False)
+    o.set_coarse_centers(np.array(g.coarse_centers, np.uint8))
+    rng = np.random.default_rng(3)
+    for tids in (np.array([5, 3, 9], np.int64), np.array([3, 3, 9, 9, 9, 700], np.int64),
+                 rng.integers(0, 4000, 900).astype(np.int64)):   # unsorted / duplicated ids: scored as given (rii.h:218-228)
+        for topk in (1, 2, 3):
+            for b in range(4):
+                assert_same_result(g.query_linear(qs[b], topk, tids), o.query_linear(qs[b], topk, tids), "odd tids")
+    dups = np.sort(rng.integers(0, 4000, 1500)).astype(np.int64)         # sorted with duplicates: binary_search still works
+    for b in range(4):
+        assert_same_result(g.query_ivf(qs[b], 3, dups, 200), o.query_ivf(qs[b], 3, dups, 200), "ivf dup tids")
     with pytest.raises(ValueError):
         g.query_linear(qs[0], 1, np.array([3, 4000], np.int64))       # out of range
     with pytest.raises(TypeError):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie, replay_stale, load_case, GOLD
+from tests.replay import CASE_NAMES, NEARTIE_DS, replay_case, replay_neartie, replay_stale, replay_state, load_case, GOLD
 
 
 @pytest.mark.parametrize("arch", ["avx512", "avx"])
@@ -39,3 +39,23 @@ def test_neartie_flavours_differ():
 @pytest.mark.parametrize("arch", ["avx512", "avx"])
 def test_oracle_stale_lists_golden(arch):
     replay_stale(lambda cw: O.OracleRii(cw, False, simd_arch=arch), arch)
+
+
+def _oracle_from_state(arch):
+    def make(state):
+        o = O.OracleRii.__new__(O.OracleRii)
+        o.arch = arch
+        o.__setstate__(state)
+        return o
+    return make
+
+
+@pytest.mark.parametrize("arch", ["avx512", "avx"])
+def test_oracle_loads_reference_pickle_state(arch):
+    """f2: the reference's own 5-tuple state (src/main.cpp:35-53) loads, and the answers are the reference's."""
+    o = replay_state(_oracle_from_state(arch), arch)
+    state = o.__getstate__()
+    from tests.replay import load_state_fixture
+    want, _ = load_state_fixture(arch)
+    assert state[1:] == want[1:]                                          # get-state emits the reference layout again
+    assert np.array_equal(np.asarray(state[0], np.float32), np.asarray(want[0], np.float32))

@@ -166,3 +166,25 @@ def test_ivf_empty_return_with_stale_lists(reference):
             n_empty += (len(want[0]) == 0)
             n_full += (len(want[0]) > 0)
     assert n_empty > 0 and n_full > 0
+
+
+def test_pickle_state_crosses_both_ways(reference):
+    """f2 (src/main.cpp:35-53): the reference's get-state tuple loads into the oracle, the oracle's into the reference,
+    and both sides answer identically afterwards."""
+    ref, arch, _ = reference
+    cw, codes, qs = make_problem(41, 8, 64, 4, 2500, "unit", dup=200)
+    r = ref.RiiCpp(cw, False)
+    r.add_codes(codes, False)
+    r.reconfigure(25, 4)
+    o = O.OracleRii.__new__(O.OracleRii)
+    o.arch = arch
+    o.__setstate__(r.__getstate__())
+    assert o.posting_lists == r.posting_lists and o.coarse_centers == r.coarse_centers
+    r2 = ref.RiiCpp.__new__(ref.RiiCpp)
+    r2.__setstate__(o.__getstate__())
+    for b in range(6):
+        for topk, L in ((1, 100), (5, 100), (3, 2500)):
+            want = r.query_ivf(qs[b], topk, E, L)
+            assert_same_result(o.query_ivf(qs[b], topk, E, L), want, "ref state -> oracle")
+            assert_same_result(r2.query_ivf(qs[b], topk, E, L), want, "oracle state -> ref")
+        assert_same_result(r2.query_linear(qs[b], 4, E), r.query_linear(qs[b], 4, E), "oracle state -> ref linear")
