@@ -105,6 +105,15 @@ int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk
                       int64_t S, int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts,
                       void *stream);
 
+/* Database sharding (NEW, not in the reference: it has no multi-device code).  Every rank sends one record per batch --
+ * [B*topk] int64 GLOBAL ids followed by [B*topk] f32 distances, padded to rii_merge_record_bytes() -- through one
+ * all-gather; `d_gathered` holds the G records back to back.  Output: per query the topk smallest of the G*topk pairs
+ * under (dist asc, id asc), computed identically on every rank.  G*topk <= 8192.  Asynchronous on `stream`
+ * (a hipStream_t, NULL = the default stream) of the current device; needs no engine. */
+int64_t rii_merge_record_bytes(int64_t B, int topk);
+int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int topk, int64_t *d_out_ids, float *d_out_dists,
+                       void *stream);
+
 /* Distance-table build alone (RiiCpp::DTable, src/rii.h:361-373) for B queries -> out[B,M,Ks] (host). */
 int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out);
 /* Coarse assignment alone (PQKMeans::predict_one over codes, src/rii.h:350-354): assign[n] in [0,nlist). */

@@ -123,6 +123,8 @@ def _lib():
         "rii_query_ivf": (c_int, [c_vp, f32p, c_i64, c_int, i64p, c_i64, c_i64, i64p, f32p, i64p]),
         "rii_query_linear_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
         "rii_query_ivf_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+        "rii_merge_record_bytes": (c_i64, [c_i64, c_int]),
+        "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
         "rii_dtable": (c_int, [c_vp, f32p, c_i64, f32p]),
         "rii_assign": (c_int, [c_vp, u8p, c_i64, i32p]),
         "rii_set_option": (c_int, [c_vp, ctypes.c_char_p, c_i64]),
@@ -138,6 +140,16 @@ def _lib():
     L._rii_signatures = sig
     _LIB = L
     return L
+
+
+def merge_record_bytes(B, topk):
+    """Bytes of one rank's record in the database-sharding all-gather (include/rii_amd.h: rii_merge_topk_dev)."""
+    return int(_lib().rii_merge_record_bytes(int(B), int(topk)))
+
+
+def merge_topk_dev(d_gathered, G, B, topk, d_out_ids, d_out_dists, stream=0):
+    """Device pointers in, asynchronous on `stream`: the topk smallest of the G gathered records per query, (dist, id) order."""
+    _check(_lib().rii_merge_topk_dev(d_gathered, int(G), int(B), int(topk), d_out_ids, d_out_dists, stream or None))
 
 
 def exported_symbols():

@@ -1217,6 +1217,18 @@ RII_API int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, 
     return r2;
 }
 
+// Database sharding (not in the reference): merge of the all-gathered per-shard top-k rows.  Stateless.
+RII_API int64_t rii_merge_record_bytes(int64_t B, int k) { return (B * k * 12 + 15) / 16 * 16; }
+RII_API int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int k, int64_t *d_out_ids, float *d_out_dists,
+                               void *stream)
+{
+    if (!d_gathered || G < 1 || B < 0 || k < 1 || (B > 0 && (!d_out_ids || !d_out_dists))) return set_err(RII_ERR_INVALID, "bad arguments");
+    if ((int64_t) G * k > merge_topk_max_keys())
+        return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d keys per query exceeds %d", G, k, merge_topk_max_keys());
+    HIP_TRY(launch_merge_topk(d_gathered, G, B, k, d_out_ids, d_out_dists, (hipStream_t) stream));
+    return RII_OK;
+}
+
 RII_API int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out)
 {
     if (!e || !queries || !out || B < 0) return set_err(RII_ERR_INVALID, "bad arguments");

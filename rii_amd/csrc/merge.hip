@@ -1,0 +1,82 @@
+// merge.hip -- database sharding: k-way merge of the per-shard top-k rows after the RCCL all-gather (gfx950).
+//
+// The reference has no multi-device code; the parity target is the single-index answer on the concatenated
+// database.  Every rank contributes, per query, its local top-k as (global id, dist); the merged answer is the k
+// smallest of the G*k pairs under (dist asc, id asc).  G*k <= 8192 keys per query: one block bitonic-sorts them in LDS.
+#include "rii_internal.h"
+#include <algorithm>
+
+namespace riiamd {
+
+constexpr int kMergeMaxKeys = 8192;
+
+// record of rank g inside the gathered buffer: [B*k] int64 ids, then [B*k] f32 dists, padded to 16 bytes (what every rank sends)
+__device__ __forceinline__ const int64_t *mrg_ids(const unsigned char *base, size_t rec, int g) { return reinterpret_cast<const int64_t *>(base + rec * g); }
+__device__ __forceinline__ const float *mrg_d(const unsigned char *base, size_t rec, int g, int64_t Bk) { return reinterpret_cast<const float *>(base + rec * g + (size_t) Bk * 8); }
+
+__global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__restrict__ gathered, int G, int64_t B, int k,
+                                                         int64_t *__restrict__ out_ids, float *__restrict__ out_dists)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *key = reinterpret_cast<unsigned long long *>(smem);        // (orderable dist << 32 | g * k + j)
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = G * k;
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    const int64_t Bk = B * k;
+    const size_t rec = ((size_t) Bk * 12 + 15) / 16 * 16;      // rii_merge_record_bytes
+    for (int i = tid; i < n2; i += 256) {
+        unsigned long long kk = ~0ull;
+        if (i < n) {
+            const int g = i / k, j = i - g * k;
+            kk = ((unsigned long long) f32_orderable(__float_as_uint(mrg_d(gathered, rec, g, Bk)[b * k + j])) << 32) | (uint32_t) i;
+        }
+        key[i] = kk;
+    }
+    auto id_of = [&](unsigned long long kk) -> int64_t {
+        const uint32_t s = (uint32_t) (kk & 0xffffffffu);
+        if (s >= (uint32_t) n) return INT64_MAX;
+        const int g = (int) (s / (uint32_t) k), j = (int) (s - (uint32_t) g * k);
+        return mrg_ids(gathered, rec, g)[b * k + j];
+    };
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < n2 / 2; t += 256) {
+                const int i = 2 * t - (t & (stride - 1));
+                const int j = i + stride;
+                const bool up = ((i & size) == 0);
+                const unsigned long long x = key[i], y = key[j];
+                bool gt;                                   // x sorts after y under (dist, id)
+                if ((x >> 32) != (y >> 32)) gt = x > y;
+                else gt = id_of(x) > id_of(y);             // exact distance tie: the ids decide (rare)
+                if (gt == up) { key[i] = y; key[j] = x; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += 256) {
+        const unsigned long long kk = key[j];
+        out_ids[b * k + j] = id_of(kk);
+        out_dists[b * k + j] = __uint_as_float(f32_unorderable((uint32_t) (kk >> 32)));
+    }
+}
+
+int merge_topk_max_keys() { return kMergeMaxKeys; }
+
+hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    int n2 = 64;
+    while (n2 < G * k) n2 <<= 1;
+    const size_t smem = (size_t) n2 * 8;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(merge_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned) B), dim3(256), smem, st,
+                       static_cast<const unsigned char *>(d_gathered), G, B, k, d_out_ids, d_out_dists);
+    return hipGetLastError();
+}
+
+}  // namespace riiamd

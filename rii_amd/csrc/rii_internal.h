@@ -154,6 +154,10 @@ hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, c
 hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
                                   int32_t *d_flag_list, int *d_nflag, hipStream_t st);
 
+// merge.hip: database sharding, k-way merge of the gathered per-shard top-k rows under (dist, id)
+int merge_topk_max_keys();
+hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int64_t *d_out_ids, float *d_out_dists, hipStream_t st);
+
 // scanorder.hip: LDS-friendly scan order for the filter stage (perm[pos] = code id, codes gathered in that order)
 bool scan_order_supported(int M, int Ks);
 hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, int rows, int64_t win0, int32_t *d_perm,

@@ -3,14 +3,19 @@ xGMI on ROCm; "gloo" in the CPU tests).  The reference has no multi-device code 
 target is the single-index result on the concatenated database.
 
 Two decompositions, both embarrassingly parallel up to one small exchange:
-  * query sharding   -- index replicated, rank r answers queries [r*B/W, (r+1)*B/W); exchange = all-gather of
-                        the per-rank (ids, dists) rows (B/W * k * 12 bytes: latency-bound).
+  * query sharding   -- index replicated, rank r answers its slice of the queries; exchange = ONE all-gather of the
+                        per-rank result rows (ids, dists[, counts] packed: B/W * (12 k [+ 8]) bytes, latency-bound).
   * database sharding -- rank r holds codes [start_r, stop_r) (Deep1B-shape: 16 GB of codes -> 2 GB per GPU);
-                        every rank answers all B queries on its shard, global id = start_r + local id; exchange =
-                        all-gather of B*k (dist, id) pairs per rank, then a k-way merge under the canonical
-                        (dist asc, id asc) rule, computed identically on every rank.
-No ring all-reduce anywhere: payloads are KBs, so the 7 x 153 GB/s xGMI links are irrelevant; what matters is
-one collective per batch.
+                        every rank answers all B queries on its shard, global id = start_r + local id; exchange = ONE
+                        all-gather of a packed record of B*k (id, dist) pairs per rank, then a k-way merge under the
+                        canonical (dist asc, id asc) rule computed identically on every rank -- by a HIP kernel
+                        (rii_merge_topk_dev, csrc/merge.hip) when the records live in HBM.
+With the "nccl" backend everything stays on the device: engine -> device tensors -> RCCL -> merge kernel, no host hop.
+No ring all-reduce anywhere: payloads are KBs, so the 7 x 153 GB/s xGMI links are irrelevant; what matters is one
+collective per batch.
+
+Ties across shards: inside one shard the engine returns the reference's std::partial_sort order; across shards exactly
+tied distances are ordered by id (the heap order of the concatenated database cannot be rebuilt from per-shard top-k rows).
 """
 import numpy as np
 import torch
@@ -36,14 +41,74 @@ def _comm_device():
     return torch.device("cpu")
 
 
+_SIDE = {}
+
+
+class _engine_stream(object):
+    """The engine's *_dev calls take a hipStream_t, and torch reports its default stream as 0 -- which the C ABI reads as
+    "the engine's own stream".  Device-resident sharding therefore runs engine call, packing, RCCL collective and merge on
+    ONE explicit (non-default) torch stream per device, fenced against the caller's current stream on entry and exit."""
+
+    def __enter__(self):
+        dev = torch.cuda.current_device()
+        if dev not in _SIDE:
+            _SIDE[dev] = torch.cuda.Stream(device=dev)
+        self.side = _SIDE[dev]
+        self.outer = torch.cuda.current_stream()
+        self.side.wait_stream(self.outer)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self.side.cuda_stream
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        self.outer.wait_stream(self.side)
+        return False
+
+
+def _handoff(*tensors):
+    """Tensors produced on the side stream and handed to the caller's stream (caching-allocator bookkeeping)."""
+    cur = torch.cuda.current_stream()
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(cur)
+    return tensors if len(tensors) != 1 else tensors[0]
+
+
 def _as_tensor(a, dtype, device):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
     return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
 
 
+def _all_gather_bytes(rec, group=None):
+    """One collective: every rank's byte record, concatenated in rank order -> uint8 [W, len(rec)].  Runs the collective
+    whenever a process group exists (world size 1 included, so that a single-GPU box exercises RCCL too)."""
+    rank, w = world()
+    if not (dist.is_available() and dist.is_initialized()):
+        return rec.reshape(1, -1)
+    out = torch.empty(w * rec.numel(), dtype=torch.uint8, device=rec.device)
+    dist.all_gather_into_tensor(out, rec.reshape(-1).contiguous(), group=group)
+    return out.reshape(w, -1)
+
+
+def _pack(parts):
+    """Byte record of the given tensors back to back, padded to 16 bytes (every rank's record starts aligned)."""
+    rec = torch.cat([p.reshape(-1).view(torch.uint8) for p in parts])
+    pad = (-rec.numel()) % 16
+    if pad:
+        rec = torch.cat([rec, torch.zeros(pad, dtype=torch.uint8, device=rec.device)])
+    return rec
+
+
+def _field(g, r, off, count, dtype):
+    """`count` elements of `dtype` at byte offset `off` of rank r's record in the gathered [W, rec] byte tensor."""
+    nbytes = count * torch.empty((), dtype=dtype).element_size()
+    return g[r, off:off + nbytes].view(dtype)
+
+
 def merge_topk(ids, dists, topk):
-    """k smallest of each row under (dist asc, id asc).  ids int64 [B, C], dists float32 [B, C] -> [B, topk]."""
+    """k smallest of each row under (dist asc, id asc).  ids int64 [B, C], dists float32 [B, C] -> [B, topk] (host path)."""
     order = torch.sort(ids, dim=1, stable=True).indices                    # secondary key first ...
     d1 = torch.gather(dists, 1, order)
     i1 = torch.gather(ids, 1, order)
@@ -52,87 +117,180 @@ def merge_topk(ids, dists, topk):
 
 
 def allgather_merge_topk(local_ids, local_dists, topk, id_offset=0, group=None):
-    """Database sharding: every rank contributes its local top-k (local ids + id_offset = global ids); returns
-    the merged global top-k on every rank."""
+    """Database sharding: every rank contributes its local top-k (local ids + id_offset = global ids, padding rows marked
+    by dist = +inf keep their id); returns the merged global top-k on every rank.  Device tensors in -> device tensors out
+    through rii_merge_topk_dev; host tensors / numpy -> torch sort on the host (gloo tests)."""
     dev = _comm_device()
-    ids = _as_tensor(local_ids, torch.int64, dev) + int(id_offset)
     d = _as_tensor(local_dists, torch.float32, dev)
+    ids = _as_tensor(local_ids, torch.int64, dev)
+    if id_offset:
+        ids = torch.where(torch.isfinite(d), ids + int(id_offset), ids)
+    B, k = ids.shape
     rank, w = world()
-    if w == 1:
+    if dev.type == "cuda" and w * k <= 8192:
+        from . import core
+        nrec = core.merge_record_bytes(B, k)
+        rec = torch.zeros(nrec, dtype=torch.uint8, device=dev)
+        rec[:B * k * 8].view(torch.int64).copy_(ids.reshape(-1))
+        rec[B * k * 8:B * k * 12].view(torch.float32).copy_(d.reshape(-1))
+        gathered = _all_gather_bytes(rec, group)
+        out_ids = torch.empty((B, topk), dtype=torch.int64, device=dev)
+        out_d = torch.empty((B, topk), dtype=torch.float32, device=dev)
+        if topk == k:
+            h = torch.cuda.current_stream().cuda_stream
+            if h == 0:                 # default stream: run the merge inside the side-stream fence
+                with _engine_stream() as sh:
+                    core.merge_topk_dev(gathered.data_ptr(), w, B, k, out_ids.data_ptr(), out_d.data_ptr(), sh)
+            else:
+                core.merge_topk_dev(gathered.data_ptr(), w, B, k, out_ids.data_ptr(), out_d.data_ptr(), h)
+            return out_ids, out_d
+    if w == 1 and not dist.is_initialized():
         return merge_topk(ids, d, topk)
-    gi = [torch.empty_like(ids) for _ in range(w)]
-    gd = [torch.empty_like(d) for _ in range(w)]
-    dist.all_gather(gi, ids, group=group)
-    dist.all_gather(gd, d, group=group)
+    g = _all_gather_bytes(_pack([ids, d]), group)
+    gi = [_field(g, r, 0, B * k, torch.int64).reshape(B, k) for r in range(g.shape[0])]
+    gd = [_field(g, r, B * k * 8, B * k, torch.float32).reshape(B, k) for r in range(g.shape[0])]
     return merge_topk(torch.cat(gi, dim=1), torch.cat(gd, dim=1), topk)
 
 
-def allgather_query_shards(local_ids, local_dists, group=None):
-    """Query sharding: concatenate the per-rank result rows in rank order (every rank gets all rows)."""
+def allgather_query_shards(local_ids, local_dists, group=None, local_counts=None, rows=None):
+    """Query sharding: concatenate the per-rank result rows in rank order (every rank gets all rows) with ONE collective
+    over a packed record.  `rows`: per-rank row counts when the batch does not divide evenly (records are padded to the
+    largest slice and trimmed after the gather).  Returns (ids, dists) or (ids, dists, counts)."""
     dev = _comm_device()
     ids = _as_tensor(local_ids, torch.int64, dev)
     d = _as_tensor(local_dists, torch.float32, dev)
+    cnt = None if local_counts is None else _as_tensor(local_counts, torch.int64, dev).reshape(-1)
     rank, w = world()
-    if w == 1:
-        return ids, d
-    gi = [torch.empty_like(ids) for _ in range(w)]
-    gd = [torch.empty_like(d) for _ in range(w)]
-    dist.all_gather(gi, ids, group=group)
-    dist.all_gather(gd, d, group=group)
-    return torch.cat(gi, dim=0), torch.cat(gd, dim=0)
+    n, k = ids.shape
+    nmax = n if rows is None else int(max(rows))
+    if nmax > n:                                           # pad the short slice: equal shapes for the all-gather
+        ids = torch.cat([ids, torch.zeros((nmax - n, k), dtype=ids.dtype, device=dev)])
+        d = torch.cat([d, torch.zeros((nmax - n, k), dtype=d.dtype, device=dev)])
+        if cnt is not None:
+            cnt = torch.cat([cnt, torch.zeros(nmax - n, dtype=cnt.dtype, device=dev)])
+    parts = [ids] + ([cnt] if cnt is not None else []) + [d]        # 8-byte fields first: every field stays aligned
+    g = _all_gather_bytes(_pack(parts), group)
+    wg = g.shape[0]
+    take = [nmax] * wg if rows is None else [int(r) for r in rows]
+    o_cnt = nmax * k * 8
+    o_d = o_cnt + (nmax * 8 if cnt is not None else 0)
+    oi = torch.cat([_field(g, r, 0, nmax * k, torch.int64).reshape(nmax, k)[:take[r]] for r in range(wg)], dim=0)
+    od = torch.cat([_field(g, r, o_d, nmax * k, torch.float32).reshape(nmax, k)[:take[r]] for r in range(wg)], dim=0)
+    if cnt is None:
+        return oi, od
+    return oi, od, torch.cat([_field(g, r, o_cnt, nmax, torch.int64)[:take[r]] for r in range(wg)], dim=0)
+
+
+def _is_device_engine(engine):
+    return hasattr(engine, "query_linear_dev") and _comm_device().type == "cuda"
 
 
 class DbShardedIndex(object):
-    """Database-sharded linear search.  `engine` is this rank's local engine (RiiGpu) holding codes
-    [start, stop) of the global database; it must offer query_linear_batch(Q, topk, target_ids)."""
+    """Database-sharded linear search.  `engine` is this rank's local engine holding codes [start, stop) of the global
+    database; it must offer query_linear_batch(Q, topk, target_ids) (and query_linear_dev for the device-resident path:
+    RiiGpu under the "nccl" backend)."""
 
     def __init__(self, engine, start, stop, group=None):
         self.engine, self.start, self.stop, self.group = engine, int(start), int(stop), group
 
-    def query_linear_batch(self, Q, topk, target_ids=None):
+    def _local_targets(self, target_ids, topk):
         n_local = self.stop - self.start
-        k_local = min(topk, n_local)
-        tl = None
-        if target_ids is not None and len(target_ids):
-            t = np.asarray(target_ids, np.int64)
-            tl = t[(t >= self.start) & (t < self.stop)] - self.start          # this shard's targets, still sorted
-            k_local = min(topk, len(tl))
+        if target_ids is None or len(target_ids) == 0:
+            return None, min(topk, n_local)
+        t = np.asarray(target_ids, np.int64)
+        tl = t[(t >= self.start) & (t < self.stop)] - self.start          # this shard's targets, still sorted
+        return tl, min(topk, len(tl))
+
+    def query_linear_batch(self, Q, topk, target_ids=None):
+        tl, k_local = self._local_targets(target_ids, topk)
+        B = Q.shape[0]
+        if _is_device_engine(self.engine):
+            dev = _comm_device()
+            q = _as_tensor(Q, torch.float32, dev)
+            t = None if tl is None else torch.from_numpy(tl).to(dev)
+            with _engine_stream() as sh:
+                ids = torch.full((B, topk), np.iinfo(np.int64).max // 2, dtype=torch.int64, device=dev)
+                d = torch.full((B, topk), float("inf"), dtype=torch.float32, device=dev)
+                if k_local > 0:
+                    li = torch.empty((B, k_local), dtype=torch.int64, device=dev)
+                    ld = torch.empty((B, k_local), dtype=torch.float32, device=dev)
+                    self.engine.query_linear_dev(q.data_ptr(), B, k_local, t.data_ptr() if t is not None else 0,
+                                                 0 if t is None else t.numel(), li.data_ptr(), ld.data_ptr(), sh)
+                    ids[:, :k_local] = li + self.start
+                    d[:, :k_local] = ld
+                out = allgather_merge_topk(ids, d, topk, 0, self.group)
+            return _handoff(*out)
         if k_local > 0:
-            ids, d = self.engine.query_linear_batch(Q, k_local, tl)
+            ids, d = self.engine.query_linear_batch(np.asarray(Q), k_local, tl)
         else:
-            ids = np.zeros((Q.shape[0], 0), np.int64)
-            d = np.zeros((Q.shape[0], 0), np.float32)
+            ids = np.zeros((B, 0), np.int64)
+            d = np.zeros((B, 0), np.float32)
         if k_local < topk:            # pad so that every rank contributes the same shape
             pad = topk - k_local
-            ids = np.concatenate([ids, np.full((Q.shape[0], pad), np.iinfo(np.int64).max // 2, np.int64)], axis=1)
-            d = np.concatenate([d, np.full((Q.shape[0], pad), np.inf, np.float32)], axis=1)
-        # global ids: add the shard offset to real entries only
-        ids = np.where(np.isfinite(d), ids + self.start, ids)
+            ids = np.concatenate([ids, np.full((B, pad), np.iinfo(np.int64).max // 2, np.int64)], axis=1)
+            d = np.concatenate([d, np.full((B, pad), np.inf, np.float32)], axis=1)
+        ids = np.where(np.isfinite(d), ids + self.start, ids)               # global ids for real entries only
         return allgather_merge_topk(ids, d, topk, 0, self.group)
 
 
 class QueryShardedIndex(object):
-    """Query-sharded search over a replicated index: rank r answers rows [r*B/W, (r+1)*B/W) of Q."""
+    """Query-sharded search over a replicated index: rank r answers rows shard_range(B, r, W) of Q (any B: slices may
+    differ by one row)."""
 
     def __init__(self, engine, group=None):
         self.engine, self.group = engine, group
 
-    def query_linear_batch(self, Q, topk, target_ids=None):
+    def _slices(self, B):
         rank, w = world()
-        assert Q.shape[0] % w == 0, "batch must divide evenly over the ranks (all-gather of equal shapes)"
-        s, e = shard_range(Q.shape[0], rank, w)
-        ids, d = self.engine.query_linear_batch(np.ascontiguousarray(Q[s:e]), topk, target_ids)
-        return allgather_query_shards(ids, d, self.group)
+        rows = [shard_range(B, r, w)[1] - shard_range(B, r, w)[0] for r in range(w)]
+        return shard_range(B, rank, w), rows
+
+    def query_linear_batch(self, Q, topk, target_ids=None):
+        (s, e), rows = self._slices(Q.shape[0])
+        n = e - s
+        if _is_device_engine(self.engine):
+            dev = _comm_device()
+            q = _as_tensor(Q, torch.float32, dev)[s:e].contiguous()
+            t = None if target_ids is None or len(target_ids) == 0 else _as_tensor(target_ids, torch.int64, dev)
+            with _engine_stream() as sh:
+                ids = torch.empty((n, topk), dtype=torch.int64, device=dev)
+                d = torch.empty((n, topk), dtype=torch.float32, device=dev)
+                if n:
+                    self.engine.query_linear_dev(q.data_ptr(), n, topk, t.data_ptr() if t is not None else 0,
+                                                 0 if t is None else t.numel(), ids.data_ptr(), d.data_ptr(), sh)
+                out = allgather_query_shards(ids, d, self.group, rows=rows)
+            return _handoff(*out)
+        else:
+            Qh = np.asarray(Q)
+            ids, d = self.engine.query_linear_batch(np.ascontiguousarray(Qh[s:e]), topk, target_ids) if n else \
+                (np.zeros((0, topk), np.int64), np.zeros((0, topk), np.float32))
+        return allgather_query_shards(ids, d, self.group, rows=rows)
 
     def query_ivf_batch(self, Q, topk, target_ids, L):
         """Inverted-index search, query-sharded (the reference's "stop at exactly L candidates in list order" rule is a
         per-query sequential rule, so the index is replicated and the queries are split).
         Returns (ids [B,topk], dists [B,topk], counts [B]) on every rank."""
-        rank, w = world()
-        assert Q.shape[0] % w == 0, "batch must divide evenly over the ranks (all-gather of equal shapes)"
-        s, e = shard_range(Q.shape[0], rank, w)
-        ids, d, cnt = self.engine.query_ivf_batch(np.ascontiguousarray(Q[s:e]), topk, target_ids, L)
-        gi, gd = allgather_query_shards(ids, d, self.group)
-        gc, _ = allgather_query_shards(np.asarray(cnt, np.int64).reshape(-1, 1),
-                                       np.zeros((len(cnt), 1), np.float32), self.group)
-        return gi, gd, gc.reshape(-1)
+        (s, e), rows = self._slices(Q.shape[0])
+        n = e - s
+        if _is_device_engine(self.engine):
+            dev = _comm_device()
+            q = _as_tensor(Q, torch.float32, dev)[s:e].contiguous()
+            t = None if target_ids is None or len(target_ids) == 0 else _as_tensor(target_ids, torch.int64, dev)
+            with _engine_stream() as sh:
+                ids = torch.empty((n, topk), dtype=torch.int64, device=dev)
+                d = torch.empty((n, topk), dtype=torch.float32, device=dev)
+                cnt = torch.zeros((n,), dtype=torch.int64, device=dev)
+                if n:
+                    self.engine.query_ivf_dev(q.data_ptr(), n, topk, t.data_ptr() if t is not None else 0,
+                                              0 if t is None else t.numel(), L, ids.data_ptr(), d.data_ptr(),
+                                              cnt.data_ptr(), sh)
+                out = allgather_query_shards(ids, d, self.group, local_counts=cnt, rows=rows)
+            return _handoff(*out)
+        else:
+            Qh = np.asarray(Q)
+            if n:
+                ids, d, cnt = self.engine.query_ivf_batch(np.ascontiguousarray(Qh[s:e]), topk, target_ids, L)
+            else:
+                ids, d, cnt = np.zeros((0, topk), np.int64), np.zeros((0, topk), np.float32), np.zeros(0, np.int64)
+        return allgather_query_shards(ids, d, self.group, local_counts=np.asarray(cnt, np.int64)
+                                      if not isinstance(cnt, torch.Tensor) else cnt, rows=rows)

@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
 OUT=gpurun_out/prof_summary; RAW=/tmp/rii_prof_raw
 mkdir -p $OUT; rm -rf $RAW; mkdir -p $RAW
-KREGEX='scan_order|scan_kernel|lut_build|ivf_|assign_kernel|finalize|fscan|rerank|lut_quant|gather_codes'
-BENCH="python bench.py --no-cpu-baseline $*"
+KREGEX='scan_order|scan_kernel|lut_build|ivf_|assign_kernel|finalize|fscan|rerank|lut_quant|gather_codes|linear_tie|qlut'
+BENCH="python bench.py --no-cpu-baseline --no-host-call $*"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/kt -o kt -- $BENCH --steps 10 --warmup 2 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $RAW/kt.err
 python tools/summarize_prof.py stats $RAW/kt > $OUT/${TAG}_kernel_stats.txt
@@ -24,6 +24,7 @@ for CTRS in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLE
   rocprofv3 --pmc $CTRS --kernel-include-regex "$KREGEX" --output-format csv -d $RAW/pmc$i -o pmc -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $RAW/pmc$i.err
 done
 python tools/summarize_prof.py pmc $RAW/pmc* > $OUT/${TAG}_pmc_counters.txt
+python tools/summarize_prof.py pmcjson $RAW/pmc* > $OUT/${TAG}_pmc.json
 tail -3 $RAW/*.err > $OUT/${TAG}_rocprof_stderr_tail.txt 2>/dev/null
 rm -rf $RAW
 ls -la $OUT

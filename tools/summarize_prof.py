@@ -59,8 +59,33 @@ def pmc(dirs):
                 print("    %-28s avg %.6g  (n=%d, min %.6g, max %.6g)" % (c, sum(vals) / len(vals), len(vals), min(vals), max(vals)))
 
 
+def pmcjson(dirs):
+    """The same averages as machine-readable JSON: {kernel: {counter: avg per dispatch}} (feeds profiles/pmc.json)."""
+    import json
+    out = {}
+    for d in dirs:
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        disp = defaultdict(lambda: defaultdict(float))
+        for r in csv.DictReader(open(files[0])):
+            disp[(r["Kernel_Name"], r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        acc = defaultdict(lambda: defaultdict(list))
+        for (k, _), cs in disp.items():
+            for c, v in cs.items():
+                acc[k][c].append(v)
+        for k, cs in acc.items():
+            o = out.setdefault(short(k, 200), {})
+            for c, vals in cs.items():
+                o[c] = sum(vals) / len(vals)
+                o["_dispatches"] = len(vals)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "pmcjson":
+        pmcjson(sys.argv[2:])
     else:
         pmc(sys.argv[2:])
