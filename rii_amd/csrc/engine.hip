@@ -114,6 +114,10 @@ struct rii_engine {
     // LDS-friendly scan order of the filter stage (scanorder.hip): codes gathered in scan order + position -> id.
     // Windows of 1024 codes are independent, so appends only (re)order the windows past `scan_cov`.
     DevBuf d_scan_codes, d_scan_perm;
+    // formatted lookups of the filter stage's conflict-free rotated layout (fastscan.hip: fs_rot_supported shapes), 2 bytes
+    // per code byte; codes are formatted independently, so appends only format the tail past `fc_cov`
+    DevBuf d_fcodes, s_fsub;
+    int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
     int64_t scan_cov = 0;       // codes [0, scan_cov) are final (whole windows)
     int64_t scan_N = -1;        // N the order was last completed for
@@ -265,6 +269,7 @@ int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
     const size_t M = (size_t) e->M;
     const size_t old_bytes = (size_t) e->N * M, add = (size_t) n * M;
     if (e->N < e->scan_cov) e->scan_cov = 0;         // the code array was restarted (clear / set_state)
+    if (e->N < e->fc_cov) e->fc_cov = 0;
     e->scan_N = -1;
     e->codes.insert(e->codes.end(), codes, codes + add);
     RII_TRY(e->d_codes.ensure(old_bytes + add, old_bytes, e->stream));
@@ -359,6 +364,19 @@ int ensure_scan_order(rii_engine *e, hipStream_t st)
     return RII_OK;
 }
 
+int ensure_fcodes(rii_engine *e, hipStream_t st)
+{
+    if (e->fc_cov == e->N) return RII_OK;
+    const size_t per = (size_t) e->M * 2;
+    RII_TRY(e->d_fcodes.ensure((size_t) e->N * per, (size_t) e->fc_cov * per, st));
+    {
+        ScopedTimer t(e, "format", st);
+        HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), nullptr, e->fc_cov, e->N, e->M, e->Ks, e->d_fcodes.as<uint16_t>(), st));
+    }
+    e->fc_cov = e->N;
+    return RII_OK;
+}
+
 // linear top-k (k > 1): the producers of the canonical (dist, id) result append the queries whose k+1 smallest distances
 // hold an exact tie to s_tie_list ([0] = count, [1..] = query indices relative to b0); linear_tie_kernel replays
 // std::partial_sort (src/rii.h:234-235) for them over the codes in the reference's index order.
@@ -368,7 +386,7 @@ int tie_list_reset(rii_engine *e, int64_t bc, hipStream_t st)
     HIP_TRY(hipMemsetAsync(e->s_tie_list.p, 0, sizeof(int32_t), st));
     return RII_OK;
 }
-int tie_fixup(rii_engine *e, const uint8_t *d_codes_idx, int64_t n_codes, int64_t b0, int64_t bc, int topk,
+int tie_fixup(rii_engine *e, const uint8_t *d_codes_idx, int indirect, int64_t n_codes, int64_t b0, int64_t bc, int topk,
               const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
     if (!linear_tie_supported(e->M, e->Ks))
@@ -381,18 +399,31 @@ int tie_fixup(rii_engine *e, const uint8_t *d_codes_idx, int64_t n_codes, int64_
     ScopedTimer t(e, "tie", st);
     HIP_TRY(launch_linear_tie(d_codes_idx, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, b0,
                               e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), d_remap, d_out_ids, d_out_dists,
-                              topk, grid, e->s_tie_hid.as<int32_t>(), e->s_tie_hd.as<float>(), st));
+                              topk, grid, e->s_tie_hid.as<int32_t>(), e->s_tie_hd.as<float>(), indirect, st));
     return RII_OK;
 }
 
-// the scan over `n_codes` codes at d_codes for B queries whose tables are in s_lut; ids are local indices
-// translated through d_remap (subset search) when given.
-int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int64_t n_codes, int64_t B, int topk,
-              const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+// subset search: the S target codes gathered once for the whole batch (plain layout), for the paths that scan plain codes
+int gather_plain(rii_engine *e, const int64_t *d_tids, int64_t S, hipStream_t st, const uint8_t **out)
 {
-    const uint8_t *const d_codes_idx = d_codes;     // the codes in the index order of the reference's `scores` array
+    RII_TRY(e->s_sub_codes.ensure((size_t) S * e->M));
+    ScopedTimer t(e, "gather", st);
+    HIP_TRY(launch_gather_codes(e->d_codes.as<uint8_t>(), e->M, d_tids, S, e->s_sub_codes.as<uint8_t>(), st));
+    *out = e->s_sub_codes.as<uint8_t>();
+    return RII_OK;
+}
+
+// the scan for B queries whose tables are in s_lut over the whole database (S == 0) or the S target ids d_remap (scored
+// in the order given: position s stands for the code d_remap[s], and ids are translated through d_remap at the end)
+int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_remap, int64_t S,
+              int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+{
+    const int64_t n_codes = S ? S : e->N;
+    const uint8_t *d_codes = S ? nullptr : e->d_codes.as<uint8_t>();     // plain codes in position order (gathered lazily)
+    const uint8_t *d_codes_idx = nullptr;           // what the re-rank / tie-order kernels index: see `indirect`
+    int indirect = 0;
     ScanParams sp;
-    sp.codes = d_codes; sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks;
+    sp.n_codes = n_codes; sp.M = e->M; sp.Ks = e->Ks;
     sp.B = (int) B; sp.QT = e->QT; sp.best = nullptr; sp.keys = nullptr; sp.b0 = 0; sp.bc = 0;
     // small top-1 batches: the exact scan needs no candidate machinery and wins below ~128 queries (tools/sweep_batch.py)
     const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
@@ -439,14 +470,33 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             int cap = (int) std::min<int64_t>(262144, std::max<int64_t>(e->cand_cap, ((int64_t) 1 << 24) / std::max<int64_t>(B, 1)));
             if (e->cand_cap_forced) cap = e->cand_cap;
             if (topk > 1) cap = std::max(cap, 16 * topk * stride);
-            // whole-database scans run over the LDS-friendly copy of the codes; the re-rank maps positions back to ids
             const int32_t *d_perm = nullptr;
-            if (e->scan_order && !d_remap && d_codes == e->d_codes.as<uint8_t>() && n_codes == e->N &&
-                n_codes >= kScanOrderMinN && scan_order_supported(e->M, e->Ks)) {
-                RII_TRY(ensure_scan_order(e, st));
-                d_codes = e->d_scan_codes.as<uint8_t>();
-                d_perm = e->d_scan_perm.as<int32_t>();
+            const uint8_t *d_scan = nullptr;          // what fscan_kernel reads
+            if (fs_rot_supported(e->M, e->Ks)) {
+                // conflict-free rotated layout: the scan reads formatted lookups, the exact stages index the database
+                if (S) {
+                    RII_TRY(e->s_fsub.ensure((size_t) S * e->M * 2));
+                    ScopedTimer t(e, "gather", st);
+                    HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), d_remap, 0, S, e->M, e->Ks, e->s_fsub.as<uint16_t>(), st));
+                    d_scan = e->s_fsub.as<uint8_t>();
+                    indirect = 1;
+                } else {
+                    RII_TRY(ensure_fcodes(e, st));
+                    d_scan = e->d_fcodes.as<uint8_t>();
+                }
+                d_codes_idx = e->d_codes.as<uint8_t>();
+            } else {
+                if (S) RII_TRY(gather_plain(e, d_remap, S, st, &d_codes));
+                d_scan = d_codes;
+                d_codes_idx = d_codes;
+                // whole-database scans run over the LDS-friendly copy of the codes; the re-rank maps positions back to ids
+                if (e->scan_order && !S && n_codes >= kScanOrderMinN && scan_order_supported(e->M, e->Ks)) {
+                    RII_TRY(ensure_scan_order(e, st));
+                    d_scan = e->d_scan_codes.as<uint8_t>();
+                    d_perm = e->d_scan_perm.as<int32_t>();
+                }
             }
+            const uint8_t *d_rr = d_perm ? d_scan : d_codes_idx;       // the re-rank reads the code at the scan position
             RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * qr));
             RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
             RII_TRY(e->s_cand.ensure((size_t) B * cap * sizeof(unsigned long long)));
@@ -465,15 +515,16 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
                     HIP_TRY(hipMemsetAsync(e->s_gthr.p, 0xff, (size_t) B * sizeof(uint32_t), st));   // > any 16-bit threshold
                 {
                     ScopedTimer t(e, "scan", st);
-                    HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
+                    HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
                                          e->s_gthr.as<uint32_t>(), 1, st));
                 }
                 ScopedTimer t(e, "rerank", st);
-                HIP_TRY(launch_rerank_top1(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
+                HIP_TRY(launch_rerank_top1(d_rr, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
                                            e->s_slack.as<int32_t>(), e->s_cand.as<unsigned long long>(),
-                                           e->s_cand_cnt.as<unsigned int>(), cap, d_remap, d_perm, B, d_out_ids, d_out_dists, topk, st));
+                                           e->s_cand_cnt.as<unsigned int>(), cap, d_remap, d_perm, B, d_out_ids, d_out_dists, topk,
+                                           indirect, st));
                 return RII_OK;
             }
             // top-k: pass 1 = per-lane-segment minima of the quantised sums, k-th smallest of them bounds the k-th
@@ -482,7 +533,7 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             RII_TRY(e->s_thr16.ensure((size_t) B * sizeof(uint32_t)));
             {
                 ScopedTimer t(e, "scan", st);
-                HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
+                HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride, st));
             }
             {
@@ -492,19 +543,19 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             }
             {
                 ScopedTimer t(e, "scan", st);
-                HIP_TRY(launch_fscan(d_codes, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
+                HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
                                      2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, st));
             }
             RII_TRY(tie_list_reset(e, B, st));
             {
                 ScopedTimer t(e, "rerank", st);
-                HIP_TRY(launch_rerank_topk(d_codes, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
+                HIP_TRY(launch_rerank_topk(d_rr, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
                                            e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap, d_remap,
                                            d_perm, B, d_out_ids, d_out_dists, topk, e->s_tie_list.as<int32_t>() + 1,
-                                           e->s_tie_list.as<int>(), st));
+                                           e->s_tie_list.as<int>(), indirect, st));
             }
-            return tie_fixup(e, d_codes_idx, n_codes, 0, B, topk, d_remap, d_out_ids, d_out_dists, st);
+            return tie_fixup(e, d_codes_idx, indirect, n_codes, 0, B, topk, d_remap, d_out_ids, d_out_dists, st);
         }
     }
     // the exhaustive kernels read the tile-interleaved layout: re-lay the tables out if they are in another one
@@ -512,12 +563,15 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
     if (e->lut_qt != qt) RII_TRY(build_lut(e, d_queries, B, st, false, qt));
     sp.lut = e->s_lut.as<float>();
     sp.QT = qt;
+    if (S) RII_TRY(gather_plain(e, d_remap, S, st, &d_codes));
+    sp.codes = d_codes;
+    d_codes_idx = d_codes;
     if (topk == 1) {
         pick_chunks(e, n_codes, B, &sp.chunks, &sp.chunk_len, qt);
         // 16-byte table rows (4 queries per row) meet the same ds_read_b128 service groups as the filter's byte tables:
         // whole-database scans walk the LDS-friendly copy of the codes
-        if (e->scan_order && qt == 4 && fastscan_rows(e->M, e->Ks) == 16 && !d_remap && d_codes == e->d_codes.as<uint8_t>() &&
-            n_codes == e->N && n_codes >= kScanOrderMinN && scan_order_supported(e->M, e->Ks)) {
+        if (e->scan_order && qt == 4 && fastscan_rows(e->M, e->Ks) == 16 && !S && n_codes >= kScanOrderMinN &&
+            scan_order_supported(e->M, e->Ks)) {
             RII_TRY(ensure_scan_order(e, st));
             sp.codes = e->d_scan_codes.as<uint8_t>();
             sp.perm = e->d_scan_perm.as<int32_t>();
@@ -563,7 +617,7 @@ int scan_topk(rii_engine *e, const float *d_queries, const uint8_t *d_codes, int
             HIP_TRY(launch_sorted_tie_flag(e->s_keys_b.as<unsigned long long>(), cur, n_codes, topk,
                                            e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), st));
         }
-        RII_TRY(tie_fixup(e, d_codes_idx, n_codes, b0, cur, topk, d_remap, d_out_ids, d_out_dists, st));
+        RII_TRY(tie_fixup(e, d_codes_idx, 0, n_codes, b0, cur, topk, d_remap, d_out_ids, d_out_dists, st));
     }
     return RII_OK;
 }
@@ -601,15 +655,7 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
         const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
         RII_TRY(build_lut(e, d_queries, B, st, !small_top1, small_top1 ? exact_tile_for(e, B, topk) : 0));
     }
-    if (S == 0)
-        return scan_topk(e, d_queries, e->d_codes.as<uint8_t>(), e->N, B, topk, nullptr, d_out_ids, d_out_dists, st);
-    // subset search: gather the S target codes once for the whole batch, scan them, map ids back
-    RII_TRY(e->s_sub_codes.ensure((size_t) S * e->M));
-    {
-        ScopedTimer t(e, "gather", st);
-        HIP_TRY(launch_gather_codes(e->d_codes.as<uint8_t>(), e->M, d_tids, S, e->s_sub_codes.as<uint8_t>(), st));
-    }
-    return scan_topk(e, d_queries, e->s_sub_codes.as<uint8_t>(), S, B, topk, d_tids, d_out_ids, d_out_dists, st);
+    return scan_topk(e, d_queries, B, topk, S ? d_tids : nullptr, S, d_out_ids, d_out_dists, st);
 }
 
 int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
@@ -794,7 +840,7 @@ int end_on(rii_engine *e, hipStream_t st)
 void free_all(rii_engine *e)
 {
     DevBuf *bufs[] = {&e->d_codewords, &e->d_cnorm, &e->d_codes, &e->d_centers, &e->d_symtab, &e->d_pl_off,
-                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->s_queries, &e->s_tids, &e->s_lut, &e->s_best, &e->s_out_ids,
+                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->d_fcodes, &e->s_fsub, &e->s_queries, &e->s_tids, &e->s_lut, &e->s_best, &e->s_out_ids,
                       &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,

@@ -323,9 +323,25 @@ __global__ __launch_bounds__(256) void lut_build_quant_regs_kernel(const float *
     build_quantize_regs(queries + b * (int64_t) (M * 4), codewords, b, M, Ks, lut, qc, slack);
 }
 
-// compact [b][M*Ks] bytes -> [tile][M*Ks][QR]: one 16-byte (QR=16) or 8-byte (QR=8) row per thread, coalesced both ways
+// Rotated table layout (fs_rot_supported shapes).  The hardware serves a wave's ds_read_b128 in groups of G = 16 lanes
+// (ds_read_b64: G = 32) and a row's bank slot is (row index mod G); with the plain [m][ks] order two lanes of a group
+// collide whenever their code bytes share ks mod G -- 2.9 LDS cycles per group on random codes, 2.2 after the scan-order
+// packing (scanorder.hip), against 1 conflict-free.  Here the rows of G consecutive subspaces are interleaved,
+//     row(m, ks) = (m / G) * G * Ks + ks * G + (m mod G),
+// so subspace m owns bank slot (m mod G), and lane l of a group works on subspace (l + t) mod G of ITS code at step t
+// (the byte sums are integers: the order of the M additions is free).  The G lanes of a group then always hit G different
+// slots: no bank conflict for any data.  The lane-dependent subspace order is baked into a formatted copy of the codes
+// (fcodes_format_kernel): lookup t of half h of code n is the 16-bit value (h, ks, slot) whose shift by log2(row bytes)
+// is the LDS address of the row.
+__host__ __device__ __forceinline__ int fs_rot_row(int i, int Ks, int G)      // i = m * Ks + ks
+{
+    const int m = i / Ks, ks = i - m * Ks;
+    return (m / G) * G * Ks + ks * G + (m % G);
+}
+
+// compact [b][M*Ks] bytes -> [tile][M*Ks][QR]: one 16-byte (QR=16) or 8-byte (QR=8) row per thread
 template <int QR>
-__global__ __launch_bounds__(256) void qlut_interleave_kernel(const uint8_t *__restrict__ qc, int64_t B, int MK,
+__global__ __launch_bounds__(256) void qlut_interleave_kernel(const uint8_t *__restrict__ qc, int64_t B, int MK, int Ks, int rot,
                                                               uint8_t *__restrict__ qlut)
 {
     const int64_t tiles = (B + QR - 1) / QR;
@@ -342,20 +358,55 @@ __global__ __launch_bounds__(256) void qlut_interleave_kernel(const uint8_t *__r
             const uint32_t v = b < B ? qc[(size_t) b * MK + i] : 0u;
             w[q >> 2] |= v << (8 * (q & 3));
         }
-        uint32_t *dst = reinterpret_cast<uint32_t *>(qlut + (size_t) t * QR);
+        const int row = rot ? fs_rot_row(i, Ks, QR == 16 ? 16 : 32) : i;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(qlut + ((size_t) tile * MK + row) * QR);
 #pragma unroll
         for (int k = 0; k < QR / 4; ++k) dst[k] = w[k];
     }
 }
 
+bool fs_rot_supported(int M, int Ks);
+
 static hipError_t launch_qlut_interleave(const uint8_t *d_qc, int64_t B, int M, int Ks, uint8_t *d_qlut, hipStream_t st)
 {
     const int qr = fastscan_rows(M, Ks);
     const int MK = M * Ks;
+    const int rot = fs_rot_supported(M, Ks) ? 1 : 0;
     const int64_t total = ((B + qr - 1) / qr) * MK;
     int blocks = (int) std::min<int64_t>((total + 255) / 256, 8192);
-    if (qr == 16) hipLaunchKernelGGL(qlut_interleave_kernel<16>, dim3(blocks), dim3(256), 0, st, d_qc, B, MK, d_qlut);
-    else hipLaunchKernelGGL(qlut_interleave_kernel<8>, dim3(blocks), dim3(256), 0, st, d_qc, B, MK, d_qlut);
+    if (qr == 16) hipLaunchKernelGGL(qlut_interleave_kernel<16>, dim3(blocks), dim3(256), 0, st, d_qc, B, MK, Ks, rot, d_qlut);
+    else hipLaunchKernelGGL(qlut_interleave_kernel<8>, dim3(blocks), dim3(256), 0, st, d_qc, B, MK, Ks, rot, d_qlut);
+    return hipGetLastError();
+}
+
+// codes [n][M] u8 -> formatted lookups [n][M] u16 for the rotated layout; ids == NULL: code n itself, else the code ids[n]
+// (subset search).  Thread per (position, lookup).
+__global__ __launch_bounds__(256) void fcodes_format_kernel(const uint8_t *__restrict__ codes, const int64_t *__restrict__ ids,
+                                                            int64_t n0, int64_t n1, int M, int G, int sh,
+                                                            uint16_t *__restrict__ out)
+{
+    const int64_t total = (n1 - n0) * M;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t n = n0 + t / M;
+        const int i = (int) (t % M);                    // lookup index = half * G + step
+        const int h = i / G, step = i - h * G;
+        const int slot = ((int) (n & (G - 1)) + step) & (G - 1);
+        const int64_t src = ids ? ids[n] : n;
+        const uint32_t ks = codes[(size_t) src * M + h * G + slot];
+        out[(size_t) n * M + i] = (uint16_t) (((uint32_t) h << (sh + 8)) | (ks << sh) | (uint32_t) slot);
+    }
+}
+
+// formats codes [n0, n1) (or the gathered codes ids[n0..n1)) for the filter scan of an (M, Ks) index
+hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, int64_t n0, int64_t n1, int M, int Ks,
+                                uint16_t *d_out, hipStream_t st)
+{
+    if (n1 <= n0) return hipSuccess;
+    const int G = fastscan_rows(M, Ks) == 16 ? 16 : 32;
+    const int sh = G == 16 ? 4 : 5;                    // value = (half, ks, slot): ks above the log2(G) slot bits
+    const int64_t total = (n1 - n0) * M;
+    const int blocks = (int) std::min<int64_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(fcodes_format_kernel, dim3(blocks), dim3(256), 0, st, d_codes, d_ids, n0, n1, M, G, sh, d_out);
     return hipGetLastError();
 }
 
@@ -497,6 +548,31 @@ template <int QR, int KST, int I> __device__ __forceinline__ void fs_word_issue(
     r[2] = fs_row_issue<QR, KST, 4 * I + 2, 2>(w);
     r[3] = fs_row_issue<QR, KST, 4 * I + 3, 3>(w);
 }
+// rotated layout: lookup J (0/1) of a formatted code dword is a 16-bit (half, ks, slot) value; shifted by log2(row bytes)
+// it IS the LDS address of the row (dynamic LDS starts at 0, the tables come first)
+template <int QR, int J> __device__ __forceinline__ typename FsVec<QR>::T fs_rot_row_issue(uint32_t w)
+{
+    uint32_t addr;
+    if constexpr (QR == 16) {
+        if constexpr (J == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(w));
+        else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(w));
+    } else {
+        if constexpr (J == 0) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(w));
+        else asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(w));
+    }
+    typename FsVec<QR>::T r;
+    if constexpr (QR == 16) asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    else asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+// the four rows of lookups 4*I .. 4*I+3 (two formatted dwords), in flight after this returns
+template <int QR> __device__ __forceinline__ void fs_rot_word_issue(uint32_t w0, uint32_t w1, typename FsVec<QR>::T (&r)[4])
+{
+    r[0] = fs_rot_row_issue<QR, 0>(w0);
+    r[1] = fs_rot_row_issue<QR, 1>(w0);
+    r[2] = fs_rot_row_issue<QR, 0>(w1);
+    r[3] = fs_rot_row_issue<QR, 1>(w1);
+}
 // wait until at most PENDING younger LDS operations are outstanding: the four rows named become valid
 template <int PENDING, typename V> __device__ __forceinline__ void fs_wait4(V (&r)[4])
 {
@@ -519,18 +595,25 @@ template <int QR> __device__ __forceinline__ void fs_word_sum(const typename FsV
     for (int d = 0; d < QR / 4; ++d) s[d] = fs_add3(r[0][d], r[1][d], r[2][d]) + r[3][d];
 }
 
-// all MW code words of one code against the byte tables: acc[] = 16-bit sums per query (packing: see fs_flush).
-// Two words (8 rows) are consumed per step while the next two are already in flight.
-template <int QR, int KST, int MW, int I> __device__ __forceinline__ void fs_code_steps(const uint32_t (&w)[MW], uint32_t (&acc)[QR / 2],
-                                                                                        typename FsVec<QR>::T (&ra)[4],
-                                                                                        typename FsVec<QR>::T (&rb)[4])
+// all MW groups of four lookups of one code against the byte tables: acc[] = 16-bit sums per query (packing: see
+// fs_flush).  Two groups (8 rows) are consumed per step while the next two are already in flight.  ROT: w[] holds the
+// formatted lookups of the rotated layout (two per dword, 2*MW dwords), else the plain code words (MW dwords).
+template <int QR, int KST, int MW, int I, bool ROT, int NW>
+__device__ __forceinline__ void fs_group_issue(const uint32_t (&w)[NW], typename FsVec<QR>::T (&r)[4])
+{
+    if constexpr (ROT) fs_rot_word_issue<QR>(w[2 * I], w[2 * I + 1], r);
+    else fs_word_issue<QR, KST, I>(w[I], r);
+}
+template <int QR, int KST, int MW, int I, bool ROT, int NW>
+__device__ __forceinline__ void fs_code_steps(const uint32_t (&w)[NW], uint32_t (&acc)[QR / 2], typename FsVec<QR>::T (&ra)[4],
+                                              typename FsVec<QR>::T (&rb)[4])
 {
     if constexpr (I < MW) {
         typename FsVec<QR>::T na[4], nb[4];
         constexpr bool more = I + 2 < MW;
         if constexpr (more) {
-            fs_word_issue<QR, KST, I + 2>(w[I + 2], na);
-            fs_word_issue<QR, KST, I + 3>(w[I + 3], nb);
+            fs_group_issue<QR, KST, MW, I + 2, ROT, NW>(w, na);
+            fs_group_issue<QR, KST, MW, I + 3, ROT, NW>(w, nb);
         }
         uint32_t sa[QR / 4], sb[QR / 4];
         fs_wait4<more ? 12 : 4>(ra);
@@ -547,16 +630,82 @@ template <int QR, int KST, int MW, int I> __device__ __forceinline__ void fs_cod
                 acc[2 * d + 1] = fs_add3(acc[2 * d + 1], fs_odd_bytes(sa[d]), fs_odd_bytes(sb[d]));
             }
         }
-        if constexpr (more) fs_code_steps<QR, KST, MW, I + 2>(w, acc, na, nb);
+        if constexpr (more) fs_code_steps<QR, KST, MW, I + 2, ROT, NW>(w, acc, na, nb);
     }
 }
-template <int QR, int KST, int MW> __device__ __forceinline__ void fs_code(const uint32_t (&w)[MW], uint32_t (&acc)[QR / 2])
+template <int QR, int KST, int MW, bool ROT, int NW>
+__device__ __forceinline__ void fs_code(const uint32_t (&w)[NW], uint32_t (&acc)[QR / 2])
 {
-    static_assert(MW % 2 == 0 && kFsFlush == 4, "pairs of code words, 4 lookups per byte-packed sum");
+    static_assert(MW % 2 == 0 && kFsFlush == 4, "pairs of lookup groups, 4 lookups per byte-packed sum");
     typename FsVec<QR>::T ra[4], rb[4];
-    fs_word_issue<QR, KST, 0>(w[0], ra);
-    fs_word_issue<QR, KST, 1>(w[1], rb);
-    fs_code_steps<QR, KST, MW, 0>(w, acc, ra, rb);
+    fs_group_issue<QR, KST, MW, 0, ROT, NW>(w, ra);
+    fs_group_issue<QR, KST, MW, 1, ROT, NW>(w, rb);
+    fs_code_steps<QR, KST, MW, 0, ROT, NW>(w, acc, ra, rb);
+}
+
+// ---- rotated layout: the whole code in one go ----
+// Byte-packed group sums s (four lookups, <= 252 per byte) feed TWO accumulators per dword column:
+//   A += s          as a plain 32-bit integer (carries between the byte fields are allowed), and
+//   O += odd bytes of s widened to two 16-bit fields (one v_perm_b32).
+// With B0..B3 the true per-query sums (<= 32 * 63 < 2^11):  A = B0 + B1*2^8 + B2*2^16 + B3*2^24 (mod 2^32) and
+// O = B1 + B3*2^16, hence  A - (O << 8) = B0 + B2*2^16  exactly: the even queries' 16-bit sums fall out of one shift and
+// one subtraction per column at the end instead of an AND per group (8 VALU ops per 8 lookups and column instead of 10).
+// The formatted lookups of the NEXT code this lane scans are fetched as soon as the last address of the current one has
+// been formed (w[] is dead from there on): the loads travel under the remaining sums instead of stalling the loop head.
+template <int QR, int MW, int I>
+__device__ __forceinline__ void fs_rot_steps(uint32_t (&w)[2 * MW], uint32_t (&A)[QR / 4], uint32_t (&O)[QR / 4],
+                                             typename FsVec<QR>::T (&ra)[4], typename FsVec<QR>::T (&rb)[4],
+                                             const uint4 *__restrict__ next, bool prefetch)
+{
+    if constexpr (I < MW) {
+        typename FsVec<QR>::T na[4], nb[4];
+        constexpr bool more = I + 2 < MW;
+        if constexpr (more) {
+            fs_rot_word_issue<QR>(w[2 * (I + 2)], w[2 * (I + 2) + 1], na);
+            fs_rot_word_issue<QR>(w[2 * (I + 3)], w[2 * (I + 3) + 1], nb);
+        }
+        if constexpr (I + 4 == MW || (MW == 2 && I == 0)) {
+            if (prefetch) {
+#pragma unroll
+                for (int i = 0; i < MW / 2; ++i) {
+                    const uint4 v = next[i];
+                    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+                }
+            }
+        }
+        uint32_t sa[QR / 4], sb[QR / 4];
+        fs_wait4<more ? 12 : 4>(ra);
+        fs_word_sum<QR>(ra, sa);
+        fs_wait4<more ? 8 : 0>(rb);
+        fs_word_sum<QR>(rb, sb);
+#pragma unroll
+        for (int d = 0; d < QR / 4; ++d) {
+            if constexpr (I == 0) {
+                A[d] = sa[d] + sb[d];
+                O[d] = fs_odd_bytes(sa[d]) + fs_odd_bytes(sb[d]);
+            } else {
+                A[d] = fs_add3(A[d], sa[d], sb[d]);
+                O[d] = fs_add3(O[d], fs_odd_bytes(sa[d]), fs_odd_bytes(sb[d]));
+            }
+        }
+        if constexpr (more) fs_rot_steps<QR, MW, I + 2>(w, A, O, na, nb, next, prefetch);
+    }
+}
+template <int QR, int MW>
+__device__ __forceinline__ void fs_rot_code(uint32_t (&w)[2 * MW], uint32_t (&acc)[QR / 2], const uint4 *__restrict__ next,
+                                            bool prefetch)
+{
+    static_assert(MW % 2 == 0 && MW >= 4 && kFsFlush == 4, "pairs of lookup groups, 4 lookups per byte-packed sum");
+    typename FsVec<QR>::T ra[4], rb[4];
+    uint32_t A[QR / 4], O[QR / 4];
+    fs_rot_word_issue<QR>(w[0], w[1], ra);
+    fs_rot_word_issue<QR>(w[2], w[3], rb);
+    fs_rot_steps<QR, MW, 0>(w, A, O, ra, rb, next, prefetch);
+#pragma unroll
+    for (int d = 0; d < QR / 4; ++d) {
+        acc[2 * d] = A[d] - (O[d] << 8);
+        acc[2 * d + 1] = O[d];
+    }
 }
 
 __device__ __forceinline__ void fs_add(uint32_t (&pb)[4], const uint4 &v)
@@ -593,7 +742,7 @@ __device__ __forceinline__ uint32_t fs_thr_of(uint32_t a, uint32_t slack)
     return t > 0xffffu ? 0xffffu : t;
 }
 
-template <int MW, int KST, int MODE, int QR>
+template <int MW, int KST, int MODE, int QR, bool ROT = false>
 __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -702,6 +851,19 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     };
     // MODE 1 only needs an UPPER bound on the k-th smallest sum, so it may look at a strided sample of the codes
     const int it_step = (MODE == 1) ? p.sample_stride : 1;
+    // rotated layout: the formatted lookups of a lane's code, fetched one trip ahead (fs_rot_code)
+    uint32_t wrot[(ROT && MW) ? 2 * MW : 1];
+    if constexpr (ROT && MW != 0) {
+        const int64_t nf = c_begin + tid;
+        if (nf < c_end) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(p.codes + (size_t) nf * (MW * 8));
+#pragma unroll
+            for (int i = 0; i < MW / 2; ++i) {
+                const uint4 v = cp[i];
+                wrot[4 * i] = v.x; wrot[4 * i + 1] = v.y; wrot[4 * i + 2] = v.z; wrot[4 * i + 3] = v.w;
+            }
+        }
+    }
     for (int it = 0; it < iters; it += it_step) {
         const int64_t n = c_begin + (int64_t) it * kFsThreads + tid;
         const bool active = n < c_end;
@@ -711,7 +873,11 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
 #pragma unroll
         for (int i = 0; i < QR / 4; ++i) pb[i] = 0u;
         if (active) {
-            if constexpr (MW != 0) {
+            if constexpr (MW != 0 && ROT) {
+                // formatted lookups: 2 bytes each, 8 * MW bytes per code
+                const int64_t nn = n + (int64_t) it_step * kFsThreads;
+                fs_rot_code<QR, MW>(wrot, acc, reinterpret_cast<const uint4 *>(p.codes + (size_t) nn * (MW * 8)), nn < c_end);
+            } else if constexpr (MW != 0) {
                 const uint8_t *cp = p.codes + (size_t) n * (MW * 4);
                 uint32_t w[MW ? MW : 1];
                 if constexpr (MW % 4 == 0) {
@@ -728,7 +894,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
                     }
                 }
                 if constexpr (kFsFlush == 4 && MW % 2 == 0) {
-                    fs_code<QR, KST, MW>(w, acc);
+                    fs_code<QR, KST, MW, false, (MW ? MW : 1)>(w, acc);
                 } else {
 #pragma unroll
                     for (int i = 0; i < MW; ++i) {          // 4 lookups per code word; flush every kFsFlush lookups
@@ -829,7 +995,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_kernel(FsArgs p)
     }
 }
 
-template <int MW, int KST, int MODE, int QR>
+template <int MW, int KST, int MODE, int QR, bool ROT = false>
 static hipError_t launch_fscan_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
     const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8;
@@ -838,7 +1004,7 @@ static hipError_t launch_fscan_t(const FsArgs &a, int chunks, int tiles, hipStre
     // more than the global ones they save (measured)
     b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) QR * 8));
     const size_t smem = tab + (size_t) QR * 8 * b.lcap;
-    auto kern = fscan_kernel<MW, KST, MODE, QR>;
+    auto kern = fscan_kernel<MW, KST, MODE, QR, ROT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
@@ -857,10 +1023,26 @@ int fastscan_rows(int M, int Ks)
 bool fastscan_supported(int M, int Ks) { return fastscan_rows(M, Ks) != 0; }
 int fastscan_max_sum(int M) { return M * kFsLevels; }
 
-template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chunks, hipStream_t st)
+// shapes with the conflict-free rotated layout: whole groups of G = 16 subspaces (the lanes of a ds_read_b128 service
+// group) and Ks = 256 (the (half, ks, slot) lookup value fits 16 bits)
+bool fs_rot_supported(int M, int Ks)
+{
+    const int qr = fastscan_rows(M, Ks);
+    if (Ks != 256) return false;
+    // (M = 64 with 8-byte rows was tried: 128 formatted bytes per code and lane make the loop load-bound, 1.9 ms against
+    //  1.3 ms with the plain codes in the scan order of scanorder.hip)
+    return qr == 16 && (M == 16 || M == 32);
+}
+
+template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chunks, bool rot, hipStream_t st)
 {
     const int qr = fastscan_rows(a.M, a.Ks);
     const int tiles = (a.B + qr - 1) / qr;
+    if (rot) {
+        if (qr == 16 && a.M == 16) return launch_fscan_t<4, 256, MODE, 16, true>(a, chunks, tiles, st);
+        if (qr == 16 && a.M == 32) return launch_fscan_t<8, 256, MODE, 16, true>(a, chunks, tiles, st);
+        return hipErrorInvalidValue;
+    }
     if (qr == 16) {
         if (a.Ks == 256 && a.M == 8) return launch_fscan_t<2, 256, MODE, 16>(a, chunks, tiles, st);
         if (a.Ks == 256 && a.M == 16) return launch_fscan_t<4, 256, MODE, 16>(a, chunks, tiles, st);
@@ -876,16 +1058,18 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
                         uint32_t *d_gthr, int sample_stride, hipStream_t st)
 {
+    // d_codes: formatted lookups (launch_fcodes_format) for fs_rot_supported shapes, the plain codes otherwise
     if (B == 0 || n_codes == 0) return hipSuccess;
+    const bool rot = fs_rot_supported(M, Ks);
     FsArgs a;
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
     a.chunk_len = chunk_len; a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.segmin = d_segmin;
     a.thr16 = d_thr16;
-    if (mode == 1) return launch_fscan_mode<1>(a, chunks, st);
-    if (mode == 2) return launch_fscan_mode<2>(a, chunks, st);
-    return launch_fscan_mode<0>(a, chunks, st);
+    if (mode == 1) return launch_fscan_mode<1>(a, chunks, rot, st);
+    if (mode == 2) return launch_fscan_mode<2>(a, chunks, rot, st);
+    return launch_fscan_mode<0>(a, chunks, rot, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -978,6 +1162,7 @@ struct RrArgs {
     int64_t *out_ids;
     float *out_dists;
     int topk;
+    int indirect = 0;                // 1: `codes` is the whole database and position n stands for the code remap[n] (subset search)
     int32_t *flag_list = nullptr;    // top-k: queries whose k+1 smallest distances hold an exact tie (redone by tieorder.hip)
     int *nflag = nullptr;
 };
@@ -1025,14 +1210,14 @@ __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
             const unsigned long long c = cand[i];
             if ((c >> 32) > lim) continue;
             const uint32_t n = (uint32_t) (c & 0xffffffffu);
-            const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
+            const float d = exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[n] : (int64_t) n) * p.M, p.M, p.Ks);
             const uint32_t id = p.perm ? (uint32_t) p.perm[n] : n;
             const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | id;
             best = key < best ? key : best;
         }
     } else {
         for (int64_t n = tid; n < p.n_codes; n += blockDim.x) {
-            const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
+            const float d = exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[n] : (int64_t) n) * p.M, p.M, p.Ks);
             const uint32_t id = p.perm ? (uint32_t) p.perm[n] : (uint32_t) n;
             const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | id;
             best = key < best ? key : best;
@@ -1057,10 +1242,11 @@ hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, in
                               const int32_t *d_slack, const unsigned long long *d_cand,
                               const unsigned int *d_cand_count, int cap, const int64_t *d_remap,
                               const int32_t *d_perm, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
-                              hipStream_t st)
+                              int indirect, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     RrArgs a;
+    a.indirect = indirect;
     a.perm = d_perm;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.slack = d_slack;
     a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.remap = d_remap; a.out_ids = d_out_ids;
@@ -1125,7 +1311,7 @@ __global__ __launch_bounds__(256) void rerank_topk_kernel(RrArgs p)
         const int64_t i = base + tid;
         if (i < total) {
             const uint32_t n = overflow ? (uint32_t) i : (uint32_t) (cand[i] & 0xffffffffu);
-            const float d = exact_adist(lds, p.codes + (size_t) n * p.M, p.M, p.Ks);
+            const float d = exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[n] : (int64_t) n) * p.M, p.M, p.Ks);
             const uint32_t id = p.perm ? (uint32_t) p.perm[n] : n;
             const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | id;
             if (key < s_thr) buf[atomicAdd(&s_cnt, 1u)] = key;
@@ -1157,10 +1343,11 @@ int rerank_topk_max_k() { return kRrBuf / 2 - 1; }      // the k+1 smallest keys
 hipError_t launch_rerank_topk(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const unsigned long long *d_cand, const unsigned int *d_cand_count, int cap,
                               const int64_t *d_remap, const int32_t *d_perm, int64_t B, int64_t *d_out_ids,
-                              float *d_out_dists, int topk, int32_t *d_flag_list, int *d_nflag, hipStream_t st)
+                              float *d_out_dists, int topk, int32_t *d_flag_list, int *d_nflag, int indirect, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     RrArgs a;
+    a.indirect = indirect;
     a.flag_list = d_flag_list; a.nflag = d_nflag;
     a.perm = d_perm;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.slack = nullptr;

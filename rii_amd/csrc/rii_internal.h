@@ -132,25 +132,29 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
                         uint32_t *d_gthr, int sample_stride, hipStream_t st);
 int fastscan_max_sum(int M);
+// conflict-free rotated table layout + formatted code copy (see fastscan.hip): launch_fscan then takes the formatted codes
+bool fs_rot_supported(int M, int Ks);
+hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, int64_t n0, int64_t n1, int M, int Ks,
+                                uint16_t *d_out, hipStream_t st);
 int rerank_topk_max_k();
 hipError_t launch_kth_threshold(const uint16_t *d_segmin, int64_t G, int64_t B, int k, int maxv, const int32_t *d_slack,
                                 uint32_t *d_thr16, hipStream_t st);
 hipError_t launch_rerank_topk(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const unsigned long long *d_cand, const unsigned int *d_cand_count, int cap,
                               const int64_t *d_remap, const int32_t *d_perm, int64_t B, int64_t *d_out_ids,
-                              float *d_out_dists, int topk, int32_t *d_flag_list, int *d_nflag, hipStream_t st);
+                              float *d_out_dists, int topk, int32_t *d_flag_list, int *d_nflag, int indirect, hipStream_t st);
 hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,
                               const int32_t *d_slack, const unsigned long long *d_cand,
                               const unsigned int *d_cand_count, int cap, const int64_t *d_remap,
                               const int32_t *d_perm, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
-                              hipStream_t st);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
+                              int indirect, hipStream_t st);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
 
 // tieorder.hip: the reference's std::partial_sort order for the queries whose k+1 smallest distances tie exactly
 bool linear_tie_supported(int M, int Ks);
 bool linear_tie_heap_in_lds(int M, int Ks, int topk);
 hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                              const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
-                             float *d_out_dists, int topk, int grid, int32_t *d_heap_ids, float *d_heap_d, hipStream_t st);
+                             float *d_out_dists, int topk, int grid, int32_t *d_heap_ids, float *d_heap_d, int indirect, hipStream_t st);
 hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
                                   int32_t *d_flag_list, int *d_nflag, hipStream_t st);
 

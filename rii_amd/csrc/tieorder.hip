@@ -39,6 +39,7 @@ struct TieArgs {
     int32_t *g_hid; float *g_hd;         // [gridDim.x][topk] heap storage when it does not fit LDS (else unused)
     int heap_in_lds;
     int capl;                            // list capacity (tie_list_cap)
+    int indirect;                        // 1: `codes` is the whole database, index i stands for the code remap[i]
 };
 
 __device__ __forceinline__ void tie_flush(unsigned long long *list, unsigned int c, int32_t *hid, float *hd, long k,
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
         }
         __syncthreads();
         for (long i = tid; i < k; i += 256) {              // the first k scores are the initial heap contents
-            hd[i] = exact_adist(lds, p.codes + (size_t) i * p.M, p.M, p.Ks);
+            hd[i] = exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[i] : (int64_t) i) * p.M, p.M, p.Ks);
             hid[i] = (int32_t) i;
         }
         if (!p.heap_in_lds) __threadfence_block();
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t i = base + u * 256 + tid;
-                d[u] = (u < U && i < p.n) ? exact_adist(lds, p.codes + (size_t) i * p.M, p.M, p.Ks) : INFINITY;
+                d[u] = (u < U && i < p.n) ? exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[i] : (int64_t) i) * p.M, p.M, p.Ks) : INFINITY;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -163,7 +164,7 @@ bool linear_tie_supported(int M, int Ks) { return tie_smem(M, Ks, 0, false) <= (
 
 hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                              const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
-                             float *d_out_dists, int topk, int grid, int32_t *d_heap_ids, float *d_heap_d, hipStream_t st)
+                             float *d_out_dists, int topk, int grid, int32_t *d_heap_ids, float *d_heap_d, int indirect, hipStream_t st)
 {
     TieArgs a;
     a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.b0 = b0; a.flag_list = d_flag_list;
@@ -171,6 +172,7 @@ hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, c
     a.g_hid = d_heap_ids; a.g_hd = d_heap_d;
     a.heap_in_lds = linear_tie_heap_in_lds(M, Ks, topk) ? 1 : 0;
     a.capl = tie_list_cap(M, Ks);
+    a.indirect = indirect;
     const size_t smem = tie_smem(M, Ks, topk, a.heap_in_lds != 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_tie_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
