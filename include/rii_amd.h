@@ -105,14 +105,35 @@ int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk
                       int64_t S, int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts,
                       void *stream);
 
+/* Database-sharded inverted index (NEW, not in the reference: it has no multi-device code).  Rank `rank` of G holds
+ * a contiguous id range of the database; coarse centres are replicated (rii_set_coarse_centers), posting lists are local.
+ * The reference's "candidates in list order, stop at exactly L" rule (src/rii.h:283-321) is global and sequential, so
+ *   1. every rank reports the lengths of its lists after the batch's target-id filter (rii_ivf_list_lengths_dev:
+ *      nlist int32, `d_tids` = the S target ids that fall into this rank's range, as LOCAL ids; S_global = size of the
+ *      whole target set, 0 = no filter -- a rank may own none of the targets: S == 0 with S_global != 0),
+ *   2. the lengths are all-gathered ([G][nlist] int32, `d_glen`, identical on every rank), and
+ *   3. rii_query_ivf_shard_dev replays the traversal on the global lengths and scores only the candidates this rank owns.
+ * Outputs per query, topk+1 rows ascending by (distance, traversal position): LOCAL ids (-1 = none), distances (+inf),
+ * traversal positions (INT32_MAX); d_out_nloc[b] = valid rows; d_out_counts[b] = topk, or 0 where the reference returns
+ * ({}, {}) (identical on every rank).  Merging the G records under (distance, position) gives the reference's answer for
+ * top-1 and for top-k whenever the k+1 smallest distances are pairwise different.  S_global / N_global: sizes of the whole
+ * target set / database (they fix `w`, src/rii.h:266-277).  Requires nlist <= 4096 and L <= 4096. */
+int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64_t S, int64_t S_global, int32_t *d_out_len,
+                             void *stream);
+int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
+                            int64_t S_global, int64_t L, int64_t N_global, const int32_t *d_glen, int G, int rank,
+                            int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos, int32_t *d_out_nloc,
+                            int64_t *d_out_counts, void *stream);
+
 /* Database sharding (NEW, not in the reference: it has no multi-device code).  Every rank sends one record per batch --
- * [B*topk] int64 GLOBAL ids followed by [B*topk] f32 distances, padded to rii_merge_record_bytes() -- through one
- * all-gather; `d_gathered` holds the G records back to back.  Output: per query the topk smallest of the G*topk pairs
- * under (dist asc, id asc), computed identically on every rank.  G*topk <= 8192.  Asynchronous on `stream`
+ * [B*k] int64 keys, (payload != 0: [B*k] int64 payload,) [B*k] f32 distances, padded to rii_merge_record_bytes() -- through
+ * one all-gather; `d_gathered` holds the G records back to back.  Output: per query the k_out smallest of the G*k entries
+ * under (distance asc, key asc), computed identically on every rank, with their payloads.  Linear search: key = GLOBAL id,
+ * no payload.  Inverted index: key = traversal position, payload = global id.  G*k <= 8192.  Asynchronous on `stream`
  * (a hipStream_t, NULL = the default stream) of the current device; needs no engine. */
-int64_t rii_merge_record_bytes(int64_t B, int topk);
-int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int topk, int64_t *d_out_ids, float *d_out_dists,
-                       void *stream);
+int64_t rii_merge_record_bytes(int64_t B, int k, int payload);
+int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_keys,
+                       float *d_out_dists, int64_t *d_out_payload, void *stream);
 
 /* Distance-table build alone (RiiCpp::DTable, src/rii.h:361-373) for B queries -> out[B,M,Ks] (host). */
 int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out);
@@ -134,7 +155,7 @@ int64_t rii_get_option(const rii_engine *e, const char *key);
 /* Per-kernel HIP-event timing (enabled by option "timing"=1): events are recorded on the launch stream
  * around every launch of the named kernel; reading synchronises the stream.
  * names: "lut", "scan", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select", "assign", "gather", "select", "quant", "rerank",
- * "ivf_fused", "ivf_exact", "kth", "scan_order", "tie". */
+ * "ivf_fused", "ivf_exact", "kth", "scan_order", "tie", "format", "ivf_shard". */
 int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms, int64_t *launches);
 int rii_timing_reset(rii_engine *e);
 int rii_synchronize(rii_engine *e);

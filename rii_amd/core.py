@@ -123,8 +123,11 @@ def _lib():
         "rii_query_ivf": (c_int, [c_vp, f32p, c_i64, c_int, i64p, c_i64, c_i64, i64p, f32p, i64p]),
         "rii_query_linear_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
         "rii_query_ivf_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
-        "rii_merge_record_bytes": (c_i64, [c_i64, c_int]),
-        "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
+        "rii_ivf_list_lengths_dev": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+        "rii_query_ivf_shard_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int,
+                                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+        "rii_merge_record_bytes": (c_i64, [c_i64, c_int, c_int]),
+        "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
         "rii_dtable": (c_int, [c_vp, f32p, c_i64, f32p]),
         "rii_assign": (c_int, [c_vp, u8p, c_i64, i32p]),
         "rii_set_option": (c_int, [c_vp, ctypes.c_char_p, c_i64]),
@@ -142,14 +145,16 @@ def _lib():
     return L
 
 
-def merge_record_bytes(B, topk):
+def merge_record_bytes(B, k, payload=False):
     """Bytes of one rank's record in the database-sharding all-gather (include/rii_amd.h: rii_merge_topk_dev)."""
-    return int(_lib().rii_merge_record_bytes(int(B), int(topk)))
+    return int(_lib().rii_merge_record_bytes(int(B), int(k), int(bool(payload))))
 
 
-def merge_topk_dev(d_gathered, G, B, topk, d_out_ids, d_out_dists, stream=0):
-    """Device pointers in, asynchronous on `stream`: the topk smallest of the G gathered records per query, (dist, id) order."""
-    _check(_lib().rii_merge_topk_dev(d_gathered, int(G), int(B), int(topk), d_out_ids, d_out_dists, stream or None))
+def merge_topk_dev(d_gathered, G, B, k, d_out_keys, d_out_dists, stream=0, k_out=None, d_out_payload=0):
+    """Device pointers in, asynchronous on `stream`: the k_out smallest of the G gathered records per query under
+    (dist, key), with their payloads when d_out_payload is given."""
+    _check(_lib().rii_merge_topk_dev(d_gathered, int(G), int(B), int(k), int(k if k_out is None else k_out),
+                                     int(bool(d_out_payload)), d_out_keys, d_out_dists, d_out_payload or None, stream or None))
 
 
 def exported_symbols():
@@ -290,6 +295,16 @@ class RiiGpu(object):
     def query_ivf_dev(self, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts, stream=0):
         _check(_lib().rii_query_ivf_dev(self._h, d_queries, B, int(topk), d_tids or None, S, int(L), d_out_ids,
                                         d_out_dists, d_out_counts, stream or None))
+
+    # ---- database-sharded inverted index (device pointers; protocol: include/rii_amd.h, rii_amd/dist.py) ----
+    def ivf_list_lengths_dev(self, d_tids, S, S_global, d_out_len, stream=0):
+        _check(_lib().rii_ivf_list_lengths_dev(self._h, d_tids or None, int(S), int(S_global), d_out_len, stream or None))
+
+    def query_ivf_shard_dev(self, d_queries, B, topk, d_tids, S, S_global, L, N_global, d_glen, G, rank, d_out_ids,
+                            d_out_dists, d_out_pos, d_out_nloc, d_out_counts, stream=0):
+        _check(_lib().rii_query_ivf_shard_dev(self._h, d_queries, int(B), int(topk), d_tids or None, int(S), int(S_global),
+                                              int(L), int(N_global), d_glen, int(G), int(rank), d_out_ids, d_out_dists,
+                                              d_out_pos, d_out_nloc, d_out_counts, stream or None))
 
     # ---- main.cpp:17-27: one query per call, python lists out ----
     def query_linear(self, query, topk, target_ids):

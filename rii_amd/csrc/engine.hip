@@ -658,6 +658,22 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
     return scan_topk(e, d_queries, B, topk, S ? d_tids : nullptr, S, d_out_ids, d_out_dists, st);
 }
 
+// target_ids: one bitmap per batch + order-preserving compaction of every posting list (s_fids / s_flen), replacing the
+// per-posting std::binary_search of src/rii.h:294
+int filter_lists_by_targets(rii_engine *e, const int64_t *d_tids, int64_t S, hipStream_t st)
+{
+    const int64_t nlist = nlist_of(e);
+    const size_t words = (size_t) ((e->N + 31) / 32);
+    RII_TRY(e->s_bitmap.ensure(words * sizeof(uint32_t)));
+    RII_TRY(e->s_fids.ensure((size_t) std::max<int64_t>(e->N, 1) * sizeof(int32_t)));
+    RII_TRY(e->s_flen.ensure((size_t) nlist * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(e->s_bitmap.p, 0, words * sizeof(uint32_t), st));
+    HIP_TRY(launch_bitmap_set(d_tids, S, e->s_bitmap.as<uint32_t>(), st));
+    HIP_TRY(launch_filter_lists(e->d_pl_off.as<int64_t>(), e->d_pl_ids.as<int32_t>(), (int) nlist, e->s_bitmap.as<uint32_t>(),
+                                e->s_fids.as<int32_t>(), e->s_flen.as<int32_t>(), st));
+    return RII_OK;
+}
+
 int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
                   int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st,
                   int32_t *d_flag_defer = nullptr)
@@ -693,14 +709,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     p.w = w;
 
     if (S != 0) {       // order-preserving filter of every list by the batch's target ids
-        const size_t words = (size_t) ((e->N + 31) / 32);
-        RII_TRY(e->s_bitmap.ensure(words * sizeof(uint32_t)));
-        RII_TRY(e->s_fids.ensure((size_t) std::max<int64_t>(e->N, 1) * sizeof(int32_t)));
-        RII_TRY(e->s_flen.ensure((size_t) nlist * sizeof(int32_t)));
-        HIP_TRY(hipMemsetAsync(e->s_bitmap.p, 0, words * sizeof(uint32_t), st));
-        HIP_TRY(launch_bitmap_set(d_tids, S, e->s_bitmap.as<uint32_t>(), st));
-        HIP_TRY(launch_filter_lists(p.pl_off, p.pl_ids, (int) nlist, e->s_bitmap.as<uint32_t>(),
-                                    e->s_fids.as<int32_t>(), e->s_flen.as<int32_t>(), st));
+        RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
         p.pl_ids = e->s_fids.as<int32_t>();
         p.list_len = e->s_flen.as<int32_t>();
     }
@@ -1263,15 +1272,92 @@ RII_API int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, 
     return r2;
 }
 
-// Database sharding (not in the reference, SURVEY 8e): merge of the all-gathered per-shard top-k rows.  Stateless.
-RII_API int64_t rii_merge_record_bytes(int64_t B, int k) { return (B * k * 12 + 15) / 16 * 16; }
-RII_API int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int k, int64_t *d_out_ids, float *d_out_dists,
-                               void *stream)
+// Database-sharded inverted index (not in the reference; kernel and protocol: ivfshard.hip).
+RII_API int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64_t S, int64_t S_global, int32_t *d_out_len,
+                                     void *stream)
 {
-    if (!d_gathered || G < 1 || B < 0 || k < 1 || (B > 0 && (!d_out_ids || !d_out_dists))) return set_err(RII_ERR_INVALID, "bad arguments");
+    if (!e || !d_out_len || (S > 0 && !d_tids) || S < 0) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    if (nlist_of(e) == 0) return set_err(RII_ERR_STATE, "no posting lists: call reconfigure() / set_coarse_centers() first");
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    RII_TRY(begin_on(e, st));
+    RII_TRY(sync_lists(e));
+    const int64_t nlist = nlist_of(e);
+    const int32_t *src = e->d_list_len.as<int32_t>();
+    if (S_global) {                // a target set exists: this rank's share of it may be empty (then every list is empty here)
+        RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
+        src = e->s_flen.as<int32_t>();
+    }
+    HIP_TRY(hipMemcpyAsync(d_out_len, src, (size_t) nlist * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return end_on(e, st);
+}
+
+RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                                    int64_t S, int64_t S_global, int64_t L, int64_t N_global, const int32_t *d_glen, int G,
+                                    int rank, int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos,
+                                    int32_t *d_out_nloc, int64_t *d_out_counts, void *stream)
+{
+    if (!e || B < 0 || (B > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_pos || !d_out_nloc || !d_out_counts)) ||
+        !d_glen || G < 1 || rank < 0 || rank >= G || (S > 0 && !d_tids) || S < 0)
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    const int64_t nlist = nlist_of(e);
+    if (nlist == 0) return set_err(RII_ERR_STATE, "no posting lists: call reconfigure() / set_coarse_centers() first");
+    if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
+    // the reference's preconditions, on the GLOBAL sizes (src/rii.h:252-253,271)
+    if (topk < 1 || (int64_t) topk > L || L > N_global || (S_global != 0 && ((int64_t) topk > S_global || S_global > N_global)))
+        return set_err(RII_ERR_INVALID, "need topk <= L <= N and topk <= len(target_ids) <= N on the whole database "
+                                        "(topk=%d, L=%lld, N=%lld, S=%lld)", topk, (long long) L, (long long) N_global, (long long) S_global);
+    if (!ivf_shard_supported(e->M, e->Ks, (int) nlist, L))
+        return set_err(RII_ERR_UNSUPPORTED, "sharded inverted index: nlist=%lld and L=%lld must both be <= 4096", (long long) nlist, (long long) L);
+    if (B == 0) return RII_OK;
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    RII_TRY(begin_on(e, st));
+    RII_TRY(sync_lists(e));
+    const int32_t *pl_ids = e->d_pl_ids.as<int32_t>();
+    const int32_t *list_len = e->d_list_len.as<int32_t>();
+    if (S_global != 0) {           // this rank's share of the target ids (possibly none: every list is then empty here)
+        RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
+        pl_ids = e->s_fids.as<int32_t>();
+        list_len = e->s_flen.as<int32_t>();
+    }
+    // w of src/rii.h:266-277 from the global sizes
+    const double wd = (S_global == 0) ? std::round((double) L * (double) nlist / (double) N_global)
+                                      : std::round((double) L * (double) nlist / (double) S_global);
+    int64_t w = (int64_t) (size_t) wd + 3;
+    if (nlist < w) w = nlist;
+    int r = RII_OK;
+    for (int64_t b0 = 0; b0 < B && r == RII_OK; b0 += kMaxBatch) {
+        const int64_t cur = std::min<int64_t>(kMaxBatch, B - b0);
+        const int64_t D = (int64_t) e->M * e->Ds;
+        r = build_lut(e, d_queries + b0 * D, cur, st, false, 1);
+        if (r != RII_OK) break;
+        ScopedTimer t(e, "ivf_shard", st);
+        if (launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
+                             e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w,
+                             d_out_ids + b0 * (topk + 1), d_out_dists + b0 * (topk + 1), d_out_pos + b0 * (topk + 1),
+                             d_out_nloc + b0, d_out_counts + b0, st) != hipSuccess)
+            r = set_err(RII_ERR_HIP, "ivf_shard_kernel launch failed");
+    }
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
+}
+
+// Database sharding (not in the reference, SURVEY 8e): merge of the all-gathered per-shard top-k rows.  Stateless.
+RII_API int64_t rii_merge_record_bytes(int64_t B, int k, int payload) { return (int64_t) merge_record_bytes(B, k, payload); }
+RII_API int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_keys,
+                               float *d_out_dists, int64_t *d_out_payload, void *stream)
+{
+    if (!d_gathered || G < 1 || B < 0 || k < 1 || k_out < 1 || k_out > G * k || (B > 0 && (!d_out_keys || !d_out_dists)) ||
+        (payload && B > 0 && !d_out_payload))
+        return set_err(RII_ERR_INVALID, "bad arguments");
     if ((int64_t) G * k > merge_topk_max_keys())
         return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d keys per query exceeds %d", G, k, merge_topk_max_keys());
-    HIP_TRY(launch_merge_topk(d_gathered, G, B, k, d_out_ids, d_out_dists, (hipStream_t) stream));
+    HIP_TRY(launch_merge_topk(d_gathered, G, B, k, k_out, payload, d_out_keys, d_out_dists, d_out_payload, (hipStream_t) stream));
     return RII_OK;
 }
 

@@ -367,11 +367,41 @@ __global__ __launch_bounds__(256) void qlut_interleave_kernel(const uint8_t *__r
 
 bool fs_rot_supported(int M, int Ks);
 
+// rotated layout, 16-byte rows: one block per (tile, group of 16 subspaces, 16 consecutive ks).  Its 256 rows are
+// contiguous in the destination (row = ks * 16 + q) and 16 runs of 16 bytes in every query's compact table (i = q * Ks + ks):
+// the block reads those runs, turns the rows around in 4 KB of LDS and writes 4 KB coalesced (the generic kernel's stores
+// were 256 bytes apart).
+__global__ __launch_bounds__(256) void qlut_interleave_rot16_kernel(const uint8_t *__restrict__ qc, int64_t B, int MK,
+                                                                    uint8_t *__restrict__ qlut)
+{
+    __shared__ uint4 s_rows[256];
+    const int64_t tile = blockIdx.x;
+    const int h = blockIdx.y, ks0 = blockIdx.z * 16;
+    const int tid = threadIdx.x;
+    const int q = tid >> 4, ks = ks0 + (tid & 15);
+    const int i = h * 4096 + q * 256 + ks;                   // source index m * Ks + ks with m = 16 h + q
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t b = tile * 16 + j;
+        const uint32_t v = b < B ? qc[(size_t) b * MK + i] : 0u;
+        w[j >> 2] |= v << (8 * (j & 3));
+    }
+    s_rows[(tid & 15) * 16 + q] = make_uint4(w[0], w[1], w[2], w[3]);
+    __syncthreads();
+    uint4 *dst = reinterpret_cast<uint4 *>(qlut + ((size_t) tile * MK + (size_t) h * 4096 + (size_t) ks0 * 16) * 16);
+    dst[tid] = s_rows[tid];
+}
+
 static hipError_t launch_qlut_interleave(const uint8_t *d_qc, int64_t B, int M, int Ks, uint8_t *d_qlut, hipStream_t st)
 {
     const int qr = fastscan_rows(M, Ks);
     const int MK = M * Ks;
     const int rot = fs_rot_supported(M, Ks) ? 1 : 0;
+    if (rot && qr == 16 && Ks == 256) {
+        hipLaunchKernelGGL(qlut_interleave_rot16_kernel, dim3((unsigned) ((B + 15) / 16), M / 16, 16), dim3(256), 0, st, d_qc, B, MK, d_qlut);
+        return hipGetLastError();
+    }
     const int64_t total = ((B + qr - 1) / qr) * MK;
     int blocks = (int) std::min<int64_t>((total + 255) / 256, 8192);
     if (qr == 16) hipLaunchKernelGGL(qlut_interleave_kernel<16>, dim3(blocks), dim3(256), 0, st, d_qc, B, MK, Ks, rot, d_qlut);

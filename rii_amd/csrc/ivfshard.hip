@@ -1,0 +1,162 @@
+// ivfshard.hip -- inverted-index search over a DATABASE-SHARDED index (gfx950).  Not in the reference (it has no
+// multi-device code); the parity target is RiiCpp::QueryIvf (src/rii.h:244-326) on the concatenated database.
+//
+// Rank r of G holds the codes of a contiguous id range and, for every coarse list, the ids of that range (ascending,
+// stored locally).  The coarse centres are replicated, so every rank derives the SAME coarse order for a query (the
+// std::partial_sort replay of ivf_exact_lds_kernel, ties and unsorted tail included).  The reference's walk is a global,
+// sequential rule -- candidates in list order, ids ascending inside a list, stop at exactly L (rii.h:283-305) -- and
+// inside one list "ids ascending" means rank 0's part, then rank 1's, ...  With the per-rank list lengths all-gathered
+// once per batch (`glen`, query independent: the target-id filter is shared by the batch) every rank computes the same
+// global plan -- traversal position of every candidate, the stop position, the "not found" outcome -- and scores exactly
+// the candidates it owns:  the element at offset o of global list `no` belongs to the rank with
+// before_r[no] <= o < before_r[no] + len_r[no],  before_r = sum of the lengths of the lower ranks.
+//
+// Output per query: the rank's k+1 best candidates as (dist, traversal position, local id), ascending by (dist, position).
+// The merge across ranks under the same key is the reference's answer for top-1 (first minimum in traversal order) and for
+// top-k whenever the k+1 smallest distances are pairwise different (rii_amd/dist.py flags the other queries).
+#include "rii_internal.h"
+#include "rii_device.h"
+#include <algorithm>
+
+namespace riiamd {
+
+constexpr int kShardMax = 4096;          // nlist and L of the sharded path (working sets live in LDS)
+
+struct ShardArgs {
+    const uint8_t *codes; int M, Ks;
+    const float *lut;                    // plain [b][M*Ks] tables
+    const uint8_t *centers; int nlist;
+    const int64_t *pl_off; const int32_t *pl_ids; const int32_t *list_len;       // this rank's (filtered) lists
+    const int32_t *glen; int G, rank;    // [G][nlist] lengths of every rank's (filtered) lists
+    int topk; int64_t L; int64_t w;
+    int64_t *out_ids; float *out_dists; int32_t *out_pos; int32_t *out_nloc; int64_t *out_counts;
+};
+
+__global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int MK = p.M * p.Ks;
+    const int nlist = p.nlist;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    float *lds = reinterpret_cast<float *>(smem);
+    unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
+    float *s_cdist = reinterpret_cast<float *>(base);                 // [nlist]   coarse distances (sorted in place)
+    int32_t *s_cid = reinterpret_cast<int32_t *>(s_cdist + nlist);    // [nlist]   list ids
+    int32_t *s_cum = s_cid + nlist;                                   // [nlist+1] cumulative GLOBAL candidate counts
+    int32_t *s_misc = s_cum + (nlist + 1);                            // [4]
+    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(
+        smem + ((reinterpret_cast<unsigned char *>(s_misc + 4) - smem + 15) & ~(size_t) 15));      // [pow2 >= L]
+
+    {
+        const float *src = p.lut + (size_t) b * MK;
+        for (int i = tid; i < MK; i += 256) lds[i] = src[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < nlist; c += 256) {
+        s_cdist[c] = exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks);       // src/rii.h:262-264
+        s_cid[c] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        pq_partial_sort(s_cid, s_cdist, (long) p.w, (long) nlist);                    // src/rii.h:279-280
+        long long cnt = 0;
+        int nv = 0;
+        bool finished = false;
+        for (int c = 0; c < nlist; ++c) {                                             // src/rii.h:286-321, global lengths
+            const int no = s_cid[c];
+            long long len = 0;
+            for (int g = 0; g < p.G; ++g) len += p.glen[(size_t) g * nlist + no];
+            s_cum[c] = (int) cnt;
+            if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+            cnt += len;
+            if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+        }
+        if (!finished) { cnt = 0; nv = 0; }
+        s_cum[nv] = (int) cnt;
+        s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = 0;
+        p.out_counts[b] = finished ? p.topk : 0;                                      // src/rii.h:324-325 when 0
+    }
+    __syncthreads();
+    const int ncand = s_misc[0], nv = s_misc[1];
+    const int k1 = p.topk + 1;
+    int n2 = 64;
+    while (n2 < ncand) n2 <<= 1;
+    for (int pos = tid; pos < n2; pos += 256) {
+        unsigned long long key = ~0ull;
+        if (pos < ncand) {
+            int lo = 0, hi = nv;                                                      // list holding traversal position pos
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+            }
+            const int no = s_cid[lo];
+            int before = 0;
+            for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
+            const int li = pos - s_cum[lo] - before;                                  // index inside this rank's part of the list
+            if (li >= 0 && li < p.list_len[no]) {
+                const int32_t id = p.pl_ids[p.pl_off[no] + li];
+                const float d = exact_adist(lds, p.codes + (size_t) id * p.M, p.M, p.Ks);
+                key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | (uint32_t) pos;
+                atomicAdd(&s_misc[2], 1);
+            }
+        }
+        s_key[pos] = key;
+    }
+    rr_bitonic_sort(s_key, tid, n2);
+    const int nloc = s_misc[2] < k1 ? s_misc[2] : k1;
+    if (tid == 0) p.out_nloc[b] = nloc;
+    for (int j = tid; j < k1; j += 256) {
+        int64_t id = -1;
+        float d = INFINITY;
+        int32_t pos = INT32_MAX;
+        if (j < nloc) {
+            const unsigned long long key = s_key[j];
+            pos = (int32_t) (key & 0xffffffffu);
+            d = __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
+            int lo = 0, hi = nv;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+            }
+            const int no = s_cid[lo];
+            int before = 0;
+            for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
+            id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo] - before)];
+        }
+        p.out_ids[b * k1 + j] = id;
+        p.out_dists[b * k1 + j] = d;
+        p.out_pos[b * k1 + j] = pos;
+    }
+}
+
+static size_t shard_smem(int M, int Ks, int nlist, int64_t L)
+{
+    size_t n2 = 64;
+    while ((int64_t) n2 < L) n2 <<= 1;
+    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 + 16 + 16 + n2 * 8;
+}
+bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L)
+{
+    return nlist <= kShardMax && L <= kShardMax && shard_smem(M, Ks, nlist, L) <= (size_t) 160 * 1024 - 512;
+}
+
+hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
+                            const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
+                            int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int64_t *d_out_ids, float *d_out_dists,
+                            int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    ShardArgs a;
+    a.codes = d_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.centers = d_centers; a.nlist = nlist; a.pl_off = d_pl_off;
+    a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w;
+    a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_pos = d_out_pos; a.out_nloc = d_out_nloc; a.out_counts = d_out_counts;
+    const size_t smem = shard_smem(M, Ks, nlist, L);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_shard_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_shard_kernel, dim3((unsigned) B), dim3(256), smem, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace riiamd

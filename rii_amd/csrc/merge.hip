@@ -10,12 +10,16 @@ namespace riiamd {
 
 constexpr int kMergeMaxKeys = 8192;
 
-// record of rank g inside the gathered buffer: [B*k] int64 ids, then [B*k] f32 dists, padded to 16 bytes (what every rank sends)
+// record of rank g inside the gathered buffer (what every rank sends): [B*k] int64 keys (ids, or traversal positions), then --
+// with a payload -- [B*k] int64 payload (the ids that go with the positions), then [B*k] f32 dists; padded to 16 bytes
+__host__ __device__ __forceinline__ size_t mrg_rec_bytes(int64_t Bk, int payload) { return ((size_t) Bk * (payload ? 20 : 12) + 15) / 16 * 16; }
 __device__ __forceinline__ const int64_t *mrg_ids(const unsigned char *base, size_t rec, int g) { return reinterpret_cast<const int64_t *>(base + rec * g); }
-__device__ __forceinline__ const float *mrg_d(const unsigned char *base, size_t rec, int g, int64_t Bk) { return reinterpret_cast<const float *>(base + rec * g + (size_t) Bk * 8); }
+__device__ __forceinline__ const int64_t *mrg_pay(const unsigned char *base, size_t rec, int g, int64_t Bk) { return reinterpret_cast<const int64_t *>(base + rec * g + (size_t) Bk * 8); }
+__device__ __forceinline__ const float *mrg_d(const unsigned char *base, size_t rec, int g, int64_t Bk, int payload) { return reinterpret_cast<const float *>(base + rec * g + (size_t) Bk * (payload ? 16 : 8)); }
 
-__global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__restrict__ gathered, int G, int64_t B, int k,
-                                                         int64_t *__restrict__ out_ids, float *__restrict__ out_dists)
+__global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__restrict__ gathered, int G, int64_t B, int k, int k_out,
+                                                         int payload, int64_t *__restrict__ out_ids, float *__restrict__ out_dists,
+                                                         int64_t *__restrict__ out_payload)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *key = reinterpret_cast<unsigned long long *>(smem);        // (orderable dist << 32 | g * k + j)
@@ -25,12 +29,12 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__
     int n2 = 64;
     while (n2 < n) n2 <<= 1;
     const int64_t Bk = B * k;
-    const size_t rec = ((size_t) Bk * 12 + 15) / 16 * 16;      // rii_merge_record_bytes
+    const size_t rec = mrg_rec_bytes(Bk, payload);           // rii_merge_record_bytes
     for (int i = tid; i < n2; i += 256) {
         unsigned long long kk = ~0ull;
         if (i < n) {
             const int g = i / k, j = i - g * k;
-            kk = ((unsigned long long) f32_orderable(__float_as_uint(mrg_d(gathered, rec, g, Bk)[b * k + j])) << 32) | (uint32_t) i;
+            kk = ((unsigned long long) f32_orderable(__float_as_uint(mrg_d(gathered, rec, g, Bk, payload)[b * k + j])) << 32) | (uint32_t) i;
         }
         key[i] = kk;
     }
@@ -56,16 +60,28 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__
         }
     }
     __syncthreads();
-    for (int j = tid; j < k; j += 256) {
+    for (int j = tid; j < k_out; j += 256) {
         const unsigned long long kk = key[j];
-        out_ids[b * k + j] = id_of(kk);
-        out_dists[b * k + j] = __uint_as_float(f32_unorderable((uint32_t) (kk >> 32)));
+        out_ids[b * k_out + j] = id_of(kk);
+        out_dists[b * k_out + j] = __uint_as_float(f32_unorderable((uint32_t) (kk >> 32)));
+        if (payload) {
+            const uint32_t s = (uint32_t) (kk & 0xffffffffu);
+            int64_t pv = -1;
+            if (s < (uint32_t) n) {
+                const int g = (int) (s / (uint32_t) k), jj = (int) (s - (uint32_t) g * k);
+                pv = mrg_pay(gathered, rec, g, Bk)[b * k + jj];
+            }
+            out_payload[b * k_out + j] = pv;
+        }
     }
 }
 
 int merge_topk_max_keys() { return kMergeMaxKeys; }
 
-hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+size_t merge_record_bytes(int64_t B, int k, int payload) { return mrg_rec_bytes(B * k, payload); }
+
+hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_ids,
+                             float *d_out_dists, int64_t *d_out_payload, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     int n2 = 64;
@@ -75,7 +91,7 @@ hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, in
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned) B), dim3(256), smem, st,
-                       static_cast<const unsigned char *>(d_gathered), G, B, k, d_out_ids, d_out_dists);
+                       static_cast<const unsigned char *>(d_gathered), G, B, k, k_out, payload, d_out_ids, d_out_dists, d_out_payload);
     return hipGetLastError();
 }
 

@@ -158,9 +158,18 @@ hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, c
 hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
                                   int32_t *d_flag_list, int *d_nflag, hipStream_t st);
 
+// ivfshard.hip: inverted-index search over a database-sharded index (global stop rule from all-gathered list lengths)
+bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L);
+hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
+                            const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
+                            int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int64_t *d_out_ids, float *d_out_dists,
+                            int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st);
+
 // merge.hip: database sharding, k-way merge of the gathered per-shard top-k rows under (dist, id)
 int merge_topk_max_keys();
-hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int64_t *d_out_ids, float *d_out_dists, hipStream_t st);
+size_t merge_record_bytes(int64_t B, int k, int payload);
+hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_ids,
+                             float *d_out_dists, int64_t *d_out_payload, hipStream_t st);
 
 // scanorder.hip: LDS-friendly scan order for the filter stage (perm[pos] = code id, codes gathered in that order)
 bool scan_order_supported(int M, int Ks);

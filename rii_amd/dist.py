@@ -14,6 +14,11 @@ With the "nccl" backend everything stays on the device: engine -> device tensors
 No ring all-reduce anywhere: payloads are KBs, so the 7 x 153 GB/s xGMI links are irrelevant; what matters is one
 collective per batch.
 
+Inverted index over a database-sharded index (DbShardedIndex.query_ivf_batch): the coarse centres are replicated and the
+posting lists local; the reference's global "stop at exactly L candidates in list order" rule is replayed identically on
+every rank from the all-gathered per-rank list lengths (nlist ints per rank and batch), each rank scores the candidates it
+owns, and the per-rank (dist, traversal position, id) rows are merged under (dist, position) -- csrc/ivfshard.hip.
+
 Ties across shards: inside one shard the engine returns the reference's std::partial_sort order; across shards exactly
 tied distances are ordered by id (the heap order of the concatenated database cannot be rebuilt from per-shard top-k rows).
 """
@@ -231,6 +236,97 @@ class DbShardedIndex(object):
             d = np.concatenate([d, np.full((B, pad), np.inf, np.float32)], axis=1)
         ids = np.where(np.isfinite(d), ids + self.start, ids)               # global ids for real entries only
         return allgather_merge_topk(ids, d, topk, 0, self.group)
+
+
+    # ---- inverted index over the sharded database (protocol: include/rii_amd.h, csrc/ivfshard.hip) ----
+    def total_codes(self):
+        """N of the whole database: the sum of the shard sizes (one all-reduce, cached)."""
+        if getattr(self, "_n_total", None) is None:
+            n = torch.tensor([self.stop - self.start], dtype=torch.int64, device=_comm_device())
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(n, op=dist.ReduceOp.SUM, group=self.group)
+            self._n_total = int(n.item())
+        return self._n_total
+
+    def query_ivf_batch(self, Q, topk, target_ids, L):
+        """RiiCpp::QueryIvf (src/rii.h:244-326) on the concatenated database.  Every rank must hold the SAME coarse centres
+        (engine.set_coarse_centers) with posting lists over its own codes.  Returns (ids [B,topk] global, dists [B,topk],
+        counts [B]) on every rank; counts[b] == 0 where the reference returns ({}, {}).  Exactly tied distances among the
+        k+1 best are ordered by traversal position (the reference's answer for top-1; `last_tie_flags` marks the top-k
+        queries whose order may differ from std::partial_sort's heap order)."""
+        rank, w = world()
+        B = Q.shape[0]
+        k1 = topk + 1
+        tl, _ = self._local_targets(target_ids, topk)
+        S_global = 0 if target_ids is None else len(target_ids)
+        N_global = self.total_codes()
+        dev = _comm_device()
+        if _is_device_engine(self.engine):
+            with _engine_stream() as sh:
+                t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).to(dev)
+                nlist = self.engine.nlist
+                lens = torch.empty(nlist, dtype=torch.int32, device=dev)
+                self.engine.ivf_list_lengths_dev(0 if t is None else t.data_ptr(), 0 if t is None else t.numel(), S_global,
+                                                 lens.data_ptr(), sh)
+                glen = _all_gather_bytes(lens.view(torch.uint8), self.group).view(torch.int32).reshape(-1, nlist).contiguous()
+                q = _as_tensor(Q, torch.float32, dev)
+                ids = torch.empty((B, k1), dtype=torch.int64, device=dev)
+                d = torch.empty((B, k1), dtype=torch.float32, device=dev)
+                pos = torch.empty((B, k1), dtype=torch.int32, device=dev)
+                nloc = torch.empty((B,), dtype=torch.int32, device=dev)
+                cnt = torch.empty((B,), dtype=torch.int64, device=dev)
+                self.engine.query_ivf_shard_dev(q.data_ptr(), B, topk, 0 if t is None else t.data_ptr(),
+                                                0 if t is None else t.numel(), S_global, L, N_global, glen.data_ptr(),
+                                                glen.shape[0], rank, ids.data_ptr(), d.data_ptr(), pos.data_ptr(),
+                                                nloc.data_ptr(), cnt.data_ptr(), sh)
+                out = self._merge_ivf(ids, d, pos, cnt, topk)
+            return _handoff(*out)
+        lens = np.asarray(self.engine.ivf_list_lengths(tl), np.int32)
+        glen = _all_gather_bytes(torch.from_numpy(lens).view(torch.uint8), self.group).view(torch.int32).reshape(-1, len(lens))
+        ids, d, pos, nloc, cnt = self.engine.query_ivf_shard(np.asarray(Q), topk, tl, S_global, L, N_global, glen.numpy(), rank)
+        return self._merge_ivf(torch.from_numpy(np.ascontiguousarray(ids)), torch.from_numpy(np.ascontiguousarray(d)),
+                               torch.from_numpy(np.ascontiguousarray(pos)), torch.from_numpy(np.ascontiguousarray(cnt)), topk)
+
+    def _merge_ivf(self, ids, d, pos, cnt, topk):
+        """all-gather of the per-rank (position, global id, dist) rows + merge under (dist, position)."""
+        rank, w = world()
+        B, k1 = ids.shape
+        dev = ids.device
+        gid = torch.where(ids >= 0, ids + self.start, ids)                  # local -> global ids, -1 stays
+        pos64 = pos.to(torch.int64)
+        if dev.type == "cuda" and w * k1 <= 8192:
+            from . import core
+            nrec = core.merge_record_bytes(B, k1, True)
+            rec = torch.zeros(nrec, dtype=torch.uint8, device=dev)
+            n = B * k1
+            rec[:n * 8].view(torch.int64).copy_(pos64.reshape(-1))
+            rec[n * 8:n * 16].view(torch.int64).copy_(gid.reshape(-1))
+            rec[n * 16:n * 20].view(torch.float32).copy_(d.reshape(-1))
+            g = _all_gather_bytes(rec, self.group)
+            mp = torch.empty((B, k1), dtype=torch.int64, device=dev)
+            md = torch.empty((B, k1), dtype=torch.float32, device=dev)
+            mi = torch.empty((B, k1), dtype=torch.int64, device=dev)
+            core.merge_topk_dev(g.data_ptr(), g.shape[0], B, k1, mp.data_ptr(), md.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream, k_out=k1, d_out_payload=mi.data_ptr())
+        else:
+            g = _all_gather_bytes(_pack([pos64, gid, d]), self.group)
+            n = B * k1
+            gp = torch.cat([_field(g, r, 0, n, torch.int64).reshape(B, k1) for r in range(g.shape[0])], dim=1)
+            gi = torch.cat([_field(g, r, n * 8, n, torch.int64).reshape(B, k1) for r in range(g.shape[0])], dim=1)
+            gd = torch.cat([_field(g, r, n * 16, n, torch.float32).reshape(B, k1) for r in range(g.shape[0])], dim=1)
+            order = torch.sort(gp, dim=1, stable=True).indices               # secondary key (position) first ...
+            d1 = torch.gather(gd, 1, order)
+            order2 = torch.sort(d1, dim=1, stable=True).indices              # ... then stable sort on the distance
+            sel = torch.gather(order, 1, order2)[:, :k1]
+            mi, md = torch.gather(gi, 1, sel), torch.gather(gd, 1, sel)
+        found = cnt > 0
+        # exact ties among the k+1 best decide nothing for top-1; for top-k they mark the rows whose order may differ from
+        # the heap order of std::partial_sort on the concatenated candidate sequence
+        tie = (md[:, 1:] == md[:, :-1]) & torch.isfinite(md[:, 1:])
+        self.last_tie_flags = (tie.any(dim=1) & found) if topk > 1 else torch.zeros_like(found)
+        out_i = torch.where(found[:, None], mi[:, :topk], torch.full_like(mi[:, :topk], -1))
+        out_d = torch.where(found[:, None], md[:, :topk], torch.full_like(md[:, :topk], float("inf")))
+        return out_i.contiguous(), out_d.contiguous(), cnt
 
 
 class QueryShardedIndex(object):

@@ -45,6 +45,83 @@ class _OracleBatch(object):
         return ids, d, cnt
 
 
+class _OracleShard(_OracleBatch):
+    """CPU stand-in for one rank of the database-sharded inverted index: the protocol of include/rii_amd.h
+    (rii_ivf_list_lengths_dev / rii_query_ivf_shard_dev) restated in numpy on top of the oracle's pieces."""
+
+    def set_coarse_centers(self, centers, n_listed=None):
+        """Lists over the first n_listed local codes only (stale lists: src/rii.h:283-326 tail walk / empty return)."""
+        n = self.o.N if n_listed is None else n_listed
+        rest = self.o.codes[n:].copy()
+        self.o.codes = np.ascontiguousarray(self.o.codes[:n])
+        self.o.set_coarse_centers(centers)
+        self.o.codes = np.ascontiguousarray(np.concatenate([self.o.codes, rest], 0))
+
+    def _lists(self, tl):
+        ls = [np.asarray(l, np.int64) for l in self.o.posting_lists]
+        if tl is not None:
+            ls = [l[np.isin(l, tl)] for l in ls]
+        return ls
+
+    def ivf_list_lengths(self, tl):
+        return np.array([len(l) for l in self._lists(tl)], np.int32)
+
+    def query_ivf_shard(self, Q, topk, tl, S_global, L, N_global, glen, rank):
+        import ctypes
+        from oracle import oracle as O
+        o = self.o
+        lists = self._lists(tl)
+        nlist = o.nlist
+        k1 = topk + 1
+        B = Q.shape[0]
+        ids = np.full((B, k1), -1, np.int64)
+        dd = np.full((B, k1), np.inf, np.float32)
+        pos = np.full((B, k1), np.iinfo(np.int32).max, np.int32)
+        nloc = np.zeros(B, np.int32)
+        cnt = np.zeros(B, np.int64)
+        w = int(np.round(L * nlist / (S_global if S_global else N_global))) + 3
+        w = min(w, nlist)
+        total = glen.sum(0)
+        before = glen[:rank].sum(0)
+        pair = np.dtype([("id", "<u8"), ("dist", "<f4")], align=True)
+        for b in range(B):
+            dt = O.dtable(o.codewords, Q[b], o.arch)
+
+            def adist(code):
+                acc = np.float32(0)
+                for m in range(o.M):
+                    acc = np.float32(acc + dt[m, code[m]])
+                return acc
+            coarse = np.zeros(nlist, pair)
+            coarse["id"] = np.arange(nlist)
+            coarse["dist"] = [adist(o.centers[c]) for c in range(nlist)]
+            O.lib().oracle_partial_sort(coarse.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(w), ctypes.c_size_t(nlist))
+            c_cnt, finished, mine = 0, False, []
+            for c in range(nlist):
+                no = int(coarse["id"][c])
+                ln = int(total[no])
+                take = min(ln, L - c_cnt)
+                for li, lid in enumerate(lists[no]):
+                    o_glob = int(before[no]) + li
+                    if o_glob < take:
+                        mine.append((adist(o.codes[lid]), c_cnt + o_glob, int(lid)))
+                if c_cnt + ln >= L:
+                    c_cnt, finished = L, True
+                    break
+                c_cnt += ln
+                if c + 1 == w and c_cnt >= topk:
+                    finished = True
+                    break
+            if not finished:
+                mine = []
+            cnt[b] = topk if finished else 0
+            mine.sort(key=lambda t: (t[0], t[1]))
+            nloc[b] = min(len(mine), k1)
+            for j, (d_, p_, i_) in enumerate(mine[:k1]):
+                ids[b, j], dd[b, j], pos[b, j] = i_, d_, p_
+        return ids, dd, pos, nloc, cnt
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -69,6 +146,94 @@ class _GpuBatch(object):
 
     def query_ivf_batch(self, Q, topk, tids, L):
         return self.g.query_ivf_batch(Q, topk, tids, L)
+
+    def set_coarse_centers(self, centers, n_listed=None):
+        """Lists over the first n_listed local codes only: re-create the engine around that prefix, then append the rest."""
+        codes = self.g.codes_array()
+        n = len(codes) if n_listed is None else n_listed
+        self.g.clear()
+        self.g.add_codes(codes[:n], False)
+        self.g.set_coarse_centers(centers)
+        if n < len(codes):
+            self.g.add_codes(codes[n:], False)
+
+    def ivf_list_lengths(self, tl):
+        t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).cuda()
+        out = torch.empty(self.g.nlist, dtype=torch.int32, device="cuda")
+        self.g.ivf_list_lengths_dev(0 if t is None else t.data_ptr(), 0 if t is None else t.numel(),
+                                    0 if tl is None else max(len(tl), 1), out.data_ptr())
+        self.g.synchronize()
+        return out.cpu().numpy()
+
+    def query_ivf_shard(self, Q, topk, tl, S_global, L, N_global, glen, rank):
+        B, k1 = Q.shape[0], topk + 1
+        t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).cuda()
+        q = torch.from_numpy(np.ascontiguousarray(Q)).cuda()
+        gl = torch.from_numpy(np.ascontiguousarray(glen, np.int32)).cuda()
+        ids = torch.empty((B, k1), dtype=torch.int64, device="cuda")
+        d = torch.empty((B, k1), dtype=torch.float32, device="cuda")
+        pos = torch.empty((B, k1), dtype=torch.int32, device="cuda")
+        nloc = torch.empty((B,), dtype=torch.int32, device="cuda")
+        cnt = torch.empty((B,), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        self.g.query_ivf_shard_dev(q.data_ptr(), B, topk, 0 if t is None else t.data_ptr(), 0 if t is None else t.numel(),
+                                   S_global, L, N_global, gl.data_ptr(), gl.shape[0], rank, ids.data_ptr(), d.data_ptr(),
+                                   pos.data_ptr(), nloc.data_ptr(), cnt.data_ptr())
+        self.g.synchronize()
+        return ids.cpu().numpy(), d.cpu().numpy(), pos.cpu().numpy(), nloc.cpu().numpy(), cnt.cpu().numpy()
+
+
+def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu):
+    """Database-sharded inverted index against the single-index oracle on the concatenated database, incl. target ids,
+    ranks without targets, stale lists (tail walk into the unsorted coarse order, `not found`)."""
+    from oracle import oracle as O
+    N = codes.shape[0]
+    s, e = rd.shard_range(N, rank, world)
+    trainer = O.OracleRii(cw, False, simd_arch="avx512")
+    trainer.add_codes(codes, False)
+    trainer.reconfigure(40, 3)
+    centers = np.array(trainer.coarse_centers, np.uint8)
+    Q = qs[:6]
+    E = np.array([], np.int64)
+    for stale in (False, True):
+        local = make_local(cw, codes[s:e])
+        n_listed = (e - s) // 9 if stale else None
+        local.set_coarse_centers(centers, n_listed)
+        # the single index with the same lists: every shard's lists, shifted to global ids, concatenated in rank order
+        full = O.OracleRii(cw, False, simd_arch="avx512")
+        full.add_codes(codes, False)
+        full.centers = centers
+        full._lists = [[] for _ in range(40)]
+        for r in range(world):
+            rs, re_ = rd.shard_range(N, r, world)
+            sh = _OracleShard(cw, codes[rs:re_])
+            sh.set_coarse_centers(centers, (re_ - rs) // 9 if stale else None)
+            for j, l in enumerate(sh.o.posting_lists):
+                full._lists[j].extend(int(x) + rs for x in l)
+        idx = rd.DbShardedIndex(local, s, e)
+        rng = np.random.default_rng(3)
+        sub = np.sort(rng.choice(N, 400, replace=False)).astype(np.int64)
+        low = np.sort(rng.choice(N // 2 - 10, 9, replace=False)).astype(np.int64)        # targets on rank 0 only
+        cases = [(1, 75, None), (1, 400, None), (5, 300, None), (3, 3, None), (10, N, None), (7, 200, sub), (2, 9, low), (1, 40, low)]
+        if stale:
+            cases += [(20, 100, None), (20, 40, None), (3, 30, None), (12, 50, None), (1, 51, None)]
+        n_empty = 0
+        for topk, L, tids in cases:
+            gi, gd, gc = idx.query_ivf_batch(Q, topk, tids, L)
+            gi, gd, gc = gi.cpu().numpy(), gd.cpu().numpy(), gc.cpu().numpy()
+            for b in range(Q.shape[0]):
+                wi, wd = full.query_ivf(Q[b], topk, E if tids is None else tids, L)
+                what = "sharded ivf stale=%s k=%d L=%d S=%s b=%d" % (stale, topk, L, None if tids is None else len(tids), b)
+                assert int(gc[b]) == len(wi), what
+                n_empty += (len(wi) == 0)
+                n = len(wi)
+                assert np.array_equal(gd[b, :n].view(np.uint32), np.asarray(wd, np.float32).view(np.uint32)), what
+                if len(set(wd)) == n:
+                    assert list(gi[b, :n]) == list(wi), what
+                else:                           # exact ties inside the top-k: same id set per distance
+                    assert sorted(gi[b, :n]) == sorted(wi), what
+        if stale:
+            assert n_empty > 0, "the stale-list cases were meant to reach the `not found` return"
 
 
 def _worker(rank, world, port, q, use_gpu=False):
@@ -121,6 +286,7 @@ def _worker(rank, world, port, q, use_gpu=False):
                 n = int(wc[b])
                 assert np.array_equal(gi.numpy()[b, :n], wi[b, :n]), "ivf ids k=%d" % topk
                 assert np.array_equal(gd.numpy()[b, :n].view(np.uint32), wd[b, :n].view(np.uint32))
+        _check_sharded_ivf(rd, rank, world, cw, codes, qs, _GpuBatch if use_gpu else _OracleShard, use_gpu)
         q.put((rank, "ok"))
     except Exception as ex:                                   # noqa: BLE001
         import traceback
@@ -205,6 +371,13 @@ def _nccl_world1_worker(port, q):
         g.reconfigure(40, 2); full.reconfigure(40, 2)
         gi, gd, gc = qidx.query_ivf_batch(Q, 5, None, 600)
         wi, wd, wc = full.query_ivf_batch(qs[:7], 5, None, 600)
+        assert np.array_equal(gc.cpu().numpy(), wc) and np.array_equal(gi.cpu().numpy(), wi)
+        # database-sharded inverted index, device path (engine -> RCCL -> merge kernel with payload), one shard = whole database
+        gi, gd, gc = idx.query_ivf_batch(Q, 5, None, 600)
+        assert gi.is_cuda and np.array_equal(gc.cpu().numpy(), wc) and np.array_equal(gd.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+        tids = np.sort(np.random.default_rng(1).choice(N, 300, replace=False)).astype(np.int64)
+        gi, gd, gc = idx.query_ivf_batch(Q, 1, tids, 100)
+        wi, wd, wc = full.query_ivf_batch(qs[:7], 1, tids, 100)
         assert np.array_equal(gc.cpu().numpy(), wc) and np.array_equal(gi.cpu().numpy(), wi)
         q.put((0, "ok"))
     except Exception:                                         # noqa: BLE001
