@@ -150,7 +150,9 @@ def roofline_scan(args, kernel_name, B, n_codes, M, Ks, avg_s, launches, steps, 
     achieved = lookups * entry / avg_s / 1e9 if avg_s > 0 else 0.0
     pmc = profile_table("pmc.json").get(pmc_key, {})
     traffic = profile_table("traffic.json").get(pmc_key, {}).get("hbm_bytes_per_launch")
-    floor = n_codes * M + B * M * Ks * entry                   # codes once + the tables the kernel stages
+    # codes once (the filter of the M = 16 / 32 shapes reads the formatted copy: 2 bytes per code byte) + the tables staged
+    fmt = 2 if (byte_tables and M in (16, 32) and Ks == 256) else 1
+    floor = n_codes * M * fmt + B * M * Ks * entry
     hbm = {"algorithmic_bytes_per_launch": lookups, "compulsory_floor_bytes": floor, "traffic_bytes": traffic,
            "achieved": (traffic / avg_s / 1e9) if (traffic and avg_s > 0) else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     if hbm["achieved"] is not None:

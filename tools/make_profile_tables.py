@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Folds a rocprofv3 --pmc summary (tools/profile_bench.sh -> gpurun_out/prof_summary/<tag>_pmc.json) into the two small
+tables bench.py reads for its `roofline` object:
+   profiles/traffic.json[key].hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024   (counters are in KB; FETCH_SIZE is
+                                                      doubled per the MI355X guide's gfx950 note)
+   profiles/pmc.json[key] = {lds_conflict_frac, lds_busy, valu_busy, ...}                   (SQ counters of the same kernel)
+usage: tools/make_profile_tables.py <pmc.json> <kernel substring> <workload key> <source label>"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    src, ksub, key, label = sys.argv[1:5]
+    tab = json.load(open(src))
+    names = [k for k in tab if ksub in k]
+    assert len(names) == 1, names
+    c = tab[names[0]]
+    n_cu, n_simd, n_xcd = 256, 1024, 8
+    cycles = c["GRBM_GUI_ACTIVE"] / n_xcd                       # shader cycles of one launch
+    pmc = {"kernel": names[0], "source": label,
+           "lds_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
+           "lds_busy": c["SQ_LDS_IDX_ACTIVE"] / n_cu / cycles,
+           "valu_busy": c["SQ_INSTS_VALU"] * 4.0 / n_simd / cycles,
+           "lds_cycles_per_read": c["SQ_LDS_IDX_ACTIVE"] / c["SQ_INSTS_LDS"],
+           "valu_insts": c["SQ_INSTS_VALU"], "lds_insts": c["SQ_INSTS_LDS"], "gpu_cycles": cycles}
+    traffic = {"kernel": names[0], "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
+               "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "source": label}
+    for name, entry in (("pmc.json", pmc), ("traffic.json", traffic)):
+        path = os.path.join(ROOT, "profiles", name)
+        t = json.load(open(path)) if os.path.exists(path) else {}
+        t[key] = entry
+        json.dump(t, open(path, "w"), indent=1)
+    print(json.dumps({"pmc": pmc, "traffic": traffic}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
