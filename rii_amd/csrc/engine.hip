@@ -95,6 +95,7 @@ struct rii_engine {
     int cand_cap = 4096;        // candidate slots per query for the re-rank stage (lower bound; grows for small batches)
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
+    int ivf_force_exact = 0;    // tests: the fused kernel flags every query, so the exact LDS kernel answers all of them
     int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
     int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)
@@ -393,13 +394,12 @@ int tie_fixup(rii_engine *e, const uint8_t *d_codes_idx, int indirect, int64_t n
         return set_err(RII_ERR_UNSUPPORTED, "M*Ks=%d tables do not fit LDS next to the tie-order work list", e->M * e->Ks);
     const int grid = (int) std::min<int64_t>(bc, 2LL * e->n_cu);
     if (!linear_tie_heap_in_lds(e->M, e->Ks, topk)) {
-        RII_TRY(e->s_tie_hid.ensure((size_t) grid * topk * sizeof(int32_t)));
-        RII_TRY(e->s_tie_hd.ensure((size_t) grid * topk * sizeof(float)));
+        RII_TRY(e->s_tie_hid.ensure((size_t) grid * topk * sizeof(unsigned long long)));
     }
     ScopedTimer t(e, "tie", st);
     HIP_TRY(launch_linear_tie(d_codes_idx, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, b0,
                               e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), d_remap, d_out_ids, d_out_dists,
-                              topk, grid, e->s_tie_hid.as<int32_t>(), e->s_tie_hd.as<float>(), indirect, st));
+                              topk, grid, e->s_tie_hid.as<unsigned long long>(), indirect, st));
     return RII_OK;
 }
 
@@ -734,6 +734,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     const bool defer = fused && d_flag_defer && bc >= B;       // one launch group: the caller inspects the flags itself
     if (defer) p.flag = d_flag_defer;
     p.sel_cap = ivf_fused_sel_cap((int) nlist, w);
+    p.force_flag = e->ivf_force_exact;
     p.flag_list = nullptr; p.nflag = nullptr;
     if (fused) {                      // [0] = count, [1..] = flagged query indices of the current launch group
         RII_TRY(e->s_flag_list.ensure((size_t) (bc + 1) * sizeof(int32_t)));
@@ -1412,6 +1413,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->scan_mode = (int) value;
     } else if (k == "ivf_fused") {
         e->ivf_fused = value ? 1 : 0;
+    } else if (k == "ivf_force_exact") {
+        e->ivf_force_exact = value ? 1 : 0;
     } else if (k == "scan_order") {
         e->scan_order = value ? 1 : 0;
     } else if (k == "fast_min_batch") {
@@ -1436,6 +1439,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "scan_mode") return e->scan_mode;
     if (k == "cand_cap") return e->cand_cap;
     if (k == "ivf_fused") return e->ivf_fused;
+    if (k == "ivf_force_exact") return e->ivf_force_exact;
     if (k == "scan_order") return e->scan_order;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)

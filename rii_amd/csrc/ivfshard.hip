@@ -41,9 +41,8 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     const int64_t b = blockIdx.x;
     float *lds = reinterpret_cast<float *>(smem);
     unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
-    float *s_cdist = reinterpret_cast<float *>(base);                 // [nlist]   coarse distances (sorted in place)
-    int32_t *s_cid = reinterpret_cast<int32_t *>(s_cdist + nlist);    // [nlist]   list ids
-    int32_t *s_cum = s_cid + nlist;                                   // [nlist+1] cumulative GLOBAL candidate counts
+    pq64_t *s_coarse = reinterpret_cast<pq64_t *>(base);              // [nlist]   (coarse distance, list id), sorted in place
+    int32_t *s_cum = reinterpret_cast<int32_t *>(s_coarse + nlist);   // [nlist+1] cumulative GLOBAL candidate counts
     int32_t *s_misc = s_cum + (nlist + 1);                            // [4]
     unsigned long long *s_key = reinterpret_cast<unsigned long long *>(
         smem + ((reinterpret_cast<unsigned char *>(s_misc + 4) - smem + 15) & ~(size_t) 15));      // [pow2 >= L]
@@ -53,18 +52,16 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
         for (int i = tid; i < MK; i += 256) lds[i] = src[i];
     }
     __syncthreads();
-    for (int c = tid; c < nlist; c += 256) {
-        s_cdist[c] = exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks);       // src/rii.h:262-264
-        s_cid[c] = c;
-    }
+    for (int c = tid; c < nlist; c += 256)                                            // src/rii.h:262-264
+        s_coarse[c] = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
     __syncthreads();
+    if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);                   // src/rii.h:279-280 (wave 0)
     if (tid == 0) {
-        pq_partial_sort(s_cid, s_cdist, (long) p.w, (long) nlist);                    // src/rii.h:279-280
         long long cnt = 0;
         int nv = 0;
         bool finished = false;
         for (int c = 0; c < nlist; ++c) {                                             // src/rii.h:286-321, global lengths
-            const int no = s_cid[c];
+            const int no = (int) pq64_id(s_coarse[c]);
             long long len = 0;
             for (int g = 0; g < p.G; ++g) len += p.glen[(size_t) g * nlist + no];
             s_cum[c] = (int) cnt;
@@ -90,7 +87,7 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
                 const int mid = (lo + hi) >> 1;
                 if (s_cum[mid] <= pos) lo = mid; else hi = mid;
             }
-            const int no = s_cid[lo];
+            const int no = (int) pq64_id(s_coarse[lo]);
             int before = 0;
             for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
             const int li = pos - s_cum[lo] - before;                                  // index inside this rank's part of the list
@@ -119,7 +116,7 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
                 const int mid = (lo + hi) >> 1;
                 if (s_cum[mid] <= pos) lo = mid; else hi = mid;
             }
-            const int no = s_cid[lo];
+            const int no = (int) pq64_id(s_coarse[lo]);
             int before = 0;
             for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
             id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo] - before)];

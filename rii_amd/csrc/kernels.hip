@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     }
     __syncthreads();
     if (tid == 0) {
-        int flag = 0;
+        int flag = p.force_flag;
         for (int r = 0; r + 1 < rounds; ++r)
             if ((s_sel[r] >> 32) == (s_sel[r + 1] >> 32)) flag = 1;         // exactly tied coarse distances
         long long cnt = 0;
@@ -1101,31 +1101,25 @@ __global__ __launch_bounds__(256) void ivf_exact_lds_kernel(IvfParams p)
     const int tid = threadIdx.x;
     float *lds = reinterpret_cast<float *>(smem);
     unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
-    float *s_cdist = reinterpret_cast<float *>(base);                 // [nlist]   coarse distances (sorted in place)
-    int32_t *s_cid = reinterpret_cast<int32_t *>(s_cdist + nlist);    // [nlist]   list ids
-    int32_t *s_cum = s_cid + nlist;                                   // [nlist+1] cumulative candidate counts
+    pq64_t *s_coarse = reinterpret_cast<pq64_t *>(base);              // [nlist]   (coarse distance, list id), sorted in place
+    int32_t *s_cum = reinterpret_cast<int32_t *>(s_coarse + nlist);   // [nlist+1] cumulative candidate counts
     int32_t *s_misc = s_cum + (nlist + 1);                            // [4]
     const int lcap = (int) (p.L < kExactLdsMax ? p.L : kExactLdsMax);
-    float *s_dd = reinterpret_cast<float *>(s_misc + 4);              // [lcap] candidate distances
-    int32_t *s_di = reinterpret_cast<int32_t *>(s_dd + lcap);         // [lcap] candidate ids
+    pq64_t *s_cand = reinterpret_cast<pq64_t *>(smem + ((reinterpret_cast<unsigned char *>(s_misc + 4) - smem + 15) & ~(size_t) 15));   // [lcap]
+    int32_t *s_cpos = reinterpret_cast<int32_t *>(s_cand + lcap);     // [lcap] ids of the candidates (the packed entry carries the position)
 
     stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);               // handed over by ivf_fused_kernel (or built before)
     __syncthreads();
-    for (int c = tid; c < nlist; c += blockDim.x) {
-        const uint8_t *code = p.centers + (size_t) c * p.M;
-        float dist = 0.f;
-        for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
-        s_cdist[c] = dist;
-        s_cid[c] = c;
-    }
+    for (int c = tid; c < nlist; c += blockDim.x)
+        s_coarse[c] = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
     __syncthreads();
+    if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);                 // src/rii.h:279-280 (wave 0)
     if (tid == 0) {
-        pq_partial_sort(s_cid, s_cdist, (long) p.w, (long) nlist);                  // src/rii.h:279-280
         long long cnt = 0;
         int nv = 0;
         bool finished = false;
         for (int c = 0; c < nlist; ++c) {                                           // src/rii.h:286-321
-            const long long len = p.list_len[s_cid[c]];
+            const long long len = p.list_len[pq64_id(s_coarse[c])];
             s_cum[c] = (int) cnt;
             if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
             cnt += len;
@@ -1147,23 +1141,19 @@ __global__ __launch_bounds__(256) void ivf_exact_lds_kernel(IvfParams p)
             const int mid = (lo + hi) >> 1;
             if (s_cum[mid] <= pos) lo = mid; else hi = mid;
         }
-        const int no = s_cid[lo];
+        const int no = (int) pq64_id(s_coarse[lo]);
         const int32_t id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo])];
-        const uint8_t *code = p.codes + (size_t) id * p.M;
-        float dist = 0.f;
-        for (int m = 0; m < p.M; ++m) dist = __fadd_rn(dist, lds[m * p.Ks + code[m]]);
-        s_dd[pos] = dist;
-        s_di[pos] = id;
+        s_cand[pos] = pq64_make(exact_adist(lds, p.codes + (size_t) id * p.M, p.M, p.Ks), (uint32_t) pos);
+        s_cpos[pos] = id;
     }
     __syncthreads();
-    if (tid == 0) {
-        pq_partial_sort(s_di, s_dd, (long) p.topk, (long) ncand);                    // src/rii.h:312-313
-        p.out_counts[bl] = p.topk;
-    }
+    if (tid < 64) wh_partial_sort(s_cand, p.topk, ncand, tid);                       // src/rii.h:312-313 (wave 0)
+    if (tid == 0) p.out_counts[bl] = p.topk;
     __syncthreads();
     for (int j = tid; j < p.topk; j += blockDim.x) {
-        p.out_ids[bl * p.topk + j] = s_di[j];
-        p.out_dists[bl * p.topk + j] = s_dd[j];
+        const pq64_t e = s_cand[j];
+        p.out_ids[bl * p.topk + j] = s_cpos[pq64_id(e)];
+        p.out_dists[bl * p.topk + j] = pq64_dist(e);
     }
     }   // flagged-query loop
 }
@@ -1171,7 +1161,7 @@ __global__ __launch_bounds__(256) void ivf_exact_lds_kernel(IvfParams p)
 bool ivf_exact_lds_supported(int M, int Ks, int nlist, int64_t L)
 {
     const size_t lcap = (size_t) (L < kExactLdsMax ? L : kExactLdsMax);
-    const size_t need = (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 + 16 + lcap * 8 + 64;
+    const size_t need = (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 + 16 + lcap * 12 + 64;
     return nlist <= kExactLdsMax && L <= kExactLdsMax && need <= 160 * 1024;
 }
 
@@ -1180,7 +1170,7 @@ hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st)
     if (p.B == 0) return hipSuccess;
     const size_t lcap = (size_t) (p.L < kExactLdsMax ? p.L : kExactLdsMax);
     const size_t smem = (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15) + (size_t) p.nlist * 8 + (size_t) (p.nlist + 1) * 4 + 16 +
-                        lcap * 8 + 64;
+                        lcap * 12 + 64;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_exact_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;

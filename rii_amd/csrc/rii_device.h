@@ -214,6 +214,245 @@ __device__ inline void pq_partial_sort(int32_t *ids, float *ds, long middle, lon
 }
 
 
+// The same algorithm on PACKED entries (orderable distance bits << 32 | id) for working sets in LDS: one lane walks the
+// heap, and every level of a sift costs one LDS round trip (the two children are adjacent: one ds_read2_b64) instead of
+// two (distance, then id).  Comparisons look at the distance half only -- the reference's comparator (src/rii.h:234) --
+// so the sequence of moves is libstdc++'s, move for move.
+typedef unsigned long long pq64_t;
+__device__ __forceinline__ pq64_t pq64_make(float d, uint32_t id) { return ((pq64_t) f32_orderable(__float_as_uint(d)) << 32) | id; }
+__device__ __forceinline__ float pq64_dist(pq64_t e) { return __uint_as_float(f32_unorderable((uint32_t) (e >> 32))); }
+__device__ __forceinline__ uint32_t pq64_id(pq64_t e) { return (uint32_t) (e & 0xffffffffu); }
+__device__ __forceinline__ bool pq64_less(pq64_t a, pq64_t b) { return (uint32_t) (a >> 32) < (uint32_t) (b >> 32); }
+
+__device__ __forceinline__ void pq64_adjust_heap(pq64_t *h, long hole, long len, pq64_t v)
+{
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        pq64_t a = h[child];
+        const pq64_t b = h[child - 1];
+        if (pq64_less(a, b)) { child--; a = b; }
+        h[hole] = a;
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h[hole] = h[child - 1];
+        hole = child - 1;
+    }
+    long parent = (hole - 1) / 2;
+    while (hole > top) {                                   // __push_heap
+        const pq64_t pv = h[parent];
+        if (!pq64_less(pv, v)) break;
+        h[hole] = pv;
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    h[hole] = v;
+}
+
+__device__ __forceinline__ void pq64_make_heap(pq64_t *h, long len)
+{
+    if (len < 2) return;
+    long parent = (len - 2) / 2;
+    for (;;) {
+        pq64_adjust_heap(h, parent, len, h[parent]);
+        if (parent == 0) break;
+        parent--;
+    }
+}
+
+__device__ __forceinline__ void pq64_sort_heap(pq64_t *h, long len)
+{
+    while (len > 1) {
+        --len;
+        const pq64_t v = h[len];
+        h[len] = h[0];
+        pq64_adjust_heap(h, 0, len, v);
+    }
+}
+
+// std::partial_sort(first, first + middle, first + n) by ONE lane; the scan over [middle, n) fetches eight entries per LDS
+// round trip (an entry that beats the heap top swaps with it in place, exactly like __pop_heap(first, middle, i))
+__device__ __forceinline__ void pq64_partial_sort(pq64_t *h, long middle, long n)
+{
+    pq64_make_heap(h, middle);
+    if (middle > 0) {
+        pq64_t topv = h[0];
+        for (long i0 = middle; i0 < n; i0 += 8) {
+            pq64_t e[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) e[u] = (i0 + u < n) ? h[i0 + u] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < n && pq64_less(e[u], topv)) {
+                    h[i0 + u] = topv;
+                    pq64_adjust_heap(h, 0, middle, e[u]);
+                    topv = h[0];
+                }
+            }
+        }
+    }
+    pq64_sort_heap(h, middle);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same heap, walked by ONE WAVE (all 64 lanes active, every argument wave-uniform) instead of one lane.  A single lane
+// pays a dependent chain of ~25 instructions plus an LDS round trip per LEVEL of a sift (~350 cycles; 7 levels for k = 100).
+// libstdc++'s __adjust_heap first moves the hole down to a leaf along the larger children -- a path that depends only on
+// the heap contents -- and then __push_heap lifts the value along that same path.  So:
+//   1. every lane compares the two children of its nodes: one ballot per 64 nodes = the direction bit of every inner node;
+//   2. the path p_0 .. p_L is followed on those bits (scalar code, no memory access);
+//   3. lane j reads the old entry o_j of path node p_j (one LDS round trip for the whole path);
+//   4. after the sift-down h[p_j] = o_{j+1}; __push_heap moves the hole back up while o_j < v (j = L, L-1, ..., 1): with
+//      t = the level where that stops, the net effect is h[p_j] = o_{j+1} for j < t, h[p_t] = v, levels above t untouched.
+// Same moves, same result, ~3 LDS round trips per adjust whatever the depth.  Heaps above 64 * kWhMaxWords inner nodes
+// take the one-lane code.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kWhMaxWords = 8;           // direction words: heaps of up to 2 * 64 * 8 + 1 entries
+
+// entry of the next lane (lanes 0..14 of a row; a path is at most 12 levels deep): DPP row_shl:1, no LDS round trip
+__device__ __forceinline__ pq64_t wh_shfl_down1(pq64_t x)
+{
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (x & 0xffffffffu), 0x101, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (x >> 32), 0x101, 0xf, 0xf, false);
+    return ((pq64_t) hi << 32) | lo;
+}
+__device__ __forceinline__ pq64_t wh_readlane(pq64_t x, int lane)
+{
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (x & 0xffffffffu), lane);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (x >> 32), lane);
+    return ((pq64_t) hi << 32) | lo;
+}
+__device__ __forceinline__ pq64_t wh_uniform(pq64_t x) { return wh_readlane(x, 0); }
+
+// all 64 lanes of one wave; hole0, len, v uniform; NW = direction words (compile time: straight-line code, the NW pairs of
+// LDS reads are in flight together): len <= 128 * NW + 1
+template <int NW>
+__device__ __forceinline__ void wh_adjust_heap(pq64_t *h, int hole0, int len, pq64_t v, int lane)
+{
+    const int ninner = (len - 1) / 2;                       // nodes n < ninner have both children inside [0, len)
+    unsigned long long W[NW];
+    {
+        pq64_t a[NW], b[NW];
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+            const int n = lane + 64 * r;
+            const int c = n < ninner ? 2 * n + 1 : 0;       // out-of-range lanes read entries 0 / 1: ignored below
+            b[r] = h[c];
+            a[r] = h[c + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < NW; ++r)                        // `if (comp(first + child, first + (child - 1))) child--`
+            W[r] = __ballot(lane + 64 * r < ninner && pq64_less(a[r], b[r]));
+    }
+    int n = hole0, L = 0, mynode = hole0;
+    if constexpr (NW == 1) {
+        const unsigned long long w = W[0];
+        while (n < ninner) {
+            n = 2 * n + 2 - (int) ((w >> n) & 1ull);
+            ++L;
+            if (lane == L) mynode = n;
+        }
+    } else {                                                // word r lives in lane r: fetched with a scalar lane index
+        int wlo = 0, whi = 0;
+#pragma unroll
+        for (int r = 0; r < NW; ++r)
+            if (lane == r) { wlo = (int) (uint32_t) (W[r] & 0xffffffffu); whi = (int) (uint32_t) (W[r] >> 32); }
+        while (n < ninner) {
+            const int r = n >> 6, bitpos = n & 63;
+            const uint32_t half = (uint32_t) (bitpos < 32 ? __builtin_amdgcn_readlane(wlo, r) : __builtin_amdgcn_readlane(whi, r));
+            n = 2 * n + 2 - (int) ((half >> (bitpos & 31)) & 1u);
+            ++L;
+            if (lane == L) mynode = n;
+        }
+    }
+    if ((len & 1) == 0 && n == (len - 2) / 2) {             // a last node with a single (left) child
+        n = 2 * n + 1;
+        ++L;
+        if (lane == L) mynode = n;
+    }
+    const pq64_t o = h[lane <= L ? mynode : 0];             // lane 0's entry is the hole: never used
+    const unsigned long long lessmask = __ballot(lane >= 1 && lane <= L && pq64_less(o, v));
+    // t = L - (number of consecutive levels L, L-1, ... whose entry is < v), at least 0
+    const unsigned long long range = ((2ull << L) - 1ull) & ~1ull;                            // bits 1 .. L (L <= 12)
+    const unsigned long long stop = ~lessmask & range;      // levels that end the climb
+    const int t = stop ? 63 - __builtin_clzll(stop) : 0;
+    const pq64_t up = wh_shfl_down1(o);                     // o_{j+1}
+    if (lane <= t) h[mynode] = lane < t ? up : v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NW>
+__device__ __forceinline__ void wh_partial_sort_t(pq64_t *h, int middle, int n, int lane)
+{
+    if (middle >= 2)                                        // __make_heap
+        for (int parent = (middle - 2) / 2; parent >= 0; --parent) wh_adjust_heap<NW>(h, parent, middle, wh_uniform(h[parent]), lane);
+    if (middle > 0) {
+        pq64_t topv = wh_uniform(h[0]);
+        for (int i0 = middle; i0 < n; i0 += 64) {           // __heap_select: 64 entries per LDS round trip
+            const int i = i0 + lane;
+            const pq64_t e = h[i < n ? i : 0];
+            unsigned long long m = __ballot(i < n && pq64_less(e, topv));
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const pq64_t ej = wh_readlane(e, j);
+                if (pq64_less(ej, topv)) {                  // the library compares with the top of THAT moment
+                    if (lane == 0) h[i0 + j] = topv;        // __pop_heap(first, middle, i)
+                    wh_adjust_heap<NW>(h, 0, middle, ej, lane);
+                    topv = wh_uniform(h[0]);
+                }
+            }
+        }
+    }
+    for (int len = middle - 1; len >= 1; --len) {           // __sort_heap
+        const pq64_t v = wh_uniform(h[len]);
+        const pq64_t top = wh_uniform(h[0]);
+        if (lane == 0) h[len] = top;
+        wh_adjust_heap<NW>(h, 0, len, v, lane);
+    }
+}
+
+// std::partial_sort(first, first + middle, first + n) by one wave (all 64 lanes call it with uniform arguments)
+__device__ __forceinline__ void wh_partial_sort(pq64_t *h, int middle, int n, int lane)
+{
+    if (middle <= 129) wh_partial_sort_t<1>(h, middle, n, lane);
+    else if (middle <= 2 * 64 * kWhMaxWords) wh_partial_sort_t<kWhMaxWords>(h, middle, n, lane);
+    else {                                                  // deeper heaps than the direction words cover: one-lane code
+        if (lane == 0) pq64_partial_sort(h, middle, n);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// single operations for callers that run the phases themselves (tieorder.hip); k <= 2 * 64 * kWhMaxWords
+__device__ __forceinline__ void wh_adjust_top(pq64_t *h, int len, pq64_t v, int lane)
+{
+    if (len <= 129) wh_adjust_heap<1>(h, 0, len, v, lane);
+    else wh_adjust_heap<kWhMaxWords>(h, 0, len, v, lane);
+}
+__device__ __forceinline__ void wh_make_heap(pq64_t *h, int len, int lane)
+{
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2; parent >= 0; --parent) {
+        const pq64_t v = wh_uniform(h[parent]);
+        if (len <= 129) wh_adjust_heap<1>(h, parent, len, v, lane);
+        else wh_adjust_heap<kWhMaxWords>(h, parent, len, v, lane);
+    }
+}
+__device__ __forceinline__ void wh_sort_heap(pq64_t *h, int len0, int lane)
+{
+    for (int len = len0 - 1; len >= 1; --len) {
+        const pq64_t v = wh_uniform(h[len]);
+        const pq64_t top = wh_uniform(h[0]);
+        if (lane == 0) h[len] = top;
+        wh_adjust_top(h, len, v, lane);
+    }
+}
+
 // sequential fp32 ADC (RiiCpp::ADist, src/rii.h:386-394) of one code against a plain [M][Ks] table in LDS
 __device__ __forceinline__ float exact_adist(const float *lds, const uint8_t *code, int M, int Ks)
 {

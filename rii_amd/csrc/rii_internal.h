@@ -89,6 +89,7 @@ struct IvfParams {
     int sel_cap;                  // ivf_fused_kernel: capacity of its list-selection array (ivf_fused_sel_cap)
     int32_t *flag_list; int *nflag;  // compact list of flagged queries + its length (filled by ivf_fused_kernel)
     int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
+    int force_flag = 0;           // debug/tests: ivf_fused_kernel flags every query (option "ivf_force_exact")
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
 bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk);
@@ -154,7 +155,7 @@ bool linear_tie_supported(int M, int Ks);
 bool linear_tie_heap_in_lds(int M, int Ks, int topk);
 hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                              const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
-                             float *d_out_dists, int topk, int grid, int32_t *d_heap_ids, float *d_heap_d, int indirect, hipStream_t st);
+                             float *d_out_dists, int topk, int grid, unsigned long long *d_heap, int indirect, hipStream_t st);
 hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
                                   int32_t *d_flag_list, int *d_nflag, hipStream_t st);
 

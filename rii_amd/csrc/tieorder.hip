@@ -36,14 +36,14 @@ struct TieArgs {
     const int32_t *flag_list; const int *nflag;
     const int64_t *remap;                // index -> id (subset search), or NULL
     int64_t *out_ids; float *out_dists; int topk;
-    int32_t *g_hid; float *g_hd;         // [gridDim.x][topk] heap storage when it does not fit LDS (else unused)
+    pq64_t *g_heap;                      // [gridDim.x][topk] heap storage when it does not fit LDS (else unused)
     int heap_in_lds;
     int capl;                            // list capacity (tie_list_cap)
     int indirect;                        // 1: `codes` is the whole database, index i stands for the code remap[i]
 };
 
-__device__ __forceinline__ void tie_flush(unsigned long long *list, unsigned int c, int32_t *hid, float *hd, long k,
-                                          float *s_thr, unsigned int *s_cnt, int tid)
+__device__ __forceinline__ void tie_flush(unsigned long long *list, unsigned int c, pq64_t *heap, long k,
+                                          uint32_t *s_thr, unsigned int *s_cnt, int tid)
 {
     // uniform: c was read between two barriers
     if (c) {
@@ -51,14 +51,41 @@ __device__ __forceinline__ void tie_flush(unsigned long long *list, unsigned int
         while (nsort < (int) c) nsort <<= 1;
         for (int i = tid; i < nsort; i += 256)
             if ((unsigned int) i >= c) list[i] = ~0ull;
-        rr_bitonic_sort(list, tid, nsort);                 // ascending (index << 32 | dist bits): index order
-        if (tid == 0) {
-            for (unsigned int j = 0; j < c; ++j) {         // __heap_select, bits/stl_algo.h
-                const unsigned long long e = list[j];
-                const float d = __uint_as_float((uint32_t) (e & 0xffffffffu));
-                if (d < hd[0]) pq_adjust_heap(hid, hd, 0, k, (int32_t) (e >> 32), d);     // __pop_heap(first, middle, i)
+        rr_bitonic_sort(list, tid, nsort);                 // ascending (index << 32 | orderable dist): index order
+        if (tid < 64 && k <= 2 * 64 * kWhMaxWords) {       // wave 0 replays __heap_select (bits/stl_algo.h), 64 entries per round trip
+            pq64_t topv = wh_uniform(heap[0]);
+            for (unsigned int j0 = 0; j0 < c; j0 += 64) {
+                const unsigned int j = j0 + (unsigned int) tid;
+                const unsigned long long e = j < c ? list[j] : 0ull;
+                const pq64_t v = (e << 32) | (e >> 32);                    // (orderable dist, index)
+                unsigned long long m = __ballot(j < c && pq64_less(v, topv));
+                while (m) {
+                    const int u = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const pq64_t vu = wh_readlane(v, u);
+                    if (pq64_less(vu, topv)) {                             // __pop_heap(first, middle, i)
+                        wh_adjust_top(heap, (int) k, vu, tid);
+                        topv = wh_uniform(heap[0]);
+                    }
+                }
             }
-            *s_thr = hd[0];
+            if (tid == 0) { *s_thr = (uint32_t) (topv >> 32); *s_cnt = 0u; }
+        } else if (tid == 0 && k > 2 * 64 * kWhMaxWords) {
+            pq64_t topv = heap[0];
+            for (unsigned int j0 = 0; j0 < c; j0 += 8) {
+                unsigned long long e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = (j0 + u < c) ? list[j0 + u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const pq64_t v = (e[u] << 32) | (e[u] >> 32);
+                    if (j0 + u < c && pq64_less(v, topv)) {
+                        pq64_adjust_heap(heap, 0, k, v);
+                        topv = heap[0];
+                    }
+                }
+            }
+            *s_thr = (uint32_t) (topv >> 32);
             *s_cnt = 0u;
         }
     }
@@ -71,18 +98,10 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
     const int MK = p.M * p.Ks;
     float *lds = reinterpret_cast<float *>(smem);
     unsigned long long *list = reinterpret_cast<unsigned long long *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));
-    float *s_thr = reinterpret_cast<float *>(list + p.capl);
+    uint32_t *s_thr = reinterpret_cast<uint32_t *>(list + p.capl);     // orderable bits of the heap top's distance
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_thr + 1);
     const long k = p.topk;
-    int32_t *hid;
-    float *hd;
-    if (p.heap_in_lds) {
-        hd = reinterpret_cast<float *>(list + p.capl + 1);
-        hid = reinterpret_cast<int32_t *>(hd + k);
-    } else {
-        hd = p.g_hd + (size_t) blockIdx.x * k;
-        hid = p.g_hid + (size_t) blockIdx.x * k;
-    }
+    pq64_t *heap = p.heap_in_lds ? reinterpret_cast<pq64_t *>(list + p.capl + 1) : p.g_heap + (size_t) blockIdx.x * k;
     const int tid = threadIdx.x;
     const int nflag = *p.nflag;
     for (int fi = blockIdx.x; fi < nflag; fi += gridDim.x) {
@@ -93,22 +112,16 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
             for (int i = tid; i < MK; i += 256) lds[i] = src[(size_t) i * p.QT];
         }
         __syncthreads();
-        for (long i = tid; i < k; i += 256) {              // the first k scores are the initial heap contents
-            hd[i] = exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[i] : (int64_t) i) * p.M, p.M, p.Ks);
-            hid[i] = (int32_t) i;
-        }
+        for (long i = tid; i < k; i += 256)                // the first k scores are the initial heap contents
+            heap[i] = pq64_make(exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[i] : (int64_t) i) * p.M, p.M, p.Ks), (uint32_t) i);
         if (!p.heap_in_lds) __threadfence_block();
         __syncthreads();
+        const bool wave_heap = k <= 2 * 64 * kWhMaxWords;  // one wave walks the heap (rii_device.h), else one lane
+        if (wave_heap && tid < 64) wh_make_heap(heap, (int) k, tid);           // __make_heap, bits/stl_heap.h
+        if (!wave_heap && tid == 0) pq64_make_heap(heap, k);
         if (tid == 0) {
-            if (k >= 2) {                                  // __make_heap, bits/stl_heap.h
-                long parent = (k - 2) / 2;
-                for (;;) {
-                    pq_adjust_heap(hid, hd, parent, k, hid[parent], hd[parent]);
-                    if (parent == 0) break;
-                    parent--;
-                }
-            }
-            *s_thr = hd[0];
+            __threadfence_block();
+            *s_thr = (uint32_t) (heap[0] >> 32);
             *s_cnt = 0u;
         }
         const int U = p.capl / 512;                        // codes per thread and trip: 4 or 1
@@ -116,8 +129,8 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
             __syncthreads();                               // appends of the previous trip are complete ...
             const unsigned int c = *s_cnt;
             __syncthreads();                               // ... and everybody saw the same count before the next ones
-            if (c + (unsigned int) U * 256u > (unsigned int) p.capl) tie_flush(list, c, hid, hd, k, s_thr, s_cnt, tid);
-            const float thr = *s_thr;
+            if (c + (unsigned int) U * 256u > (unsigned int) p.capl) tie_flush(list, c, heap, k, s_thr, s_cnt, tid);
+            const uint32_t thr = *s_thr;
             float d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -127,30 +140,23 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t i = base + u * 256 + tid;
-                if (u < U && i < p.n && d[u] < thr)
-                    list[atomicAdd(s_cnt, 1u)] = ((unsigned long long) (uint32_t) i << 32) | __float_as_uint(d[u]);
+                const uint32_t od = f32_orderable(__float_as_uint(d[u]));
+                if (u < U && i < p.n && od < thr) list[atomicAdd(s_cnt, 1u)] = ((unsigned long long) (uint32_t) i << 32) | od;
             }
         }
         __syncthreads();
         const unsigned int c = *s_cnt;
         __syncthreads();
-        tie_flush(list, c, hid, hd, k, s_thr, s_cnt, tid);
-        if (tid == 0) {                                    // __sort_heap
-            long len = k;
-            while (len > 1) {
-                --len;
-                const int32_t vid = hid[len];
-                const float vd = hd[len];
-                hid[len] = hid[0]; hd[len] = hd[0];
-                pq_adjust_heap(hid, hd, 0, len, vid, vd);
-            }
-            if (!p.heap_in_lds) __threadfence_block();
-        }
+        tie_flush(list, c, heap, k, s_thr, s_cnt, tid);
+        if (wave_heap && tid < 64) wh_sort_heap(heap, (int) k, tid);           // __sort_heap
+        if (!wave_heap && tid == 0) pq64_sort_heap(heap, k);
+        if (!p.heap_in_lds) __threadfence_block();
         __syncthreads();
         for (long j = tid; j < k; j += 256) {
-            const int32_t idx = hid[j];
+            const pq64_t e = heap[j];
+            const uint32_t idx = pq64_id(e);
             p.out_ids[b * k + j] = p.remap ? p.remap[idx] : (int64_t) idx;
-            p.out_dists[b * k + j] = hd[j];
+            p.out_dists[b * k + j] = pq64_dist(e);
         }
     }
 }
@@ -164,12 +170,12 @@ bool linear_tie_supported(int M, int Ks) { return tie_smem(M, Ks, 0, false) <= (
 
 hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                              const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
-                             float *d_out_dists, int topk, int grid, int32_t *d_heap_ids, float *d_heap_d, int indirect, hipStream_t st)
+                             float *d_out_dists, int topk, int grid, unsigned long long *d_heap, int indirect, hipStream_t st)
 {
     TieArgs a;
     a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.b0 = b0; a.flag_list = d_flag_list;
     a.nflag = d_nflag; a.remap = d_remap; a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.topk = topk;
-    a.g_hid = d_heap_ids; a.g_hd = d_heap_d;
+    a.g_heap = d_heap;
     a.heap_in_lds = linear_tie_heap_in_lds(M, Ks, topk) ? 1 : 0;
     a.capl = tie_list_cap(M, Ks);
     a.indirect = indirect;
