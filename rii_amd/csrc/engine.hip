@@ -128,7 +128,7 @@ struct rii_engine {
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
         s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
-        s_tie_list, s_tie_hid, s_tie_hd;
+        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
@@ -392,14 +392,27 @@ int tie_fixup(rii_engine *e, const uint8_t *d_codes_idx, int indirect, int64_t n
 {
     if (!linear_tie_supported(e->M, e->Ks))
         return set_err(RII_ERR_UNSUPPORTED, "M*Ks=%d tables do not fit LDS next to the tie-order work list", e->M * e->Ks);
-    const int grid = (int) std::min<int64_t>(bc, 2LL * e->n_cu);
+    // the first few flagged queries: chunk-parallel distances + one wave replaying the heap (three small launches); any
+    // further ones (tie-heavy data: every query flagged) one block each -- there all CUs are busy anyway
+    int first = 0;
+    if (linear_tie_chunked_supported(e->M, e->Ks, topk) && n_codes >= 4 * 8192) {
+        int fq = (int) std::min<int64_t>(std::min<int64_t>(bc, 16), std::max<int64_t>(1, ((int64_t) 1 << 30) / (n_codes * 9)));
+        RII_TRY(e->s_tie_chunk.ensure(linear_tie_chunked_scratch(n_codes, fq)));
+        ScopedTimer t(e, "tie", st);
+        HIP_TRY(launch_linear_tie_chunked(d_codes_idx, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, b0,
+                                          e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), d_remap, d_out_ids, d_out_dists,
+                                          topk, fq, e->s_tie_chunk.p, indirect, st));
+        first = fq;
+        if (bc <= fq) return RII_OK;
+    }
+    const int grid = (int) std::min<int64_t>(bc - first, 2LL * e->n_cu);
     if (!linear_tie_heap_in_lds(e->M, e->Ks, topk)) {
         RII_TRY(e->s_tie_hid.ensure((size_t) grid * topk * sizeof(unsigned long long)));
     }
     ScopedTimer t(e, "tie", st);
     HIP_TRY(launch_linear_tie(d_codes_idx, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, b0,
                               e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), d_remap, d_out_ids, d_out_dists,
-                              topk, grid, e->s_tie_hid.as<unsigned long long>(), indirect, st));
+                              topk, grid, e->s_tie_hid.as<unsigned long long>(), indirect, first, st));
     return RII_OK;
 }
 
@@ -855,7 +868,7 @@ void free_all(rii_engine *e)
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
                       &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr, &e->s_qc, &e->s_flag_list,
-                      &e->s_tie_list, &e->s_tie_hid, &e->s_tie_hd};
+                      &e->s_tie_list, &e->s_tie_hid, &e->s_tie_hd, &e->s_tie_chunk};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;

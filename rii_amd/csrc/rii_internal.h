@@ -155,7 +155,12 @@ bool linear_tie_supported(int M, int Ks);
 bool linear_tie_heap_in_lds(int M, int Ks, int topk);
 hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                              const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
-                             float *d_out_dists, int topk, int grid, unsigned long long *d_heap, int indirect, hipStream_t st);
+                             float *d_out_dists, int topk, int grid, unsigned long long *d_heap, int indirect, int first, hipStream_t st);
+bool linear_tie_chunked_supported(int M, int Ks, int topk);
+size_t linear_tie_chunked_scratch(int64_t n, int fq);
+hipError_t launch_linear_tie_chunked(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
+                                     const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
+                                     float *d_out_dists, int topk, int fq, void *d_scratch, int indirect, hipStream_t st);
 hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
                                   int32_t *d_flag_list, int *d_nflag, hipStream_t st);
 

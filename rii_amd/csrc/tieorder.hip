@@ -40,6 +40,7 @@ struct TieArgs {
     int heap_in_lds;
     int capl;                            // list capacity (tie_list_cap)
     int indirect;                        // 1: `codes` is the whole database, index i stands for the code remap[i]
+    int first;                           // flagged queries [first, nflag) are this kernel's (the chunked path took the others)
 };
 
 __device__ __forceinline__ void tie_flush(unsigned long long *list, unsigned int c, pq64_t *heap, long k,
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
     pq64_t *heap = p.heap_in_lds ? reinterpret_cast<pq64_t *>(list + p.capl + 1) : p.g_heap + (size_t) blockIdx.x * k;
     const int tid = threadIdx.x;
     const int nflag = *p.nflag;
-    for (int fi = blockIdx.x; fi < nflag; fi += gridDim.x) {
+    for (int fi = p.first + blockIdx.x; fi < nflag; fi += gridDim.x) {
         __syncthreads();                                   // the previous query's LDS contents are dead from here on
         const int64_t b = p.b0 + p.flag_list[fi];
         {
@@ -161,6 +162,213 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Few flagged queries (the usual case: a handful of exact ties in a batch): one block scanning all n codes for a query is
+// a ~ms tail behind a sub-ms batch.  The first `fq` flagged queries therefore take three small launches instead:
+//   1. tie_chunk_kth_kernel   grid (chunks of 8192 codes, fq): the k-th smallest exact distance of every chunk;
+//   2. tie_chunk_emit_kernel  same grid: bound of chunk c = min of the k-th smallest of the chunks before it -- an upper bound
+//                             on the heap top while chunk c is visited (each of those chunks alone holds k elements of the
+//                             prefix that small) -- and the chunk's codes below the bound are written, in index order, to the
+//                             chunk's segment of a per-query list (chunk 0 has no bound: everything, the first k included);
+//   3. tie_replay_kernel      one wave per query replays __make_heap / __heap_select / __sort_heap over the segments.
+// Same superset argument as above, so the outcome is the full run's.  The exact distances are evaluated by ~n/8192 blocks
+// per query instead of one; what stays serial is the heap (about k (1 + ln(n/k)) sifts).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTcChunk = 8192;
+
+struct TcArgs {
+    const uint8_t *codes; int64_t n; int M, Ks;
+    const float *lut; int QT; int64_t b0;
+    const int32_t *flag_list; const int *nflag; const int64_t *remap; int indirect;
+    int topk, fq, nchunks;
+    uint32_t *kth;                       // [fq][nchunks] orderable bits of the chunk's k-th smallest distance (~0 = fewer than k codes)
+    unsigned long long *elist;           // [fq][nchunks * kTcChunk] (index << 32 | orderable dist), ascending index inside a segment
+    int32_t *ecount;                     // [fq][nchunks]
+    int64_t *out_ids; float *out_dists;
+};
+
+__device__ __forceinline__ void tc_stage(const TcArgs &p, int64_t b, float *lds, int tid)
+{
+    const int MK = p.M * p.Ks;
+    const float *src = p.lut + (size_t) (b / p.QT) * MK * p.QT + (b % p.QT);
+    for (int i = tid; i < MK; i += 256) lds[i] = src[(size_t) i * p.QT];
+}
+__device__ __forceinline__ float tc_dist(const TcArgs &p, const float *lds, int64_t i)
+{
+    return exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[i] : i) * p.M, p.M, p.Ks);
+}
+
+__global__ __launch_bounds__(256) void tie_chunk_kth_kernel(TcArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int fi = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int nf = *p.nflag < p.fq ? *p.nflag : p.fq;
+    if (fi >= nf) return;
+    const int MK = p.M * p.Ks;
+    float *lds = reinterpret_cast<float *>(smem);
+    uint32_t *buf = reinterpret_cast<uint32_t *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));     // [kTcChunk] orderable distances
+    tc_stage(p, p.b0 + p.flag_list[fi], lds, tid);
+    __syncthreads();
+    const int64_t s = (int64_t) c * kTcChunk;
+    const int cnt = (int) ((p.n - s) < kTcChunk ? (p.n - s) : kTcChunk);
+    for (int j = tid; j < kTcChunk; j += 256) buf[j] = j < cnt ? f32_orderable(__float_as_uint(tc_dist(p, lds, s + j))) : 0xffffffffu;
+    __syncthreads();
+    // k-th smallest of buf[0, cnt): bisection on the 32 value bits (count of values below a pivot), 256 threads
+    __shared__ int s_count;
+    uint32_t lo = 0u, hi = 0xffffffffu;                    // invariant: #(v < lo) < k  <=  #(v <= hi)
+    if (cnt < p.topk) { if (tid == 0) p.kth[(size_t) fi * p.nchunks + c] = 0xffffffffu; return; }
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t mid = lo | (1u << bit);             // candidates with this bit set are >= mid
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        int local = 0;
+        for (int j = tid; j < kTcChunk; j += 256) local += (buf[j] < mid) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+        if ((tid & 63) == 0) atomicAdd(&s_count, local);
+        __syncthreads();
+        if (s_count < p.topk) lo = mid;                    // fewer than k values below mid: the k-th smallest is >= mid
+        __syncthreads();
+    }
+    (void) hi;
+    if (tid == 0) p.kth[(size_t) fi * p.nchunks + c] = lo; // largest value v with #(values < v) < k  ==  the k-th smallest
+}
+
+__global__ __launch_bounds__(256) void tie_chunk_emit_kernel(TcArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int fi = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int nf = *p.nflag < p.fq ? *p.nflag : p.fq;
+    if (fi >= nf) return;
+    float *lds = reinterpret_cast<float *>(smem);
+    __shared__ uint32_t s_bound;
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    tc_stage(p, p.b0 + p.flag_list[fi], lds, tid);
+    if (tid == 0) { s_bound = 0xffffffffu; s_base = 0; }
+    __syncthreads();
+    {
+        uint32_t b = 0xffffffffu;
+        for (int cc = tid; cc < c; cc += 256) {
+            const uint32_t v = p.kth[(size_t) fi * p.nchunks + cc];
+            b = v < b ? v : b;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = (uint32_t) __shfl_xor((int) b, off);
+            b = o < b ? o : b;
+        }
+        if ((tid & 63) == 0) atomicMin(&s_bound, b);
+    }
+    __syncthreads();
+    const uint32_t bound = s_bound;                        // chunk 0: ~0 = everything (a real distance is never ~0: not NaN)
+    const int64_t s = (int64_t) c * kTcChunk;
+    const int cnt = (int) ((p.n - s) < kTcChunk ? (p.n - s) : kTcChunk);
+    unsigned long long *seg = p.elist + ((size_t) fi * p.nchunks + c) * kTcChunk;
+    for (int j0 = 0; j0 < cnt; j0 += 256) {                // slabs of 256 consecutive indices: order-preserving compaction
+        const int j = j0 + tid;
+        uint32_t od = 0xffffffffu;
+        if (j < cnt) od = f32_orderable(__float_as_uint(tc_dist(p, lds, s + j)));
+        const bool keep = j < cnt && (bound == 0xffffffffu || od < bound);
+        const unsigned long long bal = __ballot(keep);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
+        if (keep) seg[off + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned long long) (uint32_t) (s + j) << 32) | od;
+        __syncthreads();
+        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) p.ecount[(size_t) fi * p.nchunks + c] = s_base;
+}
+
+__global__ __launch_bounds__(64) void tie_replay_kernel(TcArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pq64_t *heap = reinterpret_cast<pq64_t *>(smem);       // [topk]
+    const int fi = blockIdx.x, lane = threadIdx.x;
+    const int nf = *p.nflag < p.fq ? *p.nflag : p.fq;
+    if (fi >= nf) return;
+    const int k = p.topk;
+    const int64_t b = p.b0 + p.flag_list[fi];
+    const unsigned long long *list = p.elist + (size_t) fi * p.nchunks * kTcChunk;
+    const int32_t *ecount = p.ecount + (size_t) fi * p.nchunks;
+    // chunk 0 is unbounded: its segment starts with the indices 0 .. k-1 = the initial heap contents
+    for (int i = lane; i < k; i += 64) {
+        const unsigned long long e = list[i];
+        heap[i] = (e << 32) | (e >> 32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    wh_make_heap(heap, k, lane);
+    pq64_t topv = wh_uniform(heap[0]);
+    for (int c = 0; c < p.nchunks; ++c) {
+        const int cnt = ecount[c];
+        const unsigned long long *seg = list + (size_t) c * kTcChunk;
+        int j0 = c == 0 ? k : 0;
+        unsigned long long e = (j0 + lane < cnt) ? seg[j0 + lane] : 0ull;
+        for (; j0 < cnt; j0 += 64) {
+            const unsigned long long cur = e;
+            if (j0 + 64 + lane < cnt) e = seg[j0 + 64 + lane];          // next round's entries travel under this round's sifts
+            const pq64_t v = (cur << 32) | (cur >> 32);
+            unsigned long long m = __ballot(j0 + lane < cnt && pq64_less(v, topv));
+            while (m) {
+                const int u = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const pq64_t vu = wh_readlane(v, u);
+                if (pq64_less(vu, topv)) {                 // __pop_heap(first, middle, i)
+                    wh_adjust_top(heap, k, vu, lane);
+                    topv = wh_uniform(heap[0]);
+                }
+            }
+        }
+    }
+    wh_sort_heap(heap, k, lane);
+    for (int j = lane; j < k; j += 64) {
+        const pq64_t e = heap[j];
+        const uint32_t idx = pq64_id(e);
+        p.out_ids[b * k + j] = p.remap ? p.remap[idx] : (int64_t) idx;
+        p.out_dists[b * k + j] = pq64_dist(e);
+    }
+}
+
+// the chunked path handles topk <= 2 * 64 * kWhMaxWords (the wave-walked heap) on tables that leave room for a chunk of
+// distances in LDS; scratch: fq * nchunks * (kTcChunk * 8 + 8) bytes
+bool linear_tie_chunked_supported(int M, int Ks, int topk)
+{
+    return topk <= 2 * 64 * kWhMaxWords && topk <= kTcChunk &&
+           (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) kTcChunk * 4 + 64 <= (size_t) 160 * 1024 - 512;
+}
+int64_t linear_tie_chunks(int64_t n) { return (n + kTcChunk - 1) / kTcChunk; }
+size_t linear_tie_chunked_scratch(int64_t n, int fq) { return (size_t) fq * (size_t) linear_tie_chunks(n) * ((size_t) kTcChunk * 8 + 8); }
+
+hipError_t launch_linear_tie_chunked(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
+                                     const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
+                                     float *d_out_dists, int topk, int fq, void *d_scratch, int indirect, hipStream_t st)
+{
+    TcArgs a;
+    a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.b0 = b0; a.flag_list = d_flag_list;
+    a.nflag = d_nflag; a.remap = d_remap; a.indirect = indirect; a.topk = topk; a.fq = fq;
+    a.nchunks = (int) linear_tie_chunks(n);
+    unsigned char *sc = static_cast<unsigned char *>(d_scratch);
+    a.elist = reinterpret_cast<unsigned long long *>(sc);
+    a.kth = reinterpret_cast<uint32_t *>(sc + (size_t) fq * a.nchunks * kTcChunk * 8);
+    a.ecount = reinterpret_cast<int32_t *>(a.kth + (size_t) fq * a.nchunks);
+    a.out_ids = d_out_ids; a.out_dists = d_out_dists;
+    const size_t tab = (((size_t) M * Ks * 4 + 15) & ~(size_t) 15);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tie_chunk_kth_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) (tab + kTcChunk * 4));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(tie_chunk_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) tab);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tie_chunk_kth_kernel, dim3(a.nchunks, fq), dim3(256), tab + kTcChunk * 4, st, a);
+    hipLaunchKernelGGL(tie_chunk_emit_kernel, dim3(a.nchunks, fq), dim3(256), tab, st, a);
+    hipLaunchKernelGGL(tie_replay_kernel, dim3(fq), dim3(64), (size_t) topk * 8, st, a);
+    return hipGetLastError();
+}
+
 static size_t tie_smem(int M, int Ks, int topk, bool heap_in_lds)
 {
     return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) (tie_list_cap(M, Ks) + 1) * 8 + (heap_in_lds ? (size_t) topk * 8 : 0) + 16;
@@ -170,9 +378,10 @@ bool linear_tie_supported(int M, int Ks) { return tie_smem(M, Ks, 0, false) <= (
 
 hipError_t launch_linear_tie(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                              const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
-                             float *d_out_dists, int topk, int grid, unsigned long long *d_heap, int indirect, hipStream_t st)
+                             float *d_out_dists, int topk, int grid, unsigned long long *d_heap, int indirect, int first, hipStream_t st)
 {
     TieArgs a;
+    a.first = first;
     a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.b0 = b0; a.flag_list = d_flag_list;
     a.nflag = d_nflag; a.remap = d_remap; a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.topk = topk;
     a.g_heap = d_heap;

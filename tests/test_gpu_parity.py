@@ -309,7 +309,8 @@ def test_gpu_ivf_fused_equals_emulation_path():
     rng = np.random.default_rng(4)
     sub = np.sort(rng.choice(30000, 2500, replace=False)).astype(np.int64)
     Q = np.concatenate([qs, qs[::-1] * 0.7], 0)
-    for topk, L in ((1, 200), (1, 3000), (4, 200), (10, 17), (1, 1), (50, 3000), (200, 250), (7, 30000)):
+    for topk, L in ((1, 200), (1, 3000), (4, 200), (10, 17), (1, 1), (50, 3000), (129, 400), (130, 3000), (200, 250), (700, 3900),
+                    (7, 30000)):
         for tids in (None, sub):
             if tids is not None and topk > len(tids):
                 continue
@@ -317,10 +318,15 @@ def test_gpu_ivf_fused_equals_emulation_path():
             a = g.query_ivf_batch(Q, topk, tids, L)
             g.set_option("ivf_fused", 0)
             b = g.query_ivf_batch(Q, topk, tids, L)
-            assert np.array_equal(a[2], b[2])
+            g.set_option("ivf_fused", 1)
+            g.set_option("ivf_force_exact", 1)              # every query through the LDS replay (one wave walks the heap)
+            c = g.query_ivf_batch(Q, topk, tids, L)
+            g.set_option("ivf_force_exact", 0)
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[2], c[2])
             for r in range(Q.shape[0]):
                 n = int(a[2][r])
                 assert np.array_equal(a[0][r, :n], b[0][r, :n]) and np.array_equal(a[1][r, :n].view(np.uint32), b[1][r, :n].view(np.uint32))
+                assert np.array_equal(a[0][r, :n], c[0][r, :n]) and np.array_equal(a[1][r, :n].view(np.uint32), c[1][r, :n].view(np.uint32))
 
 
 @pytest.mark.parametrize("shape", [(32, 256, 4, 60000, "sift", 0), (32, 256, 4, 30000, "unit", 9000),
