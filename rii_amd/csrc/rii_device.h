@@ -330,8 +330,9 @@ __device__ __forceinline__ pq64_t wh_uniform(pq64_t x) { return wh_readlane(x, 0
 // all 64 lanes of one wave; hole0, len, v uniform; NW = direction words (compile time: straight-line code, the NW pairs of
 // LDS reads are in flight together): len <= 128 * NW + 1
 template <int NW>
-__device__ __forceinline__ void wh_adjust_heap(pq64_t *h, int hole0, int len, pq64_t v, int lane)
+__device__ __forceinline__ pq64_t wh_adjust_heap(pq64_t *h, int hole0, int len, pq64_t v, int lane)
 {
+    // returns the entry at `hole0` afterwards (the new top when hole0 == 0): the caller needs no LDS read for it
     const int ninner = (len - 1) / 2;                       // nodes n < ninner have both children inside [0, len)
     unsigned long long W[NW];
     {
@@ -347,13 +348,17 @@ __device__ __forceinline__ void wh_adjust_heap(pq64_t *h, int hole0, int len, pq
         for (int r = 0; r < NW; ++r)                        // `if (comp(first + child, first + (child - 1))) child--`
             W[r] = __ballot(lane + 64 * r < ninner && pq64_less(a[r], b[r]));
     }
-    int n = hole0, L = 0, mynode = hole0;
+    // the path in scalar registers only: n_{j+1} = 2 n_j + 2 - bit_j, i.e. n_j + 1 = (hole0 + 1) 2^j + (the j-bit number of the
+    // (1 - bit) choices so far); the lanes derive their own node from that number afterwards
+    int n = hole0, L = 0;
+    unsigned int choices = 0u;
     if constexpr (NW == 1) {
         const unsigned long long w = W[0];
         while (n < ninner) {
-            n = 2 * n + 2 - (int) ((w >> n) & 1ull);
+            const unsigned int right = 1u - (unsigned int) ((w >> n) & 1ull);
+            n = 2 * n + 1 + (int) right;
+            choices = (choices << 1) | right;
             ++L;
-            if (lane == L) mynode = n;
         }
     } else {                                                // word r lives in lane r: fetched with a scalar lane index
         int wlo = 0, whi = 0;
@@ -363,17 +368,18 @@ __device__ __forceinline__ void wh_adjust_heap(pq64_t *h, int hole0, int len, pq
         while (n < ninner) {
             const int r = n >> 6, bitpos = n & 63;
             const uint32_t half = (uint32_t) (bitpos < 32 ? __builtin_amdgcn_readlane(wlo, r) : __builtin_amdgcn_readlane(whi, r));
-            n = 2 * n + 2 - (int) ((half >> (bitpos & 31)) & 1u);
+            const unsigned int right = 1u - ((half >> (bitpos & 31)) & 1u);
+            n = 2 * n + 1 + (int) right;
+            choices = (choices << 1) | right;
             ++L;
-            if (lane == L) mynode = n;
         }
     }
     if ((len & 1) == 0 && n == (len - 2) / 2) {             // a last node with a single (left) child
-        n = 2 * n + 1;
+        choices <<= 1;
         ++L;
-        if (lane == L) mynode = n;
     }
-    const pq64_t o = h[lane <= L ? mynode : 0];             // lane 0's entry is the hole: never used
+    const int mynode = lane <= L ? (int) ((((unsigned int) hole0 + 1u) << lane) + (choices >> (L - lane))) - 1 : 0;
+    const pq64_t o = h[mynode];                             // lane 0's entry is the hole: never used
     const unsigned long long lessmask = __ballot(lane >= 1 && lane <= L && pq64_less(o, v));
     // t = L - (number of consecutive levels L, L-1, ... whose entry is < v), at least 0
     const unsigned long long range = ((2ull << L) - 1ull) & ~1ull;                            // bits 1 .. L (L <= 12)
@@ -381,8 +387,8 @@ __device__ __forceinline__ void wh_adjust_heap(pq64_t *h, int hole0, int len, pq
     const int t = stop ? 63 - __builtin_clzll(stop) : 0;
     const pq64_t up = wh_shfl_down1(o);                     // o_{j+1}
     if (lane <= t) h[mynode] = lane < t ? up : v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();                        // same wave, in-order LDS: later reads see these writes
+    return t == 0 ? v : wh_readlane(o, 1);
 }
 
 template <int NW>
@@ -402,17 +408,16 @@ __device__ __forceinline__ void wh_partial_sort_t(pq64_t *h, int middle, int n, 
                 const pq64_t ej = wh_readlane(e, j);
                 if (pq64_less(ej, topv)) {                  // the library compares with the top of THAT moment
                     if (lane == 0) h[i0 + j] = topv;        // __pop_heap(first, middle, i)
-                    wh_adjust_heap<NW>(h, 0, middle, ej, lane);
-                    topv = wh_uniform(h[0]);
+                    topv = wh_adjust_heap<NW>(h, 0, middle, ej, lane);
                 }
             }
         }
     }
+    pq64_t top = middle > 0 ? wh_uniform(h[0]) : 0ull;
     for (int len = middle - 1; len >= 1; --len) {           // __sort_heap
         const pq64_t v = wh_uniform(h[len]);
-        const pq64_t top = wh_uniform(h[0]);
         if (lane == 0) h[len] = top;
-        wh_adjust_heap<NW>(h, 0, len, v, lane);
+        top = wh_adjust_heap<NW>(h, 0, len, v, lane);
     }
 }
 
@@ -429,10 +434,10 @@ __device__ __forceinline__ void wh_partial_sort(pq64_t *h, int middle, int n, in
 }
 
 // single operations for callers that run the phases themselves (tieorder.hip); k <= 2 * 64 * kWhMaxWords
-__device__ __forceinline__ void wh_adjust_top(pq64_t *h, int len, pq64_t v, int lane)
+__device__ __forceinline__ pq64_t wh_adjust_top(pq64_t *h, int len, pq64_t v, int lane)        // returns the new top
 {
-    if (len <= 129) wh_adjust_heap<1>(h, 0, len, v, lane);
-    else wh_adjust_heap<kWhMaxWords>(h, 0, len, v, lane);
+    if (len <= 129) return wh_adjust_heap<1>(h, 0, len, v, lane);
+    return wh_adjust_heap<kWhMaxWords>(h, 0, len, v, lane);
 }
 __device__ __forceinline__ void wh_make_heap(pq64_t *h, int len, int lane)
 {
@@ -445,11 +450,11 @@ __device__ __forceinline__ void wh_make_heap(pq64_t *h, int len, int lane)
 }
 __device__ __forceinline__ void wh_sort_heap(pq64_t *h, int len0, int lane)
 {
+    pq64_t top = len0 > 0 ? wh_uniform(h[0]) : 0ull;
     for (int len = len0 - 1; len >= 1; --len) {
         const pq64_t v = wh_uniform(h[len]);
-        const pq64_t top = wh_uniform(h[0]);
         if (lane == 0) h[len] = top;
-        wh_adjust_top(h, len, v, lane);
+        top = wh_adjust_top(h, len, v, lane);
     }
 }
 

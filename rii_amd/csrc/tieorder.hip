@@ -44,7 +44,7 @@ struct TieArgs {
 };
 
 __device__ __forceinline__ void tie_flush(unsigned long long *list, unsigned int c, pq64_t *heap, long k,
-                                          uint32_t *s_thr, unsigned int *s_cnt, int tid)
+                                          uint32_t *s_thr, unsigned int *s_cnt, int tid, bool wave_heap)
 {
     // uniform: c was read between two barriers
     if (c) {
@@ -53,7 +53,7 @@ __device__ __forceinline__ void tie_flush(unsigned long long *list, unsigned int
         for (int i = tid; i < nsort; i += 256)
             if ((unsigned int) i >= c) list[i] = ~0ull;
         rr_bitonic_sort(list, tid, nsort);                 // ascending (index << 32 | orderable dist): index order
-        if (tid < 64 && k <= 2 * 64 * kWhMaxWords) {       // wave 0 replays __heap_select (bits/stl_algo.h), 64 entries per round trip
+        if (tid < 64 && wave_heap) {                       // wave 0 replays __heap_select (bits/stl_algo.h), 64 entries per round trip
             pq64_t topv = wh_uniform(heap[0]);
             for (unsigned int j0 = 0; j0 < c; j0 += 64) {
                 const unsigned int j = j0 + (unsigned int) tid;
@@ -65,13 +65,12 @@ __device__ __forceinline__ void tie_flush(unsigned long long *list, unsigned int
                     m &= m - 1ull;
                     const pq64_t vu = wh_readlane(v, u);
                     if (pq64_less(vu, topv)) {                             // __pop_heap(first, middle, i)
-                        wh_adjust_top(heap, (int) k, vu, tid);
-                        topv = wh_uniform(heap[0]);
+                        topv = wh_adjust_top(heap, (int) k, vu, tid);
                     }
                 }
             }
             if (tid == 0) { *s_thr = (uint32_t) (topv >> 32); *s_cnt = 0u; }
-        } else if (tid == 0 && k > 2 * 64 * kWhMaxWords) {
+        } else if (tid == 0 && !wave_heap) {
             pq64_t topv = heap[0];
             for (unsigned int j0 = 0; j0 < c; j0 += 8) {
                 unsigned long long e[8];
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
             heap[i] = pq64_make(exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[i] : (int64_t) i) * p.M, p.M, p.Ks), (uint32_t) i);
         if (!p.heap_in_lds) __threadfence_block();
         __syncthreads();
-        const bool wave_heap = k <= 2 * 64 * kWhMaxWords;  // one wave walks the heap (rii_device.h), else one lane
+        const bool wave_heap = k <= 2 * 64 * kWhMaxWords && p.heap_in_lds;     // one wave walks the LDS heap (rii_device.h), else one lane
         if (wave_heap && tid < 64) wh_make_heap(heap, (int) k, tid);           // __make_heap, bits/stl_heap.h
         if (!wave_heap && tid == 0) pq64_make_heap(heap, k);
         if (tid == 0) {
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
             __syncthreads();                               // appends of the previous trip are complete ...
             const unsigned int c = *s_cnt;
             __syncthreads();                               // ... and everybody saw the same count before the next ones
-            if (c + (unsigned int) U * 256u > (unsigned int) p.capl) tie_flush(list, c, heap, k, s_thr, s_cnt, tid);
+            if (c + (unsigned int) U * 256u > (unsigned int) p.capl) tie_flush(list, c, heap, k, s_thr, s_cnt, tid, wave_heap);
             const uint32_t thr = *s_thr;
             float d[4];
 #pragma unroll
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(256) void linear_tie_kernel(TieArgs p)
         __syncthreads();
         const unsigned int c = *s_cnt;
         __syncthreads();
-        tie_flush(list, c, heap, k, s_thr, s_cnt, tid);
+        tie_flush(list, c, heap, k, s_thr, s_cnt, tid, wave_heap);
         if (wave_heap && tid < 64) wh_sort_heap(heap, (int) k, tid);           // __sort_heap
         if (!wave_heap && tid == 0) pq64_sort_heap(heap, k);
         if (!p.heap_in_lds) __threadfence_block();
@@ -319,8 +318,7 @@ __global__ __launch_bounds__(64) void tie_replay_kernel(TcArgs p)
                 m &= m - 1ull;
                 const pq64_t vu = wh_readlane(v, u);
                 if (pq64_less(vu, topv)) {                 // __pop_heap(first, middle, i)
-                    wh_adjust_top(heap, k, vu, lane);
-                    topv = wh_uniform(heap[0]);
+                    topv = wh_adjust_top(heap, k, vu, lane);
                 }
             }
         }
