@@ -128,7 +128,7 @@ struct rii_engine {
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
         s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
-        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk;
+        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi;
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
@@ -292,11 +292,20 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
     if (want_quant && e->lut_mode == RII_LUT_EXACT && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
         const int qr = fastscan_rows(e->M, e->Ks);
         RII_TRY(e->s_qlut.ensure((size_t) ((B + qr - 1) / qr) * e->M * e->Ks * qr));
-        RII_TRY(e->s_qc.ensure((size_t) B * e->M * e->Ks));
         e->lut_qt = 1;                    // the fused kernel writes the plain [b][M*Ks] layout (coalesced; re-rank reads it)
         RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
         RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
         RII_TRY(e->s_gthr.ensure((size_t) B * sizeof(uint32_t)));
+        if (lut_tile_supported(e->M, e->Ks, e->Ds)) {         // by tile: exact table, extrema, rotated byte rows, slack
+            RII_TRY(e->s_lohi.ensure((size_t) B * e->M * 2 * sizeof(float)));
+            ScopedTimer t(e, "lut", st);
+            HIP_TRY(launch_lut_tile_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->s_lut.as<float>(),
+                                                e->s_lohi.as<float>(), e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
+                                                e->s_cand_cnt.as<unsigned int>(), e->s_gthr.as<uint32_t>(), st));
+            e->qlut_ready = true;
+            return RII_OK;
+        }
+        RII_TRY(e->s_qc.ensure((size_t) B * e->M * e->Ks));
         ScopedTimer t(e, "lut", st);
         HIP_TRY(launch_lut_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch,
                                        e->s_lut.as<float>(), e->s_qc.as<uint8_t>(), e->s_qlut.as<uint8_t>(),
@@ -868,7 +877,7 @@ void free_all(rii_engine *e)
                       &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
                       &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
                       &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr, &e->s_qc, &e->s_flag_list,
-                      &e->s_tie_list, &e->s_tie_hid, &e->s_tie_hd, &e->s_tie_chunk};
+                      &e->s_tie_list, &e->s_tie_hid, &e->s_tie_hd, &e->s_tie_chunk, &e->s_lohi};
     for (DevBuf *b : bufs) b->release();
     if (e->sort_temp) (void) hipFree(e->sort_temp);
     e->sort_temp = nullptr;

@@ -450,6 +450,160 @@ hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int
     return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tables of the rotated shapes (Ds = 4, Ks = 256, M = 16 / 32), built by TILE instead of by query.
+//
+// lut_build_quant_regs_kernel (block per query) reads the whole codebook (128 KiB) in every block: 134 MB of L2 traffic per
+// 1024-query batch, a compact byte table per query and a second kernel to interleave 16 of them.  Here
+//   1. lut_tile_build_kernel, grid (tile of 16 queries, group of 8 subspaces, quarter of the tile): a wave keeps the codewords
+//      of its two subspaces in registers (8 float4) and runs four queries past them: exact fp32 entries (fvec_L2sqr order)
+//      to the plain [b][M*Ks] table the re-rank stages, plus min / max per (query, subspace).  Codebook traffic: 32 MB.
+//   2. qlut_tile_quant_kernel, grid (tile, 16 subspaces, 16 ks): quantisation step per query from the 16 x M extrema, the 6-bit
+//      levels of 16 queries packed into one 16-byte row, rows turned around in 4 KB of LDS and written in the rotated order.
+// The slack of a query no longer needs the measured residuals: with c = floor((t - lo_m) / delta + 1/2) evaluated in fp32 the
+// level is off the real quotient y by at most 1/2 + 1.4e-5 (three roundings of values below 64), and (t - lo_m) / delta < 63
+// keeps it inside [0, 63] without clamping, so every residual lies in delta * [-(1/2 + 1.4e-5), +(1/2 + 1.4e-5)] and
+// Rhi - Rlo <= M * delta * (1 + 2.8e-5): slack = floor(M (1 + 1e-4) + 2 eps / delta) + 2 (the measured ranges were
+// 0.99 delta per subspace anyway).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lut_tile_build_kernel(const float *__restrict__ queries, int64_t B,
+                                                             const float *__restrict__ codewords, int M,
+                                                             float *__restrict__ lut, float2 *__restrict__ lohi)
+{
+    const int64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int m0 = blockIdx.y * 8 + wave * 2;                // this wave: subspaces m0, m0 + 1
+    const int MK = M * 256;
+    const float4 *cw4 = reinterpret_cast<const float4 *>(codewords);
+    float4 cv[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv[s][e] = cw4[(m0 + s) * 256 + lane + 64 * e];
+    {                                                        // four queries per block: their 16 reductions travel together
+        const int j0 = blockIdx.z * 4;
+        float lo[4][2], hi[4][2];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int64_t b = tile * 16 + j0 + jj;
+            const bool live = b < B;
+            const float4 *q4 = reinterpret_cast<const float4 *>(queries + (live ? b : 0) * (int64_t) (M * 4));
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float4 qm = q4[m0 + s];
+                lo[jj][s] = INFINITY; hi[jj][s] = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = fvec_l2sqr_ds4v(qm, cv[s][e]);
+                    if (live) lut[(size_t) b * MK + (m0 + s) * 256 + lane + 64 * e] = t;
+                    lo[jj][s] = fminf(lo[jj][s], t);
+                    hi[jj][s] = fmaxf(hi[jj][s], t);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    lo[jj][s] = fminf(lo[jj][s], __shfl_xor(lo[jj][s], off));
+                    hi[jj][s] = fmaxf(hi[jj][s], __shfl_xor(hi[jj][s], off));
+                }
+        if (lane < 8) {                                      // lane = jj * 2 + s writes its pair
+            const int jj = lane >> 1, s = lane & 1;
+            const int64_t b = tile * 16 + j0 + jj;
+            float l = lo[0][0], h = hi[0][0];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (a == jj && c == s) { l = lo[a][c]; h = hi[a][c]; }
+            if (b < B) lohi[(size_t) b * M + m0 + s] = make_float2(l, h);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void qlut_tile_quant_kernel(const float *__restrict__ lut, const float2 *__restrict__ lohi,
+                                                              int64_t B, int M, uint8_t *__restrict__ qlut,
+                                                              int32_t *__restrict__ slack, unsigned int *__restrict__ cand_cnt,
+                                                              uint32_t *__restrict__ gthr)
+{
+    __shared__ uint4 s_rows[256];
+    __shared__ float s_inv[16], s_delta[16];
+    const int64_t tile = blockIdx.x;
+    const int h = blockIdx.y, ks0 = blockIdx.z * 16;
+    const int tid = threadIdx.x;
+    const int MK = M * 256;
+    {   // per-query quantisation step: 16 lanes per query reduce the ranges (and |lo| + |hi| for eps) over the M subspaces
+        const int j = tid >> 4, l16 = tid & 15;
+        const int64_t b = tile * 16 + j;
+        float range = 0.f;
+        double dmax = 0.0;
+        if (b < B)
+            for (int m = l16; m < M; m += 16) {
+                const float2 lh = lohi[(size_t) b * M + m];
+                range = fmaxf(range, lh.y - lh.x);
+                dmax += fabs((double) lh.x) + fabs((double) lh.y);
+            }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            range = fmaxf(range, __shfl_xor(range, off));
+            dmax += __shfl_xor(dmax, off);
+        }
+        if (l16 == 0) {
+            float d = range / (float) kFsLevels;
+            if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
+            const float delta = d * 1.000001f;
+            s_delta[j] = delta;
+            s_inv[j] = 1.0f / delta;
+            if (h == 0 && blockIdx.z == 0 && b < B) {        // one block per tile publishes the per-query state of the filter
+                const double eps = (double) M * 1.1920928955078125e-07 * dmax;
+                double sl = (double) M * (1.0 + 1e-4) + 2.0 * eps / (double) delta;
+                sl = sl * (1.0 + 1e-9) + 2.0;
+                slack[b] = (sl >= 0.0 && sl < 60000.0) ? (int32_t) sl : 60000;
+                if (cand_cnt) cand_cnt[b] = 0u;
+                if (gthr) gthr[b] = 0xffffffffu;
+            }
+        }
+    }
+    __syncthreads();
+    const int q = tid >> 4, ks = ks0 + (tid & 15);
+    const int m = h * 16 + q;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t b = tile * 16 + j;
+        uint32_t c = 0u;
+        if (b < B) {
+            const float t = lut[(size_t) b * MK + m * 256 + ks];
+            const float l = lohi[(size_t) b * M + m].x;
+            const float x = floorf((t - l) * s_inv[j] + 0.5f);
+            c = (x >= (float) kFsLevels) ? (uint32_t) kFsLevels : (x > 0.f ? (uint32_t) x : 0u);
+        }
+        w[j >> 2] |= c << (8 * (j & 3));
+    }
+    s_rows[(tid & 15) * 16 + q] = make_uint4(w[0], w[1], w[2], w[3]);
+    __syncthreads();
+    uint4 *dst = reinterpret_cast<uint4 *>(qlut + ((size_t) tile * MK + (size_t) h * 4096 + (size_t) ks0 * 16) * 16);
+    dst[tid] = s_rows[tid];
+}
+
+bool lut_tile_supported(int M, int Ks, int Ds);
+hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, float *d_lut,
+                                       float *d_lohi, uint8_t *d_qlut, int32_t *d_slack, unsigned int *d_cand_cnt,
+                                       uint32_t *d_gthr, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    const unsigned tiles = (unsigned) ((B + 15) / 16);
+    hipLaunchKernelGGL(lut_tile_build_kernel, dim3(tiles, M / 8, 4), dim3(256), 0, st, d_queries, B, d_codewords, M, d_lut,
+                       reinterpret_cast<float2 *>(d_lohi));
+    hipLaunchKernelGGL(qlut_tile_quant_kernel, dim3(tiles, M / 16, 16), dim3(256), 0, st, d_lut,
+                       reinterpret_cast<const float2 *>(d_lohi), B, M, d_qlut, d_slack, d_cand_cnt, d_gthr);
+    return hipGetLastError();
+}
+
 // fused: exact table in the plain [b][M*Ks] layout + quantisation
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
                                   int arch, float *d_lut, uint8_t *d_qc, uint8_t *d_qlut, int32_t *d_slack,
@@ -1055,6 +1209,8 @@ int fastscan_max_sum(int M) { return M * kFsLevels; }
 
 // shapes with the conflict-free rotated layout: whole groups of G = 16 subspaces (the lanes of a ds_read_b128 service
 // group) and Ks = 256 (the (half, ks, slot) lookup value fits 16 bits)
+bool lut_tile_supported(int M, int Ks, int Ds) { return Ds == 4 && fs_rot_supported(M, Ks); }
+
 bool fs_rot_supported(int M, int Ks)
 {
     const int qr = fastscan_rows(M, Ks);

@@ -133,6 +133,11 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
                         uint32_t *d_gthr, int sample_stride, hipStream_t st);
 int fastscan_max_sum(int M);
+// tables of the rotated shapes built by tile (fastscan.hip): exact fp32 [b][M*Ks] + rotated byte rows + slack in two launches
+bool lut_tile_supported(int M, int Ks, int Ds);
+hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, float *d_lut,
+                                       float *d_lohi, uint8_t *d_qlut, int32_t *d_slack, unsigned int *d_cand_cnt,
+                                       uint32_t *d_gthr, hipStream_t st);
 // conflict-free rotated table layout + formatted code copy (see fastscan.hip): launch_fscan then takes the formatted codes
 bool fs_rot_supported(int M, int Ks);
 hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, int64_t n0, int64_t n1, int M, int Ks,
