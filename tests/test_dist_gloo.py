@@ -419,6 +419,28 @@ def test_bench_runs_under_torchrun_world1_with_rccl():
     assert 0 < line["roofline"]["frac"] <= 1.0
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_launched_like_the_driver():
+    """bench.py under `python -m torch.distributed.run --nproc-per-node 2` (the driver's N > 1 launch), both ranks on the one
+    GPU of the test box with the collectives on gloo: the N > 1 control flow (broadcast of the inputs, per-rank batches,
+    timed all-gather, MAX over ranks, one JSON line from rank 0)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RII_BENCH_BACKEND="gloo", RII_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--n-base", "100000", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2048 and line["scaling"] == "weak"
+    assert line["with_gather"]["ms_per_step"] > 0 and line["value"] > 0
+
+
 def test_merge_topk_canonical_rule():
     from rii_amd.dist import merge_topk
     ids = torch.tensor([[7, 3, 9, 1, 5]], dtype=torch.int64)
