@@ -95,6 +95,7 @@ struct rii_engine {
     int cand_cap = 4096;        // candidate slots per query for the re-rank stage (lower bound; grows for small batches)
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
+    int flag_parity = 0;        // which of the two flagged-query counters the next inverted-index launch group uses
     int ivf_force_exact = 0;    // tests: the fused kernel flags every query, so the exact LDS kernel answers all of them
     int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
@@ -758,10 +759,17 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     p.sel_cap = ivf_fused_sel_cap((int) nlist, w);
     p.force_flag = e->ivf_force_exact;
     p.flag_list = nullptr; p.nflag = nullptr;
-    if (fused) {                      // [0] = count, [1..] = flagged query indices of the current launch group
-        RII_TRY(e->s_flag_list.ensure((size_t) (bc + 1) * sizeof(int32_t)));
-        p.nflag = e->s_flag_list.as<int>();
-        p.flag_list = e->s_flag_list.as<int32_t>() + 1;
+    if (fused) {
+        // [0], [1] = two counters used by alternate launch groups, [2..] = flagged query indices of the current group.  The
+        // fused kernel zeroes the OTHER counter (its last reader, the previous group's exact kernel, is behind it in stream
+        // order), so no memset sits in front of every batch.
+        void *before = e->s_flag_list.p;
+        RII_TRY(e->s_flag_list.ensure((size_t) (bc + 2) * sizeof(int32_t)));
+        if (e->s_flag_list.p != before) {
+            HIP_TRY(hipMemsetAsync(e->s_flag_list.p, 0, 2 * sizeof(int32_t), st));
+            e->flag_parity = 0;
+        }
+        p.flag_list = e->s_flag_list.as<int32_t>() + 2;
     }
     if (fused && e->lut_mode == RII_LUT_EXACT) {
         RII_TRY(build_lut(e, d_queries, B, st, false, 1, /*alloc_only=*/true));   // tables are built inside the fused kernel
@@ -778,7 +786,9 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
         p.out_dists = d_out_dists + b0 * topk;
         p.out_counts = d_out_counts + b0;
         if (fused) {
-            HIP_TRY(hipMemsetAsync(p.nflag, 0, sizeof(int), st));
+            p.nflag = e->s_flag_list.as<int>() + e->flag_parity;
+            p.nflag_next = e->s_flag_list.as<int>() + (e->flag_parity ^ 1);
+            e->flag_parity ^= 1;
             // common case answered in one launch; queries whose answer could hinge on std::partial_sort's internal
             // order raise flag[b] and are redone by the exact emulation kernels below (which skip the others)
             ScopedTimer t(e, "ivf_fused", st);

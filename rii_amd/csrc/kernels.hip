@@ -701,7 +701,7 @@ __device__ __forceinline__ float adc_lds_wide(const float *lds, const uint4 (&cv
 
 // Instantiated per (top-1 / top-k, Ds == 4 / generic): the all-in-one kernel was 63 KB of code -- the size of the instruction
 // cache two CUs share -- of which a top-1, Ds = 4 query runs a fraction.
-template <bool TOP1, bool DS4>
+template <bool TOP1, bool DS4, bool LSEL = false>
 __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -713,16 +713,19 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     unsigned long long *s_red = s_sel + SC;                                              // [2]
     int *s_cum = reinterpret_cast<int *>(s_red + 2);                                     // [SC + 2]
     int *s_misc = s_cum + (SC + 2);                                                      // [4]: ncand, nv, flag
-    float *s_dist = reinterpret_cast<float *>(s_misc + 4);                               // [nlist]
-    int *s_len = reinterpret_cast<int *>(s_dist + p.nlist);                              // [SC + 2] lengths of the selected lists ...
+    int *s_len = s_misc + 4;                                                             // [SC + 2] lengths of the selected lists ...
     int *s_poff = s_len + (SC + 2);                                                      // [SC + 2] ... and their offsets, in visiting order
-    // top-k > 1: streaming selection buffer behind them (8-byte aligned)
+    float *s_dist = reinterpret_cast<float *>(s_poff + (SC + 2));                        // [nlist] coarse scores; LSEL: later the
+    uint32_t *s_cd = reinterpret_cast<uint32_t *>(s_dist);                               //   candidates' orderable distances [<= L]
+    // top-k > 1: key buffer behind that region (LSEL: p.kcap keys of the final sort; else the streaming buffer), 16-byte aligned
+    const int region = LSEL ? (p.nlist > (int) p.L ? p.nlist : (int) p.L) : p.nlist;
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(
-        smem + ((reinterpret_cast<unsigned char *>(s_poff + (SC + 2)) - smem + 15) & ~(size_t) 15));
+        smem + ((reinterpret_cast<unsigned char *>(s_dist + region) - smem + 15) & ~(size_t) 15));
     const int64_t bl = blockIdx.x;
     const int tid = threadIdx.x;
     const int nlist = p.nlist;
     const int w = (int) p.w;
+    if (bl == 0 && tid == 0 && p.nflag_next) *p.nflag_next = 0;
 
     if (p.queries) {
         // table built in place (exact fvec_L2sqr order): no global round trip for the common case
@@ -914,7 +917,116 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         }
         return;
     }
-    if constexpr (!TOP1)
+    if constexpr (!TOP1 && LSEL) {
+        // ---- top-k > 1, L <= 4096: every candidate's distance goes to LDS (over the coarse scores, which are dead: a query
+        // flagged from here on is redone by ivf_exact_lds_kernel, which computes its own), the (k+1)-th smallest is found by
+        // bisection on the value bits and only the keys up to it are sorted.  A 64 .. 256-key buffer instead of the 2048-key
+        // streaming buffer: four blocks per CU instead of three, so a 1024-query batch is one wave of blocks, not two. ----
+        const int k1 = (p.topk + 1 < ncand) ? p.topk + 1 : ncand;
+        const int kcap = p.kcap;
+        __syncthreads();                                   // everybody is done with the coarse scores
+        for (int p0 = tid; p0 < ncand; p0 += 4 * 256) {
+            int32_t id[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pos = p0 + u * 256;
+                id[u] = -1;
+                if (pos < ncand) {
+                    int lo = 0, hi = nv;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+                    }
+                    id[u] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
+                }
+            }
+            float dist[4];
+            if (wide) {
+                uint4 cv[4][4];
+                const int MQ = p.M >> 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint4 *cp = reinterpret_cast<const uint4 *>(p.codes + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+                        if (qd < MQ) cv[u][qd] = cp[qd];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dist[u] = adc_lds_wide(lds, cv[u], MQ, p.Ks);
+            } else {
+                for (int u = 0; u < 4; ++u)
+                    dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, p.codes + (size_t) id[u] * p.M, p.M, p.Ks);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (id[u] >= 0) s_cd[p0 + u * 256] = f32_orderable(__float_as_uint(dist[u]));
+        }
+        unsigned int &s_cnt = *reinterpret_cast<unsigned int *>(&s_red[0]);
+        uint32_t T = 0u;                                   // largest value with fewer than k1 distances below it = the k1-th smallest
+        for (int bit = 31; bit >= 0; --bit) {
+            __syncthreads();
+            if (tid == 0) s_cnt = 0u;
+            __syncthreads();
+            const uint32_t mid = T | (1u << bit);
+            int local = 0;
+            for (int i = tid; i < ncand; i += 256) local += s_cd[i] < mid ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+            if ((tid & 63) == 0 && local) atomicAdd(&s_cnt, (unsigned int) local);
+            __syncthreads();
+            if ((int) s_cnt < k1) T = mid;
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt = 0u;
+        __syncthreads();
+        for (int i0 = 0; i0 < ncand; i0 += 256) {          // keys up to the bound, appended wave by wave
+            const int i = i0 + tid;
+            const bool keep = i < ncand && s_cd[i] <= T;
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                unsigned int basepos = 0u;
+                if ((tid & 63) == 0) basepos = atomicAdd(&s_cnt, (unsigned int) __popcll(bal));
+                basepos = (unsigned int) __shfl((int) basepos, 0);
+                const unsigned int at = basepos + (unsigned int) __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+                if (keep && at < (unsigned int) kcap) s_buf[at] = ((unsigned long long) s_cd[i] << 32) | (uint32_t) i;
+            }
+        }
+        __syncthreads();
+        const unsigned int nkeep = s_cnt;
+        int tie = nkeep > (unsigned int) kcap ? 1 : 0;     // more ties at the cut than the buffer holds: exact path
+        if (!tie) {
+            for (int i = tid; i < kcap; i += 256)
+                if ((unsigned int) i >= nkeep) s_buf[i] = ~0ull;
+            rr_bitonic_sort(s_buf, tid, kcap);
+            for (int j = tid; j + 1 < k1; j += 256)
+                if ((s_buf[j] >> 32) == (s_buf[j + 1] >> 32)) tie = 1;
+        }
+        if (__syncthreads_or(tie)) {                       // the answer hinges on std::partial_sort's heap order: hand over
+            if (tid == 0) {
+                p.flag[bl] = 1;
+                if (p.flag_list) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
+            }
+            if (p.queries) {
+                float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
+                for (int i = tid; i < MK; i += blockDim.x) dst[i] = lds[i];
+            }
+            return;
+        }
+        for (int j = tid; j < p.topk; j += 256) {
+            const unsigned long long key = s_buf[j];
+            const int pos = (int) (key & 0xffffffffu);
+            int lo = 0, hi = nv;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+            }
+            p.out_ids[bl * p.topk + j] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
+            p.out_dists[bl * p.topk + j] = __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
+        }
+        if (tid == 0) p.out_counts[bl] = p.topk;
+        return;
+    }
+    if constexpr (!TOP1 && !LSEL)
     // ---- top-k > 1: stream (dist, traversal position) keys through a block-local top-(k+1); if no two of those k+1
     // distances are equal the answer is independent of std::partial_sort's internals, else hand over to the emulation ----
     {
@@ -1020,16 +1132,32 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     }
 }
 
-static size_t ivf_fused_smem(int M, int Ks, int nlist, int sel_cap, int topk)
+// LSEL (selection in LDS): candidates' distances over the coarse scores + a small key buffer (see ivf_fused_kernel)
+constexpr int kFusedSelMaxL = 4096;
+static int ivf_fused_kcap(int topk)
 {
-    return (((size_t) M * Ks * sizeof(float) + 15) & ~(size_t) 15) + (size_t) sel_cap * 8 + 16 + (size_t) (sel_cap + 2) * 4 + 16 +
-           (size_t) nlist * 4 + (size_t) (sel_cap + 2) * 8 + 32 + (topk > 1 ? (size_t) (kRrBuf + 2) * 8 : 0);
+    int c = 64;
+    while (c < 2 * (topk + 1)) c <<= 1;
+    return c;
+}
+static size_t ivf_fused_smem(int M, int Ks, int nlist, int sel_cap, int topk, int64_t L, bool lsel)
+{
+    const size_t head = (((size_t) M * Ks * sizeof(float) + 15) & ~(size_t) 15) + (size_t) sel_cap * 8 + 16 + (size_t) (sel_cap + 2) * 4 + 16 +
+                        (size_t) (sel_cap + 2) * 8;
+    const size_t region = (size_t) (lsel ? std::max<int64_t>(nlist, L) : nlist) * 4 + 32;
+    const size_t keys = topk > 1 ? (lsel ? (size_t) ivf_fused_kcap(topk) * 8 : (size_t) (kRrBuf + 2) * 8) : 0;
+    return head + region + keys;
 }
 int ivf_fused_sel_cap(int nlist, int64_t w);
+static bool ivf_fused_lsel(int M, int Ks, int nlist, int64_t w, int topk, int64_t L)
+{
+    return topk > 1 && L <= kFusedSelMaxL && ivf_fused_kcap(topk) <= 2048 && ivf_exact_lds_supported(M, Ks, nlist, L) &&
+           ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk, L, true) <= (size_t) 160 * 1024;
+}
 bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk)
 {
     return nlist <= kFusedMaxNlist && topk + 1 <= kRrBuf / 2 &&
-           ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk) <= (size_t) 160 * 1024;
+           ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk, 0, false) <= (size_t) 160 * 1024;
 }
 int ivf_fused_sel_cap(int nlist, int64_t w)
 {
@@ -1039,13 +1167,17 @@ int ivf_fused_sel_cap(int nlist, int64_t w)
     return c;
 }
 
-hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st)
+hipError_t launch_ivf_fused(const IvfParams &p0, hipStream_t st)
 {
-    if (p.B == 0) return hipSuccess;
-    const size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk);
+    if (p0.B == 0) return hipSuccess;
+    IvfParams p = p0;
+    const bool lsel = ivf_fused_lsel(p.M, p.Ks, p.nlist, p.w, p.topk, p.L);
+    p.kcap = lsel ? ivf_fused_kcap(p.topk) : 0;
+    const size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk, p.L, lsel);
     const bool top1 = p.topk == 1, ds4 = p.Ds == 4;
     auto kern = top1 ? (ds4 ? ivf_fused_kernel<true, true> : ivf_fused_kernel<true, false>)
-                     : (ds4 ? ivf_fused_kernel<false, true> : ivf_fused_kernel<false, false>);
+                     : lsel ? (ds4 ? ivf_fused_kernel<false, true, true> : ivf_fused_kernel<false, false, true>)
+                            : (ds4 ? ivf_fused_kernel<false, true> : ivf_fused_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) smem);
     if (e != hipSuccess) return e;

@@ -88,6 +88,8 @@ struct IvfParams {
     const float *codewords; int Ds; int arch;
     int sel_cap;                  // ivf_fused_kernel: capacity of its list-selection array (ivf_fused_sel_cap)
     int32_t *flag_list; int *nflag;  // compact list of flagged queries + its length (filled by ivf_fused_kernel)
+    int *nflag_next = nullptr;       // the counter of the NEXT launch group: zeroed by ivf_fused_kernel
+    int kcap = 0;                    // ivf_fused_kernel, selection in LDS: keys of the final sort (set by launch_ivf_fused)
     int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
     int force_flag = 0;           // debug/tests: ivf_fused_kernel flags every query (option "ivf_force_exact")
 };
