@@ -4,8 +4,8 @@ meaning, defaults, return dtypes and error behaviour (AssertionError on violated
 MI355X engine (`RiiGpu`, rii_amd/core.py), plus `query_batch` which the reference does not have.
 
 Structure: the argument policy of a search lives in `_SearchPlan` (one place for `query` and `query_batch`), the
-linear-vs-inverted-index crossover is learnt by `CrossoverModel` (GPU-side timing of small batches; the reference times
-one query at a time on the CPU, rii/rii.py:403-486 -- same idea, same `threshold(L)` contract: an `np.poly1d`).
+linear-vs-inverted-index crossover is learnt by `CrossoverModel` (the engine timed one query per call, like the reference
+times its CPU path, rii/rii.py:403-486 -- same idea, same `threshold(L)` contract: an `np.poly1d`).
 """
 import copy
 import time
@@ -209,22 +209,17 @@ class CrossoverModel(object):
         self.index, self.impl = index, index.impl_cpp
         self.probes = np.ascontiguousarray(probes, dtype=np.float32)
         self.rounds = rounds
-        self.batched = hasattr(self.impl, "query_linear_batch")
 
     def _seconds(self, method, tids, L, few):
+        # one query per call: the threshold steers `Rii.query`, whose single-query path (exhaustive scan, pinned staging) is
+        # not the batched one, and `query_batch(method="auto")` must take the same decision row by row
         qs = self.probes[:3] if few else self.probes
         t0 = time.perf_counter()
-        if self.batched:
+        for q in qs:
             if method == "linear":
-                self.impl.query_linear_batch(qs, 1, tids)
+                self.impl.query_linear(q, 1, tids)
             else:
-                self.impl.query_ivf_batch(qs, 1, tids, L)
-        else:
-            for q in qs:
-                if method == "linear":
-                    self.impl.query_linear(q, 1, tids)
-                else:
-                    self.impl.query_ivf(q, 1, tids, L)
+                self.impl.query_ivf(q, 1, tids, L)
         return (time.perf_counter() - t0) / len(qs)
 
     def _ivf_wins(self, s, L, few):

@@ -749,13 +749,35 @@ template <int QR, int J> __device__ __forceinline__ typename FsVec<QR>::T fs_rot
     else asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(addr));
     return r;
 }
-// the four rows of lookups 4*I .. 4*I+3 (two formatted dwords), in flight after this returns
+// the four rows of lookups 4*I .. 4*I+3 (two formatted dwords), in flight after this returns.  ONE asm statement: the
+// compiler pads every boundary between two asm statements with s_nop (it cannot see what they contain), and an s_nop costs
+// an issue slot like any other instruction: 22 of them per code in the loop before this.
 template <int QR> __device__ __forceinline__ void fs_rot_word_issue(uint32_t w0, uint32_t w1, typename FsVec<QR>::T (&r)[4])
 {
-    r[0] = fs_rot_row_issue<QR, 0>(w0);
-    r[1] = fs_rot_row_issue<QR, 1>(w0);
-    r[2] = fs_rot_row_issue<QR, 0>(w1);
-    r[3] = fs_rot_row_issue<QR, 1>(w1);
+    uint32_t a0, a1, a2, a3;
+    if constexpr (QR == 16) {
+        asm volatile("v_lshlrev_b32_sdwa %4, 4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                     "v_lshlrev_b32_sdwa %5, 4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                     "v_lshlrev_b32_sdwa %6, 4, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                     "v_lshlrev_b32_sdwa %7, 4, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                     "ds_read_b128 %0, %4\n\t"
+                     "ds_read_b128 %1, %5\n\t"
+                     "ds_read_b128 %2, %6\n\t"
+                     "ds_read_b128 %3, %7"
+                     : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                     : "v"(w0), "v"(w1));
+    } else {
+        asm volatile("v_lshlrev_b32_sdwa %4, 3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                     "v_lshlrev_b32_sdwa %5, 3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                     "v_lshlrev_b32_sdwa %6, 3, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                     "v_lshlrev_b32_sdwa %7, 3, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                     "ds_read_b64 %0, %4\n\t"
+                     "ds_read_b64 %1, %5\n\t"
+                     "ds_read_b64 %2, %6\n\t"
+                     "ds_read_b64 %3, %7"
+                     : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                     : "v"(w0), "v"(w1));
+    }
 }
 // wait until at most PENDING younger LDS operations are outstanding: the four rows named become valid
 template <int PENDING, typename V> __device__ __forceinline__ void fs_wait4(V (&r)[4])
