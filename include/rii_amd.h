@@ -113,7 +113,7 @@ int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk
  *      whole target set, 0 = no filter -- a rank may own none of the targets: S == 0 with S_global != 0),
  *   2. the lengths are all-gathered ([G][nlist] int32, `d_glen`, identical on every rank), and
  *   3. rii_query_ivf_shard_dev replays the traversal on the global lengths and scores only the candidates this rank owns.
- * Outputs per query, topk+1 rows ascending by (distance, traversal position): LOCAL ids (-1 = none), distances (+inf),
+ * Outputs per query, `rows` rows (topk+1 by default) ascending by (distance, traversal position): LOCAL ids (-1 = none), distances (+inf),
  * traversal positions (INT32_MAX); d_out_nloc[b] = valid rows; d_out_counts[b] = topk, or 0 where the reference returns
  * ({}, {}) (identical on every rank).  Merging the G records under (distance, position) gives the reference's answer for
  * top-1 and for top-k whenever the k+1 smallest distances are pairwise different.  S_global / N_global: sizes of the whole
@@ -121,9 +121,16 @@ int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk
 int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64_t S, int64_t S_global, int32_t *d_out_len,
                              void *stream);
 int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
-                            int64_t S_global, int64_t L, int64_t N_global, const int32_t *d_glen, int G, int rank,
+                            int64_t S_global, int64_t L, int64_t N_global, const int32_t *d_glen, int G, int rank, int rows,
                             int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos, int32_t *d_out_nloc,
                             int64_t *d_out_counts, void *stream);
+/* Exact ties: `rows` = output rows per query of rii_query_ivf_shard_dev (0 = topk + 1).  For a query whose merged k+1 best
+ * distances hold an exact tie, call it again with rows = L (every candidate the rank owns), all-gather the records
+ * ([nf*rows] int64 positions, [nf*rows] int64 GLOBAL ids, [nf*rows] f32 distances, padded to 16 bytes) and let
+ * rii_ivf_shard_replay_dev rebuild the candidate sequence by position and replay std::partial_sort (src/rii.h:312-313) on it:
+ * the reference's order, tied distances included, identically on every rank.  Stateless; nf = number of such queries. */
+int rii_ivf_shard_replay_dev(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
+                             float *d_out_dists, void *stream);
 
 /* Database sharding (NEW, not in the reference: it has no multi-device code).  Every rank sends one record per batch --
  * [B*k] int64 keys, (payload != 0: [B*k] int64 payload,) [B*k] f32 distances, padded to rii_merge_record_bytes() -- through

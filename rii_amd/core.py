@@ -124,8 +124,9 @@ def _lib():
         "rii_query_linear_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
         "rii_query_ivf_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
         "rii_ivf_list_lengths_dev": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
-        "rii_query_ivf_shard_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int,
+        "rii_query_ivf_shard_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int,
                                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+        "rii_ivf_shard_replay_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
         "rii_merge_record_bytes": (c_i64, [c_i64, c_int, c_int]),
         "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
         "rii_dtable": (c_int, [c_vp, f32p, c_i64, f32p]),
@@ -155,6 +156,12 @@ def merge_topk_dev(d_gathered, G, B, k, d_out_keys, d_out_dists, stream=0, k_out
     (dist, key), with their payloads when d_out_payload is given."""
     _check(_lib().rii_merge_topk_dev(d_gathered, int(G), int(B), int(k), int(k if k_out is None else k_out),
                                      int(bool(d_out_payload)), d_out_keys, d_out_dists, d_out_payload or None, stream or None))
+
+
+def ivf_shard_replay_dev(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, stream=0):
+    """std::partial_sort replayed over the gathered candidate sequences of nf tie-flagged queries (include/rii_amd.h)."""
+    _check(_lib().rii_ivf_shard_replay_dev(d_gathered, int(G), int(nf), int(rows), int(topk), d_out_ids, d_out_dists,
+                                           stream or None))
 
 
 def exported_symbols():
@@ -301,10 +308,10 @@ class RiiGpu(object):
         _check(_lib().rii_ivf_list_lengths_dev(self._h, d_tids or None, int(S), int(S_global), d_out_len, stream or None))
 
     def query_ivf_shard_dev(self, d_queries, B, topk, d_tids, S, S_global, L, N_global, d_glen, G, rank, d_out_ids,
-                            d_out_dists, d_out_pos, d_out_nloc, d_out_counts, stream=0):
+                            d_out_dists, d_out_pos, d_out_nloc, d_out_counts, stream=0, rows=0):
         _check(_lib().rii_query_ivf_shard_dev(self._h, d_queries, int(B), int(topk), d_tids or None, int(S), int(S_global),
-                                              int(L), int(N_global), d_glen, int(G), int(rank), d_out_ids, d_out_dists,
-                                              d_out_pos, d_out_nloc, d_out_counts, stream or None))
+                                              int(L), int(N_global), d_glen, int(G), int(rank), int(rows), d_out_ids,
+                                              d_out_dists, d_out_pos, d_out_nloc, d_out_counts, stream or None))
 
     # ---- main.cpp:17-27: one query per call, python lists out ----
     def query_linear(self, query, topk, target_ids):

@@ -1328,9 +1328,11 @@ RII_API int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64
 
 RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
                                     int64_t S, int64_t S_global, int64_t L, int64_t N_global, const int32_t *d_glen, int G,
-                                    int rank, int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos,
+                                    int rank, int rows, int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos,
                                     int32_t *d_out_nloc, int64_t *d_out_counts, void *stream)
 {
+    if (rows <= 0) rows = topk + 1;
+    if (rows > 4096) return set_err(RII_ERR_INVALID, "rows=%d: at most 4096 output rows per query", rows);
     if (!e || B < 0 || (B > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_pos || !d_out_nloc || !d_out_counts)) ||
         !d_glen || G < 1 || rank < 0 || rank >= G || (S > 0 && !d_tids) || S < 0)
         return set_err(RII_ERR_INVALID, "bad arguments");
@@ -1369,8 +1371,8 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
         if (r != RII_OK) break;
         ScopedTimer t(e, "ivf_shard", st);
         if (launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
-                             e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w,
-                             d_out_ids + b0 * (topk + 1), d_out_dists + b0 * (topk + 1), d_out_pos + b0 * (topk + 1),
+                             e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
+                             d_out_ids + b0 * rows, d_out_dists + b0 * rows, d_out_pos + b0 * rows,
                              d_out_nloc + b0, d_out_counts + b0, st) != hipSuccess)
             r = set_err(RII_ERR_HIP, "ivf_shard_kernel launch failed");
     }
@@ -1378,6 +1380,15 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
     const int r2 = end_on(e, st);
     if (r != RII_OK) { g_err = msg; return r; }
     return r2;
+}
+
+RII_API int rii_ivf_shard_replay_dev(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
+                                     float *d_out_dists, void *stream)
+{
+    if (!d_gathered || G < 1 || nf < 0 || rows < 1 || rows > 4096 || topk < 1 || topk > rows || (nf > 0 && (!d_out_ids || !d_out_dists)))
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(launch_shard_replay(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, (hipStream_t) stream));
+    return RII_OK;
 }
 
 // Database sharding (not in the reference): merge of the all-gathered per-shard top-k rows.  Stateless.

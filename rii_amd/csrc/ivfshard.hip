@@ -29,6 +29,7 @@ struct ShardArgs {
     const int64_t *pl_off; const int32_t *pl_ids; const int32_t *list_len;       // this rank's (filtered) lists
     const int32_t *glen; int G, rank;    // [G][nlist] lengths of every rank's (filtered) lists
     int topk; int64_t L; int64_t w;
+    int rows;                            // output rows per query: topk + 1, or L (every owned candidate: tie replay)
     int64_t *out_ids; float *out_dists; int32_t *out_pos; int32_t *out_nloc; int64_t *out_counts;
 };
 
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     }
     __syncthreads();
     const int ncand = s_misc[0], nv = s_misc[1];
-    const int k1 = p.topk + 1;
+    const int k1 = p.rows;
     int n2 = 64;
     while (n2 < ncand) n2 <<= 1;
     for (int pos = tid; pos < n2; pos += 256) {
@@ -127,6 +128,64 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     }
 }
 
+// Tie replay for the database-sharded inverted index: when two of the merged k+1 best distances are bit-equal the reference's
+// answer is what std::partial_sort (src/rii.h:312-313) makes of the WHOLE candidate sequence in traversal order.  Every rank
+// then sends all the candidates it owns for that query (rows = L) and every rank rebuilds the sequence by position and
+// replays the library's algorithm on it (one wave, rii_device.h: wh_partial_sort).  Record layout = rii_merge_topk_dev's
+// with payload: [nf*rows] int64 positions (INT32_MAX = none), [nf*rows] int64 global ids, [nf*rows] f32 distances.
+__global__ __launch_bounds__(256) void shard_replay_kernel(const unsigned char *__restrict__ gathered, int G, int64_t nf, int rows,
+                                                           int topk, int64_t *__restrict__ out_ids, float *__restrict__ out_dists)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pq64_t *seq = reinterpret_cast<pq64_t *>(smem);                     // [rows] (dist, position), in traversal order
+    int64_t *sid = reinterpret_cast<int64_t *>(seq + rows);             // [rows] global id of the candidate at a position
+    __shared__ int s_n;
+    const int64_t f = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t n = nf * rows;
+    const size_t rec = ((size_t) n * 20 + 15) / 16 * 16;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int g = 0; g < G; ++g) {
+        const unsigned char *base = gathered + rec * g;
+        const int64_t *pos = reinterpret_cast<const int64_t *>(base);
+        const int64_t *gid = reinterpret_cast<const int64_t *>(base + (size_t) n * 8);
+        const float *dd = reinterpret_cast<const float *>(base + (size_t) n * 16);
+        for (int j = tid; j < rows; j += 256) {
+            const int64_t ps = pos[f * rows + j];
+            if (ps >= 0 && ps < rows) {
+                seq[ps] = pq64_make(dd[f * rows + j], (uint32_t) ps);
+                sid[ps] = gid[f * rows + j];
+                ++mine;
+            }
+        }
+    }
+    atomicAdd(&s_n, mine);
+    __syncthreads();
+    const int ncand = s_n;                                  // positions are dense: every candidate is owned by exactly one rank
+    if (tid < 64) wh_partial_sort(seq, topk, ncand, tid);
+    __syncthreads();
+    for (int j = tid; j < topk; j += 256) {
+        const pq64_t e = seq[j];
+        out_ids[f * topk + j] = sid[pq64_id(e)];
+        out_dists[f * topk + j] = pq64_dist(e);
+    }
+}
+
+hipError_t launch_shard_replay(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
+                               float *d_out_dists, hipStream_t st)
+{
+    if (nf == 0) return hipSuccess;
+    const size_t smem = (size_t) rows * 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(shard_replay_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(shard_replay_kernel, dim3((unsigned) nf), dim3(256), smem, st, static_cast<const unsigned char *>(d_gathered),
+                       G, nf, rows, topk, d_out_ids, d_out_dists);
+    return hipGetLastError();
+}
+
 static size_t shard_smem(int M, int Ks, int nlist, int64_t L)
 {
     size_t n2 = 64;
@@ -140,13 +199,13 @@ bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L)
 
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
-                            int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int64_t *d_out_ids, float *d_out_dists,
+                            int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     ShardArgs a;
     a.codes = d_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.centers = d_centers; a.nlist = nlist; a.pl_off = d_pl_off;
-    a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w;
+    a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w; a.rows = rows;
     a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_pos = d_out_pos; a.out_nloc = d_out_nloc; a.out_counts = d_out_counts;
     const size_t smem = shard_smem(M, Ks, nlist, L);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_shard_kernel),

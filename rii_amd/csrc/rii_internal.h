@@ -175,8 +175,10 @@ hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc
 bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L);
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
-                            int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int64_t *d_out_ids, float *d_out_dists,
+                            int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st);
+hipError_t launch_shard_replay(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
+                               float *d_out_dists, hipStream_t st);
 
 // merge.hip: database sharding, k-way merge of the gathered per-shard top-k rows under (dist, id)
 int merge_topk_max_keys();

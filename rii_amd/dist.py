@@ -17,7 +17,8 @@ collective per batch.
 Inverted index over a database-sharded index (DbShardedIndex.query_ivf_batch): the coarse centres are replicated and the
 posting lists local; the reference's global "stop at exactly L candidates in list order" rule is replayed identically on
 every rank from the all-gathered per-rank list lengths (nlist ints per rank and batch), each rank scores the candidates it
-owns, and the per-rank (dist, traversal position, id) rows are merged under (dist, position) -- csrc/ivfshard.hip.
+owns, and the per-rank (dist, traversal position, id) rows are merged under (dist, position); queries whose k+1 best
+distances tie exactly get their whole candidate sequence gathered and std::partial_sort replayed on it -- csrc/ivfshard.hip.
 
 Ties across shards: inside one shard the engine returns the reference's std::partial_sort order; across shards exactly
 tied distances are ordered by id (the heap order of the concatenated database cannot be rebuilt from per-shard top-k rows).
@@ -251,9 +252,9 @@ class DbShardedIndex(object):
     def query_ivf_batch(self, Q, topk, target_ids, L):
         """RiiCpp::QueryIvf (src/rii.h:244-326) on the concatenated database.  Every rank must hold the SAME coarse centres
         (engine.set_coarse_centers) with posting lists over its own codes.  Returns (ids [B,topk] global, dists [B,topk],
-        counts [B]) on every rank; counts[b] == 0 where the reference returns ({}, {}).  Exactly tied distances among the
-        k+1 best are ordered by traversal position (the reference's answer for top-1; `last_tie_flags` marks the top-k
-        queries whose order may differ from std::partial_sort's heap order)."""
+        counts [B]) on every rank; counts[b] == 0 where the reference returns ({}, {}).  Queries whose merged k+1 best
+        distances hold an exact tie (`last_tie_flags`) are redone exactly: every rank sends all the candidates it owns
+        and std::partial_sort is replayed over the rebuilt candidate sequence (rii_ivf_shard_replay_dev)."""
         rank, w = world()
         B = Q.shape[0]
         k1 = topk + 1
@@ -279,13 +280,51 @@ class DbShardedIndex(object):
                                                 0 if t is None else t.numel(), S_global, L, N_global, glen.data_ptr(),
                                                 glen.shape[0], rank, ids.data_ptr(), d.data_ptr(), pos.data_ptr(),
                                                 nloc.data_ptr(), cnt.data_ptr(), sh)
-                out = self._merge_ivf(ids, d, pos, cnt, topk)
+                out_i, out_d, cnt = self._merge_ivf(ids, d, pos, cnt, topk)
+                flagged = torch.nonzero(self.last_tie_flags).flatten()
+                if flagged.numel():                           # exact ties among the k+1 best: replay the heap (same on all ranks)
+                    nf, rows = int(flagged.numel()), int(L)
+                    qf = q[flagged].contiguous()
+                    fi = torch.empty((nf, rows), dtype=torch.int64, device=dev)
+                    fd = torch.empty((nf, rows), dtype=torch.float32, device=dev)
+                    fp = torch.empty((nf, rows), dtype=torch.int32, device=dev)
+                    fn = torch.empty((nf,), dtype=torch.int32, device=dev)
+                    fc = torch.empty((nf,), dtype=torch.int64, device=dev)
+                    self.engine.query_ivf_shard_dev(qf.data_ptr(), nf, topk, 0 if t is None else t.data_ptr(),
+                                                    0 if t is None else t.numel(), S_global, L, N_global, glen.data_ptr(),
+                                                    glen.shape[0], rank, fi.data_ptr(), fd.data_ptr(), fp.data_ptr(),
+                                                    fn.data_ptr(), fc.data_ptr(), sh, rows=rows)
+                    g = _all_gather_bytes(_pack([fp.to(torch.int64), torch.where(fi >= 0, fi + self.start, fi), fd]), self.group)
+                    ri = torch.empty((nf, topk), dtype=torch.int64, device=dev)
+                    rd = torch.empty((nf, topk), dtype=torch.float32, device=dev)
+                    from . import core
+                    core.ivf_shard_replay_dev(g.data_ptr(), g.shape[0], nf, rows, topk, ri.data_ptr(), rd.data_ptr(), sh)
+                    out_i[flagged] = ri
+                    out_d[flagged] = rd
+                out = (out_i, out_d, cnt)
             return _handoff(*out)
         lens = np.asarray(self.engine.ivf_list_lengths(tl), np.int32)
         glen = _all_gather_bytes(torch.from_numpy(lens).view(torch.uint8), self.group).view(torch.int32).reshape(-1, len(lens))
-        ids, d, pos, nloc, cnt = self.engine.query_ivf_shard(np.asarray(Q), topk, tl, S_global, L, N_global, glen.numpy(), rank)
-        return self._merge_ivf(torch.from_numpy(np.ascontiguousarray(ids)), torch.from_numpy(np.ascontiguousarray(d)),
-                               torch.from_numpy(np.ascontiguousarray(pos)), torch.from_numpy(np.ascontiguousarray(cnt)), topk)
+        Qh = np.asarray(Q)
+        ids, d, pos, nloc, cnt = self.engine.query_ivf_shard(Qh, topk, tl, S_global, L, N_global, glen.numpy(), rank)
+        out_i, out_d, cnt = self._merge_ivf(torch.from_numpy(np.ascontiguousarray(ids)), torch.from_numpy(np.ascontiguousarray(d)),
+                                            torch.from_numpy(np.ascontiguousarray(pos)), torch.from_numpy(np.ascontiguousarray(cnt)), topk)
+        flagged = torch.nonzero(self.last_tie_flags).flatten()
+        if flagged.numel():                                   # host tensors (gloo): same protocol, the engine replays
+            nf, rows = int(flagged.numel()), int(L)
+            fi, fd, fp, _, _ = self.engine.query_ivf_shard(Qh[flagged.numpy()], topk, tl, S_global, L, N_global, glen.numpy(), rank,
+                                                           rows=rows)
+            fi = torch.from_numpy(np.ascontiguousarray(fi))
+            g = _all_gather_bytes(_pack([torch.from_numpy(np.ascontiguousarray(fp)).to(torch.int64),
+                                         torch.where(fi >= 0, fi + self.start, fi), torch.from_numpy(np.ascontiguousarray(fd))]), self.group)
+            n = nf * rows
+            gp = np.stack([_field(g, r, 0, n, torch.int64).reshape(nf, rows).numpy() for r in range(g.shape[0])])
+            gi = np.stack([_field(g, r, n * 8, n, torch.int64).reshape(nf, rows).numpy() for r in range(g.shape[0])])
+            gd = np.stack([_field(g, r, n * 16, n, torch.float32).reshape(nf, rows).numpy() for r in range(g.shape[0])])
+            ri, rd = self.engine.ivf_shard_replay(gp, gi, gd, topk)
+            out_i[flagged] = torch.from_numpy(np.ascontiguousarray(ri))
+            out_d[flagged] = torch.from_numpy(np.ascontiguousarray(rd))
+        return out_i, out_d, cnt
 
     def _merge_ivf(self, ids, d, pos, cnt, topk):
         """all-gather of the per-rank (position, global id, dist) rows + merge under (dist, position)."""

@@ -66,13 +66,13 @@ class _OracleShard(_OracleBatch):
     def ivf_list_lengths(self, tl):
         return np.array([len(l) for l in self._lists(tl)], np.int32)
 
-    def query_ivf_shard(self, Q, topk, tl, S_global, L, N_global, glen, rank):
+    def query_ivf_shard(self, Q, topk, tl, S_global, L, N_global, glen, rank, rows=None):
         import ctypes
         from oracle import oracle as O
         o = self.o
         lists = self._lists(tl)
         nlist = o.nlist
-        k1 = topk + 1
+        k1 = topk + 1 if rows is None else rows
         B = Q.shape[0]
         ids = np.full((B, k1), -1, np.int64)
         dd = np.full((B, k1), np.inf, np.float32)
@@ -121,6 +121,28 @@ class _OracleShard(_OracleBatch):
                 ids[b, j], dd[b, j], pos[b, j] = i_, d_, p_
         return ids, dd, pos, nloc, cnt
 
+    def ivf_shard_replay(self, gp, gi, gd, topk):
+        """std::partial_sort (the oracle's restatement) over the candidate sequences rebuilt by position."""
+        import ctypes
+        from oracle import oracle as O
+        pair = np.dtype([("id", "<u8"), ("dist", "<f4")], align=True)
+        G, nf, rows = gp.shape
+        ri = np.empty((nf, topk), np.int64)
+        rd = np.empty((nf, topk), np.float32)
+        for f in range(nf):
+            ok = gp[:, f, :] < rows
+            n = int(ok.sum())
+            seq = np.zeros(n, pair)
+            ids = np.zeros(n, np.int64)
+            ps = gp[:, f, :][ok]
+            seq["id"][ps] = ps
+            seq["dist"][ps] = gd[:, f, :][ok]
+            ids[ps] = gi[:, f, :][ok]
+            O.lib().oracle_partial_sort(seq.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(topk), ctypes.c_size_t(n))
+            ri[f] = ids[seq["id"][:topk].astype(np.int64)]
+            rd[f] = seq["dist"][:topk]
+        return ri, rd
+
 
 def _free_port():
     s = socket.socket()
@@ -165,8 +187,8 @@ class _GpuBatch(object):
         self.g.synchronize()
         return out.cpu().numpy()
 
-    def query_ivf_shard(self, Q, topk, tl, S_global, L, N_global, glen, rank):
-        B, k1 = Q.shape[0], topk + 1
+    def query_ivf_shard(self, Q, topk, tl, S_global, L, N_global, glen, rank, rows=None):
+        B, k1 = Q.shape[0], (topk + 1 if rows is None else rows)
         t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).cuda()
         q = torch.from_numpy(np.ascontiguousarray(Q)).cuda()
         gl = torch.from_numpy(np.ascontiguousarray(glen, np.int32)).cuda()
@@ -178,12 +200,30 @@ class _GpuBatch(object):
         torch.cuda.synchronize()
         self.g.query_ivf_shard_dev(q.data_ptr(), B, topk, 0 if t is None else t.data_ptr(), 0 if t is None else t.numel(),
                                    S_global, L, N_global, gl.data_ptr(), gl.shape[0], rank, ids.data_ptr(), d.data_ptr(),
-                                   pos.data_ptr(), nloc.data_ptr(), cnt.data_ptr())
+                                   pos.data_ptr(), nloc.data_ptr(), cnt.data_ptr(), 0, 0 if rows is None else rows)
         self.g.synchronize()
         return ids.cpu().numpy(), d.cpu().numpy(), pos.cpu().numpy(), nloc.cpu().numpy(), cnt.cpu().numpy()
 
+    def ivf_shard_replay(self, gp, gi, gd, topk):
+        from rii_amd import core
+        G, nf, rows = gp.shape
+        n = nf * rows
+        nrec = (n * 20 + 15) // 16 * 16
+        buf = torch.zeros((G, nrec), dtype=torch.uint8)
+        for r in range(G):
+            buf[r, :n * 8] = torch.from_numpy(np.ascontiguousarray(gp[r])).reshape(-1).view(torch.uint8)
+            buf[r, n * 8:n * 16] = torch.from_numpy(np.ascontiguousarray(gi[r])).reshape(-1).view(torch.uint8)
+            buf[r, n * 16:n * 20] = torch.from_numpy(np.ascontiguousarray(gd[r])).reshape(-1).view(torch.uint8)
+        dbuf = buf.cuda()
+        ri = torch.empty((nf, topk), dtype=torch.int64, device="cuda")
+        rd = torch.empty((nf, topk), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        core.ivf_shard_replay_dev(dbuf.data_ptr(), G, nf, rows, topk, ri.data_ptr(), rd.data_ptr())
+        torch.cuda.synchronize()
+        return ri.cpu().numpy(), rd.cpu().numpy()
 
-def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu):
+
+def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties=False):
     """Database-sharded inverted index against the single-index oracle on the concatenated database, incl. target ids,
     ranks without targets, stale lists (tail walk into the unsorted coarse order, `not found`)."""
     from oracle import oracle as O
@@ -195,7 +235,8 @@ def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu):
     centers = np.array(trainer.coarse_centers, np.uint8)
     Q = qs[:6]
     E = np.array([], np.int64)
-    for stale in (False, True):
+    n_tied = 0
+    for stale in ((False,) if ties else (False, True)):
         local = make_local(cw, codes[s:e])
         n_listed = (e - s) // 9 if stale else None
         local.set_coarse_centers(centers, n_listed)
@@ -228,12 +269,11 @@ def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu):
                 n_empty += (len(wi) == 0)
                 n = len(wi)
                 assert np.array_equal(gd[b, :n].view(np.uint32), np.asarray(wd, np.float32).view(np.uint32)), what
-                if len(set(wd)) == n:
-                    assert list(gi[b, :n]) == list(wi), what
-                else:                           # exact ties inside the top-k: same id set per distance
-                    assert sorted(gi[b, :n]) == sorted(wi), what
+                assert list(gi[b, :n]) == list(wi), what          # exact ties included (heap replay over the gathered sequence)
+                n_tied += int(len(set(wd)) < n)
         if stale:
             assert n_empty > 0, "the stale-list cases were meant to reach the `not found` return"
+    return n_tied
 
 
 def _worker(rank, world, port, q, use_gpu=False):
@@ -287,6 +327,15 @@ def _worker(rank, world, port, q, use_gpu=False):
                 assert np.array_equal(gi.numpy()[b, :n], wi[b, :n]), "ivf ids k=%d" % topk
                 assert np.array_equal(gd.numpy()[b, :n].view(np.uint32), wd[b, :n].view(np.uint32))
         _check_sharded_ivf(rd, rank, world, cw, codes, qs, _GpuBatch if use_gpu else _OracleShard, use_gpu)
+        # integer-valued codebooks and queries + duplicated codes: exactly tied distances inside the top-k, so the merged
+        # (dist, position) order is not enough and the heap replay over the gathered candidate sequence decides
+        rng = np.random.default_rng(77)
+        cw2 = np.round(rng.random((8, 16, 4)) * 3).astype(np.float32)
+        codes2 = rng.integers(0, 16, size=(1501, 8), dtype=np.uint8)
+        codes2[rng.integers(0, 1501, 400)] = codes2[rng.integers(0, 1501, 400)]
+        qs2 = np.round(rng.random((6, 32)) * 3).astype(np.float32)
+        n_tied = _check_sharded_ivf(rd, rank, world, cw2, codes2, qs2, _GpuBatch if use_gpu else _OracleShard, use_gpu, ties=True)
+        assert n_tied > 0
         q.put((rank, "ok"))
     except Exception as ex:                                   # noqa: BLE001
         import traceback
@@ -379,6 +428,29 @@ def _nccl_world1_worker(port, q):
         gi, gd, gc = idx.query_ivf_batch(Q, 1, tids, 100)
         wi, wd, wc = full.query_ivf_batch(qs[:7], 1, tids, 100)
         assert np.array_equal(gc.cpu().numpy(), wc) and np.array_equal(gi.cpu().numpy(), wi)
+        # exact ties (integer-valued codebooks, duplicated codes): merge flags them, the candidate sequences are gathered
+        # and std::partial_sort is replayed on the device (rii_ivf_shard_replay_dev)
+        from oracle import oracle as O
+        rng = np.random.default_rng(77)
+        cw2 = np.round(rng.random((8, 16, 4)) * 3).astype(np.float32)
+        codes2 = rng.integers(0, 16, size=(1501, 8), dtype=np.uint8)
+        codes2[rng.integers(0, 1501, 400)] = codes2[rng.integers(0, 1501, 400)]
+        qs2 = np.round(rng.random((6, 32)) * 3).astype(np.float32)
+        o2 = O.OracleRii(cw2, False, simd_arch="avx512")
+        o2.add_codes(codes2, False)
+        o2.reconfigure(40, 3)
+        g2 = RiiGpu(cw2, False, simd_arch="avx512", device=0)
+        g2.add_codes(codes2, False)
+        g2.set_coarse_centers(np.array(o2.coarse_centers, np.uint8))
+        idx2 = rd.DbShardedIndex(g2, 0, 1501)
+        n_tied = 0
+        for topk, L in ((5, 300), (10, 1501), (3, 40)):
+            gi, gd, gc = idx2.query_ivf_batch(torch.from_numpy(qs2).cuda(), topk, None, L)
+            n_tied += int(idx2.last_tie_flags.sum().item())
+            for b in range(6):
+                wi, wd = o2.query_ivf(qs2[b], topk, np.array([], np.int64), L)
+                assert int(gc[b].item()) == len(wi) and list(gi[b, :len(wi)].cpu().numpy()) == list(wi), ("tie replay", topk, L, b)
+        assert n_tied > 0
         q.put((0, "ok"))
     except Exception:                                         # noqa: BLE001
         import traceback
