@@ -41,9 +41,15 @@ def shard_range(N, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def _comm_device():
-    if dist.is_initialized() and dist.get_backend() == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
+def _comm_device(like=None):
+    """Where the exchanged tensors live: HBM under "nccl"; host memory under "gloo"; with no process group at all (a single
+    engine) wherever the caller's tensor already is."""
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_backend() == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+    if isinstance(like, torch.Tensor):
+        return like.device
     return torch.device("cpu")
 
 
@@ -126,7 +132,7 @@ def allgather_merge_topk(local_ids, local_dists, topk, id_offset=0, group=None):
     """Database sharding: every rank contributes its local top-k (local ids + id_offset = global ids, padding rows marked
     by dist = +inf keep their id); returns the merged global top-k on every rank.  Device tensors in -> device tensors out
     through rii_merge_topk_dev; host tensors / numpy -> torch sort on the host (gloo tests)."""
-    dev = _comm_device()
+    dev = _comm_device(local_ids)
     d = _as_tensor(local_dists, torch.float32, dev)
     ids = _as_tensor(local_ids, torch.int64, dev)
     if id_offset:
@@ -162,7 +168,7 @@ def allgather_query_shards(local_ids, local_dists, group=None, local_counts=None
     """Query sharding: concatenate the per-rank result rows in rank order (every rank gets all rows) with ONE collective
     over a packed record.  `rows`: per-rank row counts when the batch does not divide evenly (records are padded to the
     largest slice and trimmed after the gather).  Returns (ids, dists) or (ids, dists, counts)."""
-    dev = _comm_device()
+    dev = _comm_device(local_ids)
     ids = _as_tensor(local_ids, torch.int64, dev)
     d = _as_tensor(local_dists, torch.float32, dev)
     cnt = None if local_counts is None else _as_tensor(local_counts, torch.int64, dev).reshape(-1)
