@@ -811,8 +811,8 @@ __device__ __forceinline__ void fs_group_issue(const uint32_t (&w)[NW], typename
     else fs_word_issue<QR, KST, I>(w[I], r);
 }
 template <int QR, int KST, int MW, int I, bool ROT, int NW>
-__device__ __forceinline__ void fs_code_steps(const uint32_t (&w)[NW], uint32_t (&acc)[QR / 2], typename FsVec<QR>::T (&ra)[4],
-                                              typename FsVec<QR>::T (&rb)[4])
+__device__ __forceinline__ void fs_code_steps(const uint32_t (&w)[NW], uint32_t (&A)[QR / 4], uint32_t (&O)[QR / 4],
+                                              typename FsVec<QR>::T (&ra)[4], typename FsVec<QR>::T (&rb)[4])
 {
     if constexpr (I < MW) {
         typename FsVec<QR>::T na[4], nb[4];
@@ -827,16 +827,16 @@ __device__ __forceinline__ void fs_code_steps(const uint32_t (&w)[NW], uint32_t 
         fs_wait4<more ? 8 : 0>(rb);
         fs_word_sum<QR>(rb, sb);
 #pragma unroll
-        for (int d = 0; d < QR / 4; ++d) {
+        for (int d = 0; d < QR / 4; ++d) {                 // A / O accumulators: see fs_rot_steps
             if constexpr (I == 0) {
-                acc[2 * d] = (sa[d] & 0x00ff00ffu) + (sb[d] & 0x00ff00ffu);
-                acc[2 * d + 1] = fs_odd_bytes(sa[d]) + fs_odd_bytes(sb[d]);
+                A[d] = sa[d] + sb[d];
+                O[d] = fs_odd_bytes(sa[d]) + fs_odd_bytes(sb[d]);
             } else {
-                acc[2 * d] = fs_add3(acc[2 * d], sa[d] & 0x00ff00ffu, sb[d] & 0x00ff00ffu);
-                acc[2 * d + 1] = fs_add3(acc[2 * d + 1], fs_odd_bytes(sa[d]), fs_odd_bytes(sb[d]));
+                A[d] = fs_add3(A[d], sa[d], sb[d]);
+                O[d] = fs_add3(O[d], fs_odd_bytes(sa[d]), fs_odd_bytes(sb[d]));
             }
         }
-        if constexpr (more) fs_code_steps<QR, KST, MW, I + 2, ROT, NW>(w, acc, na, nb);
+        if constexpr (more) fs_code_steps<QR, KST, MW, I + 2, ROT, NW>(w, A, O, na, nb);
     }
 }
 template <int QR, int KST, int MW, bool ROT, int NW>
@@ -844,9 +844,15 @@ __device__ __forceinline__ void fs_code(const uint32_t (&w)[NW], uint32_t (&acc)
 {
     static_assert(MW % 2 == 0 && kFsFlush == 4, "pairs of lookup groups, 4 lookups per byte-packed sum");
     typename FsVec<QR>::T ra[4], rb[4];
+    uint32_t A[QR / 4], O[QR / 4];
     fs_group_issue<QR, KST, MW, 0, ROT, NW>(w, ra);
     fs_group_issue<QR, KST, MW, 1, ROT, NW>(w, rb);
-    fs_code_steps<QR, KST, MW, 0, ROT, NW>(w, acc, ra, rb);
+    fs_code_steps<QR, KST, MW, 0, ROT, NW>(w, A, O, ra, rb);
+#pragma unroll
+    for (int d = 0; d < QR / 4; ++d) {
+        acc[2 * d] = A[d] - (O[d] << 8);
+        acc[2 * d + 1] = O[d];
+    }
 }
 
 // ---- rotated layout: the whole code in one go ----
