@@ -85,7 +85,51 @@ struct KernelTimer {
 
 }  // namespace
 
-struct rii_engine {
+// Everything one query call writes: scratch buffers plus the per-call state that describes their contents.  An engine
+// holds two of these ("lanes"): the active one is the base sub-object of rii_engine, the other is parked.  A caller
+// that alternates between two streams gets one lane per stream (begin_on swaps them), so the latency-bound stages of
+// one batch (table build, re-rank, launch gaps) overlap the other batch's scan; single-stream callers never touch the
+// second lane, whose buffers are only allocated on first use.
+struct ScratchSet {
+    DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
+        s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
+        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
+        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub;
+    void *sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
+    size_t h_pin_cap = 0;
+    DevBuf s_out_pack;              // [ids | counts | flags | dists] of a small batch, copied back in one transfer
+    riiamd::IvfParams ivf_deferred; // host-pointer small batches: fallback kernels are launched only if a flag came back set
+    bool ivf_has_deferred = false;
+    int flag_parity = 0;        // which of the two flagged-query counters the next inverted-index launch group uses
+    int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
+    bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
+    int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)
+    // `last_stream`/`order_ev` chain this lane's users when successive calls on it come from different streams
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t order_ev = nullptr;
+
+    void release_all()
+    {
+        DevBuf *bufs[] = {&s_queries, &s_tids, &s_lut, &s_best, &s_out_ids, &s_out_dists, &s_out_counts, &s_sub_codes, &s_keys_a,
+                          &s_keys_b, &s_assign, &s_coarse_d, &s_coarse_i, &s_cum, &s_ncand, &s_nvis, &s_cand_i, &s_cand_d,
+                          &s_bitmap, &s_fids, &s_flen, &s_hist, &s_cnt, &s_sample, &s_qlut, &s_slack, &s_cand, &s_cand_cnt,
+                          &s_flag, &s_segmin, &s_thr16, &s_gthr, &s_qc, &s_flag_list, &s_tie_list, &s_tie_hid, &s_tie_hd,
+                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack};
+        for (DevBuf *b : bufs) b->release();
+        if (sort_temp) (void) hipFree(sort_temp);
+        sort_temp = nullptr; sort_temp_bytes = 0;
+        if (h_pin) (void) hipHostFree(h_pin);
+        h_pin = nullptr; h_pin_cap = 0;
+        if (order_ev) (void) hipEventDestroy(order_ev);
+        order_ev = nullptr;
+        last_stream_valid = false;
+    }
+};
+
+struct rii_engine : ScratchSet {
     int M = 0, Ks = 0, Ds = 0, arch = RII_SIMD_AVX512, verbose = 0, device = 0;
     int QT = 4;
     int lut_mode = RII_LUT_EXACT;
@@ -95,11 +139,7 @@ struct rii_engine {
     int cand_cap = 4096;        // candidate slots per query for the re-rank stage (lower bound; grows for small batches)
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
-    int flag_parity = 0;        // which of the two flagged-query counters the next inverted-index launch group uses
     int ivf_force_exact = 0;    // tests: the fused kernel flags every query, so the exact LDS kernel answers all of them
-    int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
-    bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
-    int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)
     int timing = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
@@ -118,34 +158,22 @@ struct rii_engine {
     DevBuf d_scan_codes, d_scan_perm;
     // formatted lookups of the filter stage's conflict-free rotated layout (fastscan.hip: fs_rot_supported shapes), 2 bytes
     // per code byte; codes are formatted independently, so appends only format the tail past `fc_cov`
-    DevBuf d_fcodes, s_fsub;
+    DevBuf d_fcodes;
+
     int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
     int64_t scan_cov = 0;       // codes [0, scan_cov) are final (whole windows)
     int64_t scan_N = -1;        // N the order was last completed for
     bool have_symtab = false, have_cnorm = false, lists_dirty = true;
 
-    // scratch
-    DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
-        s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
-        s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
-        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi;
-    void *sort_temp = nullptr;
-    size_t sort_temp_bytes = 0;
-    void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
-    size_t h_pin_cap = 0;
-    DevBuf s_out_pack;              // [ids | counts | flags | dists] of a small batch, copied back in one transfer
-    riiamd::IvfParams ivf_deferred; // host-pointer small batches: fallback kernels are launched only if a flag came back set
-    bool ivf_has_deferred = false;
 
     std::map<std::string, KernelTimer> timers;
 
-    // every C-ABI entry point holds `mu` while it touches engine state or enqueues work (one caller at a time);
-    // `last_stream`/`order_ev` chain the scratch buffers' users when callers alternate between streams
+    ScratchSet parked;          // the other lane (see ScratchSet)
+    int lanes = 2;              // option "lanes": 1 = every call shares one scratch set (calls on different streams serialise)
+    // every C-ABI entry point holds `mu` while it touches engine state or enqueues work (one caller at a time)
     mutable std::mutex mu;
-    hipStream_t last_stream = nullptr;
-    bool last_stream_valid = false;
-    hipEvent_t order_ev = nullptr;
+
 };
 
 namespace {
@@ -320,6 +348,7 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
         if (!e->have_cnorm) {
             RII_TRY(e->d_cnorm.ensure((size_t) e->M * e->Ks * sizeof(float)));
             HIP_TRY(launch_codeword_norms(e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->d_cnorm.as<float>(), st));
+            HIP_TRY(hipStreamSynchronize(st));
             e->have_cnorm = true;
         }
         HIP_TRY(launch_lut_build_mfma(d_queries, B, e->d_codewords.as<float>(), e->d_cnorm.as<float>(), e->M, e->Ks,
@@ -372,6 +401,7 @@ int ensure_scan_order(rii_engine *e, hipStream_t st)
     }
     e->scan_cov = (e->N / 1024) * 1024;
     e->scan_N = e->N;
+    HIP_TRY(hipStreamSynchronize(st));      // index-side state: the other lane's stream may read it next
     return RII_OK;
 }
 
@@ -385,6 +415,7 @@ int ensure_fcodes(rii_engine *e, hipStream_t st)
         HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), nullptr, e->fc_cov, e->N, e->M, e->Ks, e->d_fcodes.as<uint16_t>(), st));
     }
     e->fc_cov = e->N;
+    HIP_TRY(hipStreamSynchronize(st));      // index-side state: the other lane's stream may read it next
     return RII_OK;
 }
 
@@ -858,17 +889,37 @@ int check_tids_host(const rii_engine *e, const int64_t *tids, int64_t S)
     return RII_OK;
 }
 
-// Scratch buffers are shared by all calls of an engine, so work enqueued on a different stream than the previous
-// call's must wait for it.  User streams are only touched while the caller vouches for them (inside a call).
+// A lane's scratch buffers are shared by all calls that use it, so work enqueued on a different stream than the lane's
+// previous call must wait for it.  A call on another stream than the active lane's last one takes the parked lane instead
+// (two alternating streams: one lane each, no waits).  User streams are only touched while the caller vouches for them
+// (inside a call).
+int lane_wait(rii_engine *e, ScratchSet &l, hipStream_t st)
+{
+    if (l.last_stream_valid && l.last_stream != st) {
+        if (!l.order_ev) HIP_TRY(hipEventCreateWithFlags(&l.order_ev, hipEventDisableTiming));
+        if (l.last_stream == e->stream) HIP_TRY(hipEventRecord(l.order_ev, e->stream));
+        HIP_TRY(hipStreamWaitEvent(st, l.order_ev, 0));
+    }
+    return RII_OK;
+}
 int begin_on(rii_engine *e, hipStream_t st)
 {
-    if (e->last_stream_valid && e->last_stream != st) {
-        if (!e->order_ev) HIP_TRY(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
-        if (e->last_stream == e->stream) HIP_TRY(hipEventRecord(e->order_ev, e->stream));
-        HIP_TRY(hipStreamWaitEvent(st, e->order_ev, 0));
-    }
-    e->last_stream = st;
+    ScratchSet &act = *e;
+    if (e->lanes > 1 && act.last_stream_valid && act.last_stream != st) std::swap(act, e->parked);
+    RII_TRY(lane_wait(e, act, st));
+    act.last_stream = st;
+    act.last_stream_valid = true;
+    return RII_OK;
+}
+// index mutations and whole-engine synchronisation: the engine's stream waits for both lanes' in-flight work
+int begin_exclusive(rii_engine *e)
+{
+    RII_TRY(lane_wait(e, e->parked, e->stream));
+    e->parked.last_stream_valid = false;
+    RII_TRY(lane_wait(e, *e, e->stream));
+    e->last_stream = e->stream;
     e->last_stream_valid = true;
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return RII_OK;
 }
 int end_on(rii_engine *e, hipStream_t st)
@@ -882,23 +933,13 @@ int end_on(rii_engine *e, hipStream_t st)
 void free_all(rii_engine *e)
 {
     DevBuf *bufs[] = {&e->d_codewords, &e->d_cnorm, &e->d_codes, &e->d_centers, &e->d_symtab, &e->d_pl_off,
-                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->d_fcodes, &e->s_fsub, &e->s_queries, &e->s_tids, &e->s_lut, &e->s_best, &e->s_out_ids,
-                      &e->s_out_dists, &e->s_out_counts, &e->s_sub_codes, &e->s_keys_a, &e->s_keys_b, &e->s_assign,
-                      &e->s_coarse_d, &e->s_coarse_i, &e->s_cum, &e->s_ncand, &e->s_nvis, &e->s_cand_i, &e->s_cand_d,
-                      &e->s_bitmap, &e->s_fids, &e->s_flen, &e->s_hist, &e->s_cnt, &e->s_sample, &e->s_qlut, &e->s_slack,
-                      &e->s_cand, &e->s_cand_cnt, &e->s_flag, &e->s_segmin, &e->s_thr16, &e->s_gthr, &e->s_qc, &e->s_flag_list,
-                      &e->s_tie_list, &e->s_tie_hid, &e->s_tie_hd, &e->s_tie_chunk, &e->s_lohi};
+                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->d_fcodes};
     for (DevBuf *b : bufs) b->release();
-    if (e->sort_temp) (void) hipFree(e->sort_temp);
-    e->sort_temp = nullptr;
-    if (e->h_pin) (void) hipHostFree(e->h_pin);
-    e->h_pin = nullptr;
-    e->s_out_pack.release();
+    e->release_all();
+    e->parked.release_all();
     for (auto &kv : e->timers)
         for (auto &pr : kv.second.pending) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     e->timers.clear();
-    if (e->order_ev) (void) hipEventDestroy(e->order_ev);
-    e->order_ev = nullptr;
     if (e->stream) (void) hipStreamDestroy(e->stream);
     e->stream = nullptr;
 }
@@ -970,7 +1011,7 @@ RII_API int rii_add_codes(rii_engine *e, const uint8_t *codes, int64_t n, int up
     if (!e || (n > 0 && !codes) || n < 0) return set_err(RII_ERR_INVALID, "bad arguments");
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    RII_TRY(begin_on(e, e->stream));
+    RII_TRY(begin_exclusive(e));
     if (update_flag && e->centers.empty())
         return set_err(RII_ERR_STATE,
                        "reconfigure() must be called before add(vecs=X, update_posting_lists=True). If this is the "
@@ -993,7 +1034,7 @@ RII_API int rii_set_coarse_centers(rii_engine *e, const uint8_t *centers, int64_
     if (!e || !centers || nlist <= 0) return set_err(RII_ERR_INVALID, "bad arguments");
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    RII_TRY(begin_on(e, e->stream));
+    RII_TRY(begin_exclusive(e));
     e->centers.assign(centers, centers + (size_t) nlist * e->M);
     RII_TRY(upload_centers(e));
     e->lists.assign((size_t) nlist, std::vector<int32_t>());
@@ -1008,7 +1049,7 @@ RII_API int rii_set_state(rii_engine *e, const uint8_t *centers, int64_t nlist, 
     if (!e || nlist < 0 || N < 0) return set_err(RII_ERR_INVALID, "bad arguments");
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    RII_TRY(begin_on(e, e->stream));
+    RII_TRY(begin_exclusive(e));
     e->codes.clear(); e->N = 0;
     RII_TRY(append_codes(e, codes, N));
     e->centers.assign(centers, centers + (size_t) nlist * e->M);
@@ -1027,7 +1068,7 @@ RII_API int rii_reconfigure(rii_engine *e, int nlist, int iter)
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    RII_TRY(begin_on(e, e->stream));
+    RII_TRY(begin_exclusive(e));
     if (nlist <= 0 || (int64_t) nlist > e->N)
         return set_err(RII_ERR_INVALID, "reconfigure: need 0 < nlist=%d <= N=%lld (src/rii.h:110-111)", nlist, (long long) e->N);
     if (iter < 0) return set_err(RII_ERR_INVALID, "iter must be >= 0");
@@ -1460,6 +1501,11 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->ivf_force_exact = value ? 1 : 0;
     } else if (k == "scan_order") {
         e->scan_order = value ? 1 : 0;
+    } else if (k == "lanes") {
+        if (value != 1 && value != 2) return set_err(RII_ERR_INVALID, "lanes must be 1 or 2");
+        HIP_TRY(hipSetDevice(e->device));
+        RII_TRY(begin_exclusive(e));
+        e->lanes = (int) value;
     } else if (k == "fast_min_batch") {
         e->fast_min_batch = (int) std::max<int64_t>(0, value);
     } else if (k == "cand_cap") {
@@ -1484,6 +1530,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_fused") return e->ivf_fused;
     if (k == "ivf_force_exact") return e->ivf_force_exact;
     if (k == "scan_order") return e->scan_order;
+    if (k == "lanes") return e->lanes;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;
@@ -1504,7 +1551,7 @@ RII_API int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms,
     if (!e || !kernel) return set_err(RII_ERR_INVALID, "bad arguments");
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    RII_TRY(begin_on(e, e->stream));
+    RII_TRY(begin_exclusive(e));
     KernelTimer &t = e->timers[kernel];
     for (auto &pr : t.pending) {
         HIP_TRY(hipEventSynchronize(pr.second));
@@ -1537,7 +1584,7 @@ RII_API int rii_synchronize(rii_engine *e)
     if (!e) return set_err(RII_ERR_INVALID, "engine is NULL");
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    RII_TRY(begin_on(e, e->stream));
+    RII_TRY(begin_exclusive(e));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return RII_OK;
 }

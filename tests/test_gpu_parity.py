@@ -544,6 +544,76 @@ def test_alternating_streams_share_scratch_safely():
         assert np.array_equal(ib.cpu().numpy(), want_b[0]) and np.array_equal(db.cpu().numpy(), want_b[1])
 
 
+@pytest.mark.parametrize("lanes,nstreams", [(2, 2), (2, 3), (1, 2)])
+def test_scratch_lanes_mixed_calls(lanes, nstreams):
+    """Two scratch lanes (engine.hip: ScratchSet): calls that alternate between streams overlap on the device, each on its
+    own lane; a third stream, host-pointer calls, an append and option changes in between all stay correct.  Linear
+    top-1 / top-k / subset and inverted-index calls are mixed so that every scratch buffer is exercised on both lanes."""
+    import torch
+    from rii_amd import RiiGpu
+    cw, codes, _ = make_problem(79, 32, 256, 4, 70000, "unit")
+    rng = np.random.default_rng(79)
+    codes[rng.integers(0, 70000, 2000)] = codes[rng.integers(0, 70000, 2000)]          # exact ties
+    qs = rng.random((3 * 96, 128)).astype(np.float32)
+    tids = np.sort(rng.choice(60000, 9000, replace=False)).astype(np.int64)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes[:60000], False)
+    g.reconfigure(64, 3)
+    g.set_option("lanes", lanes)
+    assert g.get_option("lanes") == lanes
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+    d_t = torch.from_numpy(tids).to(dev)
+    kinds = [("lin", 1, False), ("lin", 10, False), ("lin", 1, True), ("ivf", 5, False), ("ivf", 1, True), ("lin", 3, True)]
+
+    def want(kind, topk, sub, q):
+        t = tids if sub else None
+        if kind == "lin":
+            return g.query_linear_batch(q, topk, t)
+        return g.query_ivf_batch(q, topk, t, 300)
+
+    def issue(kind, topk, sub, dq, st):
+        B = dq.shape[0]
+        with torch.cuda.stream(st):          # the fills are ordered before the engine's writes on the same stream
+            ids = torch.full((B, topk), -7, dtype=torch.int64, device=dev)
+            d = torch.full((B, topk), -1.0, dtype=torch.float32, device=dev)
+            cnt = torch.zeros((B,), dtype=torch.int64, device=dev)
+        pt, S = (d_t.data_ptr(), d_t.numel()) if sub else (0, 0)
+        if kind == "lin":
+            g.query_linear_dev(dq.data_ptr(), B, topk, pt, S, ids.data_ptr(), d.data_ptr(), st.cuda_stream)
+        else:
+            g.query_ivf_dev(dq.data_ptr(), B, topk, pt, S, 300, ids.data_ptr(), d.data_ptr(), cnt.data_ptr(), st.cuda_stream)
+        return ids, d, cnt
+
+    def round_(n_calls):
+        qb = [qs[i * 96:(i + 1) * 96] for i in range(3)]
+        dq = [torch.from_numpy(q).to(dev) for q in qb]
+        wants = {(k, i): want(*k, qb[i]) for k in kinds for i in range(3)}
+        torch.cuda.synchronize()
+        got = []
+        for c in range(n_calls):
+            k, i = kinds[c % len(kinds)], c % 3
+            got.append((k, i, issue(*k, dq[i], streams[c % nstreams])))
+            if c == n_calls // 2:            # a host-pointer call in the middle (engine's own stream, synchronous)
+                h = g.query_linear_batch(qb[0], 1, None)
+                assert np.array_equal(h[0], wants[(kinds[0], 0)][0])
+        torch.cuda.synchronize()
+        for k, i, (ids, d, cnt) in got:
+            w = wants[(k, i)]
+            if k[0] == "lin":
+                assert np.array_equal(ids.cpu().numpy(), w[0]) and np.array_equal(d.cpu().numpy(), w[1]), (k, i)
+            else:
+                n = cnt.cpu().numpy()
+                assert np.array_equal(n, w[2]), (k, i)
+                for b in range(len(n)):
+                    assert np.array_equal(ids[b, :n[b]].cpu().numpy(), w[0][b, :n[b]]), (k, i, b)
+                    assert np.array_equal(d[b, :n[b]].cpu().numpy(), w[1][b, :n[b]]), (k, i, b)
+
+    round_(18)
+    g.add_codes(codes[60000:], True)          # mutation between rounds: waits for both lanes
+    round_(13)
+
+
 @pytest.mark.parametrize("M,N", [(32, 70000), (16, 66000), (8, 65536 + 1000), (12, 67000), (64, 66500)])
 def test_scan_order_does_not_change_results(M, N):
     """The filter stage scans an LDS-friendly permutation of the codes (scanorder.hip); ids, distances and tie-breaks must
