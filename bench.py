@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--topk", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-call", action="store_true")
+    ap.add_argument("--no-fresh", action="store_true",
+                    help="skip the extra measurement with a different query batch every step")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra two-stream measurement (reported beside `value`, never as it)")
     ap.add_argument("--latency", action="store_true",
@@ -421,6 +423,29 @@ def main():
         host = {"ms_per_step": he / args.steps * 1e3, "value": B * args.steps / he, "unit": "queries/s",
                 "what": "rii_query_%s with host pointers: H2D of %d B of queries, the step, D2H of %d B of results, "
                         "one synchronisation per call" % ("ivf" if ivf else "linear", hq.nbytes, B * topk * 12 + (8 * B if ivf else 0))}
+    # A different batch every step (the timed loop above re-submits one batch; the engine caches nothing between calls --
+    # tables are rebuilt per call -- so this is the same number, measured rather than argued)
+    fresh = None
+    if world == 1 and not args.no_fresh:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(4242)
+        pool = [my_q] + [(my_q + 8.0 * torch.randn(my_q.shape, device=dev, generator=gen)).contiguous() for _ in range(7)]
+        torch.cuda.synchronize()
+        it_f = [0]
+
+        def step_fresh():
+            run(pool[it_f[0] % len(pool)])
+            it_f[0] += 1
+
+        for _ in range(max(args.warmup, 1)):
+            step_fresh()
+        fe = timed_loop(step_fresh, args.steps, barrier)
+        fresh = {"value": B * args.steps / fe, "unit": "queries/s", "ms_per_step": fe / args.steps * 1e3,
+                 "what": "%d distinct query batches in rotation, one stream" % len(pool)}
+        run(my_q)
+        torch.cuda.synchronize()
+        del pool
+
     # The same K steps issued alternately on two HIP streams: the engine keeps one scratch lane per stream (engine.hip:
     # ScratchSet), so the latency-bound phases of one step (table build, re-rank, launch gaps) overlap the other step's
     # scan.  Reported beside `value`; `value` and the roofline stay the one-stream numbers.  The second stream answers the
@@ -505,6 +530,8 @@ def main():
                                    "collective_share": max(0.0, 1.0 - elapsed / elapsed_g)}
         if host is not None:
             line["host_call"] = host
+        if fresh is not None:
+            line["fresh_queries"] = fresh
         if pipe is not None:
             line["pipelined"] = pipe
         if world == 1 and not args.no_cpu_baseline:

@@ -162,6 +162,7 @@ struct rii_engine : ScratchSet {
 
     int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
+    int scan_mx = 1;            // option "scan_mx": 1 = rotated shapes scan with fscan_mx_kernel (its own lookup order), 0 = fscan_kernel
     int64_t scan_cov = 0;       // codes [0, scan_cov) are final (whole windows)
     int64_t scan_N = -1;        // N the order was last completed for
     bool have_symtab = false, have_cnorm = false, lists_dirty = true;
@@ -409,10 +410,11 @@ int ensure_fcodes(rii_engine *e, hipStream_t st)
 {
     if (e->fc_cov == e->N) return RII_OK;
     const size_t per = (size_t) e->M * 2;
-    RII_TRY(e->d_fcodes.ensure((size_t) e->N * per, (size_t) e->fc_cov * per, st));
+    RII_TRY(e->d_fcodes.ensure((size_t) fcodes_padded(e->N, e->scan_mx) * per, (size_t) fcodes_padded(e->fc_cov, e->scan_mx) * per, st));
     {
         ScopedTimer t(e, "format", st);
-        HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), nullptr, e->fc_cov, e->N, e->M, e->Ks, e->d_fcodes.as<uint16_t>(), st));
+        HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), nullptr, e->fc_cov, e->N, e->M, e->Ks, e->d_fcodes.as<uint16_t>(),
+                                     e->scan_mx, st));
     }
     e->fc_cov = e->N;
     HIP_TRY(hipStreamSynchronize(st));      // index-side state: the other lane's stream may read it next
@@ -506,7 +508,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
         int64_t len = std::max<int64_t>(1, (n_codes + c - 1) / c);
         len = (len + 1023) / 1024 * 1024;                                 // chunks start on a block-iteration boundary
         const int chunks = (int) ((n_codes + len - 1) / len);
-        const int64_t G = (int64_t) chunks * 1024;                        // lane segments per query (top-k passes)
+        const int64_t G = (int64_t) chunks * fscan_segments_per_chunk(e->M, e->Ks, e->scan_mx);   // lane segments per query (top-k passes)
         // pass 1 of top-k only has to bound the k-th smallest quantised sum from above: a 1-in-`stride` sample of the
         // 1024-code slabs does (its k-th smallest is the ~(stride*k)-th smallest overall: a few more candidates, 1/stride
         // of the pass).  Needs enough sampled codes per lane segment for the bound to be tight and k distinct winners.
@@ -529,9 +531,10 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
             if (fs_rot_supported(e->M, e->Ks)) {
                 // conflict-free rotated layout: the scan reads formatted lookups, the exact stages index the database
                 if (S) {
-                    RII_TRY(e->s_fsub.ensure((size_t) S * e->M * 2));
+                    RII_TRY(e->s_fsub.ensure((size_t) fcodes_padded(S, e->scan_mx) * e->M * 2));
                     ScopedTimer t(e, "gather", st);
-                    HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), d_remap, 0, S, e->M, e->Ks, e->s_fsub.as<uint16_t>(), st));
+                    HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), d_remap, 0, S, e->M, e->Ks, e->s_fsub.as<uint16_t>(),
+                                                 e->scan_mx, st));
                     d_scan = e->s_fsub.as<uint8_t>();
                     indirect = 1;
                 } else {
@@ -572,7 +575,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                     HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
-                                         e->s_gthr.as<uint32_t>(), 1, st));
+                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st));
                 }
                 ScopedTimer t(e, "rerank", st);
                 HIP_TRY(launch_rerank_top1(d_rr, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
@@ -588,7 +591,8 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
             {
                 ScopedTimer t(e, "scan", st);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
-                                     chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride, st));
+                                     chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride,
+                                     e->scan_mx, st));
             }
             {
                 ScopedTimer t(e, "kth", st);
@@ -599,7 +603,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
-                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, st));
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st));
             }
             RII_TRY(tie_list_reset(e, B, st));
             {
@@ -1501,6 +1505,11 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->ivf_force_exact = value ? 1 : 0;
     } else if (k == "scan_order") {
         e->scan_order = value ? 1 : 0;
+    } else if (k == "scan_mx") {
+        HIP_TRY(hipSetDevice(e->device));
+        RII_TRY(begin_exclusive(e));
+        e->scan_mx = value ? 1 : 0;
+        e->fc_cov = 0;                  // the formatted lookups are laid out per kernel
     } else if (k == "lanes") {
         if (value != 1 && value != 2) return set_err(RII_ERR_INVALID, "lanes must be 1 or 2");
         HIP_TRY(hipSetDevice(e->device));
@@ -1531,6 +1540,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_force_exact") return e->ivf_force_exact;
     if (k == "scan_order") return e->scan_order;
     if (k == "lanes") return e->lanes;
+    if (k == "scan_mx") return e->scan_mx;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;

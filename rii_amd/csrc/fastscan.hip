@@ -427,11 +427,22 @@ __global__ __launch_bounds__(256) void fcodes_format_kernel(const uint8_t *__res
     }
 }
 
+// fscan_mx_kernel's order of the lookups (defined next to that kernel)
+__global__ void fcodes_mx_format_kernel(const uint8_t *__restrict__ codes, const int64_t *__restrict__ ids, int64_t n0, int64_t n1,
+                                        int M, uint16_t *__restrict__ out);
+
 // formats codes [n0, n1) (or the gathered codes ids[n0..n1)) for the filter scan of an (M, Ks) index
 hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, int64_t n0, int64_t n1, int M, int Ks,
-                                uint16_t *d_out, hipStream_t st)
+                                uint16_t *d_out, int mx, hipStream_t st)
 {
     if (n1 <= n0) return hipSuccess;
+    if (mx) {              // fscan_mx_kernel's order: whole groups of 16 codes, starting at the group n0 falls into
+        n0 = n0 / 16 * 16;
+        const int64_t tot = ((n1 + 15) / 16 * 16 - n0) * M;
+        const int nb = (int) std::min<int64_t>((tot + 255) / 256, 16384);
+        hipLaunchKernelGGL(fcodes_mx_format_kernel, dim3(nb), dim3(256), 0, st, d_codes, d_ids, n0, n1, M, d_out);
+        return hipGetLastError();
+    }
     const int G = fastscan_rows(M, Ks) == 16 ? 16 : 32;
     const int sh = G == 16 ? 4 : 5;                    // value = (half, ks, slot): ks above the log2(G) slot bits
     const int64_t total = (n1 - n0) * M;
@@ -1248,10 +1259,349 @@ bool fs_rot_supported(int M, int Ks)
     return qr == 16 && (M == 16 || M == 32);
 }
 
-template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chunks, bool rot, hipStream_t st)
+// =====================================================================================================================
+// fscan_mx_kernel: the filter scan of the rotated shapes (Ks = 256, 16-byte rows, M = 16 / 32) with the byte sums taken by
+// the matrix cores.
+//
+// fscan_kernel above spends 128 of its ~207 VALU instructions per 64 codes on adding table bytes; it is bound by VALU issue
+// with the LDS half idle.  v_smfmac_i32_16x16x128_i8 can do those additions: its dense operand takes 32 bytes per lane --
+// TWO table rows as the ds_read_b128 delivered them -- and with the sparse operand set to a one-hot pattern
+//     A[i][k] = 1  <=>  k is byte i or byte 16 + i of a lane's 32          (row i of the output = query i of the tile)
+// the instruction computes  D[i][n] = sum over the four lanes 16 g + n (g = 0..3) of (row0[i] + row1[i]):  the eight rows
+// four lanes fetched for code n, summed per query, as 32-bit integers, already transposed (lane 16 (i / 4) + n holds queries
+// 4 (i / 4) .. + 3 of code n in its four accumulator registers).  No byte packing, no carries, no widening: M / 8 matrix
+// instructions per 16 codes replace all the additions.  (Operand semantics probed on the device: tools/ubench/
+// smfmac_probe.hip, mfma_reduce.hip.  This is not a GEMM in disguise: 1/16 of the multiplier array does useful work, the
+// instruction is used as a 128-input adder tree with a free transpose.)
+//
+// Work split: a wave owns groups of 16 consecutive codes; lane (g, n) = 16 g + n fetches M / 4 of code n's M rows.  Which
+// ones is chosen so that every ds_read_b128 service group of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32) meets 16
+// different bank slots whatever the data: with the rotated table layout (slot = subspace mod 16) lookup t of lane (g, n) is
+//     subspace 16 (t / 4) + (n + 4 (t mod 4) + e(g, n)) mod 16,   e = (g & 1) ^ [n in 4..11]  +  2 (g >> 1),
+// (per code the four lanes cover offsets e = 0..3 once each; inside a service group the lanes of one g form either
+// {0-3,12-15} or {4-11} and a common shift keeps 16 columns on 16 slots).  The order is baked into the formatted lookups
+// (fcodes_mx_format_kernel): per group 64 lanes x M / 4 lookups of 16 bits, one coalesced 1 KB (M = 32) load per wave.
+// =====================================================================================================================
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+
+__host__ __device__ __forceinline__ int fs_mx_subspace(int g, int col, int t)
+{
+    const int in_mid = (col >= 4 && col < 12) ? 1 : 0;
+    const int e = ((g & 1) ^ in_mid) + 2 * (g >> 1);
+    return 16 * (t >> 2) + ((col + 4 * (t & 3) + e) & 15);
+}
+
+// codes [n][M] u8 -> [group = n / 16][lane = 16 g + n % 16][t] u16 (half, ks, slot) row indices; positions in [n1, end of
+// the last group) are filled with row 0 (their sums are never judged).  n0 must be a multiple of 16.
+__global__ __launch_bounds__(256) void fcodes_mx_format_kernel(const uint8_t *__restrict__ codes, const int64_t *__restrict__ ids,
+                                                               int64_t n0, int64_t n1, int M, uint16_t *__restrict__ out)
+{
+    const int T = M / 4;
+    const int64_t n1p = (n1 + 15) / 16 * 16;
+    const int64_t total = (n1p - n0) * M;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        // consecutive threads write consecutive lookups: i = ((group * 64 + lane) * T + t) relative to n0's group
+        const int t = (int) (i % T);
+        const int64_t gl = i / T;
+        const int lane = (int) (gl & 63);
+        const int64_t n = n0 + (gl >> 6) * 16 + (lane & 15);
+        const int m = fs_mx_subspace(lane >> 4, lane & 15, t);
+        uint32_t ks = 0;
+        if (n < n1) {
+            const int64_t src = ids ? ids[n] : n;
+            ks = codes[(size_t) src * M + m];
+        }
+        out[(size_t) n0 * M + i] = (uint16_t) (((uint32_t) (m >> 4) << 12) | (ks << 4) | (uint32_t) (m & 15));
+    }
+}
+
+// the compressed one-hot operand for output row i (see the header comment): stored bytes 2 (i / 4) and 8 + 2 (i / 4) are 1 and
+// carry the 2-bit index i % 4; the other stored bytes are 0 (their indices only have to differ from their pair's)
+__device__ __forceinline__ void fs_mx_pattern(int i, v4i_t &a, int &idx)
+{
+    const int s1 = 2 * (i >> 2), s2 = 8 + s1;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    uint32_t x = 0u;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        const bool one = (f == s1 || f == s2), pair = ((f ^ 1) == s1 || (f ^ 1) == s2);
+        if (one) w[f >> 2] |= 1u << (8 * (f & 3));
+        const uint32_t v = one ? (uint32_t) (i & 3) : pair ? (uint32_t) ((i + 2) & 3) : (uint32_t) (f & 1);
+        x |= v << (2 * f);
+    }
+    a = v4i_t{(int) w[0], (int) w[1], (int) w[2], (int) w[3]};
+    idx = (int) x;
+}
+
+typedef const __attribute__((address_space(3))) v4i_t *fs_lds_row_t;
+// the row a 16-bit formatted lookup names (J = which half of the dword): dynamic LDS starts at address 0 in this kernel, so
+// (lookup << 4) IS the LDS address; the SDWA shift selects the half on the way in (one VALU instruction per row)
+template <int J> __device__ __forceinline__ v4i_t fs_mx_row(uint32_t w)
+{
+    uint32_t addr;
+    if constexpr (J == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(w));
+    return *(fs_lds_row_t) (uintptr_t) addr;
+}
+template <int T> struct FsMxW;                                      // the T lookups of a lane for one group
+template <> struct FsMxW<8> { typedef uint4 V; };
+template <> struct FsMxW<4> { typedef uint2 V; };
+template <int T> __device__ __forceinline__ void fs_mx_issue(const typename FsMxW<T>::V &w, v4i_t (&r)[T])
+{
+    r[0] = fs_mx_row<0>(w.x); r[1] = fs_mx_row<1>(w.x);
+    r[2] = fs_mx_row<0>(w.y); r[3] = fs_mx_row<1>(w.y);
+    if constexpr (T == 8) {
+        r[4] = fs_mx_row<0>(w.z); r[5] = fs_mx_row<1>(w.z);
+        r[6] = fs_mx_row<0>(w.w); r[7] = fs_mx_row<1>(w.w);
+    }
+}
+template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce(const v4i_t (&r)[T], const v4i_t &spa, int spidx)
+{
+    v4i_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < T; t += 2) {
+        const v8i_t b = __builtin_shufflevector(r[t], r[t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+    }
+    return acc;
+}
+
+constexpr int kFsMxSeg = 256;        // MODE 1 segments per chunk and query: (wave, column) pairs
+
+// grid = (chunks, ceil(B / 16)), 1024 threads.  Thresholds: 16 words in LDS, candidate <=> a < thr (thr = bound + slack + 1).
+template <int T, int MODE>
+__global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
+{
+    constexpr int M = 4 * T, QR = 16;
+    typedef typename FsMxW<T>::V W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, tile = blockIdx.y;
+    constexpr size_t lut_bytes = (size_t) M * 256 * QR;
+    uint32_t *s_thr = reinterpret_cast<uint32_t *>(smem + lut_bytes);                       // [16]
+    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(smem + lut_bytes + 64);                  // [16] staged, [16] global bases
+    unsigned long long *s_lcand = reinterpret_cast<unsigned long long *>(smem + lut_bytes + 64 + QR * 8);
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
+        uint4 *d4 = reinterpret_cast<uint4 *>(smem);
+        for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
+        if (tid < QR) {
+            // queries past the end of the batch (last tile) get threshold 0: they never hit
+            const int b = tile * QR + tid;
+            uint32_t t = b < p.B ? 0xffffu : 0u;
+            if constexpr (MODE == 2) t = b < p.B ? p.thr16[b] : 0u;
+            s_thr[tid] = t;
+        }
+        if (tid < 2 * QR) s_lcnt[tid] = 0u;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, col = lane & 15, gq = lane >> 4;      // this lane judges queries 4 gq .. 4 gq + 3
+    v4i_t spa;
+    int spidx;
+    fs_mx_pattern(col, spa, spidx);
+
+    const int64_t c_begin = (int64_t) blockIdx.x * p.chunk_len;         // a multiple of 1024
+    int64_t c_end = c_begin + p.chunk_len;
+    if (c_end > p.n_codes) c_end = p.n_codes;
+    const int64_t span = c_end > c_begin ? c_end - c_begin : 0;
+    const int full = (int) (span / kFsThreads);                         // trips of 64 whole groups (1024 codes)
+    const int tail_groups = (int) ((span - (int64_t) full * kFsThreads + 15) / 16);
+    const W *fc = reinterpret_cast<const W *>(p.codes) + (size_t) (c_begin / 16) * 64 + lane;
+
+    auto emit = [&](int q, uint32_t a, uint32_t t, int64_t n) {
+        const int b = tile * QR + q;
+        if (b >= p.B) return;
+        if constexpr (MODE == 0) {
+            const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
+            if (nt < t) {
+                atomicMin(&s_thr[q], nt);
+                atomicMin(&p.gthr[b], nt);       // let the other chunks of this tile prune with it too
+            }
+        }
+        const unsigned long long rec = ((unsigned long long) a << 32) | (uint32_t) n;
+        bool staged = false;
+        if (p.lcap > 0) {
+            const unsigned int lp = atomicAdd(&s_lcnt[q], 1u);
+            if (lp < (unsigned int) p.lcap) { s_lcand[(size_t) q * p.lcap + lp] = rec; staged = true; }
+        }
+        if (!staged) {
+            const unsigned int pos = atomicAdd(&p.cand_count[b], 1u);
+            if (pos < (unsigned int) p.cap) p.cand[(size_t) b * p.cap + pos] = rec;
+        }
+    };
+    // the sums of one group (code n = first + col) against the thresholds
+    auto judge = [&](const v4i_t &acc, const v4i_t &thr, int64_t n) {
+        const bool h0 = acc[0] < thr[0], h1 = acc[1] < thr[1], h2 = acc[2] < thr[2], h3 = acc[3] < thr[3];
+        if (h0 | h1 | h2 | h3) {
+            // rare path: walk the queries that hit (usually exactly one), one emission site
+            uint32_t mask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
+            while (mask) {
+                const int r = __ffs((int) mask) - 1;
+                mask &= mask - 1u;
+                const int a = r == 0 ? acc[0] : r == 1 ? acc[1] : r == 2 ? acc[2] : acc[3];
+                const int t = r == 0 ? thr[0] : r == 1 ? thr[1] : r == 2 ? thr[2] : thr[3];
+                emit(4 * gq + r, (uint32_t) a, (uint32_t) t, n);
+            }
+        }
+    };
+    v4i_t keep = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};     // MODE 0: warm-up minima; MODE 1: segment minima
+    auto take_min = [&](const v4i_t &acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[r] = acc[r] < keep[r] ? acc[r] : keep[r];
+    };
+    // MODE 0 warm-up: the minima of the block's first trip become the first thresholds
+    auto publish = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int v = keep[r];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const int o = __shfl_xor(v, off);
+                v = o < v ? o : v;
+            }
+            const int b = tile * QR + 4 * gq + r;
+            if (col == 0 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[4 * gq + r], fs_thr_of((uint32_t) v, (uint32_t) p.slack[b]));
+        }
+    };
+    auto load_thr = [&]() { return *reinterpret_cast<const v4i_t *>(s_thr + 4 * gq); };
+    // adopt thresholds published by the blocks scanning the other chunks for the same queries (stale = a few more candidates)
+    auto adopt = [&](bool first) {
+        if (MODE == 0 && tid < QR) {
+            const int b = tile * QR + tid;
+            if (b < p.B) {
+                const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (first) {
+                    const uint32_t mine = s_thr[tid];
+                    if (mine < g) atomicMin(&p.gthr[b], mine);
+                }
+                atomicMin(&s_thr[tid], g);
+            }
+        }
+    };
+    // one group at a time (warm-up, tail): group index gi counted from the chunk's first group
+    auto slow_group = [&](int64_t gi, bool minima, const v4i_t &thr) {
+        const W w = fc[(size_t) gi * 64];
+        v4i_t r[T];
+        fs_mx_issue<T>(w, r);
+        v4i_t acc = fs_mx_reduce<T>(r, spa, spidx);
+        const int64_t n = c_begin + gi * 16 + col;
+        if (n >= c_end) acc = v4i_t{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};     // columns past the end are never judged
+        if (minima) take_min(acc);
+        else judge(acc, thr, n);
+    };
+    auto tail = [&](bool minima) {
+        const v4i_t thr = load_thr();
+        for (int gi = wave; gi < tail_groups; gi += kFsThreads / 64) slow_group((int64_t) full * 64 + gi, minima, thr);
+    };
+
+    // MODE 0 warm-up: the minima of the chunk's first trip (or of the tail, when that is all there is) become the first
+    // thresholds before anything is judged; that trip is then judged LAST, with thresholds that know the whole chunk
+    if constexpr (MODE == 0) {
+        if (full > 0) {
+            const v4i_t none = {0, 0, 0, 0};
+            for (int j = 0; j < 4; ++j) slow_group(wave * 4 + j, true, none);
+        } else {
+            tail(true);
+        }
+        publish();
+        __syncthreads();
+        adopt(true);
+        __syncthreads();
+    }
+    // whole trips, software-pipelined: a wave takes four consecutive groups per trip; the rows of group j + 1 are in flight
+    // while the matrix instructions of group j run, the lookups of the next trip's groups while this trip's are consumed.
+    // Order: MODE 0: 1, 2, .., full - 1, 0;  MODE 2: 0 .. full - 1;  MODE 1: every sample_stride-th (an upper bound needs
+    // only a sample)
+    const int step = (MODE == 1) ? p.sample_stride : 1;
+    const int ntrip = (MODE == 1) ? (full + step - 1) / step : full;
+    auto trip_of = [&](int k) { return (MODE == 0) ? (k + 1 < full ? k + 1 : 0) : k * step; };
+    if (ntrip > 0) {
+        const W *pw = fc + (size_t) wave * 4 * 64;
+        W w[4];
+        {
+            const W *p0 = pw + (size_t) trip_of(0) * 64 * 64;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = p0[j * 64];
+        }
+        v4i_t ra[T], rb[T];
+        fs_mx_issue<T>(w[0], ra);
+        for (int k = 0; k < ntrip; ++k) {
+            const int it = trip_of(k);
+            // the trip after this one (the last trip re-reads its own lookups: always a valid address, never used)
+            const W *pn = pw + (size_t) trip_of(k + 1 < ntrip ? k + 1 : k) * 64 * 64;
+            const v4i_t thr = load_thr();
+            const int64_t n = c_begin + (int64_t) it * kFsThreads + wave * 64 + col;
+            v4i_t acc;
+            w[0] = pn[0];                         // group 0's lookups were consumed at the end of the previous trip
+            fs_mx_issue<T>(w[1], rb);
+            w[1] = pn[64];
+            acc = fs_mx_reduce<T>(ra, spa, spidx);
+            if (MODE == 1) take_min(acc); else judge(acc, thr, n);
+            fs_mx_issue<T>(w[2], ra);
+            w[2] = pn[128];
+            acc = fs_mx_reduce<T>(rb, spa, spidx);
+            if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
+            fs_mx_issue<T>(w[3], rb);
+            w[3] = pn[192];
+            acc = fs_mx_reduce<T>(ra, spa, spidx);
+            if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
+            fs_mx_issue<T>(w[0], ra);
+            acc = fs_mx_reduce<T>(rb, spa, spidx);
+            if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
+            adopt(false);
+        }
+    }
+    tail(MODE == 1);
+
+    if (MODE == 0 && p.lcap > 0) {
+        __syncthreads();
+        if (tid < QR) {
+            const int b = tile * QR + tid;
+            const unsigned int c = min(s_lcnt[tid], (unsigned int) p.lcap);
+            s_lcnt[QR + tid] = (c && b < p.B) ? atomicAdd(&p.cand_count[b], c) : 0u;
+        }
+        __syncthreads();
+        for (int q = tid >> 6; q < QR; q += kFsThreads >> 6) {        // one wave per query
+            const int b = tile * QR + q;
+            const unsigned int c = min(s_lcnt[q], (unsigned int) p.lcap), base = s_lcnt[QR + q];
+            for (unsigned int i = tid & 63; i < c; i += 64)
+                if (base + i < (unsigned int) p.cap) p.cand[(size_t) b * p.cap + base + i] = s_lcand[(size_t) q * p.lcap + i];
+        }
+    }
+    if constexpr (MODE == 1) {
+        const size_t G = (size_t) gridDim.x * kFsMxSeg;
+        const size_t seg = (size_t) blockIdx.x * kFsMxSeg + wave * 16 + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = tile * QR + 4 * gq + r;
+            if (b < p.B) p.segmin[(size_t) b * G + seg] = (uint16_t) (keep[r] > 0xffff ? 0xffff : keep[r]);
+        }
+    }
+}
+
+template <int T, int MODE> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
+{
+    constexpr int QR = 16;
+    const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8;
+    FsArgs b = a;
+    b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) QR * 8));
+    const size_t smem = tab + (size_t) QR * 8 * b.lcap;
+    auto kern = fscan_mx_kernel<T, MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
+    return hipGetLastError();
+}
+
+template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chunks, bool rot, bool mx, hipStream_t st)
 {
     const int qr = fastscan_rows(a.M, a.Ks);
     const int tiles = (a.B + qr - 1) / qr;
+    if (rot && mx) {
+        if (a.M == 16) return launch_fscan_mx_t<4, MODE>(a, chunks, tiles, st);
+        if (a.M == 32) return launch_fscan_mx_t<8, MODE>(a, chunks, tiles, st);
+        return hipErrorInvalidValue;
+    }
     if (rot) {
         if (qr == 16 && a.M == 16) return launch_fscan_t<4, 256, MODE, 16, true>(a, chunks, tiles, st);
         if (qr == 16 && a.M == 32) return launch_fscan_t<8, 256, MODE, 16, true>(a, chunks, tiles, st);
@@ -1270,9 +1620,9 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, hipStream_t st)
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st)
 {
-    // d_codes: formatted lookups (launch_fcodes_format) for fs_rot_supported shapes, the plain codes otherwise
+    // d_codes: formatted lookups (launch_fcodes_format, same `mx`) for fs_rot_supported shapes, the plain codes otherwise
     if (B == 0 || n_codes == 0) return hipSuccess;
     const bool rot = fs_rot_supported(M, Ks);
     FsArgs a;
@@ -1281,9 +1631,15 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
     a.chunk_len = chunk_len; a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.segmin = d_segmin;
     a.thr16 = d_thr16;
-    if (mode == 1) return launch_fscan_mode<1>(a, chunks, rot, st);
-    if (mode == 2) return launch_fscan_mode<2>(a, chunks, rot, st);
-    return launch_fscan_mode<0>(a, chunks, rot, st);
+    if (mode == 1) return launch_fscan_mode<1>(a, chunks, rot, mx != 0, st);
+    if (mode == 2) return launch_fscan_mode<2>(a, chunks, rot, mx != 0, st);
+    return launch_fscan_mode<0>(a, chunks, rot, mx != 0, st);
+}
+
+// lane segments per chunk and query of the MODE 1 pass (the G of launch_kth_threshold is chunks times this)
+int fscan_segments_per_chunk(int M, int Ks, int mx) { return (mx && fs_rot_supported(M, Ks)) ? kFsMxSeg : kFsThreads; }
+// codes the formatted copy must hold for n codes (the mx format is written in whole groups of 16)
+int64_t fcodes_padded(int64_t n, int mx) { return mx ? (n + 15) / 16 * 16 : n;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -133,8 +133,11 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, hipStream_t st);
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st);
 int fastscan_max_sum(int M);
+// mx != 0: the rotated shapes run fscan_mx_kernel (byte sums on the matrix cores) over its own order of the formatted lookups
+int fscan_segments_per_chunk(int M, int Ks, int mx);
+int64_t fcodes_padded(int64_t n, int mx);
 // tables of the rotated shapes built by tile (fastscan.hip): exact fp32 [b][M*Ks] + rotated byte rows + slack in two launches
 bool lut_tile_supported(int M, int Ks, int Ds);
 hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, float *d_lut,
@@ -143,7 +146,7 @@ hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const 
 // conflict-free rotated table layout + formatted code copy (see fastscan.hip): launch_fscan then takes the formatted codes
 bool fs_rot_supported(int M, int Ks);
 hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, int64_t n0, int64_t n1, int M, int Ks,
-                                uint16_t *d_out, hipStream_t st);
+                                uint16_t *d_out, int mx, hipStream_t st);
 int rerank_topk_max_k();
 hipError_t launch_kth_threshold(const uint16_t *d_segmin, int64_t G, int64_t B, int k, int maxv, const int32_t *d_slack,
                                 uint32_t *d_thr16, hipStream_t st);
