@@ -131,6 +131,7 @@ def _lib():
         "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
         "rii_dtable": (c_int, [c_vp, f32p, c_i64, f32p]),
         "rii_assign": (c_int, [c_vp, u8p, c_i64, i32p]),
+        "rii_fscan_lane_subspace": (c_int, [c_int, c_int, c_int]),
         "rii_set_option": (c_int, [c_vp, ctypes.c_char_p, c_i64]),
         "rii_get_option": (c_i64, [c_vp, ctypes.c_char_p]),
         "rii_timing_read": (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), i64p]),
@@ -162,6 +163,11 @@ def ivf_shard_replay_dev(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, 
     """std::partial_sort replayed over the gathered candidate sequences of nf tie-flagged queries (include/rii_amd.h)."""
     _check(_lib().rii_ivf_shard_replay_dev(d_gathered, int(G), int(nf), int(rows), int(topk), d_out_ids, d_out_dists,
                                            stream or None))
+
+
+def fscan_lane_subspace(M, lane, t):
+    """Subspace whose table row lane `lane` of a wave fetches as lookup t in fscan_mx_kernel (host-only introspection)."""
+    return int(_lib().rii_fscan_lane_subspace(int(M), int(lane), int(t)))
 
 
 def exported_symbols():

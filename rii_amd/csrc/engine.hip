@@ -1484,6 +1484,12 @@ RII_API int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *
     return RII_OK;
 }
 
+RII_API int rii_fscan_lane_subspace(int M, int lane, int t)
+{
+    if ((M != 16 && M != 32) || lane < 0 || lane > 63 || t < 0 || t >= M / 4) return -1;
+    return fscan_mx_subspace(lane, t);
+}
+
 RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
 {
     if (!e || !key) return set_err(RII_ERR_INVALID, "bad arguments");

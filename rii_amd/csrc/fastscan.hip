@@ -1345,8 +1345,17 @@ template <int J> __device__ __forceinline__ v4i_t fs_mx_row(uint32_t w)
     return *(fs_lds_row_t) (uintptr_t) addr;
 }
 template <int T> struct FsMxW;                                      // the T lookups of a lane for one group
-template <> struct FsMxW<8> { typedef uint4 V; };
-template <> struct FsMxW<4> { typedef uint2 V; };
+template <> struct FsMxW<8> { typedef u32x4 V; };
+template <> struct FsMxW<4> { typedef u32x2 V; };
+__device__ __forceinline__ uint32_t fs_mx_z(const u32x4 &w) { return w.z; }
+__device__ __forceinline__ uint32_t fs_mx_z(const u32x2 &) { return 0u; }
+__device__ __forceinline__ uint32_t fs_mx_w(const u32x4 &w) { return w.w; }
+__device__ __forceinline__ uint32_t fs_mx_w(const u32x2 &) { return 0u; }
+// lookups of a later trip, fetched from asm for the same reason as the rows (the compiler would wait with vmcnt(0), i.e. for the
+// load it issued a moment ago): four loads are in flight per wave, every use has exactly three younger ones behind it
+template <int OFF> __device__ __forceinline__ void fs_mx_load(u32x4 &q, const u32x4 *p) { asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void fs_mx_load(u32x2 &q, const u32x2 *p) { asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF)); }
+template <int N, typename V> __device__ __forceinline__ void fs_mx_vmwait(V &q) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q) : "n"(N)); }
 template <int T> __device__ __forceinline__ void fs_mx_issue(const typename FsMxW<T>::V &w, v4i_t (&r)[T])
 {
     r[0] = fs_mx_row<0>(w.x); r[1] = fs_mx_row<1>(w.x);
@@ -1355,6 +1364,65 @@ template <int T> __device__ __forceinline__ void fs_mx_issue(const typename FsMx
         r[4] = fs_mx_row<0>(w.z); r[5] = fs_mx_row<1>(w.z);
         r[6] = fs_mx_row<0>(w.w); r[7] = fs_mx_row<1>(w.w);
     }
+}
+// The same, with hand-placed ds_read instructions and waits (the hot loop).  The compiler's own waitcnt bookkeeping loses
+// track of which loads are outstanding across the (rare) candidate branch and the loop edge and falls back to lgkmcnt(0) in
+// front of every group -- draining the reads issued for the NEXT group, i.e. one group in flight instead of two.  Issued
+// from asm the reads are invisible to it; fs_mx_wait names the registers that become valid (LDS returns in order, so the
+// compiler's own waits for its own LDS operations only get stricter).
+__device__ __forceinline__ void fs_mx_issue4(uint32_t w0, uint32_t w1, v4i_t &r0, v4i_t &r1, v4i_t &r2, v4i_t &r3)
+{
+    uint32_t a0, a1, a2, a3;
+    asm volatile("v_lshlrev_b32_sdwa %4, 4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                 "v_lshlrev_b32_sdwa %5, 4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                 "v_lshlrev_b32_sdwa %6, 4, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                 "v_lshlrev_b32_sdwa %7, 4, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                 "ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %5\n\t"
+                 "ds_read_b128 %2, %6\n\t"
+                 "ds_read_b128 %3, %7"
+                 : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                 : "v"(w0), "v"(w1));
+}
+// two rows (the two lookups of one formatted dword): what one matrix instruction consumes
+__device__ __forceinline__ void fs_mx_issue2(uint32_t w, v4i_t &r0, v4i_t &r1)
+{
+    uint32_t a0, a1;
+    asm volatile("v_lshlrev_b32_sdwa %2, 4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                 "v_lshlrev_b32_sdwa %3, 4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                 "ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %3"
+                 : "=v"(r0), "=v"(r1), "=&v"(a0), "=&v"(a1)
+                 : "v"(w));
+}
+// one group: the rows in r[] (already waited for) go through the matrix core pair by pair, and as soon as a pair has been
+// issued its registers take the rows of the group two ahead (lookups wn) -- the reads travel under the remaining matrix
+// instructions and the whole next group
+template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce_refill(v4i_t (&r)[T], const typename FsMxW<T>::V &wn, const v4i_t &spa, int spidx)
+{
+    v4i_t acc = {0, 0, 0, 0};
+    const uint32_t wd[4] = {wn.x, wn.y, fs_mx_z(wn), fs_mx_w(wn)};
+#pragma unroll
+    for (int t = 0; t < T; t += 2) {
+        const v8i_t b = __builtin_shufflevector(r[t], r[t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+        fs_mx_issue2(wd[t >> 1], r[t], r[t + 1]);
+    }
+    return acc;
+}
+template <int T> __device__ __forceinline__ void fs_mx_issue_hot(const typename FsMxW<T>::V &w, v4i_t (&r)[T])
+{
+    fs_mx_issue4(w.x, w.y, r[0], r[1], r[2], r[3]);
+    if constexpr (T == 8) fs_mx_issue4(w.z, w.w, r[4], r[5], r[6], r[7]);
+}
+// at most PENDING younger LDS operations stay outstanding: the rows named are valid after this
+template <int PENDING> __device__ __forceinline__ void fs_mx_wait(v4i_t (&r)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(PENDING));
+}
+template <int PENDING> __device__ __forceinline__ void fs_mx_wait(v4i_t (&r)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(PENDING));
 }
 template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce(const v4i_t (&r)[T], const v4i_t &spa, int spidx)
 {
@@ -1408,7 +1476,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     const int tail_groups = (int) ((span - (int64_t) full * kFsThreads + 15) / 16);
     const W *fc = reinterpret_cast<const W *>(p.codes) + (size_t) (c_begin / 16) * 64 + lane;
 
-    auto emit = [&](int q, uint32_t a, uint32_t t, int64_t n) {
+    auto emit = [&](int q, uint32_t a, uint32_t t, uint32_t n) {
         const int b = tile * QR + q;
         if (b >= p.B) return;
         if constexpr (MODE == 0) {
@@ -1418,7 +1486,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 atomicMin(&p.gthr[b], nt);       // let the other chunks of this tile prune with it too
             }
         }
-        const unsigned long long rec = ((unsigned long long) a << 32) | (uint32_t) n;
+        const unsigned long long rec = ((unsigned long long) a << 32) | n;
         bool staged = false;
         if (p.lcap > 0) {
             const unsigned int lp = atomicAdd(&s_lcnt[q], 1u);
@@ -1430,7 +1498,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
         }
     };
     // the sums of one group (code n = first + col) against the thresholds
-    auto judge = [&](const v4i_t &acc, const v4i_t &thr, int64_t n) {
+    auto judge = [&](const v4i_t &acc, const v4i_t &thr, uint32_t n) {
         const bool h0 = acc[0] < thr[0], h1 = acc[1] < thr[1], h2 = acc[2] < thr[2], h3 = acc[3] < thr[3];
         if (h0 | h1 | h2 | h3) {
             // rare path: walk the queries that hit (usually exactly one), one emission site
@@ -1487,7 +1555,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
         const int64_t n = c_begin + gi * 16 + col;
         if (n >= c_end) acc = v4i_t{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};     // columns past the end are never judged
         if (minima) take_min(acc);
-        else judge(acc, thr, n);
+        else judge(acc, thr, (uint32_t) n);
     };
     auto tail = [&](bool minima) {
         const v4i_t thr = load_thr();
@@ -1516,40 +1584,62 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     const int ntrip = (MODE == 1) ? (full + step - 1) / step : full;
     auto trip_of = [&](int k) { return (MODE == 0) ? (k + 1 < full ? k + 1 : 0) : k * step; };
     if (ntrip > 0) {
+        // Per wave the groups form one sequence g = 4 * trip + j.  Two register sets of T rows alternate (even / odd groups);
+        // while group g runs through the matrix core, the rows of g + 1 are in flight and those of g + 2 are being issued into
+        // g's own registers (fs_mx_reduce_refill).  q[j] holds the lookups of the next group of column j that still needs
+        // its rows fetched; it is reloaded right after use, a whole trip ahead of its next use.
         const W *pw = fc + (size_t) wave * 4 * 64;
-        W w[4];
-        {
-            const W *p0 = pw + (size_t) trip_of(0) * 64 * 64;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = p0[j * 64];
-        }
+        auto trip_ptr = [&](int k) { return pw + (size_t) trip_of(k < ntrip ? k : ntrip - 1) * 64 * 64; };   // past the end: a valid address, rows never used
         v4i_t ra[T], rb[T];
-        fs_mx_issue<T>(w[0], ra);
+        W q[4];
+        {
+            const W *p0 = trip_ptr(0), *p1 = trip_ptr(1);
+            const W g0 = p0[0], g1 = p0[64];
+            fs_mx_issue_hot<T>(g0, ra);
+            fs_mx_issue_hot<T>(g1, rb);
+            constexpr int S = 64 * (int) sizeof(W);
+            fs_mx_load<2 * S>(q[2], p0);        // in the order of their use: every use has three younger loads behind it
+            fs_mx_load<3 * S>(q[3], p0);
+            fs_mx_load<0>(q[0], p1);
+            fs_mx_load<S>(q[1], p1);
+        }
+        const uint32_t thr_addr = (uint32_t) (lut_bytes + 16 * gq);       // s_thr + 4 * gq as an LDS address (dynamic LDS starts at 0)
+        v4i_t thr;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(thr) : "v"(thr_addr));     // (not a compiler-visible load: it would be waited for inside the loop)
         for (int k = 0; k < ntrip; ++k) {
             const int it = trip_of(k);
-            // the trip after this one (the last trip re-reads its own lookups: always a valid address, never used)
-            const W *pn = pw + (size_t) trip_of(k + 1 < ntrip ? k + 1 : k) * 64 * 64;
-            const v4i_t thr = load_thr();
-            const int64_t n = c_begin + (int64_t) it * kFsThreads + wave * 64 + col;
+            const W *pn = trip_ptr(k + 1), *pnn = trip_ptr(k + 2);
+            const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;     // positions fit 32 bits (the records hold 32)
             v4i_t acc;
-            w[0] = pn[0];                         // group 0's lookups were consumed at the end of the previous trip
-            fs_mx_issue<T>(w[1], rb);
-            w[1] = pn[64];
-            acc = fs_mx_reduce<T>(ra, spa, spidx);
+            constexpr int S = 64 * (int) sizeof(W);                // bytes between the lookups of consecutive groups
+            fs_mx_vmwait<3>(q[2]);
+            fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
+            acc = fs_mx_reduce_refill<T>(ra, q[2], spa, spidx);   // ... refilled with group 2's rows
+            fs_mx_load<2 * S>(q[2], pn);
             if (MODE == 1) take_min(acc); else judge(acc, thr, n);
-            fs_mx_issue<T>(w[2], ra);
-            w[2] = pn[128];
-            acc = fs_mx_reduce<T>(rb, spa, spidx);
+            fs_mx_vmwait<3>(q[3]);
+            fs_mx_wait<T>(rb);                                    // group 1
+            acc = fs_mx_reduce_refill<T>(rb, q[3], spa, spidx);
+            fs_mx_load<3 * S>(q[3], pn);
             if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
-            fs_mx_issue<T>(w[3], rb);
-            w[3] = pn[192];
-            acc = fs_mx_reduce<T>(ra, spa, spidx);
+            // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
+            // of old and new words is a valid set of thresholds (each word is an upper bound at all times)
+            if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1" : "+v"(thr) : "v"(thr_addr));
+            fs_mx_vmwait<3>(q[0]);
+            fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
+            acc = fs_mx_reduce_refill<T>(ra, q[0], spa, spidx);   // next trip's group 0
+            fs_mx_load<0>(q[0], pnn);
             if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
-            fs_mx_issue<T>(w[0], ra);
-            acc = fs_mx_reduce<T>(rb, spa, spidx);
+            fs_mx_vmwait<3>(q[1]);
+            fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
+            acc = fs_mx_reduce_refill<T>(rb, q[1], spa, spidx);
+            fs_mx_load<S>(q[1], pnn);
             if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
             adopt(false);
         }
+        fs_mx_wait<0>(ra);            // the rows and lookups fetched past the last trip are never used, but must have landed
+        fs_mx_wait<0>(rb);
+        fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
     }
     tail(MODE == 1);
 
@@ -1636,6 +1726,7 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     return launch_fscan_mode<0>(a, chunks, rot, mx != 0, st);
 }
 
+int fscan_mx_subspace(int lane, int t) { return fs_mx_subspace(lane >> 4, lane & 15, t); }
 // lane segments per chunk and query of the MODE 1 pass (the G of launch_kth_threshold is chunks times this)
 int fscan_segments_per_chunk(int M, int Ks, int mx) { return (mx && fs_rot_supported(M, Ks)) ? kFsMxSeg : kFsThreads; }
 // codes the formatted copy must hold for n codes (the mx format is written in whole groups of 16)

@@ -137,6 +137,7 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
 int fastscan_max_sum(int M);
 // mx != 0: the rotated shapes run fscan_mx_kernel (byte sums on the matrix cores) over its own order of the formatted lookups
 int fscan_segments_per_chunk(int M, int Ks, int mx);
+int fscan_mx_subspace(int lane, int t);       // subspace whose table row lane `lane` of a wave fetches as its lookup t
 int64_t fcodes_padded(int64_t n, int mx);
 // tables of the rotated shapes built by tile (fastscan.hip): exact fp32 [b][M*Ks] + rotated byte rows + slack in two launches
 bool lut_tile_supported(int M, int Ks, int Ds);

@@ -544,6 +544,54 @@ def test_alternating_streams_share_scratch_safely():
         assert np.array_equal(ib.cpu().numpy(), want_b[0]) and np.array_equal(db.cpu().numpy(), want_b[1])
 
 
+@pytest.mark.parametrize("M", [32, 16])
+def test_matrix_core_scan_equals_vector_scan(M):
+    """fscan_mx_kernel (option scan_mx = 1, default: table bytes summed by v_smfmac) against fscan_kernel (scan_mx = 0) and the
+    exhaustive scan: identical ids and distances for top-1, top-k and subset search; sizes that end inside a group of 16
+    codes, inside a 1024-code trip, below one trip and below one group; appends that re-format a partial last group; exact
+    duplicates in the database (ties)."""
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(4100 + M)
+    cw = rng.random((M, 256, 4)).astype(np.float32)
+    N = 70000 + 13
+    codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
+    codes[rng.integers(0, N, 2000)] = codes[rng.integers(0, N, 2000)]
+    qs = rng.random((150, M * 4)).astype(np.float32)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    assert g.get_option("scan_mx") == 1
+
+    def both(topk, tids=None):
+        out = []
+        for mx, mode in ((1, 1), (0, 1), (1, 0)):
+            g.set_option("scan_mx", mx)
+            g.set_option("scan_mode", mode)
+            out.append(g.query_linear_batch(qs, topk, tids))
+        g.set_option("scan_mx", 1)
+        g.set_option("scan_mode", 1)
+        a, b, c = out
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (topk, g.N)
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), (topk, g.N)
+        return a
+
+    sizes = [7, 16, 100, 1024, 1500, 5000, 33000 + 5, 66000 + 9, N]          # cumulative appends
+    done = 0
+    for n in sizes:
+        g.add_codes(codes[done:n], False)
+        done = n
+        both(1)
+        if n >= 100:
+            both(min(10, n))
+        if n >= 5000:
+            both(100)
+            tids = np.sort(rng.choice(n, 3001, replace=False)).astype(np.int64)
+            both(1, tids)
+            both(7, tids)
+    g.clear()
+    g.add_codes(codes[:2049], False)
+    both(1)
+    both(5)
+
+
 @pytest.mark.parametrize("lanes,nstreams", [(2, 2), (2, 3), (1, 2)])
 def test_scratch_lanes_mixed_calls(lanes, nstreams):
     """Two scratch lanes (engine.hip: ScratchSet): calls that alternate between streams overlap on the device, each on its

@@ -82,7 +82,7 @@ template <int MODE> __global__ __launch_bounds__(1024) void rate(const uint4 *__
             uint32_t ad;
             if (t & 1) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(ad) : "v"(ws[t >> 1]));
             else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(ad) : "v"(ws[t >> 1]));
-            if (MODE == 2 || MODE == 5 || MODE == 7) rows[t] = v4i{(int) ad, (int) ad, (int) ad, (int) ad};
+            if (MODE == 2 || MODE == 5 || MODE == 7 || MODE == 8 || MODE == 9) rows[t] = v4i{(int) ad, (int) ad, (int) ad, (int) ad};
             else rows[t] = *reinterpret_cast<const v4i *>(smem + ad);
         }
     };
@@ -90,14 +90,24 @@ template <int MODE> __global__ __launch_bounds__(1024) void rate(const uint4 *__
     // positive int8), one MFMA per pair.  MODE 3: in fours (only meaningful as a rate: 4 x 63 overflows int8).
     auto reduce = [&](const v4i (&rows)[8]) {
         v4i acc = {0, 0, 0, 0};
-        if (MODE == 6 || MODE == 7) {
+        if (MODE == 10) {                      // two chains of two, joined by four adds
+            v4i acc2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const v8i b = {rows[2 * t][0], rows[2 * t][1], rows[2 * t][2], rows[2 * t][3],
+                               rows[2 * t + 1][0], rows[2 * t + 1][1], rows[2 * t + 1][2], rows[2 * t + 1][3]};
+                if (t & 1) acc2 = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc2, spidx, 0, 0);
+                else acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+            }
+            acc += acc2;
+        } else if (MODE == 6 || MODE == 7 || MODE == 8) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const v8i b = {rows[2 * t][0], rows[2 * t][1], rows[2 * t][2], rows[2 * t][3],
                                rows[2 * t + 1][0], rows[2 * t + 1][1], rows[2 * t + 1][2], rows[2 * t + 1][3]};
                 acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
             }
-        } else if (MODE == 0 || MODE == 2) {
+        } else if (MODE == 0 || MODE == 2 || MODE == 9) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(rows[t], onehot, acc, 0, 0, 0);
         } else if (MODE == 4 || MODE == 5) {          // no MFMA, one VALU op per row: the ceiling of the loads alone
@@ -116,6 +126,7 @@ template <int MODE> __global__ __launch_bounds__(1024) void rate(const uint4 *__
     // two groups' rows in flight: the reads of group j + 1 are issued before the MFMAs of group j (16 DS operations per wave)
     v4i ra[8], rb[8];
     issue(ra, w[0]);
+    if (MODE == 8 || MODE == 9) issue(rb, w[1]);
     for (int64_t g = wave * NG; g < groups_per_block; g += 16 * NG) {
         const uint4 *pn = p + 16 * NG * 64;
         uint4 cur[NG];
@@ -128,13 +139,74 @@ template <int MODE> __global__ __launch_bounds__(1024) void rate(const uint4 *__
         }
         p = pn;
         static_assert(NG == 4, "unrolled by hand");
-        issue(rb, cur[1]); reduce(ra);
-        issue(ra, cur[2]); reduce(rb);
-        issue(rb, cur[3]); reduce(ra);
-        if (more) issue(ra, w[0]);
-        reduce(rb);
+        if (MODE == 8 || MODE == 9) {          // matrix pipe alone: constant operands, nothing else in the loop
+            reduce(ra); reduce(rb); reduce(ra); reduce(rb);
+        } else {
+            issue(rb, cur[1]); reduce(ra);
+            issue(ra, cur[2]); reduce(rb);
+            issue(rb, cur[3]); reduce(ra);
+            if (more) issue(ra, w[0]);
+            reduce(rb);
+        }
     }
     if (hits == 0x7fffffff) out[0] = hits;
+    out[1 + blockIdx.x * 1024 + threadIdx.x] = hits;
+}
+
+// byte lookups: 8 bytes per lane and group (half the stream); address = per-lane constant (half, slot) with ks spliced in
+// as byte 1 by one v_perm_b32 per row
+__global__ __launch_bounds__(1024) void rate_bytes(const uint2 *__restrict__ fc, int64_t groups_per_block,
+                                                   const uint4 *__restrict__ table, int *out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int i = threadIdx.x; i < 8192; i += 1024) reinterpret_cast<uint4 *>(smem)[i] = table[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, g4 = lane >> 4;
+    const int thr = 40 + col;
+    v4i spa; int spidx;
+    sparse_pattern(col, spa, spidx);
+    const int in_mid = (col >= 4 && col < 12) ? 1 : 0;
+    const int e = ((g4 & 1) ^ in_mid) + 2 * (g4 >> 1);
+    uint32_t C[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) C[t] = ((uint32_t) (t >> 2) << 16) | ((uint32_t) ((col + 4 * (t & 3) + e) & 15) << 4);
+    int hits = 0;
+    constexpr int NG = 4;
+    const uint2 *p = fc + ((size_t) (blockIdx.x & 3) * groups_per_block + wave * NG) * 64 + lane;
+    uint2 w[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) w[j] = p[j * 64];
+    typedef const __attribute__((address_space(3))) v4i *lds_row;
+    auto issue = [&](v4i (&rows)[8], const uint2 &c) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            // result bytes: [C.b0, w.byte(t & 3), C.b2, C.b3]; v_perm_b32 selector bytes index {S0 = 4..7, S1 = 0..3}
+            const uint32_t sel = 0x07060004u | ((uint32_t) (t & 3) << 8);     // byte1 <- S1 (w) byte t&3; others <- S0 (C) bytes 4,6,7
+            const uint32_t ad = __builtin_amdgcn_perm(C[t], (t < 4) ? c.x : c.y, sel);
+            rows[t] = *(lds_row) (uintptr_t) ad;
+        }
+    };
+    auto reduce = [&](const v4i (&rows)[8]) {
+        v4i acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const v8i b = {rows[2 * t][0], rows[2 * t][1], rows[2 * t][2], rows[2 * t][3],
+                           rows[2 * t + 1][0], rows[2 * t + 1][1], rows[2 * t + 1][2], rows[2 * t + 1][3]};
+            acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+        }
+        if (acc[0] < thr || acc[1] < thr || acc[2] < thr || acc[3] < thr) ++hits;
+    };
+    v4i ra[8], rb[8];
+    issue(ra, w[0]);
+    for (int64_t g = wave * NG; g < groups_per_block; g += 16 * NG) {
+        const uint2 *pn = (g + 16 * NG < groups_per_block) ? p + 16 * NG * 64 : p;
+        w[0] = pn[0];
+        issue(rb, w[1]); w[1] = pn[64]; reduce(ra);
+        issue(ra, w[2]); w[2] = pn[128]; reduce(rb);
+        issue(rb, w[3]); w[3] = pn[192]; reduce(ra);
+        issue(ra, w[0]); reduce(rb);
+        p = pn;
+    }
     out[1 + blockIdx.x * 1024 + threadIdx.x] = hits;
 }
 
@@ -202,8 +274,11 @@ int main()
     hipFuncSetAttribute(reinterpret_cast<const void *>(rate<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(rate<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(rate<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(rate<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(rate<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(rate<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int layout = 0; layout < 2; ++layout) {
+    for (int layout = 0; layout < 1; ++layout) {
         uint32_t x = 12345u;
         for (size_t i = 0; i < n_lane; ++i) {
             const int lane = (int) (i & 63), g = lane >> 4, n = lane & 15;
@@ -218,7 +293,7 @@ int main()
             }
         }
         hipMemcpy(d_fc, fc.data(), fc.size() * 2, hipMemcpyHostToDevice);
-        for (int mode = 0; mode < 8; ++mode) {
+        for (int mode = 0; mode < 11; ++mode) {
             float best = 1e9f;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(a);
@@ -230,15 +305,34 @@ int main()
                 if (mode == 5) hipLaunchKernelGGL(rate<5>, dim3(256), dim3(1024), 128 * 1024, 0, d_fc, gpb, d_tab, d_out);
                 if (mode == 6) hipLaunchKernelGGL(rate<6>, dim3(256), dim3(1024), 128 * 1024, 0, d_fc, gpb, d_tab, d_out);
                 if (mode == 7) hipLaunchKernelGGL(rate<7>, dim3(256), dim3(1024), 128 * 1024, 0, d_fc, gpb, d_tab, d_out);
+                if (mode == 10) hipLaunchKernelGGL(rate<10>, dim3(256), dim3(1024), 128 * 1024, 0, d_fc, gpb, d_tab, d_out);
+                if (mode == 9) hipLaunchKernelGGL(rate<9>, dim3(256), dim3(1024), 128 * 1024, 0, d_fc, gpb, d_tab, d_out);
+                if (mode == 8) hipLaunchKernelGGL(rate<8>, dim3(256), dim3(1024), 128 * 1024, 0, d_fc, gpb, d_tab, d_out);
                 hipEventRecord(b); hipEventSynchronize(b);
                 float ms; hipEventElapsedTime(&ms, a, b);
                 if (ms < best) best = ms;
             }
             const double lookups = 256.0 * gpb * 64 * 8;
             printf("layout %s mode %d (%s): %.3f ms for 256 blocks x %lld codes  [%.1f TB/s of 16-byte rows; the bench's fscan_kernel: 0.49 ms]\n",
-                   layout == 0 ? "rotated" : "plain  ", mode, mode == 0 ? "lds + 8 mfma" : mode == 1 ? "lds + pair adds + 4 mfma" : mode == 2 ? "8 mfma only" : mode == 3 ? "lds + quad adds + 2 mfma" : mode == 4 ? "lds only" : mode == 5 ? "lookup stream only" : mode == 6 ? "lds + 4 smfmac" : "4 smfmac only",
+                   layout == 0 ? "rotated" : "plain  ", mode, mode == 0 ? "lds + 8 mfma" : mode == 1 ? "lds + pair adds + 4 mfma" : mode == 2 ? "8 mfma only" : mode == 3 ? "lds + quad adds + 2 mfma" : mode == 4 ? "lds only" : mode == 5 ? "lookup stream only" : mode == 6 ? "lds + 4 smfmac" : mode == 7 ? "4 smfmac + synthesized rows" : mode == 8 ? "4 smfmac, constant operands" : mode == 9 ? "8 mfma, constant operands" : "lds + 2 x 2 smfmac + adds",
                    best, (long long) gpb * 16, lookups * 16 / (best * 1e-3) / 1e12);
         }
+    }
+    {
+        std::vector<uint8_t> fb(n_lane * 8);
+        uint32_t x = 777u;
+        for (auto &v : fb) { x = x * 1664525u + 1013904223u; v = (uint8_t) (x >> 13); }
+        hipMemcpy(d_fc, fb.data(), fb.size(), hipMemcpyHostToDevice);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(rate_bytes), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(rate_bytes, dim3(256), dim3(1024), 128 * 1024, 0, reinterpret_cast<const uint2 *>(d_fc), gpb, d_tab, d_out);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (ms < best) best = ms;
+        }
+        printf("byte lookups + v_perm addresses + lds + 4 smfmac: %.3f ms\n", best);
     }
     printf("hip status: %s\n", hipGetErrorString(hipGetLastError()));
     return 0;
