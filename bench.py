@@ -10,7 +10,7 @@ RCCL/xGMI inside the timed region.  deep (configs[4] shape): the database is sha
 same batch and the timed region holds the all-gather + (dist, id) merge.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel (fscan_kernel for the linear scans, ivf_fused_kernel for the inverted index) timed by
+  roofline      the dominant kernel (fscan_mx_kernel / fscan_kernel for the linear scans, ivf_fused_kernel for the inverted index) timed by
                 HIP events recorded around each of its launches in the timed region, against the resource that binds it:
                 the LDS table-gather rate for the scans (157.3 TB/s = ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz), HBM
                 for the inverted index and the single-query Deep scan.  `hbm` inside it holds the counter traffic.
@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--lut-mode", default="exact", choices=["exact", "mfma"])
     ap.add_argument("--scan-order", type=int, default=1, choices=[0, 1],
                     help="1: scan the LDS-friendly permutation of the codes (default), 0: id order")
+    ap.add_argument("--scan-mx", type=int, default=1, choices=[0, 1],
+                    help="1 (default): the filter scan of the M = 16 / 32 shapes sums its table bytes on the matrix cores "
+                         "(fscan_mx_kernel); 0: on the vector ALU (fscan_kernel)")
     ap.add_argument("--scan-mode", type=int, default=1, choices=[0, 1],
                     help="1: 8-bit filter + exact re-rank (default), 0: exact scan of every code; identical results")
     return ap.parse_args()
@@ -137,9 +140,15 @@ def profile_table(name):
         return {}
 
 
+def filter_kernel_name(args, M):
+    return "fscan_mx_kernel" if (args.scan_mx and M in (16, 32)) else "fscan_kernel"
+
+
 def workload_key(args, n_scanned):
     key = "%s/scan_mode=%d/M=%d/N=%d/B=%d" % (args.workload, args.scan_mode, args.M if args.workload != "deep" else 16,
                                               n_scanned, args.batch)
+    if args.scan_mode == 1 and not args.scan_mx:
+        key += "/scan_mx=0"
     if args.topk != 1:
         key += "/topk=%d" % args.topk
     return key
@@ -165,10 +174,12 @@ def roofline_scan(args, kernel_name, B, n_codes, M, Ks, avg_s, launches, steps, 
             "frac": achieved / LDS_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": launches,
             "launches_per_step": launches / max(steps, 1), "table_lookups_per_launch": lookups, "entry_bytes": entry,
             "conflict_frac": pmc.get("lds_conflict_frac"), "lds_busy": pmc.get("lds_busy"), "valu_busy": pmc.get("valu_busy"),
+            "mfma_busy": pmc.get("mfma_busy"), "shader_clock_ghz": pmc.get("shader_clock_ghz"),
             "hbm": hbm,
             "note": "achieved = table-entry bytes gathered from LDS per second (B*N*M lookups x entry_bytes / kernel time); "
-                    "peak = conflict-free ds_read_b128 rate; conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE from the "
-                    "rocprofv3 --pmc pass of the same command (profiles/)"}
+                    "peak = conflict-free ds_read_b128 rate at the nominal 2.4 GHz; conflict_frac = SQ_LDS_BANK_CONFLICT / "
+                    "SQ_LDS_IDX_ACTIVE, lds_busy / valu_busy / mfma_busy = busy cycles over the launch's shader cycles, from the "
+                    "rocprofv3 --pmc passes of the same command (profiles/)"}
 
 
 def roofline_hbm(kernel_name, alg_bytes, avg_s, launches, steps, traffic):
@@ -207,6 +218,7 @@ def main_deep(args, world, rank, local, dev, arch):
     eng.add_codes(codes, False)
     eng.set_option("scan_mode", args.scan_mode)
     eng.set_option("scan_order", args.scan_order)
+    eng.set_option("scan_mx", args.scan_mx)
     del codes
     topk = args.topk
     q = torch.from_numpy(np.ascontiguousarray(query[:B])).to(dev)
@@ -248,7 +260,7 @@ def main_deep(args, world, rank, local, dev, arch):
             roof = roofline_hbm("scan_kernel", n_shard * M, avg_s, k_n, args.steps,
                                 profile_table("traffic.json").get(key, {}).get("hbm_bytes_per_launch"))
         else:
-            roof = roofline_scan(args, "fscan_kernel" if filt else "scan_kernel", B, n_shard, M, Ks, avg_s, k_n, args.steps,
+            roof = roofline_scan(args, filter_kernel_name(args, M) if filt else "scan_kernel", B, n_shard, M, Ks, avg_s, k_n, args.steps,
                                  filt, key)
         print(json.dumps({
             "metric": "queries/sec", "value": B * args.steps / elapsed, "unit": "queries/s", "n_gpus": world,
@@ -331,6 +343,7 @@ def main():
     eng.set_option("lut_mode", args.lut_mode)
     eng.set_option("scan_mode", args.scan_mode)
     eng.set_option("scan_order", args.scan_order)
+    eng.set_option("scan_mx", args.scan_mx)
     topk = args.topk
     ivf = args.workload in ("ivf", "subset-ivf")
     S, L, d_tids, h_tids = 0, 0, 0, None
@@ -505,7 +518,7 @@ def main():
             roof["note"] = ("latency-bound random 32-byte gathers: algorithmic bytes = B*(nlist*M + w*mean_list_len*4 + L*M)")
         else:
             filt = bool(args.scan_mode and (topk > 1 or B >= eng.get_option("fast_min_batch")))
-            roof = roofline_scan(args, "fscan_kernel" if filt else "scan_kernel", B, n_scanned, M, Ks, avg_s, k_n, args.steps,
+            roof = roofline_scan(args, filter_kernel_name(args, M) if filt else "scan_kernel", B, n_scanned, M, Ks, avg_s, k_n, args.steps,
                                  filt, key)
         roof.update(extra)
         line = {

@@ -156,8 +156,9 @@ struct rii_engine : ScratchSet {
     // LDS-friendly scan order of the filter stage (scanorder.hip): codes gathered in scan order + position -> id.
     // Windows of 1024 codes are independent, so appends only (re)order the windows past `scan_cov`.
     DevBuf d_scan_codes, d_scan_perm;
-    // formatted lookups of the filter stage's conflict-free rotated layout (fastscan.hip: fs_rot_supported shapes), 2 bytes
-    // per code byte; codes are formatted independently, so appends only format the tail past `fc_cov`
+    // formatted lookups of the filter stage's conflict-free rotated layout (fastscan.hip: fs_rot_supported shapes): the code
+    // bytes in fscan_mx_kernel's lane order (scan_mx = 1) or 2 bytes per code byte (fscan_kernel); codes are formatted
+    // independently, so appends only format the tail past `fc_cov`
     DevBuf d_fcodes;
 
     int64_t fc_cov = 0;
@@ -409,8 +410,7 @@ int ensure_scan_order(rii_engine *e, hipStream_t st)
 int ensure_fcodes(rii_engine *e, hipStream_t st)
 {
     if (e->fc_cov == e->N) return RII_OK;
-    const size_t per = (size_t) e->M * 2;
-    RII_TRY(e->d_fcodes.ensure((size_t) fcodes_padded(e->N, e->scan_mx) * per, (size_t) fcodes_padded(e->fc_cov, e->scan_mx) * per, st));
+    RII_TRY(e->d_fcodes.ensure((size_t) fcodes_bytes(e->N, e->M, e->scan_mx), (size_t) fcodes_bytes(e->fc_cov, e->M, e->scan_mx), st));
     {
         ScopedTimer t(e, "format", st);
         HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), nullptr, e->fc_cov, e->N, e->M, e->Ks, e->d_fcodes.as<uint16_t>(),
@@ -531,7 +531,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
             if (fs_rot_supported(e->M, e->Ks)) {
                 // conflict-free rotated layout: the scan reads formatted lookups, the exact stages index the database
                 if (S) {
-                    RII_TRY(e->s_fsub.ensure((size_t) fcodes_padded(S, e->scan_mx) * e->M * 2));
+                    RII_TRY(e->s_fsub.ensure((size_t) fcodes_bytes(S, e->M, e->scan_mx)));
                     ScopedTimer t(e, "gather", st);
                     HIP_TRY(launch_fcodes_format(e->d_codes.as<uint8_t>(), d_remap, 0, S, e->M, e->Ks, e->s_fsub.as<uint16_t>(),
                                                  e->scan_mx, st));

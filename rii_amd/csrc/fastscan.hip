@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void fcodes_format_kernel(const uint8_t *__res
 
 // fscan_mx_kernel's order of the lookups (defined next to that kernel)
 __global__ void fcodes_mx_format_kernel(const uint8_t *__restrict__ codes, const int64_t *__restrict__ ids, int64_t n0, int64_t n1,
-                                        int M, uint16_t *__restrict__ out);
+                                        int M, uint8_t *__restrict__ out);
 
 // formats codes [n0, n1) (or the gathered codes ids[n0..n1)) for the filter scan of an (M, Ks) index
 hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, int64_t n0, int64_t n1, int M, int Ks,
@@ -440,7 +440,8 @@ hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, in
         n0 = n0 / 16 * 16;
         const int64_t tot = ((n1 + 15) / 16 * 16 - n0) * M;
         const int nb = (int) std::min<int64_t>((tot + 255) / 256, 16384);
-        hipLaunchKernelGGL(fcodes_mx_format_kernel, dim3(nb), dim3(256), 0, st, d_codes, d_ids, n0, n1, M, d_out);
+        hipLaunchKernelGGL(fcodes_mx_format_kernel, dim3(nb), dim3(256), 0, st, d_codes, d_ids, n0, n1, M,
+                           reinterpret_cast<uint8_t *>(d_out));
         return hipGetLastError();
     }
     const int G = fastscan_rows(M, Ks) == 16 ? 16 : 32;
@@ -1279,8 +1280,9 @@ bool fs_rot_supported(int M, int Ks)
 // different bank slots whatever the data: with the rotated table layout (slot = subspace mod 16) lookup t of lane (g, n) is
 //     subspace 16 (t / 4) + (n + 4 (t mod 4) + e(g, n)) mod 16,   e = (g & 1) ^ [n in 4..11]  +  2 (g >> 1),
 // (per code the four lanes cover offsets e = 0..3 once each; inside a service group the lanes of one g form either
-// {0-3,12-15} or {4-11} and a common shift keeps 16 columns on 16 slots).  The order is baked into the formatted lookups
-// (fcodes_mx_format_kernel): per group 64 lanes x M / 4 lookups of 16 bits, one coalesced 1 KB (M = 32) load per wave.
+// {0-3,12-15} or {4-11} and a common shift keeps 16 columns on 16 slots).  The order is baked into a permuted copy of the code
+// bytes (fcodes_mx_format_kernel): per group 64 lanes x M / 4 bytes, one coalesced 512-byte (M = 32) load per wave; the subspace
+// of a byte follows from its position, so the (half, slot) part of a row's LDS address is a per-lane constant.
 // =====================================================================================================================
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
@@ -1292,10 +1294,11 @@ __host__ __device__ __forceinline__ int fs_mx_subspace(int g, int col, int t)
     return 16 * (t >> 2) + ((col + 4 * (t & 3) + e) & 15);
 }
 
-// codes [n][M] u8 -> [group = n / 16][lane = 16 g + n % 16][t] u16 (half, ks, slot) row indices; positions in [n1, end of
-// the last group) are filled with row 0 (their sums are never judged).  n0 must be a multiple of 16.
+// codes [n][M] u8 -> [group = n / 16][lane = 16 g + n % 16][t] u8: the code bytes in the order the lanes consume them (which
+// subspace a byte belongs to follows from its position: fs_mx_subspace); positions in [n1, end of the last group) are
+// filled with 0 (their sums are never judged).  n0 must be a multiple of 16.
 __global__ __launch_bounds__(256) void fcodes_mx_format_kernel(const uint8_t *__restrict__ codes, const int64_t *__restrict__ ids,
-                                                               int64_t n0, int64_t n1, int M, uint16_t *__restrict__ out)
+                                                               int64_t n0, int64_t n1, int M, uint8_t *__restrict__ out)
 {
     const int T = M / 4;
     const int64_t n1p = (n1 + 15) / 16 * 16;
@@ -1312,7 +1315,7 @@ __global__ __launch_bounds__(256) void fcodes_mx_format_kernel(const uint8_t *__
             const int64_t src = ids ? ids[n] : n;
             ks = codes[(size_t) src * M + m];
         }
-        out[(size_t) n0 * M + i] = (uint16_t) (((uint32_t) (m >> 4) << 12) | (ks << 4) | (uint32_t) (m & 15));
+        out[(size_t) n0 * M + i] = (uint8_t) ks;
     }
 }
 
@@ -1335,85 +1338,96 @@ __device__ __forceinline__ void fs_mx_pattern(int i, v4i_t &a, int &idx)
 }
 
 typedef const __attribute__((address_space(3))) v4i_t *fs_lds_row_t;
-// the row a 16-bit formatted lookup names (J = which half of the dword): dynamic LDS starts at address 0 in this kernel, so
-// (lookup << 4) IS the LDS address; the SDWA shift selects the half on the way in (one VALU instruction per row)
-template <int J> __device__ __forceinline__ v4i_t fs_mx_row(uint32_t w)
+// The lookups are the code bytes themselves (one byte per row to fetch).  The LDS address of the row of lookup t is
+//     (half << 16) | (ks << 8) | (slot << 4)          (rotated layout: row = half * 4096 + ks * 16 + slot, 16 bytes each;
+// dynamic LDS starts at address 0 in this kernel); half and slot depend on the lane and on t only, so they sit in T registers per
+// lane (fs_mx_consts) and ONE v_perm_b32 splices the code byte in as byte 1.
+template <int T> __device__ __forceinline__ void fs_mx_consts(int lane, uint32_t (&C)[T])
 {
-    uint32_t addr;
-    if constexpr (J == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(w));
-    else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(w));
-    return *(fs_lds_row_t) (uintptr_t) addr;
-}
-template <int T> struct FsMxW;                                      // the T lookups of a lane for one group
-template <> struct FsMxW<8> { typedef u32x4 V; };
-template <> struct FsMxW<4> { typedef u32x2 V; };
-__device__ __forceinline__ uint32_t fs_mx_z(const u32x4 &w) { return w.z; }
-__device__ __forceinline__ uint32_t fs_mx_z(const u32x2 &) { return 0u; }
-__device__ __forceinline__ uint32_t fs_mx_w(const u32x4 &w) { return w.w; }
-__device__ __forceinline__ uint32_t fs_mx_w(const u32x2 &) { return 0u; }
-// lookups of a later trip, fetched from asm for the same reason as the rows (the compiler would wait with vmcnt(0), i.e. for the
-// load it issued a moment ago): four loads are in flight per wave, every use has exactly three younger ones behind it
-template <int OFF> __device__ __forceinline__ void fs_mx_load(u32x4 &q, const u32x4 *p) { asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF)); }
-template <int OFF> __device__ __forceinline__ void fs_mx_load(u32x2 &q, const u32x2 *p) { asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF)); }
-template <int N, typename V> __device__ __forceinline__ void fs_mx_vmwait(V &q) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q) : "n"(N)); }
-template <int T> __device__ __forceinline__ void fs_mx_issue(const typename FsMxW<T>::V &w, v4i_t (&r)[T])
-{
-    r[0] = fs_mx_row<0>(w.x); r[1] = fs_mx_row<1>(w.x);
-    r[2] = fs_mx_row<0>(w.y); r[3] = fs_mx_row<1>(w.y);
-    if constexpr (T == 8) {
-        r[4] = fs_mx_row<0>(w.z); r[5] = fs_mx_row<1>(w.z);
-        r[6] = fs_mx_row<0>(w.w); r[7] = fs_mx_row<1>(w.w);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int m = fs_mx_subspace(lane >> 4, lane & 15, t);
+        C[t] = ((uint32_t) (m >> 4) << 16) | ((uint32_t) (m & 15) << 4);
     }
 }
-// The same, with hand-placed ds_read instructions and waits (the hot loop).  The compiler's own waitcnt bookkeeping loses
-// track of which loads are outstanding across the (rare) candidate branch and the loop edge and falls back to lgkmcnt(0) in
-// front of every group -- draining the reads issued for the NEXT group, i.e. one group in flight instead of two.  Issued
-// from asm the reads are invisible to it; fs_mx_wait names the registers that become valid (LDS returns in order, so the
-// compiler's own waits for its own LDS operations only get stricter).
-__device__ __forceinline__ void fs_mx_issue4(uint32_t w0, uint32_t w1, v4i_t &r0, v4i_t &r1, v4i_t &r2, v4i_t &r3)
+// selector of v_perm_b32(C, w, sel): bytes [C.0, w.J, C.2, C.3]  ({C, w} are bytes {4..7, 0..3} of the instruction's source pair)
+__device__ __forceinline__ constexpr uint32_t fs_mx_sel(int J) { return 0x07060004u | ((uint32_t) J << 8); }
+template <int T> struct FsMxW;                                      // the T lookups (bytes) of a lane for one group
+template <> struct FsMxW<8> { typedef u32x2 V; };
+template <> struct FsMxW<4> { typedef uint32_t V; };
+template <int I> __device__ __forceinline__ uint32_t fs_mx_dword(const u32x2 &w) { return I == 0 ? w.x : w.y; }
+template <int I> __device__ __forceinline__ uint32_t fs_mx_dword(const uint32_t &w) { return w; }
+// lookups of a later trip, fetched from asm (the compiler would wait for them with vmcnt(0), i.e. for the load it issued a moment
+// ago): four loads are in flight per wave, every use has exactly three younger ones behind it
+template <int OFF> __device__ __forceinline__ void fs_mx_load(u32x2 &q, const u32x2 *p) { asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void fs_mx_load(uint32_t &q, const uint32_t *p) { asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF)); }
+template <int N, typename V> __device__ __forceinline__ void fs_mx_vmwait(V &q) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q) : "n"(N)); }
+
+// compiler-scheduled form (warm-up and tail groups)
+template <int T> __device__ __forceinline__ void fs_mx_issue(const typename FsMxW<T>::V &w, const uint32_t (&C)[T], v4i_t (&r)[T])
 {
-    uint32_t a0, a1, a2, a3;
-    asm volatile("v_lshlrev_b32_sdwa %4, 4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
-                 "v_lshlrev_b32_sdwa %5, 4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-                 "v_lshlrev_b32_sdwa %6, 4, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
-                 "v_lshlrev_b32_sdwa %7, 4, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-                 "ds_read_b128 %0, %4\n\t"
-                 "ds_read_b128 %1, %5\n\t"
-                 "ds_read_b128 %2, %6\n\t"
-                 "ds_read_b128 %3, %7"
-                 : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
-                 : "v"(w0), "v"(w1));
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint32_t wd = (t < 4) ? fs_mx_dword<0>(w) : fs_mx_dword<1>(w);
+        const uint32_t addr = __builtin_amdgcn_perm(C[t], wd, fs_mx_sel(t & 3));
+        r[t] = *(fs_lds_row_t) (uintptr_t) addr;
+    }
 }
-// two rows (the two lookups of one formatted dword): what one matrix instruction consumes
-__device__ __forceinline__ void fs_mx_issue2(uint32_t w, v4i_t &r0, v4i_t &r1)
+// The same with hand-placed ds_read instructions and waits (the hot loop).  The compiler's own waitcnt bookkeeping loses
+// track of which loads are outstanding across the (rare) candidate branch and the loop edge and falls back to lgkmcnt(0) in
+// front of every group -- draining the reads issued for the NEXT groups.  Issued from asm the reads are invisible to it;
+// fs_mx_wait names the registers that become valid (LDS returns in order, so the compiler's own waits for its own LDS
+// operations only get stricter).
+// two rows (lookups J, J + 1 of dword w): what one matrix instruction consumes
+template <int J> __device__ __forceinline__ void fs_mx_issue2(uint32_t w, uint32_t c0, uint32_t c1, v4i_t &r0, v4i_t &r1)
 {
     uint32_t a0, a1;
-    asm volatile("v_lshlrev_b32_sdwa %2, 4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
-                 "v_lshlrev_b32_sdwa %3, 4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+    asm volatile("v_perm_b32 %2, %4, %6, %7\n\t"
+                 "v_perm_b32 %3, %5, %6, %8\n\t"
                  "ds_read_b128 %0, %2\n\t"
                  "ds_read_b128 %1, %3"
                  : "=v"(r0), "=v"(r1), "=&v"(a0), "=&v"(a1)
-                 : "v"(w));
+                 : "v"(c0), "v"(c1), "v"(w), "s"(fs_mx_sel(J)), "s"(fs_mx_sel(J + 1)));
+}
+template <int T> __device__ __forceinline__ void fs_mx_issue_hot(const typename FsMxW<T>::V &w, const uint32_t (&C)[T], v4i_t (&r)[T])
+{
+    fs_mx_issue2<0>(fs_mx_dword<0>(w), C[0], C[1], r[0], r[1]);
+    fs_mx_issue2<2>(fs_mx_dword<0>(w), C[2], C[3], r[2], r[3]);
+    if constexpr (T == 8) {
+        fs_mx_issue2<0>(fs_mx_dword<1>(w), C[4], C[5], r[4], r[5]);
+        fs_mx_issue2<2>(fs_mx_dword<1>(w), C[6], C[7], r[6], r[7]);
+    }
 }
 // one group: the rows in r[] (already waited for) go through the matrix core pair by pair, and as soon as a pair has been
 // issued its registers take the rows of the group two ahead (lookups wn) -- the reads travel under the remaining matrix
 // instructions and the whole next group
-template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce_refill(v4i_t (&r)[T], const typename FsMxW<T>::V &wn, const v4i_t &spa, int spidx)
+template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce_refill(v4i_t (&r)[T], const typename FsMxW<T>::V &wn, const uint32_t (&C)[T],
+                                                                      const v4i_t &spa, int spidx)
 {
     v4i_t acc = {0, 0, 0, 0};
-    const uint32_t wd[4] = {wn.x, wn.y, fs_mx_z(wn), fs_mx_w(wn)};
-#pragma unroll
-    for (int t = 0; t < T; t += 2) {
-        const v8i_t b = __builtin_shufflevector(r[t], r[t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+    {
+        const v8i_t b = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3, 4, 5, 6, 7);
         acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
-        fs_mx_issue2(wd[t >> 1], r[t], r[t + 1]);
+        fs_mx_issue2<0>(fs_mx_dword<0>(wn), C[0], C[1], r[0], r[1]);
+    }
+    {
+        const v8i_t b = __builtin_shufflevector(r[2], r[3], 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+        fs_mx_issue2<2>(fs_mx_dword<0>(wn), C[2], C[3], r[2], r[3]);
+    }
+    if constexpr (T == 8) {
+        {
+            const v8i_t b = __builtin_shufflevector(r[4], r[5], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+            fs_mx_issue2<0>(fs_mx_dword<1>(wn), C[4], C[5], r[4], r[5]);
+        }
+        {
+            const v8i_t b = __builtin_shufflevector(r[6], r[7], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+            fs_mx_issue2<2>(fs_mx_dword<1>(wn), C[6], C[7], r[6], r[7]);
+        }
     }
     return acc;
-}
-template <int T> __device__ __forceinline__ void fs_mx_issue_hot(const typename FsMxW<T>::V &w, v4i_t (&r)[T])
-{
-    fs_mx_issue4(w.x, w.y, r[0], r[1], r[2], r[3]);
-    if constexpr (T == 8) fs_mx_issue4(w.z, w.w, r[4], r[5], r[6], r[7]);
 }
 // at most PENDING younger LDS operations stay outstanding: the rows named are valid after this
 template <int PENDING> __device__ __forceinline__ void fs_mx_wait(v4i_t (&r)[8])
@@ -1467,6 +1481,8 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     v4i_t spa;
     int spidx;
     fs_mx_pattern(col, spa, spidx);
+    uint32_t C[T];
+    fs_mx_consts<T>(lane, C);
 
     const int64_t c_begin = (int64_t) blockIdx.x * p.chunk_len;         // a multiple of 1024
     int64_t c_end = c_begin + p.chunk_len;
@@ -1550,7 +1566,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     auto slow_group = [&](int64_t gi, bool minima, const v4i_t &thr) {
         const W w = fc[(size_t) gi * 64];
         v4i_t r[T];
-        fs_mx_issue<T>(w, r);
+        fs_mx_issue<T>(w, C, r);
         v4i_t acc = fs_mx_reduce<T>(r, spa, spidx);
         const int64_t n = c_begin + gi * 16 + col;
         if (n >= c_end) acc = v4i_t{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};     // columns past the end are never judged
@@ -1595,8 +1611,8 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
         {
             const W *p0 = trip_ptr(0), *p1 = trip_ptr(1);
             const W g0 = p0[0], g1 = p0[64];
-            fs_mx_issue_hot<T>(g0, ra);
-            fs_mx_issue_hot<T>(g1, rb);
+            fs_mx_issue_hot<T>(g0, C, ra);
+            fs_mx_issue_hot<T>(g1, C, rb);
             constexpr int S = 64 * (int) sizeof(W);
             fs_mx_load<2 * S>(q[2], p0);        // in the order of their use: every use has three younger loads behind it
             fs_mx_load<3 * S>(q[3], p0);
@@ -1614,12 +1630,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
             constexpr int S = 64 * (int) sizeof(W);                // bytes between the lookups of consecutive groups
             fs_mx_vmwait<3>(q[2]);
             fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
-            acc = fs_mx_reduce_refill<T>(ra, q[2], spa, spidx);   // ... refilled with group 2's rows
+            acc = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx);   // ... refilled with group 2's rows
             fs_mx_load<2 * S>(q[2], pn);
             if (MODE == 1) take_min(acc); else judge(acc, thr, n);
             fs_mx_vmwait<3>(q[3]);
             fs_mx_wait<T>(rb);                                    // group 1
-            acc = fs_mx_reduce_refill<T>(rb, q[3], spa, spidx);
+            acc = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx);
             fs_mx_load<3 * S>(q[3], pn);
             if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
             // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
@@ -1627,12 +1643,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
             if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1" : "+v"(thr) : "v"(thr_addr));
             fs_mx_vmwait<3>(q[0]);
             fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
-            acc = fs_mx_reduce_refill<T>(ra, q[0], spa, spidx);   // next trip's group 0
+            acc = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx);   // next trip's group 0
             fs_mx_load<0>(q[0], pnn);
             if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
             fs_mx_vmwait<3>(q[1]);
             fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
-            acc = fs_mx_reduce_refill<T>(rb, q[1], spa, spidx);
+            acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx);
             fs_mx_load<S>(q[1], pnn);
             if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
             adopt(false);
@@ -1729,8 +1745,9 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
 int fscan_mx_subspace(int lane, int t) { return fs_mx_subspace(lane >> 4, lane & 15, t); }
 // lane segments per chunk and query of the MODE 1 pass (the G of launch_kth_threshold is chunks times this)
 int fscan_segments_per_chunk(int M, int Ks, int mx) { return (mx && fs_rot_supported(M, Ks)) ? kFsMxSeg : kFsThreads; }
-// codes the formatted copy must hold for n codes (the mx format is written in whole groups of 16)
-int64_t fcodes_padded(int64_t n, int mx) { return mx ? (n + 15) / 16 * 16 : n;
+// bytes of the formatted copy of n codes: fscan_mx_kernel's is a permutation of the code bytes written in whole groups of 16
+// codes, fscan_kernel's holds a 16-bit (half, ks, slot) value per code byte
+int64_t fcodes_bytes(int64_t n, int M, int mx) { return mx ? (n + 15) / 16 * 16 * M : n * M * 2;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -138,7 +138,7 @@ int fastscan_max_sum(int M);
 // mx != 0: the rotated shapes run fscan_mx_kernel (byte sums on the matrix cores) over its own order of the formatted lookups
 int fscan_segments_per_chunk(int M, int Ks, int mx);
 int fscan_mx_subspace(int lane, int t);       // subspace whose table row lane `lane` of a wave fetches as its lookup t
-int64_t fcodes_padded(int64_t n, int mx);
+int64_t fcodes_bytes(int64_t n, int M, int mx);      // size of the formatted copy of n codes
 // tables of the rotated shapes built by tile (fastscan.hip): exact fp32 [b][M*Ks] + rotated byte rows + slack in two launches
 bool lut_tile_supported(int M, int Ks, int Ds);
 hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, float *d_lut,

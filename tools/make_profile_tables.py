@@ -4,7 +4,7 @@ tables bench.py reads for its `roofline` object:
    profiles/traffic.json[key].hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024   (counters are in KB; FETCH_SIZE is
                                                       doubled per the MI355X guide's gfx950 note)
    profiles/pmc.json[key] = {lds_conflict_frac, lds_busy, valu_busy, ...}                   (SQ counters of the same kernel)
-usage: tools/make_profile_tables.py <pmc.json> <kernel substring> <workload key> <source label>"""
+usage: tools/make_profile_tables.py <pmc.json> <kernel substring> <workload key> <source label> [launch ms]"""
 import json
 import os
 import sys
@@ -26,6 +26,11 @@ def main():
            "valu_busy": c["SQ_INSTS_VALU"] * 4.0 / n_simd / cycles,
            "lds_cycles_per_read": c["SQ_LDS_IDX_ACTIVE"] / c["SQ_INSTS_LDS"],
            "valu_insts": c["SQ_INSTS_VALU"], "lds_insts": c["SQ_INSTS_LDS"], "gpu_cycles": cycles}
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        pmc["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / n_simd / cycles
+        pmc["mfma_insts"] = c.get("SQ_INSTS_MFMA")
+    if len(sys.argv) > 5:                                      # the launch's duration in ms (kernel trace) -> shader clock
+        pmc["shader_clock_ghz"] = cycles / (float(sys.argv[5]) * 1e-3) / 1e9
     traffic = {"kernel": names[0], "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
                "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "source": label}
     for name, entry in (("pmc.json", pmc), ("traffic.json", traffic)):
