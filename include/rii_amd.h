@@ -159,7 +159,7 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  * exact fallback [default], 0 = always the std::partial_sort emulation kernels; results are identical),
  * "fast_min_batch" (top-1 batches smaller than this use the exact scan; default 33), "scan_order" (1 = the filter
  * scans an LDS-friendly permutation of the codes [default], 0 = id order; results are identical), "cand_cap",
- * "scan_chunks" (0 = auto), "timing" (0/1), "lanes" (2 [default] or 1, see below), "scan_mx" (1 = the M = 16 / 32, Ks = 256
+ * "scan_chunks" (0 = auto), "timing" (0/1/2), "lanes" (2 [default] or 1, see below), "scan_mx" (1 = the M = 16 / 32, Ks = 256
  * filter scan sums its table bytes on the matrix cores [default], 0 = on the vector ALU; results are identical).
  *
  * Threading: every entry point locks the engine, concurrent callers are serialised.  The *_dev calls return after
@@ -172,7 +172,8 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
 int rii_set_option(rii_engine *e, const char *key, int64_t value);
 int64_t rii_get_option(const rii_engine *e, const char *key);
 
-/* Per-kernel HIP-event timing (enabled by option "timing"=1): events are recorded on the launch stream
+/* Per-kernel HIP-event timing (option "timing" = 1: every kernel; 2: only the kernel that dominates a query step -- "scan",
+ * "ivf_fused", "ivf_scan" -- two event records per step instead of ten): events are recorded on the launch stream
  * around every launch of the named kernel; reading synchronises the stream.
  * names: "lut", "scan", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select", "assign", "gather", "select", "quant", "rerank",
  * "ivf_fused", "ivf_exact", "kth", "scan_order", "tie", "format", "ivf_shard". */

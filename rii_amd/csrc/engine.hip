@@ -170,6 +170,7 @@ struct rii_engine : ScratchSet {
 
 
     std::map<std::string, KernelTimer> timers;
+    std::vector<hipEvent_t> event_pool;     // timing events are recycled (creating a pair per launch costs more than recording it)
 
     ScratchSet parked;          // the other lane (see ScratchSet)
     int lanes = 2;              // option "lanes": 1 = every call shares one scratch set (calls on different streams serialise)
@@ -182,6 +183,26 @@ namespace {
 
 int64_t nlist_of(const rii_engine *e) { return e->M ? (int64_t) (e->centers.size() / (size_t) e->M) : 0; }
 
+// option "timing": 1 = every kernel, 2 = only the kernels that dominate a query step (what bench.py keeps on inside its timed
+// region: two event records per step instead of ten)
+bool timer_wanted(const rii_engine *e, const char *name)
+{
+    if (e->timing == 1) return true;
+    if (e->timing == 2) return !strcmp(name, "scan") || !strcmp(name, "ivf_fused") || !strcmp(name, "ivf_scan");
+    return false;
+}
+hipEvent_t timer_event(rii_engine *e)
+{
+    if (!e->event_pool.empty()) {
+        hipEvent_t ev = e->event_pool.back();
+        e->event_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
 struct ScopedTimer {
     rii_engine *e;
     hipStream_t st;
@@ -189,8 +210,10 @@ struct ScopedTimer {
     const char *name;
     ScopedTimer(rii_engine *e_, const char *name_, hipStream_t st_) : e(e_), st(st_), name(name_)
     {
-        if (e->timing) {
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        if (e->timing && timer_wanted(e, name)) {
+            a = timer_event(e);
+            b = timer_event(e);
+            if (!a || !b) { a = b = nullptr; return; }
             (void) hipEventRecord(a, st);
         }
     }
@@ -207,8 +230,8 @@ struct ScopedTimer {
                     t.total_ms += ms;
                     t.launches += 1;
                 }
-                (void) hipEventDestroy(t.pending.front().first);
-                (void) hipEventDestroy(t.pending.front().second);
+                e->event_pool.push_back(t.pending.front().first);
+                e->event_pool.push_back(t.pending.front().second);
                 t.pending.erase(t.pending.begin());
             }
         }
@@ -944,6 +967,8 @@ void free_all(rii_engine *e)
     for (auto &kv : e->timers)
         for (auto &pr : kv.second.pending) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     e->timers.clear();
+    for (hipEvent_t ev : e->event_pool) (void) hipEventDestroy(ev);
+    e->event_pool.clear();
     if (e->stream) (void) hipStreamDestroy(e->stream);
     e->stream = nullptr;
 }
@@ -1501,7 +1526,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
     } else if (k == "scan_chunks") {
         e->scan_chunks = (int) value;
     } else if (k == "timing") {
-        e->timing = value ? 1 : 0;
+        if (value < 0 || value > 2) return set_err(RII_ERR_INVALID, "timing must be 0, 1 (every kernel) or 2 (dominant kernels only)");
+        e->timing = (int) value;
     } else if (k == "scan_mode") {
         if (value != 0 && value != 1) return set_err(RII_ERR_INVALID, "scan_mode must be 0 (exact) or 1 (filter + re-rank)");
         e->scan_mode = (int) value;
@@ -1575,8 +1601,8 @@ RII_API int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms,
         HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
         t.total_ms += ms;
         t.launches += 1;
-        (void) hipEventDestroy(pr.first);
-        (void) hipEventDestroy(pr.second);
+        e->event_pool.push_back(pr.first);
+        e->event_pool.push_back(pr.second);
     }
     t.pending.clear();
     if (total_ms) *total_ms = t.total_ms;
