@@ -463,9 +463,8 @@ def main():
     # tables are rebuilt per call -- so this is the same number, measured rather than argued)
     fresh = None
     if world == 1 and not args.no_fresh:
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(4242)
-        pool = [my_q] + [(my_q + 8.0 * torch.randn(my_q.shape, device=dev, generator=gen)).contiguous() for _ in range(7)]
+        more = bd.more_queries(7 * B, D=D)                 # same distribution as the timed batch (same cluster means)
+        pool = [my_q] + [torch.from_numpy(more[i * B:(i + 1) * B]).to(dev) for i in range(7)]
         torch.cuda.synchronize()
         it_f = [0]
 

@@ -44,6 +44,15 @@ def sift_like(n_base=1_000_000, n_train=100_000, n_query=10_000, D=128, seed=123
     return draw(n_base), draw(n_train), draw(n_query)
 
 
+def more_queries(n, D=128, seed=1234, n_clusters=4096, stream=1):
+    """n more query vectors from the distribution sift_like(seed=seed) draws from (same cluster means, fresh noise)."""
+    means = (np.random.default_rng(seed).random((n_clusters, D), dtype=np.float32) * 128.0)
+    rng = np.random.default_rng([seed, stream])
+    c = rng.integers(0, n_clusters, n)
+    x = means[c] + rng.standard_normal((n, D), dtype=np.float32) * 24.0
+    return np.rint(np.clip(x, 0.0, 255.0)).astype(np.float32)
+
+
 def train_pq(train, M, Ks=256, iters=10, seed=123, device=None):
     """k-means PQ codebooks (M, Ks, Ds) float32.  torch when available (GPU if `device` says so)."""
     import torch

@@ -47,6 +47,10 @@ static int set_err(int code, const char *fmt, ...)
         if (_r != RII_OK) return _r;  \
     } while (0)
 
+namespace riiamd {
+thread_local LaunchEvents g_launch_events;
+}
+
 namespace {
 
 struct DevBuf {
@@ -208,19 +212,31 @@ struct ScopedTimer {
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
     const char *name;
-    ScopedTimer(rii_engine *e_, const char *name_, hipStream_t st_) : e(e_), st(st_), name(name_)
+    bool attach;
+    // attach = true: the scope holds exactly ONE launch that goes through launch_timed(), which takes the two events with the
+    // dispatch (no event packets in the stream)
+    ScopedTimer(rii_engine *e_, const char *name_, hipStream_t st_, bool attach_ = false) : e(e_), st(st_), name(name_), attach(attach_)
     {
         if (e->timing && timer_wanted(e, name)) {
             a = timer_event(e);
             b = timer_event(e);
             if (!a || !b) { a = b = nullptr; return; }
-            (void) hipEventRecord(a, st);
+            if (attach) { g_launch_events.start = a; g_launch_events.stop = b; }
+            else (void) hipEventRecord(a, st);
         }
     }
     ~ScopedTimer()
     {
+        if (a && b && attach) {
+            if (g_launch_events.start == a) {          // the launch never happened (an error on the way): nothing to read
+                g_launch_events = LaunchEvents();
+                e->event_pool.push_back(a);
+                e->event_pool.push_back(b);
+                return;
+            }
+        }
         if (a && b) {
-            (void) hipEventRecord(b, st);
+            if (!attach) (void) hipEventRecord(b, st);
             KernelTimer &t = e->timers[name];
             t.pending.emplace_back(a, b);
             // fold finished pairs into the totals so that an unread timer does not pile up events
@@ -594,7 +610,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 if (!e->qlut_ready)
                     HIP_TRY(hipMemsetAsync(e->s_gthr.p, 0xff, (size_t) B * sizeof(uint32_t), st));   // > any 16-bit threshold
                 {
-                    ScopedTimer t(e, "scan", st);
+                    ScopedTimer t(e, "scan", st, true);
                     HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
@@ -612,7 +628,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
             RII_TRY(e->s_segmin.ensure((size_t) B * G * sizeof(uint16_t)));
             RII_TRY(e->s_thr16.ensure((size_t) B * sizeof(uint32_t)));
             {
-                ScopedTimer t(e, "scan", st);
+                ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride,
                                      e->scan_mx, st));
@@ -623,7 +639,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                                              e->s_slack.as<int32_t>(), e->s_thr16.as<uint32_t>(), st));
             }
             {
-                ScopedTimer t(e, "scan", st);
+                ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
                                      2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st));
@@ -663,7 +679,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
         sp.best = e->s_best.as<unsigned long long>();
         HIP_TRY(hipMemsetAsync(sp.best, 0xff, (size_t) B * sizeof(unsigned long long), st));
         {
-            ScopedTimer t(e, "scan", st);
+            ScopedTimer t(e, "scan", st, true);
             HIP_TRY(launch_scan(sp, st));
         }
         HIP_TRY(launch_finalize_top1(sp.best, B, d_remap, d_out_ids, d_out_dists, topk, st));
@@ -685,7 +701,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
         sp.b0 = (int) b0; sp.bc = (int) cur;
         pick_chunks(e, n_codes, cur, &sp.chunks, &sp.chunk_len);
         {
-            ScopedTimer t(e, "scan", st);
+            ScopedTimer t(e, "scan", st, true);
             HIP_TRY(launch_scan(sp, st));
         }
         {
@@ -849,7 +865,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             e->flag_parity ^= 1;
             // common case answered in one launch; queries whose answer could hinge on std::partial_sort's internal
             // order raise flag[b] and are redone by the exact emulation kernels below (which skip the others)
-            ScopedTimer t(e, "ivf_fused", st);
+            ScopedTimer t(e, "ivf_fused", st, true);
             HIP_TRY(launch_ivf_fused(p, st));
             if (defer) {
                 e->ivf_deferred = p;

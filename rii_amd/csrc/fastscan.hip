@@ -1232,7 +1232,7 @@ static hipError_t launch_fscan_t(const FsArgs &a, int chunks, int tiles, hipStre
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
+    launch_timed(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
     return hipGetLastError();
 }
 
@@ -1695,7 +1695,7 @@ template <int T, int MODE> static hipError_t launch_fscan_mx_t(const FsArgs &a, 
     auto kern = fscan_mx_kernel<T, MODE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
+    launch_timed(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
     return hipGetLastError();
 }
 

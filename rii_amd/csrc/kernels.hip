@@ -368,7 +368,7 @@ static hipError_t launch_scan_t(const ScanParams &sp, int tile0, int ntiles, hip
     a.codes = sp.codes; a.n_codes = sp.n_codes; a.M = sp.M; a.Ks = sp.Ks; a.lut = sp.lut; a.B = sp.B;
     a.tile0 = tile0; a.chunk_len = sp.chunk_len; a.best = sp.best; a.keys = sp.keys; a.b0 = sp.b0;
     a.perm = PERM ? sp.perm : nullptr;
-    hipLaunchKernelGGL(kern, dim3(sp.chunks, ntiles), dim3(kScanThreads), smem, st, a);
+    launch_timed(kern, dim3(sp.chunks, ntiles), dim3(kScanThreads), smem, st, a);
     return hipGetLastError();
 }
 
@@ -1181,7 +1181,7 @@ hipError_t launch_ivf_fused(const IvfParams &p0, hipStream_t st)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned) p.B), dim3(256), smem, st, p);
+    launch_timed(kern, dim3((unsigned) p.B), dim3(256), smem, st, p);
     return hipGetLastError();
 }
 

@@ -2,10 +2,29 @@
 // engine (engine.cpp).  gfx950 / CDNA4 only.  Nothing here is part of the public C ABI (include/rii_amd.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 
 namespace riiamd {
+
+// Timing of the kernels that dominate a query step: the engine arms a pair of events (engine.hip: ScopedTimer) and the
+// launcher hands them to the dispatch itself (hipExtLaunchKernelGGL: start / stop timestamps of THIS dispatch).  An event
+// recorded into the stream is a barrier packet of its own; two of them around every scan cost ~8 % of a 0.4 ms step.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+extern thread_local LaunchEvents g_launch_events;
+template <typename K, typename A>
+inline void launch_timed(K kern, dim3 grid, dim3 block, size_t smem, hipStream_t st, const A &arg)
+{
+    if (g_launch_events.start && g_launch_events.stop) {
+        hipExtLaunchKernelGGL(kern, grid, block, (uint32_t) smem, st, g_launch_events.start, g_launch_events.stop, 0, arg);
+        g_launch_events = LaunchEvents();
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, smem, st, arg);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Device data layouts (all in HBM, owned by the engine)
