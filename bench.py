@@ -141,7 +141,7 @@ def profile_table(name):
 
 
 def filter_kernel_name(args, M):
-    return "fscan_mx_kernel" if (args.scan_mx and M in (16, 32)) else "fscan_kernel"
+    return "fscan_mx_kernel" if (args.scan_mx and M in (16, 32, 64)) else "fscan_kernel"
 
 
 def workload_key(args, n_scanned):
@@ -165,7 +165,7 @@ def roofline_scan(args, kernel_name, B, n_codes, M, Ks, avg_s, launches, steps, 
     traffic = profile_table("traffic.json").get(pmc_key, {}).get("hbm_bytes_per_launch")
     # codes once (fscan_kernel's formatted copy of the M = 16 / 32 shapes holds 2 bytes per code byte; fscan_mx_kernel's is a
     # permutation of the code bytes) + the tables staged
-    fmt = 2 if (byte_tables and M in (16, 32) and Ks == 256 and not args.scan_mx) else 1
+    fmt = 2 if (byte_tables and M in (16, 32) and Ks == 256 and not args.scan_mx) else 1      # (M = 64: plain or permuted code bytes)
     floor = n_codes * M * fmt + B * M * Ks * entry
     hbm = {"algorithmic_bytes_per_launch": lookups, "compulsory_floor_bytes": floor, "traffic_bytes": traffic,
            "achieved": (traffic / avg_s / 1e9) if (traffic and avg_s > 0) else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}

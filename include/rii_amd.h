@@ -147,11 +147,12 @@ int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out);
 /* Coarse assignment alone (PQKMeans::predict_one over codes, src/rii.h:350-354): assign[n] in [0,nlist). */
 int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *assign);
 
-/* Layout introspection (host only, no device needed): the filter scan of the M = 16 / 32, Ks = 256 shapes (fscan_mx_kernel)
- * splits the M table rows of a code over four lanes of a wave; this returns the subspace whose row lane `lane` (0..63: lane
- * 16 g + n works on code n of its group of 16) fetches as its lookup t (0 .. M/4 - 1), or -1 for bad arguments.  The choice
- * makes every ds_read_b128 service group of 16 lanes hit 16 different LDS bank slots (tests/test_capi.py checks both that
- * and that the four lanes of a code cover its M subspaces exactly once). */
+/* Layout introspection (host only, no device needed): the filter scan of the M = 16 / 32 / 64, Ks = 256 shapes
+ * (fscan_mx_kernel) splits the M table rows of a code over four lanes of a wave; this returns the subspace whose row lane
+ * `lane` (0..63: lane 16 g + n works on code n of its group of 16) fetches as its lookup t (0 .. M/4 - 1), or -1 for bad
+ * arguments.  The choice makes every LDS service group (16 lanes of a ds_read_b128 for M = 16 / 32, 32 lanes of a ds_read_b64
+ * for M = 64) hit that many different bank slots (tests/test_capi.py checks both that and that the four lanes of a code cover
+ * its M subspaces exactly once). */
 int rii_fscan_lane_subspace(int M, int lane, int t);
 
 /* Options: "lut_mode" (RII_LUT_*), "scan_mode" (1 = 8-bit filter + exact re-rank for top-1 [default], 0 = exact scan
@@ -159,7 +160,7 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  * exact fallback [default], 0 = always the std::partial_sort emulation kernels; results are identical),
  * "fast_min_batch" (top-1 batches smaller than this use the exact scan; default 33), "scan_order" (1 = the filter
  * scans an LDS-friendly permutation of the codes [default], 0 = id order; results are identical), "cand_cap",
- * "scan_chunks" (0 = auto), "timing" (0/1/2), "lanes" (2 [default] or 1, see below), "scan_mx" (1 = the M = 16 / 32, Ks = 256
+ * "scan_chunks" (0 = auto), "timing" (0/1/2), "lanes" (2 [default] or 1, see below), "scan_mx" (1 = the M = 16 / 32 / 64, Ks = 256
  * filter scan sums its table bytes on the matrix cores [default], 0 = on the vector ALU; results are identical).
  *
  * Threading: every entry point locks the engine, concurrent callers are serialised.  The *_dev calls return after

@@ -366,10 +366,10 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
         RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
         RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
         RII_TRY(e->s_gthr.ensure((size_t) B * sizeof(uint32_t)));
-        if (lut_tile_supported(e->M, e->Ks, e->Ds)) {         // by tile: exact table, extrema, rotated byte rows, slack
+        if (lut_tile_supported(e->M, e->Ks, e->Ds, e->scan_mx)) {         // by tile: exact table, extrema, rotated byte rows, slack
             RII_TRY(e->s_lohi.ensure((size_t) B * e->M * 2 * sizeof(float)));
             ScopedTimer t(e, "lut", st);
-            HIP_TRY(launch_lut_tile_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->s_lut.as<float>(),
+            HIP_TRY(launch_lut_tile_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ds, e->s_lut.as<float>(),
                                                 e->s_lohi.as<float>(), e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                                 e->s_cand_cnt.as<unsigned int>(), e->s_gthr.as<uint32_t>(), st));
             e->qlut_ready = true;
@@ -380,7 +380,7 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
         HIP_TRY(launch_lut_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch,
                                        e->s_lut.as<float>(), e->s_qc.as<uint8_t>(), e->s_qlut.as<uint8_t>(),
                                        e->s_slack.as<int32_t>(),
-                                       e->s_cand_cnt.as<unsigned int>(), e->s_gthr.as<uint32_t>(), st));
+                                       e->s_cand_cnt.as<unsigned int>(), e->s_gthr.as<uint32_t>(), e->scan_mx, st));
         e->qlut_ready = true;            // ... and the candidate counters / shared thresholds are already reset
         return RII_OK;
     }
@@ -567,7 +567,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
             if (topk > 1) cap = std::max(cap, 16 * topk * stride);
             const int32_t *d_perm = nullptr;
             const uint8_t *d_scan = nullptr;          // what fscan_kernel reads
-            if (fs_rot_supported(e->M, e->Ks)) {
+            if (fs_rot_supported(e->M, e->Ks, e->scan_mx)) {
                 // conflict-free rotated layout: the scan reads formatted lookups, the exact stages index the database
                 if (S) {
                     RII_TRY(e->s_fsub.ensure((size_t) fcodes_bytes(S, e->M, e->scan_mx)));
@@ -601,7 +601,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "quant", st);
                 RII_TRY(e->s_qc.ensure((size_t) B * e->M * e->Ks));
                 HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->lut_qt, e->s_qc.as<uint8_t>(),
-                                            e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), st));
+                                            e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), e->scan_mx, st));
             }
             if (!e->qlut_ready) HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
             e->last_fs_B = B;
@@ -1527,8 +1527,8 @@ RII_API int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *
 
 RII_API int rii_fscan_lane_subspace(int M, int lane, int t)
 {
-    if ((M != 16 && M != 32) || lane < 0 || lane > 63 || t < 0 || t >= M / 4) return -1;
-    return fscan_mx_subspace(lane, t);
+    if ((M != 16 && M != 32 && M != 64) || lane < 0 || lane > 63 || t < 0 || t >= M / 4) return -1;
+    return fscan_mx_subspace(M, lane, t);
 }
 
 RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)

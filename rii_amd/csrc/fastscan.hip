@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void qlut_interleave_kernel(const uint8_t *__r
     }
 }
 
-bool fs_rot_supported(int M, int Ks);
+bool fs_rot_supported(int M, int Ks, int mx);
 
 // rotated layout, 16-byte rows: one block per (tile, group of 16 subspaces, 16 consecutive ks).  Its 256 rows are
 // contiguous in the destination (row = ks * 16 + q) and 16 runs of 16 bytes in every query's compact table (i = q * Ks + ks):
@@ -393,11 +393,11 @@ __global__ __launch_bounds__(256) void qlut_interleave_rot16_kernel(const uint8_
     dst[tid] = s_rows[tid];
 }
 
-static hipError_t launch_qlut_interleave(const uint8_t *d_qc, int64_t B, int M, int Ks, uint8_t *d_qlut, hipStream_t st)
+static hipError_t launch_qlut_interleave(const uint8_t *d_qc, int64_t B, int M, int Ks, uint8_t *d_qlut, int mx, hipStream_t st)
 {
     const int qr = fastscan_rows(M, Ks);
     const int MK = M * Ks;
-    const int rot = fs_rot_supported(M, Ks) ? 1 : 0;
+    const int rot = fs_rot_supported(M, Ks, mx) ? 1 : 0;
     if (rot && qr == 16 && Ks == 256) {
         hipLaunchKernelGGL(qlut_interleave_rot16_kernel, dim3((unsigned) ((B + 15) / 16), M / 16, 16), dim3(256), 0, st, d_qc, B, MK, d_qlut);
         return hipGetLastError();
@@ -453,13 +453,13 @@ hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, in
 }
 
 hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qc, uint8_t *d_qlut,
-                               int32_t *d_slack, hipStream_t st)
+                               int32_t *d_slack, int mx, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned) B), dim3(256), 0, st, d_lut, B, M, Ks, QT, d_qc, d_slack);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, st);
+    return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, mx, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -478,6 +478,7 @@ hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int
 // Rhi - Rlo <= M * delta * (1 + 2.8e-5): slack = floor(M (1 + 1e-4) + 2 eps / delta) + 2 (the measured ranges were
 // 0.99 delta per subspace anyway).
 // ---------------------------------------------------------------------------------------------------------------------
+template <typename Vec>          // float4: Ds = 4, float2: Ds = 2
 __global__ __launch_bounds__(256) void lut_tile_build_kernel(const float *__restrict__ queries, int64_t B,
                                                              const float *__restrict__ codewords, int M,
                                                              float *__restrict__ lut, float2 *__restrict__ lohi)
@@ -487,8 +488,9 @@ __global__ __launch_bounds__(256) void lut_tile_build_kernel(const float *__rest
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int m0 = blockIdx.y * 8 + wave * 2;                // this wave: subspaces m0, m0 + 1
     const int MK = M * 256;
-    const float4 *cw4 = reinterpret_cast<const float4 *>(codewords);
-    float4 cv[2][4];
+    constexpr int Ds = (int) (sizeof(Vec) / sizeof(float));
+    const Vec *cw4 = reinterpret_cast<const Vec *>(codewords);
+    Vec cv[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -500,14 +502,14 @@ __global__ __launch_bounds__(256) void lut_tile_build_kernel(const float *__rest
         for (int jj = 0; jj < 4; ++jj) {
             const int64_t b = tile * 16 + j0 + jj;
             const bool live = b < B;
-            const float4 *q4 = reinterpret_cast<const float4 *>(queries + (live ? b : 0) * (int64_t) (M * 4));
+            const Vec *q4 = reinterpret_cast<const Vec *>(queries + (live ? b : 0) * (int64_t) (M * Ds));
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const float4 qm = q4[m0 + s];
+                const Vec qm = q4[m0 + s];
                 lo[jj][s] = INFINITY; hi[jj][s] = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = fvec_l2sqr_ds4v(qm, cv[s][e]);
+                    const float t = fvec_l2sqr_vec(qm, cv[s][e]);
                     if (live) lut[(size_t) b * MK + (m0 + s) * 256 + lane + 64 * e] = t;
                     lo[jj][s] = fminf(lo[jj][s], t);
                     hi[jj][s] = fmaxf(hi[jj][s], t);
@@ -602,24 +604,98 @@ __global__ __launch_bounds__(256) void qlut_tile_quant_kernel(const float *__res
     dst[tid] = s_rows[tid];
 }
 
-bool lut_tile_supported(int M, int Ks, int Ds);
-hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, float *d_lut,
+// the same for M = 64 (8 queries per tile, 8-byte rows, 32 subspaces per rotated half: row = half * 8192 + ks * 32 + slot):
+// grid (tile of 8 queries, half, 8 consecutive ks); the block's 256 rows are contiguous in the destination
+__global__ __launch_bounds__(256) void qlut_tile_quant8_kernel(const float *__restrict__ lut, const float2 *__restrict__ lohi,
+                                                               int64_t B, int M, uint8_t *__restrict__ qlut,
+                                                               int32_t *__restrict__ slack, unsigned int *__restrict__ cand_cnt,
+                                                               uint32_t *__restrict__ gthr)
+{
+    __shared__ uint2 s_rows[256];
+    __shared__ float s_inv[8];
+    const int64_t tile = blockIdx.x;
+    const int h = blockIdx.y, ks0 = blockIdx.z * 8;
+    const int tid = threadIdx.x;
+    const int MK = M * 256;
+    {   // per-query quantisation step: 32 lanes per query reduce the ranges (and |lo| + |hi| for eps) over the M subspaces
+        const int j = tid >> 5, l32 = tid & 31;
+        const int64_t b = tile * 8 + j;
+        float range = 0.f;
+        double dmax = 0.0;
+        if (b < B)
+            for (int m = l32; m < M; m += 32) {
+                const float2 lh = lohi[(size_t) b * M + m];
+                range = fmaxf(range, lh.y - lh.x);
+                dmax += fabs((double) lh.x) + fabs((double) lh.y);
+            }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            range = fmaxf(range, __shfl_xor(range, off));
+            dmax += __shfl_xor(dmax, off);
+        }
+        if (l32 == 0) {
+            float d = range / (float) kFsLevels;
+            if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
+            const float delta = d * 1.000001f;
+            s_inv[j] = 1.0f / delta;
+            if (h == 0 && blockIdx.z == 0 && b < B) {        // one block per tile publishes the per-query state of the filter
+                const double eps = (double) M * 1.1920928955078125e-07 * dmax;
+                double sl = (double) M * (1.0 + 1e-4) + 2.0 * eps / (double) delta;
+                sl = sl * (1.0 + 1e-9) + 2.0;
+                slack[b] = (sl >= 0.0 && sl < 60000.0) ? (int32_t) sl : 60000;
+                if (cand_cnt) cand_cnt[b] = 0u;
+                if (gthr) gthr[b] = 0xffffffffu;
+            }
+        }
+    }
+    __syncthreads();
+    const int slot = tid >> 3, ks = ks0 + (tid & 7);
+    const int m = h * 32 + slot;
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t b = tile * 8 + j;
+        uint32_t c = 0u;
+        if (b < B) {
+            const float t = lut[(size_t) b * MK + m * 256 + ks];
+            const float l = lohi[(size_t) b * M + m].x;
+            const float x = floorf((t - l) * s_inv[j] + 0.5f);
+            c = (x >= (float) kFsLevels) ? (uint32_t) kFsLevels : (x > 0.f ? (uint32_t) x : 0u);
+        }
+        w[j >> 2] |= c << (8 * (j & 3));
+    }
+    s_rows[(tid & 7) * 32 + slot] = make_uint2(w[0], w[1]);
+    __syncthreads();
+    uint2 *dst = reinterpret_cast<uint2 *>(qlut + ((size_t) tile * MK + (size_t) h * 8192 + (size_t) ks0 * 32) * 8);
+    dst[tid] = s_rows[tid];
+}
+
+bool lut_tile_supported(int M, int Ks, int Ds, int mx);
+hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ds, float *d_lut,
                                        float *d_lohi, uint8_t *d_qlut, int32_t *d_slack, unsigned int *d_cand_cnt,
                                        uint32_t *d_gthr, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     const unsigned tiles = (unsigned) ((B + 15) / 16);
-    hipLaunchKernelGGL(lut_tile_build_kernel, dim3(tiles, M / 8, 4), dim3(256), 0, st, d_queries, B, d_codewords, M, d_lut,
-                       reinterpret_cast<float2 *>(d_lohi));
-    hipLaunchKernelGGL(qlut_tile_quant_kernel, dim3(tiles, M / 16, 16), dim3(256), 0, st, d_lut,
-                       reinterpret_cast<const float2 *>(d_lohi), B, M, d_qlut, d_slack, d_cand_cnt, d_gthr);
+    if (Ds == 4)
+        hipLaunchKernelGGL(lut_tile_build_kernel<float4>, dim3(tiles, M / 8, 4), dim3(256), 0, st, d_queries, B, d_codewords, M, d_lut,
+                           reinterpret_cast<float2 *>(d_lohi));
+    else
+        hipLaunchKernelGGL(lut_tile_build_kernel<float2>, dim3(tiles, M / 8, 4), dim3(256), 0, st, d_queries, B, d_codewords, M, d_lut,
+                           reinterpret_cast<float2 *>(d_lohi));
+    if (M == 64)
+        hipLaunchKernelGGL(qlut_tile_quant8_kernel, dim3((unsigned) ((B + 7) / 8), M / 32, 32), dim3(256), 0, st, d_lut,
+                           reinterpret_cast<const float2 *>(d_lohi), B, M, d_qlut, d_slack, d_cand_cnt, d_gthr);
+    else
+        hipLaunchKernelGGL(qlut_tile_quant_kernel, dim3(tiles, M / 16, 16), dim3(256), 0, st, d_lut,
+                           reinterpret_cast<const float2 *>(d_lohi), B, M, d_qlut, d_slack, d_cand_cnt, d_gthr);
     return hipGetLastError();
 }
 
 // fused: exact table in the plain [b][M*Ks] layout + quantisation
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
                                   int arch, float *d_lut, uint8_t *d_qc, uint8_t *d_qlut, int32_t *d_slack,
-                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st)
+                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, int mx, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     if (Ds == 4 && M <= 32 && Ks <= 256) {          // Ds == 4: all three fvec_L2sqr variants coincide (rii_device.h)
@@ -627,7 +703,7 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
                            d_lut, d_qc, d_slack, d_cand_cnt, d_gthr);
         hipError_t e0 = hipGetLastError();
         if (e0 != hipSuccess) return e0;
-        return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, st);
+        return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, mx, st);
     }
     const size_t smem = (size_t) M * Ks * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lut_build_quant_kernel),
@@ -637,7 +713,7 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
                        Ds, arch, d_lut, d_qc, d_slack, d_cand_cnt, d_gthr);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, st);
+    return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, mx, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1249,15 +1325,16 @@ int fastscan_max_sum(int M) { return M * kFsLevels; }
 
 // shapes with the conflict-free rotated layout: whole groups of G = 16 subspaces (the lanes of a ds_read_b128 service
 // group) and Ks = 256 (the (half, ks, slot) lookup value fits 16 bits)
-bool lut_tile_supported(int M, int Ks, int Ds) { return Ds == 4 && fs_rot_supported(M, Ks); }
+bool lut_tile_supported(int M, int Ks, int Ds, int mx) { return (Ds == 4 || Ds == 2) && fs_rot_supported(M, Ks, mx); }
 
-bool fs_rot_supported(int M, int Ks)
+bool fs_rot_supported(int M, int Ks, int mx)
 {
     const int qr = fastscan_rows(M, Ks);
     if (Ks != 256) return false;
-    // (M = 64 with 8-byte rows was tried: 128 formatted bytes per code and lane make the loop load-bound, 1.9 ms against
-    //  1.3 ms with the plain codes in the scan order of scanorder.hip)
-    return qr == 16 && (M == 16 || M == 32);
+    if (qr == 16 && (M == 16 || M == 32)) return true;
+    // M = 64 (8-byte rows): only fscan_mx_kernel has a rotated form (as 16-bit lookups for fscan_kernel it was tried and lost:
+    // 128 formatted bytes per code and lane make that loop load-bound, 1.9 ms against 1.3 ms with the plain codes in scan order)
+    return mx && qr == 8 && M == 64;
 }
 
 // =====================================================================================================================
@@ -1287,6 +1364,10 @@ bool fs_rot_supported(int M, int Ks)
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 
+// M = 64 (8-byte rows, ds_read_b64: service groups {0-31}, {32-63}, 32 bank slots): lookup t of lane (g, n) is subspace
+//     32 (g >> 1) + (n + 16 (g & 1) + t) mod 32,   t = 0 .. 15
+// (the two lanes of a half cover the 32 offsets once; a service group holds g = 0, 1 or g = 2, 3 with all 16 columns).
+__host__ __device__ __forceinline__ int fs_mx_subspace64(int g, int col, int t) { return 32 * (g >> 1) + ((col + 16 * (g & 1) + t) & 31); }
 __host__ __device__ __forceinline__ int fs_mx_subspace(int g, int col, int t)
 {
     const int in_mid = (col >= 4 && col < 12) ? 1 : 0;
@@ -1309,7 +1390,7 @@ __global__ __launch_bounds__(256) void fcodes_mx_format_kernel(const uint8_t *__
         const int64_t gl = i / T;
         const int lane = (int) (gl & 63);
         const int64_t n = n0 + (gl >> 6) * 16 + (lane & 15);
-        const int m = fs_mx_subspace(lane >> 4, lane & 15, t);
+        const int m = (M == 64) ? fs_mx_subspace64(lane >> 4, lane & 15, t) : fs_mx_subspace(lane >> 4, lane & 15, t);
         uint32_t ks = 0;
         if (n < n1) {
             const int64_t src = ids ? ids[n] : n;
@@ -1355,6 +1436,7 @@ __device__ __forceinline__ constexpr uint32_t fs_mx_sel(int J) { return 0x070600
 template <int T> struct FsMxW;                                      // the T lookups (bytes) of a lane for one group
 template <> struct FsMxW<8> { typedef u32x2 V; };
 template <> struct FsMxW<4> { typedef uint32_t V; };
+template <> struct FsMxW<16> { typedef u32x4 V; };
 template <int I> __device__ __forceinline__ uint32_t fs_mx_dword(const u32x2 &w) { return I == 0 ? w.x : w.y; }
 template <int I> __device__ __forceinline__ uint32_t fs_mx_dword(const uint32_t &w) { return w; }
 // lookups of a later trip, fetched from asm (the compiler would wait for them with vmcnt(0), i.e. for the load it issued a moment
@@ -1449,13 +1531,117 @@ template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce(const v4i_t (&r)[
     return acc;
 }
 
+// ---- M = 64: 8-byte rows (8 queries per tile), four rows per matrix instruction ----
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) v2i_t *fs_lds_row8_t;
+// one-hot operand for 8-byte rows: output row i < 8 selects bytes i, 8 + i, 16 + i, 24 + i of every lane's 32 (stored bytes
+// 2 (i / 4), 4 + 2 (i / 4), 8 + 2 (i / 4), 12 + 2 (i / 4), index i % 4); rows 8..15 stay empty (their sums are 0, their thresholds 0)
+__device__ __forceinline__ void fs_mx_pattern8(int i, v4i_t &a, int &idx)
+{
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    uint32_t x = 0u;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        const int base = 2 * ((i & 7) >> 2);
+        const bool one = (i < 8) && ((f & 3) == base) && true, pair = (i < 8) && (((f ^ 1) & 3) == base);
+        if (one) w[f >> 2] |= 1u << (8 * (f & 3));
+        const uint32_t v = one ? (uint32_t) (i & 3) : pair ? (uint32_t) ((i + 2) & 3) : (uint32_t) (f & 1);
+        x |= v << (2 * f);
+    }
+    a = v4i_t{(int) w[0], (int) w[1], (int) w[2], (int) w[3]};
+    idx = (int) x;
+}
+// address parts: LDS address of the row of lookup t = (half << 16) | (ks << 8) | (slot << 3); K[j] = bytes {slot << 3 of lookups
+// 3j, 3j+1, 3j+2, half}: one v_perm_b32(K[t / 3], w, sel) builds [slot byte, ks, half, 0]
+__device__ __forceinline__ void fs_mx_consts8(int lane, uint32_t (&K)[6])
+{
+    const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        uint32_t v = (uint32_t) (g >> 1) << 24;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = 3 * j + i;
+            if (t < 16) v |= (uint32_t) ((((col + 16 * (g & 1) + t) & 31) << 3) & 0xff) << (8 * i);
+        }
+        K[j] = v;
+    }
+}
+__device__ __forceinline__ constexpr uint32_t fs_mx_sel8(int t) { return 0x0c070000u | ((uint32_t) (t & 3) << 8) | (uint32_t) (4 + t % 3); }
+template <int U> __device__ __forceinline__ uint32_t fs_mx_dword4(const u32x4 &w) { return U == 0 ? w.x : U == 1 ? w.y : U == 2 ? w.z : w.w; }
+template <int OFF> __device__ __forceinline__ void fs_mx_load(u32x4 &q, const u32x4 *p) { asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF)); }
+// compiler-scheduled form (warm-up and tail groups)
+__device__ __forceinline__ v4i_t fs_mx_group8_slow(const u32x4 &w, const uint32_t (&K)[6], const v4i_t &spa, int spidx)
+{
+    const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+    v4i_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        v2i_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = 4 * u + i;
+            const uint32_t addr = __builtin_amdgcn_perm(K[t / 3], wd[u], fs_mx_sel8(t));
+            r[i] = *(fs_lds_row8_t) (uintptr_t) addr;
+        }
+        const v4i_t lo = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3), hi = __builtin_shufflevector(r[2], r[3], 0, 1, 2, 3);
+        const v8i_t b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+    }
+    return acc;
+}
+// the four rows of matrix instruction U (lookups 4U .. 4U+3 = the four bytes of dword w), from asm.  (The allocator keeps two of
+// the four rows outside the instruction's 8-register operand and copies them in after the wait: 4 moves per instruction.
+// Pinning the rows to fixed registers removes the moves but makes it shuffle rows that are still IN FLIGHT around the
+// candidate branch -- the loads are invisible to it -- so that was not kept.)
+template <int U> __device__ __forceinline__ void fs_mx_issue8(uint32_t w, const uint32_t (&K)[6], v2i_t &r0, v2i_t &r1, v2i_t &r2, v2i_t &r3)
+{
+    uint32_t a0, a1, a2, a3;
+    constexpr int t = 4 * U;
+    asm volatile("v_perm_b32 %4, %8, %12, %13\n\t"
+                 "v_perm_b32 %5, %9, %12, %14\n\t"
+                 "v_perm_b32 %6, %10, %12, %15\n\t"
+                 "v_perm_b32 %7, %11, %12, %16\n\t"
+                 "ds_read_b64 %0, %4\n\t"
+                 "ds_read_b64 %1, %5\n\t"
+                 "ds_read_b64 %2, %6\n\t"
+                 "ds_read_b64 %3, %7"
+                 : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                 : "v"(K[t / 3]), "v"(K[(t + 1) / 3]), "v"(K[(t + 2) / 3]), "v"(K[(t + 3) / 3]), "v"(w),
+                   "s"(fs_mx_sel8(t)), "s"(fs_mx_sel8(t + 1)), "s"(fs_mx_sel8(t + 2)), "s"(fs_mx_sel8(t + 3)));
+}
+template <int PENDING> __device__ __forceinline__ void fs_mx_wait8(v2i_t &r0, v2i_t &r1, v2i_t &r2, v2i_t &r3)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(PENDING));
+}
+// one matrix instruction of the rolling pipeline: wait for its four rows (PENDING younger reads stay outstanding), run it,
+// refill the four registers with the same lookups' rows of the NEXT group (dword U of wn)
+template <int U, int PENDING> __device__ __forceinline__ void fs_mx_step8(v2i_t (&r)[16], v4i_t &acc, const u32x4 &wn, const uint32_t (&K)[6],
+                                                                         const v4i_t &spa, int spidx)
+{
+    fs_mx_wait8<PENDING>(r[4 * U], r[4 * U + 1], r[4 * U + 2], r[4 * U + 3]);
+    const v8i_t b = {r[4 * U][0], r[4 * U][1], r[4 * U + 1][0], r[4 * U + 1][1], r[4 * U + 2][0], r[4 * U + 2][1], r[4 * U + 3][0], r[4 * U + 3][1]};
+    acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
+    fs_mx_issue8<U>(fs_mx_dword4<U>(wn), K, r[4 * U], r[4 * U + 1], r[4 * U + 2], r[4 * U + 3]);
+}
+template <int PENDING> __device__ __forceinline__ v4i_t fs_mx_group8(v2i_t (&r)[16], const u32x4 &wn, const uint32_t (&K)[6], const v4i_t &spa, int spidx)
+{
+    v4i_t acc = {0, 0, 0, 0};
+    fs_mx_step8<0, PENDING>(r, acc, wn, K, spa, spidx);
+    fs_mx_step8<1, PENDING>(r, acc, wn, K, spa, spidx);
+    fs_mx_step8<2, PENDING>(r, acc, wn, K, spa, spidx);
+    fs_mx_step8<3, PENDING>(r, acc, wn, K, spa, spidx);
+    return acc;
+}
+
 constexpr int kFsMxSeg = 256;        // MODE 1 segments per chunk and query: (wave, column) pairs
 
 // grid = (chunks, ceil(B / 16)), 1024 threads.  Thresholds: 16 words in LDS, candidate <=> a < thr (thr = bound + slack + 1).
-template <int T, int MODE>
+template <int T, int MODE, int QR = 16>
 __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
 {
-    constexpr int M = 4 * T, QR = 16;
+    static_assert((QR == 16 && (T == 4 || T == 8)) || (QR == 8 && T == 16), "M = 16 / 32 with 16-byte rows, M = 64 with 8-byte rows");
+    constexpr int M = 4 * T;
     typedef typename FsMxW<T>::V W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, tile = blockIdx.y;
@@ -1467,11 +1653,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
         const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
         uint4 *d4 = reinterpret_cast<uint4 *>(smem);
         for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
-        if (tid < QR) {
-            // queries past the end of the batch (last tile) get threshold 0: they never hit
+        if (tid < 16) {
+            // queries past the end of the batch (last tile) and the unused rows of an 8-query tile get threshold 0: they never hit
             const int b = tile * QR + tid;
-            uint32_t t = b < p.B ? 0xffffu : 0u;
-            if constexpr (MODE == 2) t = b < p.B ? p.thr16[b] : 0u;
+            const bool live = tid < QR && b < p.B;
+            uint32_t t = live ? 0xffffu : 0u;
+            if constexpr (MODE == 2) t = live ? p.thr16[b] : 0u;
             s_thr[tid] = t;
         }
         if (tid < 2 * QR) s_lcnt[tid] = 0u;
@@ -1480,9 +1667,14 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     const int lane = tid & 63, wave = tid >> 6, col = lane & 15, gq = lane >> 4;      // this lane judges queries 4 gq .. 4 gq + 3
     v4i_t spa;
     int spidx;
-    fs_mx_pattern(col, spa, spidx);
-    uint32_t C[T];
-    fs_mx_consts<T>(lane, C);
+    uint32_t C[QR == 16 ? T : 6];
+    if constexpr (QR == 16) {
+        fs_mx_pattern(col, spa, spidx);
+        fs_mx_consts<T>(lane, C);
+    } else {
+        fs_mx_pattern8(col, spa, spidx);
+        fs_mx_consts8(lane, C);
+    }
 
     const int64_t c_begin = (int64_t) blockIdx.x * p.chunk_len;         // a multiple of 1024
     int64_t c_end = c_begin + p.chunk_len;
@@ -1544,7 +1736,8 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 v = o < v ? o : v;
             }
             const int b = tile * QR + 4 * gq + r;
-            if (col == 0 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[4 * gq + r], fs_thr_of((uint32_t) v, (uint32_t) p.slack[b]));
+            if (col == 0 && 4 * gq + r < QR && v != 0x7fffffff && b < p.B)
+                atomicMin(&s_thr[4 * gq + r], fs_thr_of((uint32_t) v, (uint32_t) p.slack[b]));
         }
     };
     auto load_thr = [&]() { return *reinterpret_cast<const v4i_t *>(s_thr + 4 * gq); };
@@ -1565,9 +1758,14 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     // one group at a time (warm-up, tail): group index gi counted from the chunk's first group
     auto slow_group = [&](int64_t gi, bool minima, const v4i_t &thr) {
         const W w = fc[(size_t) gi * 64];
-        v4i_t r[T];
-        fs_mx_issue<T>(w, C, r);
-        v4i_t acc = fs_mx_reduce<T>(r, spa, spidx);
+        v4i_t acc;
+        if constexpr (QR == 16) {
+            v4i_t r[T];
+            fs_mx_issue<T>(w, C, r);
+            acc = fs_mx_reduce<T>(r, spa, spidx);
+        } else {
+            acc = fs_mx_group8_slow(w, C, spa, spidx);
+        }
         const int64_t n = c_begin + gi * 16 + col;
         if (n >= c_end) acc = v4i_t{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};     // columns past the end are never judged
         if (minima) take_min(acc);
@@ -1606,56 +1804,110 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
         // its rows fetched; it is reloaded right after use, a whole trip ahead of its next use.
         const W *pw = fc + (size_t) wave * 4 * 64;
         auto trip_ptr = [&](int k) { return pw + (size_t) trip_of(k < ntrip ? k : ntrip - 1) * 64 * 64; };   // past the end: a valid address, rows never used
-        v4i_t ra[T], rb[T];
-        W q[4];
-        {
-            const W *p0 = trip_ptr(0), *p1 = trip_ptr(1);
-            const W g0 = p0[0], g1 = p0[64];
-            fs_mx_issue_hot<T>(g0, C, ra);
-            fs_mx_issue_hot<T>(g1, C, rb);
+        if constexpr (QR == 16) {
+            v4i_t ra[T], rb[T];
+            W q[4];
+            {
+                const W *p0 = trip_ptr(0), *p1 = trip_ptr(1);
+                const W g0 = p0[0], g1 = p0[64];
+                fs_mx_issue_hot<T>(g0, C, ra);
+                fs_mx_issue_hot<T>(g1, C, rb);
+                constexpr int S = 64 * (int) sizeof(W);
+                fs_mx_load<2 * S>(q[2], p0);        // in the order of their use: every use has three younger loads behind it
+                fs_mx_load<3 * S>(q[3], p0);
+                fs_mx_load<0>(q[0], p1);
+                fs_mx_load<S>(q[1], p1);
+            }
+            const uint32_t thr_addr = (uint32_t) (lut_bytes + 16 * gq);       // s_thr + 4 * gq as an LDS address (dynamic LDS starts at 0)
+            v4i_t thr;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(thr) : "v"(thr_addr));     // (not a compiler-visible load: it would be waited for inside the loop)
+            for (int k = 0; k < ntrip; ++k) {
+                const int it = trip_of(k);
+                const W *pn = trip_ptr(k + 1), *pnn = trip_ptr(k + 2);
+                const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;     // positions fit 32 bits (the records hold 32)
+                v4i_t acc;
+                constexpr int S = 64 * (int) sizeof(W);                // bytes between the lookups of consecutive groups
+                fs_mx_vmwait<3>(q[2]);
+                fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
+                acc = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx);   // ... refilled with group 2's rows
+                fs_mx_load<2 * S>(q[2], pn);
+                if (MODE == 1) take_min(acc); else judge(acc, thr, n);
+                fs_mx_vmwait<3>(q[3]);
+                fs_mx_wait<T>(rb);                                    // group 1
+                acc = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx);
+                fs_mx_load<3 * S>(q[3], pn);
+                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
+                // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
+                // of old and new words is a valid set of thresholds (each word is an upper bound at all times)
+                if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1" : "+v"(thr) : "v"(thr_addr));
+                fs_mx_vmwait<3>(q[0]);
+                fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
+                acc = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx);   // next trip's group 0
+                fs_mx_load<0>(q[0], pnn);
+                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
+                fs_mx_vmwait<3>(q[1]);
+                fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
+                acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx);
+                fs_mx_load<S>(q[1], pnn);
+                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
+                adopt(false);
+            }
+            fs_mx_wait<0>(ra);            // the rows and lookups fetched past the last trip are never used, but must have landed
+            fs_mx_wait<0>(rb);
+            fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
+    
+        } else {
+            // M = 64: one register set of 16 rows, rolling at matrix-instruction granularity (the LDS counter of a wave holds 15
+            // operations, so two groups of 16 reads cannot be in flight anyway): instruction u of group j waits for its four
+            // rows -- the twelve reads issued since stay outstanding -- runs, and its registers take instruction u's rows of
+            // group j + 1.  q[j]: lookups of column j's next group, reloaded a trip ahead as above.
+            v2i_t r[16];
+            W q[4];
             constexpr int S = 64 * (int) sizeof(W);
-            fs_mx_load<2 * S>(q[2], p0);        // in the order of their use: every use has three younger loads behind it
-            fs_mx_load<3 * S>(q[3], p0);
-            fs_mx_load<0>(q[0], p1);
-            fs_mx_load<S>(q[1], p1);
+            {
+                const W *p0 = trip_ptr(0), *p1 = trip_ptr(1);
+                const W g0 = p0[0];
+                fs_mx_issue8<0>(g0.x, C, r[0], r[1], r[2], r[3]);
+                fs_mx_issue8<1>(g0.y, C, r[4], r[5], r[6], r[7]);
+                fs_mx_issue8<2>(g0.z, C, r[8], r[9], r[10], r[11]);
+                fs_mx_issue8<3>(g0.w, C, r[12], r[13], r[14], r[15]);
+                fs_mx_load<S>(q[1], p0);            // in the order of their use: every use has three younger loads behind it
+                fs_mx_load<2 * S>(q[2], p0);
+                fs_mx_load<3 * S>(q[3], p0);
+                fs_mx_load<0>(q[0], p1);
+            }
+            const uint32_t thr_addr = (uint32_t) (lut_bytes + 16 * gq);
+            v4i_t thr;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(thr) : "v"(thr_addr));
+            for (int k = 0; k < ntrip; ++k) {
+                const int it = trip_of(k);
+                const W *pn = trip_ptr(k + 1), *pnn = trip_ptr(k + 2);
+                const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;
+                v4i_t acc;
+                fs_mx_vmwait<3>(q[1]);
+                acc = fs_mx_group8<12>(r, q[1], C, spa, spidx);          // group 0; refills = group 1's rows
+                fs_mx_load<S>(q[1], pn);
+                if (MODE == 1) take_min(acc); else judge(acc, thr, n);
+                fs_mx_vmwait<3>(q[2]);
+                acc = fs_mx_group8<12>(r, q[2], C, spa, spidx);          // group 1
+                fs_mx_load<2 * S>(q[2], pn);
+                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
+                // thresholds: re-read once per trip into the live registers (any mix of old and new words is valid); the read
+                // sits behind group 2's rows in the queue, so group 2's four waits see one more outstanding operation
+                if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1" : "+v"(thr) : "v"(thr_addr));
+                fs_mx_vmwait<3>(q[3]);
+                acc = fs_mx_group8<(MODE == 0) ? 13 : 12>(r, q[3], C, spa, spidx);   // group 2
+                fs_mx_load<3 * S>(q[3], pn);
+                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
+                fs_mx_vmwait<3>(q[0]);
+                acc = fs_mx_group8<12>(r, q[0], C, spa, spidx);          // group 3; refills = next trip's group 0
+                fs_mx_load<0>(q[0], pnn);
+                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
+                adopt(false);
+            }
+            fs_mx_wait8<0>(r[0], r[1], r[2], r[3]);       // everything fetched past the last trip has landed
+            fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
         }
-        const uint32_t thr_addr = (uint32_t) (lut_bytes + 16 * gq);       // s_thr + 4 * gq as an LDS address (dynamic LDS starts at 0)
-        v4i_t thr;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(thr) : "v"(thr_addr));     // (not a compiler-visible load: it would be waited for inside the loop)
-        for (int k = 0; k < ntrip; ++k) {
-            const int it = trip_of(k);
-            const W *pn = trip_ptr(k + 1), *pnn = trip_ptr(k + 2);
-            const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;     // positions fit 32 bits (the records hold 32)
-            v4i_t acc;
-            constexpr int S = 64 * (int) sizeof(W);                // bytes between the lookups of consecutive groups
-            fs_mx_vmwait<3>(q[2]);
-            fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
-            acc = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx);   // ... refilled with group 2's rows
-            fs_mx_load<2 * S>(q[2], pn);
-            if (MODE == 1) take_min(acc); else judge(acc, thr, n);
-            fs_mx_vmwait<3>(q[3]);
-            fs_mx_wait<T>(rb);                                    // group 1
-            acc = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx);
-            fs_mx_load<3 * S>(q[3], pn);
-            if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
-            // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
-            // of old and new words is a valid set of thresholds (each word is an upper bound at all times)
-            if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1" : "+v"(thr) : "v"(thr_addr));
-            fs_mx_vmwait<3>(q[0]);
-            fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
-            acc = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx);   // next trip's group 0
-            fs_mx_load<0>(q[0], pnn);
-            if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
-            fs_mx_vmwait<3>(q[1]);
-            fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
-            acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx);
-            fs_mx_load<S>(q[1], pnn);
-            if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
-            adopt(false);
-        }
-        fs_mx_wait<0>(ra);            // the rows and lookups fetched past the last trip are never used, but must have landed
-        fs_mx_wait<0>(rb);
-        fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
     }
     tail(MODE == 1);
 
@@ -1680,19 +1932,18 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = tile * QR + 4 * gq + r;
-            if (b < p.B) p.segmin[(size_t) b * G + seg] = (uint16_t) (keep[r] > 0xffff ? 0xffff : keep[r]);
+            if (4 * gq + r < QR && b < p.B) p.segmin[(size_t) b * G + seg] = (uint16_t) (keep[r] > 0xffff ? 0xffff : keep[r]);
         }
     }
 }
 
-template <int T, int MODE> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
+template <int T, int MODE, int QR = 16> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
-    constexpr int QR = 16;
     const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8;
     FsArgs b = a;
     b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) QR * 8));
     const size_t smem = tab + (size_t) QR * 8 * b.lcap;
-    auto kern = fscan_mx_kernel<T, MODE>;
+    auto kern = fscan_mx_kernel<T, MODE, QR>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     launch_timed(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
@@ -1706,6 +1957,7 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
     if (rot && mx) {
         if (a.M == 16) return launch_fscan_mx_t<4, MODE>(a, chunks, tiles, st);
         if (a.M == 32) return launch_fscan_mx_t<8, MODE>(a, chunks, tiles, st);
+        if (a.M == 64) return launch_fscan_mx_t<16, MODE, 8>(a, chunks, tiles, st);
         return hipErrorInvalidValue;
     }
     if (rot) {
@@ -1730,7 +1982,7 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
 {
     // d_codes: formatted lookups (launch_fcodes_format, same `mx`) for fs_rot_supported shapes, the plain codes otherwise
     if (B == 0 || n_codes == 0) return hipSuccess;
-    const bool rot = fs_rot_supported(M, Ks);
+    const bool rot = fs_rot_supported(M, Ks, mx);
     FsArgs a;
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
@@ -1742,9 +1994,12 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     return launch_fscan_mode<0>(a, chunks, rot, mx != 0, st);
 }
 
-int fscan_mx_subspace(int lane, int t) { return fs_mx_subspace(lane >> 4, lane & 15, t); }
+int fscan_mx_subspace(int M, int lane, int t)
+{
+    return M == 64 ? fs_mx_subspace64(lane >> 4, lane & 15, t) : fs_mx_subspace(lane >> 4, lane & 15, t);
+}
 // lane segments per chunk and query of the MODE 1 pass (the G of launch_kth_threshold is chunks times this)
-int fscan_segments_per_chunk(int M, int Ks, int mx) { return (mx && fs_rot_supported(M, Ks)) ? kFsMxSeg : kFsThreads; }
+int fscan_segments_per_chunk(int M, int Ks, int mx) { return (mx && fs_rot_supported(M, Ks, mx)) ? kFsMxSeg : kFsThreads; }
 // bytes of the formatted copy of n codes: fscan_mx_kernel's is a permutation of the code bytes written in whole groups of 16
 // codes, fscan_kernel's holds a 16-bit (half, ks, slot) value per code byte
 int64_t fcodes_bytes(int64_t n, int M, int mx) { return mx ? (n + 15) / 16 * 16 * M : n * M * 2;

@@ -71,6 +71,15 @@ __device__ __forceinline__ float fvec_l2sqr_ds4v(const float4 &a, const float4 &
     const float t0 = __fsub_rn(a.x, c.x), t1 = __fsub_rn(a.y, c.y), t2 = __fsub_rn(a.z, c.z), t3 = __fsub_rn(a.w, c.w);
     return __fadd_rn(__fadd_rn(__fmul_rn(t0, t0), __fmul_rn(t1, t1)), __fadd_rn(__fmul_rn(t2, t2), __fmul_rn(t3, t3)));
 }
+// Ds == 2 (D = 128 at M = 64, the reference's own benchmark shape): one partial chunk into zeroed lanes, lanes 2 and 3 stay +0:
+// (t0^2 + t1^2) + (0 + 0), the same for all three SIMD variants
+__device__ __forceinline__ float fvec_l2sqr_ds2v(const float2 &a, const float2 &c)
+{
+    const float t0 = __fsub_rn(a.x, c.x), t1 = __fsub_rn(a.y, c.y);
+    return __fadd_rn(__fadd_rn(__fmul_rn(t0, t0), __fmul_rn(t1, t1)), 0.0f);
+}
+__device__ __forceinline__ float fvec_l2sqr_vec(const float4 &a, const float4 &c);
+__device__ __forceinline__ float fvec_l2sqr_vec(const float2 &a, const float2 &c) { return fvec_l2sqr_ds2v(a, c); }
 __device__ __forceinline__ float fvec_l2sqr_ds4(const float *__restrict__ x, const float *__restrict__ y)
 {
     const float4 a = *reinterpret_cast<const float4 *>(x);
@@ -78,6 +87,8 @@ __device__ __forceinline__ float fvec_l2sqr_ds4(const float *__restrict__ x, con
     const float t0 = __fsub_rn(a.x, c.x), t1 = __fsub_rn(a.y, c.y), t2 = __fsub_rn(a.z, c.z), t3 = __fsub_rn(a.w, c.w);
     return __fadd_rn(__fadd_rn(__fmul_rn(t0, t0), __fmul_rn(t1, t1)), __fadd_rn(__fmul_rn(t2, t2), __fmul_rn(t3, t3)));
 }
+
+__device__ __forceinline__ float fvec_l2sqr_vec(const float4 &a, const float4 &c) { return fvec_l2sqr_ds4v(a, c); }
 
 // dispatcher used by the table kernels (x = query sub-vector at m*Ds floats, y = codeword at i*Ds floats: both 16-byte
 // aligned when Ds == 4 because the query rows and the codeword array are)

@@ -145,10 +145,10 @@ int lut_tile_for(int M, int Ks);
 bool fastscan_supported(int M, int Ks);
 int fastscan_rows(int M, int Ks);
 hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qc, uint8_t *d_qlut,
-                               int32_t *d_slack, hipStream_t st);
+                               int32_t *d_slack, int mx, hipStream_t st);
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
                                   int arch, float *d_lut, uint8_t *d_qc, uint8_t *d_qlut, int32_t *d_slack,
-                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st);
+                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, int mx, hipStream_t st);
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
@@ -156,15 +156,15 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
 int fastscan_max_sum(int M);
 // mx != 0: the rotated shapes run fscan_mx_kernel (byte sums on the matrix cores) over its own order of the formatted lookups
 int fscan_segments_per_chunk(int M, int Ks, int mx);
-int fscan_mx_subspace(int lane, int t);       // subspace whose table row lane `lane` of a wave fetches as its lookup t
+int fscan_mx_subspace(int M, int lane, int t);       // subspace whose table row lane `lane` of a wave fetches as its lookup t
 int64_t fcodes_bytes(int64_t n, int M, int mx);      // size of the formatted copy of n codes
 // tables of the rotated shapes built by tile (fastscan.hip): exact fp32 [b][M*Ks] + rotated byte rows + slack in two launches
-bool lut_tile_supported(int M, int Ks, int Ds);
-hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, float *d_lut,
+bool lut_tile_supported(int M, int Ks, int Ds, int mx);
+hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ds, float *d_lut,
                                        float *d_lohi, uint8_t *d_qlut, int32_t *d_slack, unsigned int *d_cand_cnt,
                                        uint32_t *d_gthr, hipStream_t st);
 // conflict-free rotated table layout + formatted code copy (see fastscan.hip): launch_fscan then takes the formatted codes
-bool fs_rot_supported(int M, int Ks);
+bool fs_rot_supported(int M, int Ks, int mx);      // mx: the engine's scan_mx option (M = 64 has a rotated form only there)
 hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, int64_t n0, int64_t n1, int M, int Ks,
                                 uint16_t *d_out, int mx, hipStream_t st);
 int rerank_topk_max_k();

@@ -544,7 +544,7 @@ def test_alternating_streams_share_scratch_safely():
         assert np.array_equal(ib.cpu().numpy(), want_b[0]) and np.array_equal(db.cpu().numpy(), want_b[1])
 
 
-@pytest.mark.parametrize("M", [32, 16])
+@pytest.mark.parametrize("M", [32, 16, 64])
 def test_matrix_core_scan_equals_vector_scan(M):
     """fscan_mx_kernel (option scan_mx = 1, default: table bytes summed by v_smfmac) against fscan_kernel (scan_mx = 0) and the
     exhaustive scan: identical ids and distances for top-1, top-k and subset search; sizes that end inside a group of 16
@@ -552,11 +552,12 @@ def test_matrix_core_scan_equals_vector_scan(M):
     duplicates in the database (ties)."""
     from rii_amd import RiiGpu
     rng = np.random.default_rng(4100 + M)
-    cw = rng.random((M, 256, 4)).astype(np.float32)
+    Ds = 2 if M == 64 else 4                 # M = 64: the reference's own benchmark shape (D = 128), tables built by tile for Ds = 2
+    cw = rng.random((M, 256, Ds)).astype(np.float32)
     N = 70000 + 13
     codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
     codes[rng.integers(0, N, 2000)] = codes[rng.integers(0, N, 2000)]
-    qs = rng.random((150, M * 4)).astype(np.float32)
+    qs = rng.random((150, M * Ds)).astype(np.float32)
     g = RiiGpu(cw, False, simd_arch="avx512")
     assert g.get_option("scan_mx") == 1
 
