@@ -1839,7 +1839,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
                 // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
                 // of old and new words is a valid set of thresholds (each word is an upper bound at all times)
-                if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1" : "+v"(thr) : "v"(thr_addr));
+                if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thr) : "v"(thr_addr));
                 fs_mx_vmwait<3>(q[0]);
                 fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
                 acc = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx);   // next trip's group 0
@@ -1894,7 +1894,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
                 // thresholds: re-read once per trip into the live registers (any mix of old and new words is valid); the read
                 // sits behind group 2's rows in the queue, so group 2's four waits see one more outstanding operation
-                if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1" : "+v"(thr) : "v"(thr_addr));
+                if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thr) : "v"(thr_addr));
                 fs_mx_vmwait<3>(q[3]);
                 acc = fs_mx_group8<(MODE == 0) ? 13 : 12>(r, q[3], C, spa, spidx);   // group 2
                 fs_mx_load<3 * S>(q[3], pn);
