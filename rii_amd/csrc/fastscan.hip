@@ -1484,9 +1484,9 @@ template <int T> __device__ __forceinline__ void fs_mx_issue_hot(const typename 
 // issued its registers take the rows of the group two ahead (lookups wn) -- the reads travel under the remaining matrix
 // instructions and the whole next group
 template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce_refill(v4i_t (&r)[T], const typename FsMxW<T>::V &wn, const uint32_t (&C)[T],
-                                                                      const v4i_t &spa, int spidx)
+                                                                      const v4i_t &spa, int spidx, const v4i_t &zero)
 {
-    v4i_t acc = {0, 0, 0, 0};
+    v4i_t acc = zero;
     {
         const v8i_t b = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3, 4, 5, 6, 7);
         acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
@@ -1624,9 +1624,10 @@ template <int U, int PENDING> __device__ __forceinline__ void fs_mx_step8(v2i_t 
     acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
     fs_mx_issue8<U>(fs_mx_dword4<U>(wn), K, r[4 * U], r[4 * U + 1], r[4 * U + 2], r[4 * U + 3]);
 }
-template <int PENDING> __device__ __forceinline__ v4i_t fs_mx_group8(v2i_t (&r)[16], const u32x4 &wn, const uint32_t (&K)[6], const v4i_t &spa, int spidx)
+template <int PENDING> __device__ __forceinline__ v4i_t fs_mx_group8(v2i_t (&r)[16], const u32x4 &wn, const uint32_t (&K)[6], const v4i_t &spa, int spidx,
+                                                                     const v4i_t &zero)
 {
-    v4i_t acc = {0, 0, 0, 0};
+    v4i_t acc = zero;
     fs_mx_step8<0, PENDING>(r, acc, wn, K, spa, spidx);
     fs_mx_step8<1, PENDING>(r, acc, wn, K, spa, spidx);
     fs_mx_step8<2, PENDING>(r, acc, wn, K, spa, spidx);
@@ -1798,6 +1799,10 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     const int ntrip = (MODE == 1) ? (full + step - 1) / step : full;
     auto trip_of = [&](int k) { return (MODE == 0) ? (k + 1 < full ? k + 1 : 0) : k * step; };
     if (ntrip > 0) {
+        // a zero accumulator kept in registers: the matrix instruction accumulates in place, and built from a literal the
+        // compiler clears it with six moves per group instead of two
+        v4i_t zero4 = {0, 0, 0, 0};
+        asm volatile("" : "+v"(zero4));
         // Per wave the groups form one sequence g = 4 * trip + j.  Two register sets of T rows alternate (even / odd groups);
         // while group g runs through the matrix core, the rows of g + 1 are in flight and those of g + 2 are being issued into
         // g's own registers (fs_mx_reduce_refill).  q[j] holds the lookups of the next group of column j that still needs
@@ -1829,12 +1834,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 constexpr int S = 64 * (int) sizeof(W);                // bytes between the lookups of consecutive groups
                 fs_mx_vmwait<3>(q[2]);
                 fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
-                acc = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx);   // ... refilled with group 2's rows
+                acc = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx, zero4);   // ... refilled with group 2's rows
                 fs_mx_load<2 * S>(q[2], pn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n);
                 fs_mx_vmwait<3>(q[3]);
                 fs_mx_wait<T>(rb);                                    // group 1
-                acc = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx);
+                acc = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx, zero4);
                 fs_mx_load<3 * S>(q[3], pn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
                 // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
@@ -1842,12 +1847,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thr) : "v"(thr_addr));
                 fs_mx_vmwait<3>(q[0]);
                 fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
-                acc = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx);   // next trip's group 0
+                acc = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx, zero4);   // next trip's group 0
                 fs_mx_load<0>(q[0], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
                 fs_mx_vmwait<3>(q[1]);
                 fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
-                acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx);
+                acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx, zero4);
                 fs_mx_load<S>(q[1], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
                 adopt(false);
@@ -1885,22 +1890,22 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;
                 v4i_t acc;
                 fs_mx_vmwait<3>(q[1]);
-                acc = fs_mx_group8<12>(r, q[1], C, spa, spidx);          // group 0; refills = group 1's rows
+                acc = fs_mx_group8<12>(r, q[1], C, spa, spidx, zero4);          // group 0; refills = group 1's rows
                 fs_mx_load<S>(q[1], pn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n);
                 fs_mx_vmwait<3>(q[2]);
-                acc = fs_mx_group8<12>(r, q[2], C, spa, spidx);          // group 1
+                acc = fs_mx_group8<12>(r, q[2], C, spa, spidx, zero4);          // group 1
                 fs_mx_load<2 * S>(q[2], pn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
                 // thresholds: re-read once per trip into the live registers (any mix of old and new words is valid); the read
                 // sits behind group 2's rows in the queue, so group 2's four waits see one more outstanding operation
                 if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thr) : "v"(thr_addr));
                 fs_mx_vmwait<3>(q[3]);
-                acc = fs_mx_group8<(MODE == 0) ? 13 : 12>(r, q[3], C, spa, spidx);   // group 2
+                acc = fs_mx_group8<(MODE == 0) ? 13 : 12>(r, q[3], C, spa, spidx, zero4);   // group 2
                 fs_mx_load<3 * S>(q[3], pn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
                 fs_mx_vmwait<3>(q[0]);
-                acc = fs_mx_group8<12>(r, q[0], C, spa, spidx);          // group 3; refills = next trip's group 0
+                acc = fs_mx_group8<12>(r, q[0], C, spa, spidx, zero4);          // group 3; refills = next trip's group 0
                 fs_mx_load<0>(q[0], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
                 adopt(false);
