@@ -121,3 +121,42 @@ def test_fuzz_large_db_paths_agree(seed):
             assert np.array_equal(gotk[0], refk[0]), "topk ids seed=%d" % seed       # both sides use the canonical (dist, id) order
         if stage == 0:
             g.add_codes(codes[n1:], False)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_fuzz_matrix_core_filter_against_oracle(seed):
+    """The shapes whose filter scan sums its table bytes on the matrix cores (M = 16 / 32 / 64 at Ks = 256, fscan_mx_kernel),
+    forced onto that path at any batch size (fast_min_batch = 0), against the CPU oracle: random Ds and SIMD flavour, sizes
+    that end inside a 16-code group or a 1024-code trip, heavy duplication (exact ties: the reference's std::partial_sort
+    order), appends, subsets, top-1 and top-k; bit-exact ids and distances."""
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(8800 + seed)
+    M = int(rng.choice([16, 32, 64]))
+    Ks = 256
+    Ds = int(rng.choice([1, 2, 3, 4, 8]))
+    N = int(rng.choice([15, 16, 17, 1023, 1024, 1040, 2500, 4097, 7000]))
+    arch = str(rng.choice(["avx512", "avx", "sse"]))
+    scale = str(rng.choice(["unit", "sift"]))
+    dup = int(N * rng.choice([0.0, 0.2, 0.9]))
+    cw, codes, qs = make_problem(300 + seed, M, Ks, Ds, N, scale, dup=dup)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    g.set_option("fast_min_batch", 0)
+    assert g.get_option("scan_mx") == 1
+    n1 = int(rng.integers(1, N + 1))
+    done = 0
+    for part in (codes[:n1], codes[n1:]):
+        if not len(part):
+            continue
+        g.add_codes(part, False); o.add_codes(part, False)
+        done += len(part)
+        Q = qs[:int(rng.choice([1, 2, 3, 5, 6, 16]))]          # (the oracle takes ~60 ms per query: few queries, many shapes)
+        for _ in range(3):
+            S = int(rng.integers(1, done + 1)) if rng.random() < 0.5 else 0
+            tids = np.sort(rng.choice(done, S, replace=False)).astype(np.int64) if S else E
+            pool = S if S else done
+            topk = 1 if rng.random() < 0.4 else int(rng.integers(1, min(pool, 70) + 1))
+            ids, d = g.query_linear_batch(Q, topk, tids)
+            for b in range(len(Q)):
+                want = o.query_linear(Q[b], topk, tids)
+                assert_same_result((ids[b], d[b]), want, "mx M=%d Ds=%d N=%d k=%d S=%d seed=%d b=%d" % (M, Ds, done, topk, S, seed, b))
