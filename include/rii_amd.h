@@ -132,6 +132,23 @@ int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, in
 int rii_ivf_shard_replay_dev(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
                              float *d_out_dists, void *stream);
 
+/* Database-sharded LINEAR search, exact ties (NEW; tieorder.hip).  The merge below orders bit-equal distances of different
+ * shards by id; the reference's order is what std::partial_sort (src/rii.h:234-235) makes of all N distances in index order.
+ * For a query whose merged k+1 best distances hold an exact tie every rank calls rii_linear_tie_emit_dev: in index order, the
+ * codes of its shard (or of its share of the target ids) that can touch the reference's heap -- distance below `d_bound[f]`
+ * (+inf = none: the k-th smallest distance of any earlier shard with >= k codes is a valid bound) and below the k-th smallest
+ * of every earlier 8192-code chunk of the shard -- as rows of `cap` (global id = id_offset + local id, distance), plus the
+ * row's true length in d_out_count (> cap: the row is truncated and must not be used).  The ranks' records
+ * ([nf] int32 counts padded to 8 bytes, [nf*cap] int64 ids, [nf*cap] f32 distances, padded to rii_linear_tie_record_bytes())
+ * are all-gathered in rank order = index order, and rii_linear_tie_replay_dev (stateless) replays the library's heap over
+ * them: the reference's ids, distances and order, identically on every rank.  topk <= 1024, G * cap < 2^32. */
+int rii_linear_tie_emit_dev(rii_engine *e, const float *d_queries, int64_t nf, int topk, const int64_t *d_tids, int64_t S,
+                            const float *d_bound, int64_t id_offset, int cap, int64_t *d_out_ids, float *d_out_dists,
+                            int32_t *d_out_count, void *stream);
+int64_t rii_linear_tie_record_bytes(int64_t nf, int cap);
+int rii_linear_tie_replay_dev(const void *d_gathered, int G, int64_t nf, int cap, int topk, int64_t *d_out_ids,
+                              float *d_out_dists, void *stream);
+
 /* Database sharding (NEW, not in the reference: it has no multi-device code).  Every rank sends one record per batch --
  * [B*k] int64 keys, (payload != 0: [B*k] int64 payload,) [B*k] f32 distances, padded to rii_merge_record_bytes() -- through
  * one all-gather; `d_gathered` holds the G records back to back.  Output: per query the k_out smallest of the G*k entries

@@ -127,6 +127,9 @@ def _lib():
         "rii_query_ivf_shard_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int,
                                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "rii_ivf_shard_replay_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+        "rii_linear_tie_emit_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
+        "rii_linear_tie_record_bytes": (c_i64, [c_i64, c_int]),
+        "rii_linear_tie_replay_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
         "rii_merge_record_bytes": (c_i64, [c_i64, c_int, c_int]),
         "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
         "rii_dtable": (c_int, [c_vp, f32p, c_i64, f32p]),
@@ -163,6 +166,15 @@ def ivf_shard_replay_dev(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, 
     """std::partial_sort replayed over the gathered candidate sequences of nf tie-flagged queries (include/rii_amd.h)."""
     _check(_lib().rii_ivf_shard_replay_dev(d_gathered, int(G), int(nf), int(rows), int(topk), d_out_ids, d_out_dists,
                                            stream or None))
+
+
+def linear_tie_record_bytes(nf, cap):
+    return int(_lib().rii_linear_tie_record_bytes(int(nf), int(cap)))
+
+
+def linear_tie_replay_dev(d_gathered, G, nf, cap, topk, d_out_ids, d_out_dists, stream=0):
+    """Replay of std::partial_sort over the all-gathered candidate lists of database-sharded linear search (include/rii_amd.h)."""
+    _check(_lib().rii_linear_tie_replay_dev(d_gathered, int(G), int(nf), int(cap), int(topk), d_out_ids, d_out_dists, stream))
 
 
 def fscan_lane_subspace(M, lane, t):
@@ -310,6 +322,11 @@ class RiiGpu(object):
                                         d_out_dists, d_out_counts, stream or None))
 
     # ---- database-sharded inverted index (device pointers; protocol: include/rii_amd.h, rii_amd/dist.py) ----
+    def linear_tie_emit_dev(self, d_queries, nf, topk, d_tids, S, d_bound, id_offset, cap, d_out_ids, d_out_dists, d_out_count,
+                            stream=0):
+        _check(_lib().rii_linear_tie_emit_dev(self._h, d_queries, int(nf), int(topk), d_tids, int(S), d_bound, int(id_offset),
+                                              int(cap), d_out_ids, d_out_dists, d_out_count, stream))
+
     def ivf_list_lengths_dev(self, d_tids, S, S_global, d_out_len, stream=0):
         _check(_lib().rii_ivf_list_lengths_dev(self._h, d_tids or None, int(S), int(S_global), d_out_len, stream or None))
 

@@ -1477,6 +1477,63 @@ RII_API int rii_ivf_shard_replay_dev(const void *d_gathered, int G, int64_t nf, 
     return RII_OK;
 }
 
+// Database-sharded linear search, exact ties (not in the reference; kernels and argument: tieorder.hip).
+RII_API int rii_linear_tie_emit_dev(rii_engine *e, const float *d_queries, int64_t nf, int topk, const int64_t *d_tids, int64_t S,
+                                    const float *d_bound, int64_t id_offset, int cap, int64_t *d_out_ids, float *d_out_dists,
+                                    int32_t *d_out_count, void *stream)
+{
+    if (!e || nf < 0 || topk < 1 || cap < 1 || S < 0 || (S > 0 && !d_tids) || (nf > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_count)))
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    if (S > e->N) return set_err(RII_ERR_INVALID, "S=%lld must satisfy S <= N", (long long) S);
+    if (e->QT == 0 || !linear_tie_chunked_supported(e->M, e->Ks, topk))
+        return set_err(RII_ERR_UNSUPPORTED, "tie emission: topk=%d / M*Ks=%d not supported", topk, e->M * e->Ks);
+    if (nf == 0) return RII_OK;
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    RII_TRY(begin_on(e, st));
+    const int64_t n = S ? S : e->N;
+    int r = RII_OK;
+    if (n == 0) {
+        if (hipMemsetAsync(d_out_count, 0, (size_t) nf * sizeof(int32_t), st) != hipSuccess) r = set_err(RII_ERR_HIP, "memset failed");
+    } else {
+        const int64_t D = (int64_t) e->M * e->Ds;
+        const int64_t fq_max = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t) 1 << 30) / (n * 9 + 1)));
+        std::vector<int32_t> ident((size_t) fq_max + 1);
+        for (int64_t f0 = 0; f0 < nf && r == RII_OK; f0 += fq_max) {
+            const int cur = (int) std::min<int64_t>(fq_max, nf - f0);
+            r = build_lut(e, d_queries + f0 * D, cur, st, false, 0);
+            if (r != RII_OK) break;
+            if ((r = e->s_tie_list.ensure((size_t) (cur + 1) * sizeof(int32_t))) != RII_OK) break;
+            if ((r = e->s_tie_chunk.ensure(linear_tie_chunked_scratch(n, cur))) != RII_OK) break;
+            ident[0] = cur;
+            for (int i = 0; i < cur; ++i) ident[(size_t) i + 1] = i;
+            if (hipMemcpyAsync(e->s_tie_list.p, ident.data(), (size_t) (cur + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+            ScopedTimer t(e, "tie", st);
+            if (launch_linear_tie_emit(e->d_codes.as<uint8_t>(), n, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, 0,
+                                       e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), S ? d_tids : nullptr, topk, cur,
+                                       e->s_tie_chunk.p, S ? 1 : 0, d_bound ? d_bound + f0 : nullptr, id_offset, cap,
+                                       d_out_ids + f0 * cap, d_out_dists + f0 * cap, d_out_count + f0, st) != hipSuccess)
+                r = set_err(RII_ERR_HIP, "tie emission launch failed");
+        }
+    }
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
+}
+RII_API int64_t rii_linear_tie_record_bytes(int64_t nf, int cap) { return (int64_t) linear_tie_record_bytes(nf, cap); }
+RII_API int rii_linear_tie_replay_dev(const void *d_gathered, int G, int64_t nf, int cap, int topk, int64_t *d_out_ids,
+                                      float *d_out_dists, void *stream)
+{
+    if (!d_gathered || G < 1 || nf < 0 || cap < 1 || topk < 1 || topk > 1024 || (int64_t) G * cap >= ((int64_t) 1 << 32) ||
+        (nf > 0 && (!d_out_ids || !d_out_dists)))
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(launch_linear_shard_replay(d_gathered, G, nf, cap, topk, d_out_ids, d_out_dists, (hipStream_t) stream));
+    return RII_OK;
+}
+
 // Database sharding (not in the reference): merge of the all-gathered per-shard top-k rows.  Stateless.
 RII_API int64_t rii_merge_record_bytes(int64_t B, int k, int payload) { return (int64_t) merge_record_bytes(B, k, payload); }
 RII_API int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_keys,

@@ -184,6 +184,10 @@ struct TcArgs {
     unsigned long long *elist;           // [fq][nchunks * kTcChunk] (index << 32 | orderable dist), ascending index inside a segment
     int32_t *ecount;                     // [fq][nchunks]
     int64_t *out_ids; float *out_dists;
+    // database sharding (launch_linear_tie_emit): an upper bound on the heap top from the shards in front of this one, and
+    // the compacted candidate list as output instead of the replay
+    const float *ext_bound = nullptr;    // [fq] (+inf = none)
+    int64_t *em_ids = nullptr; float *em_dists = nullptr; int32_t *em_count = nullptr; int em_cap = 0; int64_t id_offset = 0;
 };
 
 __device__ __forceinline__ void tc_stage(const TcArgs &p, int64_t b, float *lds, int tid)
@@ -260,6 +264,11 @@ __global__ __launch_bounds__(256) void tie_chunk_emit_kernel(TcArgs p)
         if ((tid & 63) == 0) atomicMin(&s_bound, b);
     }
     __syncthreads();
+    if (p.ext_bound && tid == 0) {                         // codes of earlier shards come first in the reference's index order
+        const float eb = p.ext_bound[fi];
+        if (eb < INFINITY) atomicMin(&s_bound, f32_orderable(__float_as_uint(eb)));
+    }
+    __syncthreads();
     const uint32_t bound = s_bound;                        // chunk 0: ~0 = everything (a real distance is never ~0: not NaN)
     const int64_t s = (int64_t) c * kTcChunk;
     const int cnt = (int) ((p.n - s) < kTcChunk ? (p.n - s) : kTcChunk);
@@ -332,6 +341,106 @@ __global__ __launch_bounds__(64) void tie_replay_kernel(TcArgs p)
     }
 }
 
+// database sharding: the segments of one query, concatenated in index order, as (global id, distance) rows
+__global__ __launch_bounds__(256) void tie_concat_kernel(TcArgs p)
+{
+    const int fi = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long *list = p.elist + (size_t) fi * p.nchunks * kTcChunk;
+    const int32_t *ecount = p.ecount + (size_t) fi * p.nchunks;
+    int64_t base = 0;
+    for (int c = 0; c < p.nchunks; ++c) {
+        const int cnt = ecount[c];
+        const unsigned long long *seg = list + (size_t) c * kTcChunk;
+        for (int j = tid; j < cnt; j += 256) {
+            const int64_t o = base + j;
+            if (o < p.em_cap) {
+                const unsigned long long e = seg[j];
+                const uint32_t idx = (uint32_t) (e >> 32);
+                p.em_ids[(size_t) fi * p.em_cap + o] = p.id_offset + (p.remap ? p.remap[idx] : (int64_t) idx);
+                p.em_dists[(size_t) fi * p.em_cap + o] = __uint_as_float(f32_unorderable((uint32_t) (e & 0xffffffffu)));
+            }
+        }
+        base += cnt;
+    }
+    if (tid == 0) p.em_count[fi] = (int32_t) (base > 0x7fffffff ? 0x7fffffff : base);
+}
+
+// Database-sharded linear search, exact ties (not in the reference): every rank sends, for a flagged query, the
+// codes of its shard that can touch the reference's heap (launch_linear_tie_emit), in index order; the ranks' lists one after
+// the other ARE a superset of the entering elements in the reference's index order (shards are contiguous id ranges), so one
+// wave replays std::partial_sort (src/rii.h:234-235) over them exactly as tie_replay_kernel does over the chunks of one engine.
+// Record of a rank: [nf] int32 counts (padded to a multiple of 8 bytes), [nf * cap] int64 global ids, [nf * cap] f32
+// distances, padded to 16 bytes.  The heap payload is the entry's place in the gathered records (g * cap + j).
+size_t linear_tie_record_bytes(int64_t nf, int cap)
+{
+    const size_t cb = ((size_t) nf * 4 + 7) / 8 * 8;
+    return (cb + (size_t) nf * cap * 12 + 15) / 16 * 16;
+}
+__global__ __launch_bounds__(64) void linear_shard_replay_kernel(const unsigned char *__restrict__ gathered, int G, int64_t nf, int cap, int topk,
+                                                                 int64_t *__restrict__ out_ids, float *__restrict__ out_dists)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pq64_t *heap = reinterpret_cast<pq64_t *>(smem);       // [topk]
+    const int64_t f = blockIdx.x;
+    const int lane = threadIdx.x, k = topk;
+    const size_t cb = ((size_t) nf * 4 + 7) / 8 * 8;
+    const size_t rec = (cb + (size_t) nf * cap * 12 + 15) / 16 * 16;
+    auto count_of = [&](int g) {
+        const int c = reinterpret_cast<const int32_t *>(gathered + rec * g)[f];
+        return c < cap ? c : cap;
+    };
+    auto dist_of = [&](int g, int j) { return reinterpret_cast<const float *>(gathered + rec * g + cb + (size_t) nf * cap * 8)[f * cap + j]; };
+    auto id_of = [&](uint32_t pay) {
+        const int g = (int) (pay / (uint32_t) cap), j = (int) (pay % (uint32_t) cap);
+        return reinterpret_cast<const int64_t *>(gathered + rec * g + cb)[f * cap + j];
+    };
+    // the first k entries of the sequence (= the indices 0 .. k-1 of the whole database: nothing bounds them) fill the heap
+    int g0 = 0, j0 = 0, filled = 0;
+    while (filled < k && g0 < G) {
+        const int c = count_of(g0);
+        const int take = (c - j0) < (k - filled) ? (c - j0) : (k - filled);
+        for (int i = lane; i < take; i += 64) heap[filled + i] = pq64_make(dist_of(g0, j0 + i), (uint32_t) (g0 * cap + j0 + i));
+        filled += take;
+        j0 += take;
+        if (j0 >= c) { ++g0; j0 = 0; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (filled == k) {
+        wh_make_heap(heap, k, lane);
+        pq64_t topv = wh_uniform(heap[0]);
+        for (int g = g0; g < G; ++g) {
+            const int cnt = count_of(g);
+            for (int jj = (g == g0 ? j0 : 0); jj < cnt; jj += 64) {
+                const int j = jj + lane;
+                const pq64_t v = j < cnt ? pq64_make(dist_of(g, j), (uint32_t) (g * cap + j)) : 0ull;
+                unsigned long long m = __ballot(j < cnt && pq64_less(v, topv));
+                while (m) {
+                    const int u = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const pq64_t vu = wh_readlane(v, u);
+                    if (pq64_less(vu, topv)) topv = wh_adjust_top(heap, k, vu, lane);      // __pop_heap(first, middle, i)
+                }
+            }
+        }
+        wh_sort_heap(heap, k, lane);
+    }
+    for (int j = lane; j < k; j += 64) {
+        const bool ok = filled == k;
+        const pq64_t e = heap[j];
+        out_ids[f * k + j] = ok ? id_of(pq64_id(e)) : (int64_t) -1;          // fewer than k entries in all: a caller's error
+        out_dists[f * k + j] = ok ? pq64_dist(e) : INFINITY;
+    }
+}
+hipError_t launch_linear_shard_replay(const void *d_gathered, int G, int64_t nf, int cap, int topk, int64_t *d_out_ids,
+                                      float *d_out_dists, hipStream_t st)
+{
+    if (nf == 0) return hipSuccess;
+    hipLaunchKernelGGL(linear_shard_replay_kernel, dim3((unsigned) nf), dim3(64), (size_t) topk * 8, st,
+                       static_cast<const unsigned char *>(d_gathered), G, nf, cap, topk, d_out_ids, d_out_dists);
+    return hipGetLastError();
+}
+
 // the chunked path handles topk <= 2 * 64 * kWhMaxWords (the wave-walked heap) on tables that leave room for a chunk of
 // distances in LDS; scratch: fq * nchunks * (kTcChunk * 8 + 8) bytes
 bool linear_tie_chunked_supported(int M, int Ks, int topk)
@@ -364,6 +473,35 @@ hipError_t launch_linear_tie_chunked(const uint8_t *d_codes, int64_t n, int M, i
     hipLaunchKernelGGL(tie_chunk_kth_kernel, dim3(a.nchunks, fq), dim3(256), tab + kTcChunk * 4, st, a);
     hipLaunchKernelGGL(tie_chunk_emit_kernel, dim3(a.nchunks, fq), dim3(256), tab, st, a);
     hipLaunchKernelGGL(tie_replay_kernel, dim3(fq), dim3(64), (size_t) topk * 8, st, a);
+    return hipGetLastError();
+}
+
+// database sharding: the candidate lists of fq queries (tables in d_lut at b0 .. b0 + fq - 1) over this shard's n codes
+hipError_t launch_linear_tie_emit(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
+                                  const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int topk, int fq,
+                                  void *d_scratch, int indirect, const float *d_ext_bound, int64_t id_offset, int cap,
+                                  int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_count, hipStream_t st)
+{
+    TcArgs a;
+    a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.b0 = b0; a.flag_list = d_flag_list;
+    a.nflag = d_nflag; a.remap = d_remap; a.indirect = indirect; a.topk = topk; a.fq = fq;
+    a.nchunks = (int) linear_tie_chunks(n);
+    unsigned char *sc = static_cast<unsigned char *>(d_scratch);
+    a.elist = reinterpret_cast<unsigned long long *>(sc);
+    a.kth = reinterpret_cast<uint32_t *>(sc + (size_t) fq * a.nchunks * kTcChunk * 8);
+    a.ecount = reinterpret_cast<int32_t *>(a.kth + (size_t) fq * a.nchunks);
+    a.out_ids = nullptr; a.out_dists = nullptr;
+    a.ext_bound = d_ext_bound; a.em_ids = d_out_ids; a.em_dists = d_out_dists; a.em_count = d_out_count; a.em_cap = cap;
+    a.id_offset = id_offset;
+    const size_t tab = (((size_t) M * Ks * 4 + 15) & ~(size_t) 15);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tie_chunk_kth_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) (tab + kTcChunk * 4));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(tie_chunk_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) tab);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tie_chunk_kth_kernel, dim3(a.nchunks, fq), dim3(256), tab + kTcChunk * 4, st, a);
+    hipLaunchKernelGGL(tie_chunk_emit_kernel, dim3(a.nchunks, fq), dim3(256), tab, st, a);
+    hipLaunchKernelGGL(tie_concat_kernel, dim3(fq), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

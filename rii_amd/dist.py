@@ -78,6 +78,17 @@ class _engine_stream(object):
         return False
 
 
+class _NullCtx(object):
+    def __init__(self, value=None):
+        self.value = value
+
+    def __enter__(self):
+        return self.value
+
+    def __exit__(self, *exc):
+        return False
+
+
 def _handoff(*tensors):
     """Tensors produced on the side stream and handed to the caller's stream (caching-allocator bookkeeping)."""
     cur = torch.cuda.current_stream()
@@ -213,16 +224,27 @@ class DbShardedIndex(object):
         tl = t[(t >= self.start) & (t < self.stop)] - self.start          # this shard's targets, still sorted
         return tl, min(topk, len(tl))
 
+    TIE_CAP = 12288          # rows of a flagged query's candidate list per rank (8192 = one unbounded chunk, + the bounded rest)
+
     def query_linear_batch(self, Q, topk, target_ids=None):
-        tl, k_local = self._local_targets(target_ids, topk)
+        """Top-k over the whole sharded database, in the reference's order.  Every rank contributes its k + 1 best rows
+        (global ids); the merge under (dist, id) is the reference's answer unless two of the merged k + 1 best distances are
+        bit-equal -- then the order (and, at the cut, the membership) is what std::partial_sort makes of ALL distances in
+        index order, and those queries are replayed exactly: rii_linear_tie_emit_dev / rii_linear_tie_replay_dev
+        (include/rii_amd.h).  `last_tie_flags` holds the flags of the last call (identical on every rank)."""
+        rows = topk + 1
+        tl, k_local = self._local_targets(target_ids, rows)
         B = Q.shape[0]
-        if _is_device_engine(self.engine):
-            dev = _comm_device()
-            q = _as_tensor(Q, torch.float32, dev)
-            t = None if tl is None else torch.from_numpy(tl).to(dev)
-            with _engine_stream() as sh:
-                ids = torch.full((B, topk), np.iinfo(np.int64).max // 2, dtype=torch.int64, device=dev)
-                d = torch.full((B, topk), float("inf"), dtype=torch.float32, device=dev)
+        device = _is_device_engine(self.engine)
+        dev = _comm_device() if device else torch.device("cpu")
+        big = np.iinfo(np.int64).max // 2
+        ids = torch.full((B, rows), big, dtype=torch.int64, device=dev)
+        d = torch.full((B, rows), float("inf"), dtype=torch.float32, device=dev)
+        ctx = _engine_stream() if device else _NullCtx()
+        with ctx as sh:
+            if device:
+                q = _as_tensor(Q, torch.float32, dev)
+                t = None if tl is None else torch.from_numpy(tl).to(dev)
                 if k_local > 0:
                     li = torch.empty((B, k_local), dtype=torch.int64, device=dev)
                     ld = torch.empty((B, k_local), dtype=torch.float32, device=dev)
@@ -230,20 +252,85 @@ class DbShardedIndex(object):
                                                  0 if t is None else t.numel(), li.data_ptr(), ld.data_ptr(), sh)
                     ids[:, :k_local] = li + self.start
                     d[:, :k_local] = ld
-                out = allgather_merge_topk(ids, d, topk, 0, self.group)
-            return _handoff(*out)
-        if k_local > 0:
-            ids, d = self.engine.query_linear_batch(np.asarray(Q), k_local, tl)
-        else:
-            ids = np.zeros((B, 0), np.int64)
-            d = np.zeros((B, 0), np.float32)
-        if k_local < topk:            # pad so that every rank contributes the same shape
-            pad = topk - k_local
-            ids = np.concatenate([ids, np.full((B, pad), np.iinfo(np.int64).max // 2, np.int64)], axis=1)
-            d = np.concatenate([d, np.full((B, pad), np.inf, np.float32)], axis=1)
-        ids = np.where(np.isfinite(d), ids + self.start, ids)               # global ids for real entries only
-        return allgather_merge_topk(ids, d, topk, 0, self.group)
+            elif k_local > 0:
+                li, ld = self.engine.query_linear_batch(np.asarray(Q), k_local, tl)
+                ids[:, :k_local] = torch.from_numpy(np.asarray(li, np.int64)) + self.start
+                d[:, :k_local] = torch.from_numpy(np.asarray(ld, np.float32))
+            g = _all_gather_bytes(_pack([ids, d]), self.group)
+            G = g.shape[0]
+            gi = [_field(g, r, 0, B * rows, torch.int64).reshape(B, rows) for r in range(G)]
+            gd = [_field(g, r, B * rows * 8, B * rows, torch.float32).reshape(B, rows) for r in range(G)]
+            mi, md = merge_topk(torch.cat(gi, dim=1), torch.cat(gd, dim=1), rows)
+            tie = (md[:, :topk] == md[:, 1:rows]) & torch.isfinite(md[:, 1:rows])
+            flags = tie.any(dim=1)
+            out_i, out_d = mi[:, :topk].contiguous(), md[:, :topk].contiguous()
+            self.last_tie_flags = flags.cpu().numpy()
+            fidx = np.nonzero(self.last_tie_flags)[0]
+            if len(fidx) and (hasattr(self.engine, "linear_tie_emit_dev") or hasattr(self.engine, "linear_tie_emit")):
+                self._replay_linear_ties(Q, fidx, topk, tl, gd, out_i, out_d, dev, sh)
+        if device:
+            return _handoff(out_i, out_d)
+        return out_i, out_d
 
+    def _replay_linear_ties(self, Q, fidx, topk, tl, gd, out_i, out_d, dev, sh):
+        """The flagged queries redone in the reference's order (see query_linear_batch).  bound of this rank = the smallest
+        k-th distance any earlier shard reported (an earlier shard's codes come first in the reference's index order, so the
+        heap top is already at or below it when this shard's first code is visited)."""
+        rank, G = world()
+        nf, cap = len(fidx), self.TIE_CAP
+        fsel = torch.from_numpy(fidx).to(gd[0].device)
+        bound = torch.full((nf,), float("inf"), dtype=torch.float32, device=gd[0].device)
+        for s in range(rank):
+            bound = torch.minimum(bound, gd[s][fsel, topk - 1])           # +inf when shard s holds fewer than k codes
+        Qf = np.ascontiguousarray(np.asarray(Q.cpu() if isinstance(Q, torch.Tensor) else Q, np.float32)[fidx])
+        if hasattr(self.engine, "linear_tie_emit_dev") and torch.cuda.is_available():
+            from . import core
+            cdev = torch.device("cuda", torch.cuda.current_device())
+            own = sh is None
+            ctx = _engine_stream() if own else _NullCtx(sh)
+            with ctx as st:
+                qf = torch.from_numpy(Qf).to(cdev)
+                t = None if tl is None else torch.from_numpy(tl).to(cdev)
+                bd = bound.to(cdev)
+                e_ids = torch.zeros((nf, cap), dtype=torch.int64, device=cdev)
+                e_d = torch.zeros((nf, cap), dtype=torch.float32, device=cdev)
+                e_cnt = torch.zeros((nf + (nf & 1),), dtype=torch.int32, device=cdev)      # padded to 8 bytes
+                self.engine.linear_tie_emit_dev(qf.data_ptr(), nf, topk, t.data_ptr() if t is not None else 0,
+                                                0 if t is None else t.numel(), bd.data_ptr(), self.start, cap, e_ids.data_ptr(),
+                                                e_d.data_ptr(), e_cnt.data_ptr(), st)
+                rec = _pack([e_cnt, e_ids, e_d])
+                assert rec.numel() == core.linear_tie_record_bytes(nf, cap)
+                g = _all_gather_bytes(rec.to(dev), self.group).to(cdev)
+                cnts = torch.stack([_field(g, r, 0, nf, torch.int32) for r in range(g.shape[0])])
+                ok = (cnts <= cap).all(dim=0)                                                # a truncated list cannot be replayed
+                r_i = torch.empty((nf, topk), dtype=torch.int64, device=cdev)
+                r_d = torch.empty((nf, topk), dtype=torch.float32, device=cdev)
+                core.linear_tie_replay_dev(g.data_ptr(), g.shape[0], nf, cap, topk, r_i.data_ptr(), r_d.data_ptr(), st)
+                sel = fsel.to(out_i.device)[ok.to(out_i.device)]
+                out_i[sel] = r_i.to(out_i.device)[ok.to(out_i.device)]
+                out_d[sel] = r_d.to(out_d.device)[ok.to(out_d.device)]
+            return
+        # host engines (the CPU stand-ins of the gloo tests): same protocol through engine.linear_tie_emit / linear_tie_replay
+        e_ids, e_d, e_cnt = self.engine.linear_tie_emit(Qf, topk, tl, bound.cpu().numpy(), self.start, cap)
+        cnt_t = torch.zeros((nf + (nf & 1),), dtype=torch.int32)
+        cnt_t[:nf] = torch.from_numpy(np.asarray(e_cnt, np.int32))
+        rec = _pack([cnt_t, torch.from_numpy(np.ascontiguousarray(e_ids, np.int64)), torch.from_numpy(np.ascontiguousarray(e_d, np.float32))])
+        g = _all_gather_bytes(rec, self.group)
+        cb = cnt_t.numel() * 4
+        lists = []
+        for r in range(g.shape[0]):
+            c = _field(g, r, 0, nf, torch.int32).numpy()
+            li = _field(g, r, cb, nf * cap, torch.int64).reshape(nf, cap).numpy()
+            ld = _field(g, r, cb + nf * cap * 8, nf * cap, torch.float32).reshape(nf, cap).numpy()
+            lists.append((c, li, ld))
+        for j, f in enumerate(fidx):
+            if any(int(c[j]) > cap for c, _, _ in lists):
+                continue
+            seq_i = np.concatenate([li[j, :int(c[j])] for c, li, _ in lists])
+            seq_d = np.concatenate([ld[j, :int(c[j])] for c, _, ld in lists])
+            ri, rd = self.engine.linear_tie_replay(seq_i, seq_d, topk)
+            out_i[f] = torch.from_numpy(np.asarray(ri, np.int64))
+            out_d[f] = torch.from_numpy(np.asarray(rd, np.float32))
 
     # ---- inverted index over the sharded database (protocol: include/rii_amd.h, csrc/ivfshard.hip) ----
     def total_codes(self):

@@ -30,6 +30,41 @@ class _OracleBatch(object):
             ids[b], d[b] = i, dd
         return ids, d
 
+    # ---- database-sharded linear search, exact ties: the protocol of rii_linear_tie_emit_dev / rii_linear_tie_replay_dev ----
+    def linear_tie_emit(self, Qf, topk, tl, bound, start, cap):
+        """Candidate rows of this shard in index order: every code below the bound (any superset of the codes that touch the
+        reference's heap is valid; this stand-in applies the external bound only, the engine also bounds chunk by chunk)."""
+        from oracle import oracle as O
+        o = self.o
+        loc = np.arange(o.N, dtype=np.int64) if tl is None else np.asarray(tl, np.int64)
+        nf = Qf.shape[0]
+        ids = np.zeros((nf, cap), np.int64)
+        dd = np.zeros((nf, cap), np.float32)
+        cnt = np.zeros(nf, np.int32)
+        for f in range(nf):
+            dt = O.dtable(o.codewords, Qf[f], o.arch)
+            acc = np.zeros(len(loc), np.float32)
+            for m in range(o.M):
+                acc = (acc + dt[m, o.codes[loc, m]]).astype(np.float32)
+            keep = np.nonzero(acc < bound[f])[0] if np.isfinite(bound[f]) else np.arange(len(loc))
+            cnt[f] = len(keep)
+            n = min(len(keep), cap)
+            ids[f, :n] = loc[keep[:n]] + start
+            dd[f, :n] = acc[keep[:n]]
+        return ids, dd, cnt
+
+    def linear_tie_replay(self, seq_ids, seq_d, topk):
+        """std::partial_sort (the oracle's libstdc++ replay) over the gathered sequence."""
+        import ctypes
+        from oracle import oracle as O
+        pair = np.dtype([("id", "<u8"), ("dist", "<f4")], align=True)
+        arr = np.zeros(len(seq_d), pair)
+        arr["id"] = np.arange(len(seq_d))
+        arr["dist"] = seq_d
+        O.lib().oracle_partial_sort(arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(topk), ctypes.c_size_t(len(seq_d)))
+        sel = arr["id"][:topk].astype(np.int64)
+        return np.asarray(seq_ids)[sel], np.asarray(seq_d)[sel]
+
     def reconfigure(self, nlist, it):
         self.o.reconfigure(nlist, it)
 
@@ -162,6 +197,9 @@ class _GpuBatch(object):
 
     def query_linear_batch(self, Q, topk, tids=None):
         return self.g.query_linear_batch(Q, topk, tids)
+
+    def linear_tie_emit_dev(self, *a):
+        return self.g.linear_tie_emit_dev(*a)
 
     def reconfigure(self, nlist, it):
         self.g.reconfigure(nlist, it)
@@ -304,6 +342,25 @@ def _worker(rank, world, port, q, use_gpu=False):
         gi, gd = idx.query_linear_batch(Q, 3, few)
         wi, wd = full.query_linear_batch(Q, 3, few)
         assert np.array_equal(gi.numpy(), wi)
+        # exactly tied distances ACROSS the shards: integer-valued tables + duplicated codes.  The merged (dist, id) order is
+        # not the reference's there; the flagged queries are replayed over the candidate lists of all shards
+        rngt = np.random.default_rng(91)
+        cwt = np.round(rngt.random((8, 16, 4)) * 3).astype(np.float32)
+        codest = rngt.integers(0, 16, size=(2203, 8), dtype=np.uint8)
+        codest[rngt.integers(0, 2203, 900)] = codest[rngt.integers(0, 2203, 900)]
+        qst = np.round(rngt.random((6, 32)) * 3).astype(np.float32)
+        fullt = _OracleBatch(cwt, codest)
+        st_, et_ = rd.shard_range(2203, rank, world)
+        idxt = rd.DbShardedIndex((_GpuBatch if use_gpu else _OracleBatch)(cwt, codest[st_:et_]), st_, et_)
+        tidt = np.sort(rngt.choice(2203, 700, replace=False)).astype(np.int64)
+        n_flag = 0
+        for topk, t in ((1, None), (4, None), (30, None), (100, None), (6, tidt), (1000, None)):
+            gi, gd = idxt.query_linear_batch(qst, topk, t)
+            wi, wd = fullt.query_linear_batch(qst, topk, t)
+            n_flag += int(idxt.last_tie_flags.sum())
+            assert np.array_equal(gd.numpy().view(np.uint32), wd.view(np.uint32)), "tied db-sharded dists k=%d" % topk
+            assert np.array_equal(gi.numpy(), wi), "tied db-sharded ids k=%d (the reference's heap order)" % topk
+        assert n_flag > 0
         # --- query sharding ---
         rep = _GpuBatch(cw, codes) if use_gpu else full
         qidx = rd.QueryShardedIndex(rep)
