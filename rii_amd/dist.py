@@ -263,6 +263,8 @@ class DbShardedIndex(object):
             mi, md = merge_topk(torch.cat(gi, dim=1), torch.cat(gd, dim=1), rows)
             tie = (md[:, :topk] == md[:, 1:rows]) & torch.isfinite(md[:, 1:rows])
             flags = tie.any(dim=1)
+            if topk == 1:                        # a heap of one keeps the FIRST minimum in index order = the smallest id: no replay
+                flags = torch.zeros_like(flags)
             out_i, out_d = mi[:, :topk].contiguous(), md[:, :topk].contiguous()
             self.last_tie_flags = flags.cpu().numpy()
             fidx = np.nonzero(self.last_tie_flags)[0]
