@@ -158,6 +158,14 @@ int rii_linear_tie_replay_dev(const void *d_gathered, int G, int64_t nf, int cap
 int64_t rii_merge_record_bytes(int64_t B, int k, int payload);
 int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_keys,
                        float *d_out_dists, int64_t *d_out_payload, void *stream);
+/* The same with (i) `id_offsets` (HOST array of G int64, or NULL): added to the keys of rank g's record while merging, so a
+ * rank can hand the engine's LOCAL ids to the all-gather untouched (keys < 0 or >= 2^62 are padding and stay as they are);
+ * (ii) `d_out_tie` [B] int32 (or NULL): 1 where two of the first `tie_cols` merged distances are bit-equal and finite -- the
+ * queries whose order the caller must replay (rii_linear_tie_* above) -- and `d_out_any` [1] int32 (or NULL; zeroed by the
+ * caller): OR of those flags, so that ONE 4-byte read tells whether any replay is needed.  G <= 64 with id_offsets. */
+int rii_merge_topk_ex_dev(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, const int64_t *id_offsets,
+                          int64_t *d_out_keys, float *d_out_dists, int64_t *d_out_payload, int tie_cols, int32_t *d_out_tie,
+                          int32_t *d_out_any, void *stream);
 
 /* Distance-table build alone (RiiCpp::DTable, src/rii.h:361-373) for B queries -> out[B,M,Ks] (host). */
 int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out);

@@ -132,6 +132,7 @@ def _lib():
         "rii_linear_tie_replay_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
         "rii_merge_record_bytes": (c_i64, [c_i64, c_int, c_int]),
         "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+        "rii_merge_topk_ex_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, i64p, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
         "rii_dtable": (c_int, [c_vp, f32p, c_i64, f32p]),
         "rii_assign": (c_int, [c_vp, u8p, c_i64, i32p]),
         "rii_fscan_lane_subspace": (c_int, [c_int, c_int, c_int]),
@@ -160,6 +161,17 @@ def merge_topk_dev(d_gathered, G, B, k, d_out_keys, d_out_dists, stream=0, k_out
     (dist, key), with their payloads when d_out_payload is given."""
     _check(_lib().rii_merge_topk_dev(d_gathered, int(G), int(B), int(k), int(k if k_out is None else k_out),
                                      int(bool(d_out_payload)), d_out_keys, d_out_dists, d_out_payload or None, stream or None))
+
+
+def merge_topk_ex_dev(d_gathered, G, B, k, k_out, id_offsets, d_out_keys, d_out_dists, tie_cols=0, d_out_tie=0, d_out_any=0, stream=0,
+                      d_out_payload=0):
+    """rii_merge_topk_ex_dev: merge with per-rank id offsets (host sequence of G ints or None) and device-side tie flags."""
+    off = None
+    if id_offsets is not None:
+        off = (ctypes.c_int64 * int(G))(*[int(x) for x in id_offsets])
+    _check(_lib().rii_merge_topk_ex_dev(d_gathered, int(G), int(B), int(k), int(k_out), int(bool(d_out_payload)), off, d_out_keys,
+                                        d_out_dists, d_out_payload or None, int(tie_cols), d_out_tie or None, d_out_any or None,
+                                        stream or None))
 
 
 def ivf_shard_replay_dev(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, stream=0):

@@ -98,7 +98,8 @@ struct ScratchSet {
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
         s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
-        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub;
+        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident;
+    bool have_ident = false;    // s_ident = [count | 0 .. 63]: work list of rii_linear_tie_emit_dev (every query of the call is "flagged")
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
@@ -121,7 +122,7 @@ struct ScratchSet {
                           &s_keys_b, &s_assign, &s_coarse_d, &s_coarse_i, &s_cum, &s_ncand, &s_nvis, &s_cand_i, &s_cand_d,
                           &s_bitmap, &s_fids, &s_flen, &s_hist, &s_cnt, &s_sample, &s_qlut, &s_slack, &s_cand, &s_cand_cnt,
                           &s_flag, &s_segmin, &s_thr16, &s_gthr, &s_qc, &s_flag_list, &s_tie_list, &s_tie_hid, &s_tie_hd,
-                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack};
+                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident};
         for (DevBuf *b : bufs) b->release();
         if (sort_temp) (void) hipFree(sort_temp);
         sort_temp = nullptr; sort_temp_bytes = 0;
@@ -130,6 +131,7 @@ struct ScratchSet {
         if (order_ev) (void) hipEventDestroy(order_ev);
         order_ev = nullptr;
         last_stream_valid = false;
+        have_ident = false;
     }
 };
 
@@ -1401,15 +1403,20 @@ RII_API int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64
     if (nlist_of(e) == 0) return set_err(RII_ERR_STATE, "no posting lists: call reconfigure() / set_coarse_centers() first");
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     RII_TRY(begin_on(e, st));
-    RII_TRY(sync_lists(e));
+    // from here on the lane's ordering event is recorded on every path (work already enqueued on `st` uses the shared scratch)
     const int64_t nlist = nlist_of(e);
+    int r = sync_lists(e);
     const int32_t *src = e->d_list_len.as<int32_t>();
-    if (S_global) {                // a target set exists: this rank's share of it may be empty (then every list is empty here)
-        RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
+    if (r == RII_OK && S_global) {   // a target set exists: this rank's share of it may be empty (then every list is empty here)
+        r = filter_lists_by_targets(e, d_tids, S, st);
         src = e->s_flen.as<int32_t>();
     }
-    HIP_TRY(hipMemcpyAsync(d_out_len, src, (size_t) nlist * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    return end_on(e, st);
+    if (r == RII_OK && hipMemcpyAsync(d_out_len, src, (size_t) nlist * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        r = set_err(RII_ERR_HIP, "copy of the list lengths failed");
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
 }
 
 RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
@@ -1436,11 +1443,11 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
     if (B == 0) return RII_OK;
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     RII_TRY(begin_on(e, st));
-    RII_TRY(sync_lists(e));
+    int r = sync_lists(e);          // (end_on runs on every path below)
     const int32_t *pl_ids = e->d_pl_ids.as<int32_t>();
     const int32_t *list_len = e->d_list_len.as<int32_t>();
-    if (S_global != 0) {           // this rank's share of the target ids (possibly none: every list is then empty here)
-        RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
+    if (r == RII_OK && S_global != 0) {   // this rank's share of the target ids (possibly none: every list is then empty here)
+        r = filter_lists_by_targets(e, d_tids, S, st);
         pl_ids = e->s_fids.as<int32_t>();
         list_len = e->s_flen.as<int32_t>();
     }
@@ -1449,7 +1456,6 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
                                       : std::round((double) L * (double) nlist / (double) S_global);
     int64_t w = (int64_t) (size_t) wd + 3;
     if (nlist < w) w = nlist;
-    int r = RII_OK;
     for (int64_t b0 = 0; b0 < B && r == RII_OK; b0 += kMaxBatch) {
         const int64_t cur = std::min<int64_t>(kMaxBatch, B - b0);
         const int64_t D = (int64_t) e->M * e->Ds;
@@ -1498,21 +1504,31 @@ RII_API int rii_linear_tie_emit_dev(rii_engine *e, const float *d_queries, int64
         if (hipMemsetAsync(d_out_count, 0, (size_t) nf * sizeof(int32_t), st) != hipSuccess) r = set_err(RII_ERR_HIP, "memset failed");
     } else {
         const int64_t D = (int64_t) e->M * e->Ds;
+        // Cost: the emit scans the whole shard once per group of flagged queries with ~9 bytes of scratch per code and query, so
+        // the group size is what fits 1 GiB of scratch (64 queries up to 1.8 M codes, ONE query per launch at a 125 M-code shard:
+        // a tie-heavy batch on a Deep1B-sized shard costs nf full-shard passes -- exactness first; docs: DESIGN.md section 6).
         const int64_t fq_max = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t) 1 << 30) / (n * 9 + 1)));
-        std::vector<int32_t> ident((size_t) fq_max + 1);
+        // work list of a group = [count | 0, 1, 2, ...]: the indices are uploaded once per engine, the count is a 4-byte memset in
+        // stream order (no host synchronisation inside the loop)
+        if (!e->have_ident) {
+            int32_t ident[65];
+            ident[0] = 0;
+            for (int i = 0; i < 64; ++i) ident[i + 1] = i;
+            if ((r = e->s_ident.ensure(sizeof(ident))) == RII_OK &&
+                (hipMemcpyAsync(e->s_ident.p, ident, sizeof(ident), hipMemcpyHostToDevice, st) != hipSuccess ||
+                 hipStreamSynchronize(st) != hipSuccess))
+                r = set_err(RII_ERR_HIP, "copy failed");
+            e->have_ident = (r == RII_OK);
+        }
         for (int64_t f0 = 0; f0 < nf && r == RII_OK; f0 += fq_max) {
             const int cur = (int) std::min<int64_t>(fq_max, nf - f0);
             r = build_lut(e, d_queries + f0 * D, cur, st, false, 0);
             if (r != RII_OK) break;
-            if ((r = e->s_tie_list.ensure((size_t) (cur + 1) * sizeof(int32_t))) != RII_OK) break;
             if ((r = e->s_tie_chunk.ensure(linear_tie_chunked_scratch(n, cur))) != RII_OK) break;
-            ident[0] = cur;
-            for (int i = 0; i < cur; ++i) ident[(size_t) i + 1] = i;
-            if (hipMemcpyAsync(e->s_tie_list.p, ident.data(), (size_t) (cur + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+            if (hipMemsetD32Async((hipDeviceptr_t) e->s_ident.p, cur, 1, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
             ScopedTimer t(e, "tie", st);
             if (launch_linear_tie_emit(e->d_codes.as<uint8_t>(), n, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, 0,
-                                       e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), S ? d_tids : nullptr, topk, cur,
+                                       e->s_ident.as<int32_t>() + 1, e->s_ident.as<int>(), S ? d_tids : nullptr, topk, cur,
                                        e->s_tie_chunk.p, S ? 1 : 0, d_bound ? d_bound + f0 : nullptr, id_offset, cap,
                                        d_out_ids + f0 * cap, d_out_dists + f0 * cap, d_out_count + f0, st) != hipSuccess)
                 r = set_err(RII_ERR_HIP, "tie emission launch failed");
@@ -1545,6 +1561,20 @@ RII_API int rii_merge_topk_dev(const void *d_gathered, int G, int64_t B, int k, 
     if ((int64_t) G * k > merge_topk_max_keys())
         return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d keys per query exceeds %d", G, k, merge_topk_max_keys());
     HIP_TRY(launch_merge_topk(d_gathered, G, B, k, k_out, payload, d_out_keys, d_out_dists, d_out_payload, (hipStream_t) stream));
+    return RII_OK;
+}
+
+RII_API int rii_merge_topk_ex_dev(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, const int64_t *id_offsets,
+                                  int64_t *d_out_keys, float *d_out_dists, int64_t *d_out_payload, int tie_cols,
+                                  int32_t *d_out_tie, int32_t *d_out_any, void *stream)
+{
+    if (!d_gathered || G < 1 || B < 0 || k < 1 || k_out < 1 || k_out > G * k || (B > 0 && (!d_out_keys || !d_out_dists)) ||
+        (payload && B > 0 && !d_out_payload) || tie_cols < 0 || tie_cols > k_out || (id_offsets && G > 64))
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    if ((int64_t) G * k > merge_topk_max_keys())
+        return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d keys per query exceeds %d", G, k, merge_topk_max_keys());
+    HIP_TRY(launch_merge_topk(d_gathered, G, B, k, k_out, payload, d_out_keys, d_out_dists, d_out_payload, (hipStream_t) stream,
+                              id_offsets, tie_cols, d_out_tie, d_out_any));
     return RII_OK;
 }
 

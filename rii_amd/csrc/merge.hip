@@ -17,9 +17,17 @@ __device__ __forceinline__ const int64_t *mrg_ids(const unsigned char *base, siz
 __device__ __forceinline__ const int64_t *mrg_pay(const unsigned char *base, size_t rec, int g, int64_t Bk) { return reinterpret_cast<const int64_t *>(base + rec * g + (size_t) Bk * 8); }
 __device__ __forceinline__ const float *mrg_d(const unsigned char *base, size_t rec, int g, int64_t Bk, int payload) { return reinterpret_cast<const float *>(base + rec * g + (size_t) Bk * (payload ? 16 : 8)); }
 
+// per-rank id offsets (linear search over contiguous id ranges: the ranks send LOCAL ids, the merge adds the shard's first id),
+// passed by value with the launch; all zero = the records already hold global keys
+constexpr int kMergeMaxRanks = 64;
+struct MergeOffsets {
+    int64_t off[kMergeMaxRanks];
+};
+
 __global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__restrict__ gathered, int G, int64_t B, int k, int k_out,
                                                          int payload, int64_t *__restrict__ out_ids, float *__restrict__ out_dists,
-                                                         int64_t *__restrict__ out_payload)
+                                                         int64_t *__restrict__ out_payload, MergeOffsets offs, int tie_cols,
+                                                         int32_t *__restrict__ out_tie, int32_t *__restrict__ out_any)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *key = reinterpret_cast<unsigned long long *>(smem);        // (orderable dist << 32 | g * k + j)
@@ -42,7 +50,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__
         const uint32_t s = (uint32_t) (kk & 0xffffffffu);
         if (s >= (uint32_t) n) return INT64_MAX;
         const int g = (int) (s / (uint32_t) k), j = (int) (s - (uint32_t) g * k);
-        return mrg_ids(gathered, rec, g)[b * k + j];
+        const int64_t v = mrg_ids(gathered, rec, g)[b * k + j];
+        return (v < 0 || v >= INT64_MAX / 2) ? v : v + offs.off[g];      // padding keys (-1 / huge) stay what they are
     };
     for (int size = 2; size <= n2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -74,6 +83,20 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__
             out_payload[b * k_out + j] = pv;
         }
     }
+    // tie flag of this query: two of the first tie_cols merged distances are bit-equal and finite -- then the reference's
+    // order is std::partial_sort's, not (dist, id): the caller replays it (rii_linear_tie_* / rii_ivf_shard_replay_dev)
+    if (out_tie) {
+        int tie = 0;
+        for (int j = tid; j + 1 < tie_cols; j += 256) {
+            const uint32_t a = (uint32_t) (key[j] >> 32), c = (uint32_t) (key[j + 1] >> 32);
+            if (a == c && c < f32_orderable(0x7f800000u)) tie = 1;
+        }
+        tie = __syncthreads_or(tie);
+        if (tid == 0) {
+            out_tie[b] = tie;
+            if (tie && out_any) atomicOr(out_any, 1);
+        }
+    }
 }
 
 int merge_topk_max_keys() { return kMergeMaxKeys; }
@@ -81,9 +104,13 @@ int merge_topk_max_keys() { return kMergeMaxKeys; }
 size_t merge_record_bytes(int64_t B, int k, int payload) { return mrg_rec_bytes(B * k, payload); }
 
 hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_ids,
-                             float *d_out_dists, int64_t *d_out_payload, hipStream_t st)
+                             float *d_out_dists, int64_t *d_out_payload, hipStream_t st, const int64_t *id_offsets, int tie_cols,
+                             int32_t *d_out_tie, int32_t *d_out_any)
 {
     if (B == 0) return hipSuccess;
+    if (G > kMergeMaxRanks && id_offsets) return hipErrorInvalidValue;
+    MergeOffsets offs;
+    for (int g = 0; g < kMergeMaxRanks; ++g) offs.off[g] = (id_offsets && g < G) ? id_offsets[g] : 0;
     int n2 = 64;
     while (n2 < G * k) n2 <<= 1;
     const size_t smem = (size_t) n2 * 8;
@@ -91,7 +118,8 @@ hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, in
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned) B), dim3(256), smem, st,
-                       static_cast<const unsigned char *>(d_gathered), G, B, k, k_out, payload, d_out_ids, d_out_dists, d_out_payload);
+                       static_cast<const unsigned char *>(d_gathered), G, B, k, k_out, payload, d_out_ids, d_out_dists, d_out_payload,
+                       offs, tie_cols, d_out_tie, d_out_any);
     return hipGetLastError();
 }
 

@@ -206,8 +206,11 @@ hipError_t launch_shard_replay(const void *d_gathered, int G, int64_t nf, int ro
 // merge.hip: database sharding, k-way merge of the gathered per-shard top-k rows under (dist, id)
 int merge_topk_max_keys();
 size_t merge_record_bytes(int64_t B, int k, int payload);
+// id_offsets: host array of G per-rank offsets added to the (non-padding) keys, or NULL; d_out_tie [B] / d_out_any [1]: optional
+// tie flags over the first tie_cols merged distances (d_out_any must be zeroed by the caller)
 hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_ids,
-                             float *d_out_dists, int64_t *d_out_payload, hipStream_t st);
+                             float *d_out_dists, int64_t *d_out_payload, hipStream_t st, const int64_t *id_offsets = nullptr,
+                             int tie_cols = 0, int32_t *d_out_tie = nullptr, int32_t *d_out_any = nullptr);
 
 // scanorder.hip: LDS-friendly scan order for the filter stage (perm[pos] = code id, codes gathered in that order)
 bool scan_order_supported(int M, int Ks);

@@ -20,8 +20,10 @@ every rank from the all-gathered per-rank list lengths (nlist ints per rank and 
 owns, and the per-rank (dist, traversal position, id) rows are merged under (dist, position); queries whose k+1 best
 distances tie exactly get their whole candidate sequence gathered and std::partial_sort replayed on it -- csrc/ivfshard.hip.
 
-Ties across shards: inside one shard the engine returns the reference's std::partial_sort order; across shards exactly
-tied distances are ordered by id (the heap order of the concatenated database cannot be rebuilt from per-shard top-k rows).
+Ties across shards of the linear search: the merge orders bit-equal distances of different shards by id; whenever two of the
+merged k+1 best distances are bit-equal the query is replayed in the reference's std::partial_sort order over the candidates
+every shard emits in index order (DbShardedIndex.query_linear_batch; csrc/tieorder.hip).  The tie flags are computed by the
+merge kernel on the device; the host reads one 4-byte word per batch (none for top-1).
 """
 import numpy as np
 import torch
@@ -226,94 +228,184 @@ class DbShardedIndex(object):
 
     TIE_CAP = 12288          # rows of a flagged query's candidate list per rank (8192 = one unbounded chunk, + the bounded rest)
 
+    def all_starts(self):
+        """First global id of every rank's shard, in rank order (one tiny all-gather, cached): the merge kernel adds them to the
+        LOCAL ids the engines wrote, so no rank rewrites its own rows."""
+        if getattr(self, "_all_starts", None) is None:
+            rank, w = world()
+            if dist.is_available() and dist.is_initialized():
+                t = torch.tensor([self.start], dtype=torch.int64, device=_comm_device())
+                out = torch.empty(w, dtype=torch.int64, device=t.device)
+                dist.all_gather_into_tensor(out, t, group=self.group)
+                self._all_starts = [int(x) for x in out.cpu()]
+            else:
+                self._all_starts = [self.start]
+        return self._all_starts
+
     def query_linear_batch(self, Q, topk, target_ids=None):
-        """Top-k over the whole sharded database, in the reference's order.  Every rank contributes its k + 1 best rows
-        (global ids); the merge under (dist, id) is the reference's answer unless two of the merged k + 1 best distances are
-        bit-equal -- then the order (and, at the cut, the membership) is what std::partial_sort makes of ALL distances in
-        index order, and those queries are replayed exactly: rii_linear_tie_emit_dev / rii_linear_tie_replay_dev
-        (include/rii_amd.h).  `last_tie_flags` holds the flags of the last call (identical on every rank)."""
-        rows = topk + 1
+        """Top-k over the whole sharded database, in the reference's order.  Every rank contributes its k + 1 best rows (k = 1:
+        its best row -- a heap of one keeps the first minimum in index order = the smallest id, so top-1 never needs a replay);
+        the merge under (dist, id) is the reference's answer unless two of the merged k + 1 best distances are bit-equal -- then
+        the order (and, at the cut, the membership) is what std::partial_sort makes of ALL distances in index order, and those
+        queries are replayed exactly: rii_linear_tie_emit_dev / rii_linear_tie_replay_dev (include/rii_amd.h).
+
+        Device engines ("nccl", or a single engine): engine -> record -> all-gather -> rii_merge_topk_ex_dev, all on one stream;
+        the tie flags are computed by the merge kernel and the host reads ONE 4-byte word per batch (none for top-1) to learn
+        whether any replay is needed.  `last_tie_flags` (bool tensor [B], identical on every rank) holds the flags of the last
+        call, `last_tie_overflow` the flagged queries whose candidate list exceeded TIE_CAP rows on some rank: those keep the
+        (dist, id) order among exactly tied distances instead of the reference's (a warning is issued)."""
+        rows = topk if topk == 1 else topk + 1
         tl, k_local = self._local_targets(target_ids, rows)
         B = Q.shape[0]
-        device = _is_device_engine(self.engine)
-        dev = _comm_device() if device else torch.device("cpu")
+        if _is_device_engine(self.engine):
+            return self._query_linear_device(Q, B, topk, rows, tl, k_local)
         big = np.iinfo(np.int64).max // 2
-        ids = torch.full((B, rows), big, dtype=torch.int64, device=dev)
-        d = torch.full((B, rows), float("inf"), dtype=torch.float32, device=dev)
-        ctx = _engine_stream() if device else _NullCtx()
-        with ctx as sh:
-            if device:
-                q = _as_tensor(Q, torch.float32, dev)
-                t = None if tl is None else torch.from_numpy(tl).to(dev)
+        ids = torch.full((B, rows), big, dtype=torch.int64)
+        d = torch.full((B, rows), float("inf"), dtype=torch.float32)
+        if k_local > 0:
+            li, ld = self.engine.query_linear_batch(np.asarray(Q), k_local, tl)
+            ids[:, :k_local] = torch.from_numpy(np.asarray(li, np.int64)) + self.start
+            d[:, :k_local] = torch.from_numpy(np.asarray(ld, np.float32))
+        g = _all_gather_bytes(_pack([ids, d]), self.group)
+        G = g.shape[0]
+        gi = [_field(g, r, 0, B * rows, torch.int64).reshape(B, rows) for r in range(G)]
+        gd = [_field(g, r, B * rows * 8, B * rows, torch.float32).reshape(B, rows) for r in range(G)]
+        mi, md = merge_topk(torch.cat(gi, dim=1), torch.cat(gd, dim=1), rows)
+        if topk == 1:
+            flags = torch.zeros(B, dtype=torch.bool)
+        else:
+            flags = ((md[:, :topk] == md[:, 1:rows]) & torch.isfinite(md[:, 1:rows])).any(dim=1)
+        out_i, out_d = mi[:, :topk].contiguous(), md[:, :topk].contiguous()
+        self.last_tie_flags = flags
+        self.last_tie_overflow = torch.zeros(B, dtype=torch.bool)
+        fidx = np.nonzero(flags.numpy())[0]
+        if len(fidx) and hasattr(self.engine, "linear_tie_emit"):
+            self._replay_linear_ties_host(Q, fidx, topk, tl, gd, out_i, out_d)
+        elif len(fidx) and hasattr(self.engine, "linear_tie_emit_dev") and torch.cuda.is_available():
+            # real engines under a host collective (gloo; the tests' two ranks on one GPU): device emit / replay, host gather
+            cdev = torch.device("cuda", torch.cuda.current_device())
+            self._replay_linear_ties_device(_as_tensor(Q, torch.float32, cdev), torch.from_numpy(fidx).to(cdev), topk, rows,
+                                            None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).to(cdev), tl,
+                                            g.to(cdev), out_i, out_d, cdev, None)
+        return out_i, out_d
+
+    def _query_linear_device(self, Q, B, topk, rows, tl, k_local):
+        from . import core
+        dev = _comm_device()
+        if dev.type != "cuda":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        with _engine_stream() as sh:
+            q = _as_tensor(Q, torch.float32, dev)
+            t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).to(dev)
+            nrec = core.merge_record_bytes(B, rows)
+            nid = B * rows * 8
+            if k_local == rows:            # the engine writes its LOCAL ids and distances straight into the record
+                rec = torch.empty(nrec, dtype=torch.uint8, device=dev)
+                self.engine.query_linear_dev(q.data_ptr(), B, rows, t.data_ptr() if t is not None else 0,
+                                             0 if t is None else t.numel(), rec.data_ptr(), rec.data_ptr() + nid, sh)
+            else:                          # fewer local codes / targets than rows: padding rows (key 2^62, distance +inf)
+                ids = torch.full((B, rows), np.iinfo(np.int64).max // 2, dtype=torch.int64, device=dev)
+                d = torch.full((B, rows), float("inf"), dtype=torch.float32, device=dev)
                 if k_local > 0:
                     li = torch.empty((B, k_local), dtype=torch.int64, device=dev)
                     ld = torch.empty((B, k_local), dtype=torch.float32, device=dev)
                     self.engine.query_linear_dev(q.data_ptr(), B, k_local, t.data_ptr() if t is not None else 0,
                                                  0 if t is None else t.numel(), li.data_ptr(), ld.data_ptr(), sh)
-                    ids[:, :k_local] = li + self.start
+                    ids[:, :k_local] = li
                     d[:, :k_local] = ld
-            elif k_local > 0:
-                li, ld = self.engine.query_linear_batch(np.asarray(Q), k_local, tl)
-                ids[:, :k_local] = torch.from_numpy(np.asarray(li, np.int64)) + self.start
-                d[:, :k_local] = torch.from_numpy(np.asarray(ld, np.float32))
-            g = _all_gather_bytes(_pack([ids, d]), self.group)
+                rec = torch.zeros(nrec, dtype=torch.uint8, device=dev)
+                rec[:nid].view(torch.int64).copy_(ids.reshape(-1))
+                rec[nid:nid + B * rows * 4].view(torch.float32).copy_(d.reshape(-1))
+            g = _all_gather_bytes(rec, self.group)
+            if g.device != dev:            # gloo with real engines (tests on a one-GPU box): the collective ran on the host
+                g = g.to(dev)
             G = g.shape[0]
-            gi = [_field(g, r, 0, B * rows, torch.int64).reshape(B, rows) for r in range(G)]
-            gd = [_field(g, r, B * rows * 8, B * rows, torch.float32).reshape(B, rows) for r in range(G)]
-            mi, md = merge_topk(torch.cat(gi, dim=1), torch.cat(gd, dim=1), rows)
-            tie = (md[:, :topk] == md[:, 1:rows]) & torch.isfinite(md[:, 1:rows])
-            flags = tie.any(dim=1)
-            if topk == 1:                        # a heap of one keeps the FIRST minimum in index order = the smallest id: no replay
-                flags = torch.zeros_like(flags)
-            out_i, out_d = mi[:, :topk].contiguous(), md[:, :topk].contiguous()
-            self.last_tie_flags = flags.cpu().numpy()
-            fidx = np.nonzero(self.last_tie_flags)[0]
-            if len(fidx) and (hasattr(self.engine, "linear_tie_emit_dev") or hasattr(self.engine, "linear_tie_emit")):
-                self._replay_linear_ties(Q, fidx, topk, tl, gd, out_i, out_d, dev, sh)
-        if device:
-            return _handoff(out_i, out_d)
-        return out_i, out_d
+            mi = torch.empty((B, rows), dtype=torch.int64, device=dev)
+            md = torch.empty((B, rows), dtype=torch.float32, device=dev)
+            self.last_tie_overflow = self._zero_flags(B, dev)
+            if topk == 1:
+                core.merge_topk_ex_dev(g.data_ptr(), G, B, rows, rows, self.all_starts(), mi.data_ptr(), md.data_ptr(), stream=sh)
+                self.last_tie_flags = self._zero_flags(B, dev)
+                out = (mi, md)
+            else:
+                tie = torch.empty(B, dtype=torch.int32, device=dev)
+                anyf = torch.zeros(1, dtype=torch.int32, device=dev)
+                core.merge_topk_ex_dev(g.data_ptr(), G, B, rows, rows, self.all_starts(), mi.data_ptr(), md.data_ptr(),
+                                       tie_cols=rows, d_out_tie=tie.data_ptr(), d_out_any=anyf.data_ptr(), stream=sh)
+                out_i, out_d = mi[:, :topk].contiguous(), md[:, :topk].contiguous()
+                self.last_tie_flags = tie.bool()
+                if int(anyf.item()) and hasattr(self.engine, "linear_tie_emit_dev"):     # the batch's one host read
+                    self._replay_linear_ties_device(q, torch.nonzero(tie).flatten(), topk, rows, t, tl, g, out_i, out_d, dev, sh)
+                out = (out_i, out_d)
+        return _handoff(*out)
 
-    def _replay_linear_ties(self, Q, fidx, topk, tl, gd, out_i, out_d, dev, sh):
-        """The flagged queries redone in the reference's order (see query_linear_batch).  bound of this rank = the smallest
-        k-th distance any earlier shard reported (an earlier shard's codes come first in the reference's index order, so the
-        heap top is already at or below it when this shard's first code is visited)."""
+    def _zero_flags(self, B, dev):
+        z = getattr(self, "_zflags", None)
+        if z is None or z.numel() != B or z.device != dev:
+            z = self._zflags = torch.zeros(B, dtype=torch.bool, device=dev)
+        return z
+
+    def _tie_bound(self, gd, fsel, topk):
+        """bound of this rank = the smallest k-th distance any EARLIER shard reported (an earlier shard's codes come first in the
+        reference's index order, so the heap top is already at or below it when this shard's first code is visited)."""
         rank, G = world()
-        nf, cap = len(fidx), self.TIE_CAP
-        fsel = torch.from_numpy(fidx).to(gd[0].device)
-        bound = torch.full((nf,), float("inf"), dtype=torch.float32, device=gd[0].device)
+        bound = torch.full((fsel.numel(),), float("inf"), dtype=torch.float32, device=fsel.device)
         for s in range(rank):
             bound = torch.minimum(bound, gd[s][fsel, topk - 1])           # +inf when shard s holds fewer than k codes
-        Qf = np.ascontiguousarray(np.asarray(Q.cpu() if isinstance(Q, torch.Tensor) else Q, np.float32)[fidx])
-        if hasattr(self.engine, "linear_tie_emit_dev") and torch.cuda.is_available():
-            from . import core
-            cdev = torch.device("cuda", torch.cuda.current_device())
-            own = sh is None
-            ctx = _engine_stream() if own else _NullCtx(sh)
-            with ctx as st:
-                qf = torch.from_numpy(Qf).to(cdev)
-                t = None if tl is None else torch.from_numpy(tl).to(cdev)
-                bd = bound.to(cdev)
-                e_ids = torch.zeros((nf, cap), dtype=torch.int64, device=cdev)
-                e_d = torch.zeros((nf, cap), dtype=torch.float32, device=cdev)
-                e_cnt = torch.zeros((nf + (nf & 1),), dtype=torch.int32, device=cdev)      # padded to 8 bytes
+        return bound
+
+    def _note_overflow(self, fsel, ok):
+        """A list longer than TIE_CAP rows cannot be replayed: the query keeps its (dist, id) answer, and says so."""
+        bad = fsel[~ok]
+        if bad.numel():
+            self.last_tie_overflow = self.last_tie_overflow.clone()
+            self.last_tie_overflow[bad] = True
+            import warnings
+            warnings.warn("rii_amd.dist: %d tied quer%s produced more than TIE_CAP=%d replay candidates on some shard; exactly tied "
+                          "distances of those rows are ordered by id, not in std::partial_sort's order (see last_tie_overflow)"
+                          % (int(bad.numel()), "y" if bad.numel() == 1 else "ies", self.TIE_CAP))
+
+    def _replay_linear_ties_device(self, q, fsel, topk, rows, t, tl, g, out_i, out_d, dev, sh):
+        """The flagged queries `fsel` redone in the reference's order with the engine's emit / replay kernels.  q, fsel, t, g live
+        on `dev`; the candidate lists travel through the process group's own device (HBM under "nccl", host under "gloo")."""
+        from . import core
+        nf, cap, B = int(fsel.numel()), self.TIE_CAP, q.shape[0]
+        gd = [_field(g, r, B * rows * 8, B * rows, torch.float32).reshape(B, rows) for r in range(g.shape[0])]
+        ctx = _engine_stream() if sh is None else _NullCtx(sh)
+        with ctx as st:
+            bd = self._tie_bound(gd, fsel, topk).contiguous()
+            qf = q[fsel].contiguous()
+            e_ids = torch.zeros((nf, cap), dtype=torch.int64, device=dev)
+            e_d = torch.zeros((nf, cap), dtype=torch.float32, device=dev)
+            e_cnt = torch.zeros((nf + (nf & 1),), dtype=torch.int32, device=dev)      # padded to 8 bytes
+            # a rank whose share of the target ids is EMPTY contributes nothing (S = 0 would mean "no target set" to the engine)
+            if not (tl is not None and len(tl) == 0):
                 self.engine.linear_tie_emit_dev(qf.data_ptr(), nf, topk, t.data_ptr() if t is not None else 0,
                                                 0 if t is None else t.numel(), bd.data_ptr(), self.start, cap, e_ids.data_ptr(),
                                                 e_d.data_ptr(), e_cnt.data_ptr(), st)
-                rec = _pack([e_cnt, e_ids, e_d])
-                assert rec.numel() == core.linear_tie_record_bytes(nf, cap)
-                g = _all_gather_bytes(rec.to(dev), self.group).to(cdev)
-                cnts = torch.stack([_field(g, r, 0, nf, torch.int32) for r in range(g.shape[0])])
-                ok = (cnts <= cap).all(dim=0)                                                # a truncated list cannot be replayed
-                r_i = torch.empty((nf, topk), dtype=torch.int64, device=cdev)
-                r_d = torch.empty((nf, topk), dtype=torch.float32, device=cdev)
-                core.linear_tie_replay_dev(g.data_ptr(), g.shape[0], nf, cap, topk, r_i.data_ptr(), r_d.data_ptr(), st)
-                sel = fsel.to(out_i.device)[ok.to(out_i.device)]
-                out_i[sel] = r_i.to(out_i.device)[ok.to(out_i.device)]
-                out_d[sel] = r_d.to(out_d.device)[ok.to(out_d.device)]
-            return
-        # host engines (the CPU stand-ins of the gloo tests): same protocol through engine.linear_tie_emit / linear_tie_replay
-        e_ids, e_d, e_cnt = self.engine.linear_tie_emit(Qf, topk, tl, bound.cpu().numpy(), self.start, cap)
+            rec = _pack([e_cnt, e_ids, e_d])
+            assert rec.numel() == core.linear_tie_record_bytes(nf, cap)
+            gg = _all_gather_bytes(rec.to(_comm_device(rec)), self.group).to(dev)
+            cnts = torch.stack([_field(gg, r, 0, nf, torch.int32) for r in range(gg.shape[0])])
+            ok = (cnts <= cap).all(dim=0)                                            # a truncated list cannot be replayed
+            r_i = torch.empty((nf, topk), dtype=torch.int64, device=dev)
+            r_d = torch.empty((nf, topk), dtype=torch.float32, device=dev)
+            core.linear_tie_replay_dev(gg.data_ptr(), gg.shape[0], nf, cap, topk, r_i.data_ptr(), r_d.data_ptr(), st)
+            sel = fsel[ok].to(out_i.device)
+            out_i[sel] = r_i[ok].to(out_i.device)
+            out_d[sel] = r_d[ok].to(out_d.device)
+        self._note_overflow(fsel.to(self.last_tie_overflow.device), ok.to(self.last_tie_overflow.device))
+
+    def _replay_linear_ties_host(self, Q, fidx, topk, tl, gd, out_i, out_d):
+        """host engines (the CPU stand-ins of the gloo tests): same protocol through engine.linear_tie_emit / linear_tie_replay"""
+        nf, cap = len(fidx), self.TIE_CAP
+        fsel = torch.from_numpy(fidx)
+        bound = self._tie_bound(gd, fsel, topk)
+        Qf = np.ascontiguousarray(np.asarray(Q.cpu() if isinstance(Q, torch.Tensor) else Q, np.float32)[fidx])
+        if tl is not None and len(tl) == 0:
+            e_ids, e_d, e_cnt = np.zeros((nf, cap), np.int64), np.zeros((nf, cap), np.float32), np.zeros(nf, np.int32)
+        else:
+            e_ids, e_d, e_cnt = self.engine.linear_tie_emit(Qf, topk, tl, bound.numpy(), self.start, cap)
         cnt_t = torch.zeros((nf + (nf & 1),), dtype=torch.int32)
         cnt_t[:nf] = torch.from_numpy(np.asarray(e_cnt, np.int32))
         rec = _pack([cnt_t, torch.from_numpy(np.ascontiguousarray(e_ids, np.int64)), torch.from_numpy(np.ascontiguousarray(e_d, np.float32))])
@@ -325,14 +417,17 @@ class DbShardedIndex(object):
             li = _field(g, r, cb, nf * cap, torch.int64).reshape(nf, cap).numpy()
             ld = _field(g, r, cb + nf * cap * 8, nf * cap, torch.float32).reshape(nf, cap).numpy()
             lists.append((c, li, ld))
+        ok = torch.ones(nf, dtype=torch.bool)
         for j, f in enumerate(fidx):
             if any(int(c[j]) > cap for c, _, _ in lists):
+                ok[j] = False
                 continue
             seq_i = np.concatenate([li[j, :int(c[j])] for c, li, _ in lists])
             seq_d = np.concatenate([ld[j, :int(c[j])] for c, _, ld in lists])
             ri, rd = self.engine.linear_tie_replay(seq_i, seq_d, topk)
             out_i[f] = torch.from_numpy(np.asarray(ri, np.int64))
             out_d[f] = torch.from_numpy(np.asarray(rd, np.float32))
+        self._note_overflow(fsel, ok)
 
     # ---- inverted index over the sharded database (protocol: include/rii_amd.h, csrc/ivfshard.hip) ----
     def total_codes(self):

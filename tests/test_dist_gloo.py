@@ -361,6 +361,33 @@ def _worker(rank, world, port, q, use_gpu=False):
             assert np.array_equal(gd.numpy().view(np.uint32), wd.view(np.uint32)), "tied db-sharded dists k=%d" % topk
             assert np.array_equal(gi.numpy(), wi), "tied db-sharded ids k=%d (the reference's heap order)" % topk
         assert n_flag > 0
+        assert idxt.last_tie_flags.dtype == torch.bool and not bool(idxt.last_tie_overflow.any())
+        # ties again with every target id on rank 0: rank 1's share of the targets is EMPTY, it must contribute no candidate
+        # (not "all of its codes": an empty share is not "no target set")
+        tid0 = np.sort(rngt.choice(rd.shard_range(2203, 0, world)[1], 500, replace=False)).astype(np.int64)
+        n_flag0 = 0
+        for topk in (3, 12, 60):
+            gi, gd = idxt.query_linear_batch(qst, topk, tid0)
+            wi, wd = fullt.query_linear_batch(qst, topk, tid0)
+            n_flag0 += int(idxt.last_tie_flags.sum())
+            assert np.array_equal(gd.numpy().view(np.uint32), wd.view(np.uint32)) and np.array_equal(gi.numpy(), wi), \
+                "ties with all targets on rank 0, k=%d" % topk
+            assert np.isin(gi.numpy(), tid0).all()
+        assert n_flag0 > 0
+        # a candidate list longer than TIE_CAP cannot be replayed: the query keeps the (dist, id) answer and SAYS so
+        import warnings
+        idxt.TIE_CAP = 8
+        with warnings.catch_warnings(record=True) as wlog:
+            warnings.simplefilter("always")
+            gi, gd = idxt.query_linear_batch(qst, 30, None)
+        idxt.TIE_CAP = rd.DbShardedIndex.TIE_CAP
+        wi, wd = fullt.query_linear_batch(qst, 30, None)
+        ov = idxt.last_tie_overflow.numpy()
+        assert ov.any() and (ov <= idxt.last_tie_flags.numpy()).all() and any("TIE_CAP" in str(w.message) for w in wlog)
+        assert np.array_equal(gd.numpy().view(np.uint32), wd.view(np.uint32))            # the distances are still the reference's
+        assert np.array_equal(gi.numpy()[~ov], wi[~ov])                                  # ... and every other row is exact
+        for b in np.nonzero(ov)[0]:                                                      # overflowed rows: (dist, id) order
+            assert list(gi.numpy()[b]) == [i for _, i in sorted(zip(gd.numpy()[b].tolist(), gi.numpy()[b].tolist()))]
         # --- query sharding ---
         rep = _GpuBatch(cw, codes) if use_gpu else full
         qidx = rd.QueryShardedIndex(rep)
@@ -450,8 +477,35 @@ def _nccl_world1_worker(port, q):
             # duplicated codes: bit-equal distances inside the top-k -> flagged, emitted, gathered over RCCL and replayed on the
             # device in the reference's heap order (rii_linear_tie_emit_dev / rii_linear_tie_replay_dev)
             assert np.array_equal(gi.cpu().numpy(), wi), "db-sharded ids k=%d" % topk
+            assert idx.last_tie_flags.is_cuda and idx.last_tie_flags.dtype == torch.bool      # flags never leave the device
             n_lin_flag = n_lin_flag + int(idx.last_tie_flags.sum()) if topk > 1 else 0
-        assert n_lin_flag > 0
+        assert n_lin_flag > 0 and not bool(idx.last_tie_overflow.any())
+        # the device path reads ONE word per batch (none for top-1): untied data -> no replay, flags all clear
+        cwu, codesu, qsu = make_problem(6, M, Ks, Ds, 2000, "unit")
+        gu = RiiGpu(cwu, False, simd_arch="avx512", device=0)
+        gu.add_codes(codesu, False)
+        iu = rd.DbShardedIndex(gu, 0, 2000)
+        ui, ud = iu.query_linear_batch(torch.from_numpy(qsu[:7]).cuda(), 5)
+        wi, wd = _OracleBatch(cwu, codesu).query_linear_batch(qsu[:7], 5)
+        assert np.array_equal(ui.cpu().numpy(), wi) and not bool(iu.last_tie_flags.any())
+        # merge kernel with per-rank id offsets and tie flags (rii_merge_topk_ex_dev)
+        Bm, km, Gm = 2, 3, 2
+        idm = torch.tensor([[[0, 4, 2], [1, 0, 3]], [[0, 1, 2], [5, 6, 7]]], dtype=torch.int64)
+        ddm = torch.tensor([[[1., 2., 2.], [0., 1., 9.]], [[1., 3., 4.], [2., 3., 4.]]], dtype=torch.float32)
+        nrm = core.merge_record_bytes(Bm, km)
+        bm = torch.zeros((Gm, nrm), dtype=torch.uint8)
+        for r in range(Gm):
+            bm[r, :Bm * km * 8] = idm[r].reshape(-1).view(torch.uint8)
+            bm[r, Bm * km * 8:Bm * km * 12] = ddm[r].reshape(-1).view(torch.uint8)
+        dbm = bm.cuda()
+        oi = torch.empty((Bm, 4), dtype=torch.int64, device="cuda")
+        od = torch.empty((Bm, 4), dtype=torch.float32, device="cuda")
+        tf = torch.empty(Bm, dtype=torch.int32, device="cuda")
+        af = torch.zeros(1, dtype=torch.int32, device="cuda")
+        core.merge_topk_ex_dev(dbm.data_ptr(), Gm, Bm, km, 4, [0, 100], oi.data_ptr(), od.data_ptr(), tie_cols=4,
+                               d_out_tie=tf.data_ptr(), d_out_any=af.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        assert oi.cpu().tolist() == [[0, 100, 2, 4], [1, 0, 105, 106]] and od.cpu().tolist() == [[1., 1., 2., 2.], [0., 1., 2., 3.]]
+        assert tf.cpu().tolist() == [1, 0] and int(af.item()) == 1
         # the merge kernel alone: 3 fake shards with exact ties across shards -> (dist, id) order
         B, k, G = 2, 4, 3
         ids = torch.tensor([[[9, 1, 5, 7], [2, 3, 4, 6]], [[8, 0, 10, 11], [12, 13, 14, 15]],

@@ -36,17 +36,40 @@ def test_full_filter_rerank_equals_exhaustive_scan(world):
     assert np.array_equal(again[0], i1) and np.array_equal(again[1], d1)          # idempotent
 
 
+SAMPLE = list(range(16)) + [100, 333, 512, 777, 1000, 1023]
+
+
 def test_full_oracle_spot_check(world):
+    """The DEFAULT path of a 1024-query batch (tile tables -> fscan_mx_kernel -> re-rank: B >= fast_min_batch) compared with the
+    oracle directly at N = 1M on a sample of rows; a 6-query batch (exact scan_kernel path) as well."""
     g, cw, codes, Q = world
+    assert B >= g.get_option("fast_min_batch") and g.get_option("scan_mode") == 1 and g.get_option("scan_mx") == 1
     o = O.OracleRii(cw, False, simd_arch="avx512")
     o.add_codes(codes, False)
-    ids, d = g.query_linear_batch(Q[:6], 1, None)
-    ids10, d10 = g.query_linear_batch(Q[:6], 10, None)
     E = np.array([], np.int64)
+    idb, db = g.query_linear_batch(Q, 1, None)                  # the filter path (what bench.py times)
+    for b in SAMPLE:
+        assert_same_result((idb[b], db[b]), o.query_linear(Q[b], 1, E), "N=1M top-1, B=1024 batch, b=%d" % b)
+    ids, d = g.query_linear_batch(Q[:6], 1, None)               # B < fast_min_batch: the exhaustive scan
+    ids10, d10 = g.query_linear_batch(Q[:6], 10, None)
     for b in range(6):
         assert_same_result((ids[b], d[b]), o.query_linear(Q[b], 1, E), "N=1M top-1 b=%d" % b)
         wi, wd = o.query_linear(Q[b], 10, E)
         assert np.array_equal(np.asarray(wd, np.float32).view(np.uint32), d10[b].view(np.uint32))
+
+
+def test_full_batch_equals_the_real_reference_on_every_row(world, reference):
+    """All 1024 rows of the default-path batch against the compiled reference's query_linear (src/rii.h:195-242) when oracle/_ref
+    loads on this host (~1.5 ms per query with OpenMP)."""
+    g, cw, codes, Q = world
+    ref, arch, flav = reference           # Ds = 4: fvec_L2sqr is the same arithmetic in all three build flavours
+    r = ref.RiiCpp(cw, False)
+    r.add_codes(codes, False)
+    E = np.array([], np.int64)
+    idb, db = g.query_linear_batch(Q, 1, None)
+    for b in range(B):
+        wi, wd = r.query_linear(Q[b], 1, E)
+        assert int(idb[b, 0]) == int(wi[0]) and np.float32(wd[0]).view(np.uint32) == db[b, 0].view(np.uint32), "row %d" % b
 
 
 def test_full_shard_minimum_is_global_minimum(world):
@@ -126,9 +149,6 @@ def test_full_reconfigure_equals_oracle(ivf_world):
     g, o, Q = ivf_world
     assert g.coarse_centers == o.coarse_centers
     assert g.posting_lists == o.posting_lists
-
-
-SAMPLE = list(range(16)) + [100, 333, 512, 777, 1000, 1023]
 
 
 def test_full_config3_ivf_known_answers(ivf_world):

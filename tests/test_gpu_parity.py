@@ -78,6 +78,13 @@ def test_gpu_vs_oracle_linear_ivf_batch(shape):
             for b in range(Q.shape[0]):
                 want = o.query_linear(Q[b], topk, tids)
                 assert_same_result((ids[b], d[b]), want, "linear k=%d S=%d b=%d" % (topk, len(tids), b))
+    # top-1 again with the filter path forced (11 queries are below fast_min_batch: the leg above took the exhaustive scan)
+    g.set_option("fast_min_batch", 0)
+    for tids in (E, sub):
+        ids, d = g.query_linear_batch(Q, 1, tids)
+        for b in range(Q.shape[0]):
+            assert_same_result((ids[b], d[b]), o.query_linear(Q[b], 1, tids), "filter top-1 S=%d b=%d" % (len(tids), b))
+    g.set_option("fast_min_batch", 33)
     nlist = max(2, int(np.sqrt(N)) // 2)
     g.reconfigure(nlist, 3); o.reconfigure(nlist, 3)
     assert g.coarse_centers == o.coarse_centers
