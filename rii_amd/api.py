@@ -4,8 +4,10 @@ meaning, defaults, return dtypes and error behaviour (AssertionError on violated
 MI355X engine (`RiiGpu`, rii_amd/core.py), plus `query_batch` which the reference does not have.
 
 Structure: the argument policy of a search lives in `_SearchPlan` (one place for `query` and `query_batch`), the
-linear-vs-inverted-index crossover is learnt by `CrossoverModel` (the engine timed one query per call, like the reference
-times its CPU path, rii/rii.py:403-486 -- same idea, same `threshold(L)` contract: an `np.poly1d`).
+linear-vs-inverted-index crossover is learnt by `CrossoverModel` (the engine timed like the reference times its CPU path,
+rii/rii.py:403-486 -- same idea, same `threshold(L)` contract: an `np.poly1d`).  Two models are kept: `threshold` (one query
+per call: what `query` experiences, the reference's attribute) and `threshold_batch` (a batch per call: per-query cost is
+~100x lower there and the crossover sits elsewhere), used by `query_batch(method="auto")`.
 """
 import copy
 import time
@@ -27,7 +29,7 @@ class _SearchPlan(object):
 
     __slots__ = ("topk", "L", "tids", "n_targets", "method")
 
-    def __init__(self, index, topk, L, target_ids, sort_target_ids, method):
+    def __init__(self, index, topk, L, target_ids, sort_target_ids, method, batched=False):
         N = index.N
         _require(N > 0, "the index holds no vectors yet")
         _require(index.nlist > 0, "posting lists are missing: call add_configure() or reconfigure() first")
@@ -50,7 +52,7 @@ class _SearchPlan(object):
                  "need topk <= len(target_ids) <= N, got topk={}, len(target_ids)={}, N={}".format(
                      self.topk, self.n_targets, N))
         if method == "auto":
-            method = "linear" if index._use_linear(self.n_targets, self.L) else "ivf"
+            method = "linear" if index._use_linear(self.n_targets, self.L, batched=batched) else "ivf"
         self.method = method
 
 
@@ -73,6 +75,7 @@ class Rii(object):
         else:                                   # tests inject another engine with the same surface
             self.impl_cpp = _impl_factory(table, bool(fine_quantizer.verbose))
         self.threshold = None
+        self.threshold_batch = None
 
     # ---- read-only views ------------------------------------------------------------------------------------------
     M = property(lambda self: self.fine_quantizer.M)
@@ -126,6 +129,7 @@ class Rii(object):
         self.impl_cpp.reconfigure(nlist, iter)
         probes = self.fine_quantizer.decode(self.codes[:min(100, self.N)])
         self.threshold = estimate_best_threshold_function(e=self, queries=probes)
+        self.threshold_batch = None            # learnt on the first query_batch(method="auto") (engines with a batch entry point)
 
     def add_configure(self, vecs, nlist=None, iter=5):
         self.add(vecs=vecs, update_posting_lists=False)
@@ -143,6 +147,7 @@ class Rii(object):
     def clear(self):
         self.impl_cpp.clear()
         self.threshold = None
+        self.threshold_batch = None
 
     # ---- searching --------------------------------------------------------------------------------------------------
     def _rotated(self, x):
@@ -163,7 +168,11 @@ class Rii(object):
         """B queries in one call (Q float32 [B, D]); row b equals `query(Q[b], ...)`.
         Returns (ids int64 [B, topk], dists float32 [B, topk], counts int64 [B]) with counts[b] in {topk, 0}."""
         _require(Q.ndim == 2 and Q.dtype == np.float32, "Q must be float32 (B, D)")
-        plan = _SearchPlan(self, topk, L, target_ids, sort_target_ids, method)
+        if method == "auto" and getattr(self, "threshold_batch", None) is None and self.threshold is not None and \
+                hasattr(self.impl_cpp, "query_linear_batch"):
+            probes = self.fine_quantizer.decode(self.codes[:min(256, self.N)])
+            self.threshold_batch = CrossoverModel(self, probes, batched=True).fit()
+        plan = _SearchPlan(self, topk, L, target_ids, sort_target_ids, method, batched=True)
         Qv = self._rotated(Q)
         if plan.method == "linear":
             ids, dists = self.impl_cpp.query_linear_batch(Qv, plan.topk, plan.tids)
@@ -193,8 +202,10 @@ class Rii(object):
         step = self.L0
         return min(step * (topk // step + 1), self.N)
 
-    def _use_linear(self, len_target_ids, L):
-        return bool(len_target_ids <= self.threshold(L))
+    def _use_linear(self, len_target_ids, L, batched=False):
+        fb = getattr(self, "threshold_batch", None)          # (absent in pickles written before it existed)
+        f = fb if (batched and fb is not None) else self.threshold
+        return bool(len_target_ids <= f(L))
 
     def _resolve_update_posting_lists_flag(self, flag):
         _require(flag in ("auto", True, False), "update_posting_lists must be 'auto', True or False")
@@ -203,24 +214,38 @@ class Rii(object):
 
 class CrossoverModel(object):
     """Learns, per candidate budget L, the subset size |S|* at which the inverted index starts to beat the linear scan,
-    by timing both on the engine itself, and fits |S|* = f(L) with a line."""
+    by timing both on the engine itself, and fits |S|* = f(L) with a line.  batched=False: one query per call (the decision
+    `Rii.query` experiences: exhaustive single-query scan, pinned staging); batched=True: all probes in one call (what
+    `query_batch` experiences: tile tables, filter scan, one launch group per batch)."""
 
-    def __init__(self, index, probes, rounds=5):
+    def __init__(self, index, probes, rounds=5, batched=False):
         self.index, self.impl = index, index.impl_cpp
         self.probes = np.ascontiguousarray(probes, dtype=np.float32)
         self.rounds = rounds
+        self.batched = batched
 
     def _seconds(self, method, tids, L, few):
-        # one query per call: the threshold steers `Rii.query`, whose single-query path (exhaustive scan, pinned staging) is
-        # not the batched one, and `query_batch(method="auto")` must take the same decision row by row
+        """Per-query seconds: the MINIMUM over a few repetitions (a timing is only ever inflated by noise, never deflated)."""
+        best = float("inf")
+        if self.batched:
+            for _ in range(2 if few else 4):
+                t0 = time.perf_counter()
+                if method == "linear":
+                    self.impl.query_linear_batch(self.probes, 1, tids)
+                else:
+                    self.impl.query_ivf_batch(self.probes, 1, tids, L)
+                best = min(best, (time.perf_counter() - t0) / len(self.probes))
+            return best
         qs = self.probes[:3] if few else self.probes
-        t0 = time.perf_counter()
-        for q in qs:
-            if method == "linear":
-                self.impl.query_linear(q, 1, tids)
-            else:
-                self.impl.query_ivf(q, 1, tids, L)
-        return (time.perf_counter() - t0) / len(qs)
+        for _ in range(2 if few else 3):
+            t0 = time.perf_counter()
+            for q in qs:
+                if method == "linear":
+                    self.impl.query_linear(q, 1, tids)
+                else:
+                    self.impl.query_ivf(q, 1, tids, L)
+            best = min(best, (time.perf_counter() - t0) / len(qs))
+        return best
 
     def _ivf_wins(self, s, L, few):
         tids = np.arange(s, dtype=np.int64)
@@ -230,17 +255,18 @@ class CrossoverModel(object):
         N = self.index.N
         if N <= 128:
             return N
-        s = 128
-        while True:                                   # doubling search: 128, 256, ..., N
+        s = max(128, min(int(L), N))                  # |S| < L makes no sense for the inverted index (it must collect L candidates)
+        first = s
+        while True:                                   # doubling search: first, 2 first, ..., N
             if self._ivf_wins(s, L, few=True):
                 break
             if s == N:
                 return N                              # the linear scan never loses
             s = N if s * 2 >= N else s * 2
-        if s == 128:
+        if s == first:
             if self.index.verbose:
-                print("the inverted index already wins at |S|=128; using 128 as the crossover")
-            return 128
+                print("the inverted index already wins at |S|=%d; using it as the crossover" % first)
+            return first
         lo, hi = s // 2, s
         for _ in range(self.rounds):                  # bisection between the last loss and the first win
             mid = int(np.round((lo + hi) / 2))
@@ -262,6 +288,10 @@ class CrossoverModel(object):
             if cuts[-1] == idx.N:
                 break
         coeff = [0, cuts[0]] if len(Ls) == 1 else np.polyfit(Ls, cuts, 1)
+        # a larger candidate budget can only make the inverted index dearer, so the crossover cannot fall with L: a negative
+        # slope is timing noise -- fall back to the mean crossover (constant in L)
+        if len(Ls) > 1 and (not np.all(np.isfinite(coeff)) or coeff[0] < 0):
+            coeff = [0, float(np.mean(cuts))]
         model = np.poly1d(coeff)
         if idx.verbose:
             print("crossover |S|* per L:", dict(zip(Ls, cuts)), "->", model)

@@ -231,3 +231,96 @@ def test_codec_roundtrip_and_eq():
     opq = OPQ(M=4, Ks=64, verbose=False).fit(vecs=X, pq_iter=3, rotation_iter=3)
     assert np.allclose(opq.R @ opq.R.T, np.eye(40), atol=1e-4)
     assert np.allclose(opq.rotate(X[0]), opq.rotate(X[:1])[0])
+
+
+# ---- f3: the learnt linear / inverted-index crossover (rii/rii.py:383-388,403-486 in the reference) -------------------------------
+def _median_seconds(fn, reps=20):
+    import time
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+@pytest.mark.gpu
+def test_crossover_model_is_sane_and_picks_the_faster_side():
+    """After add_configure on N = 200k: threshold(L) is finite and non-decreasing in L, and at |S| = threshold / 3 and 3 x threshold
+    the side `_use_linear` picks is the faster one by direct timing (median of 20), for the single-query model (`query`) and for
+    the batched one (`query_batch`) separately.  Tolerance 25 %: both sides are a handful of latency-bound launches, and a model
+    fitted through five noisy crossovers may sit up to ~2x off the true one; a constant or inverted model still fails."""
+    rng = np.random.default_rng(7)
+    N, D = 200_000, 64
+    means = rng.random((256, D)).astype(np.float32) * 4
+    X = (means[rng.integers(0, 256, N)] + rng.standard_normal((N, D)).astype(np.float32) * 0.3).astype(np.float32)
+    fq = PQ(M=16, Ks=256, verbose=False).fit(vecs=X[:20000], iter=4)
+    e = Rii(fine_quantizer=fq)
+    e.add_configure(vecs=X)                                   # nlist = sqrt(N) = 447
+    Q = X[rng.integers(0, N, 128)] + 0.01
+    e.query_batch(Q, topk=1, method="auto")                   # learns threshold_batch
+    assert e.threshold is not None and e.threshold_batch is not None
+    L0 = e.L0
+    for name, f, batched in (("single", e.threshold, False), ("batch", e.threshold_batch, True)):
+        vals = [float(f(k * L0)) for k in (1, 2, 4, 8, 16)]
+        assert all(np.isfinite(v) and v > 0 for v in vals), (name, vals)
+        assert all(b >= a - 1e-6 for a, b in zip(vals, vals[1:])), "%s threshold must not fall with L: %s" % (name, vals)
+        L = L0
+        thr = float(f(L))
+        for S in (int(thr / 3), int(thr * 3)):
+            S = max(S, L, 128)
+            if S > N:
+                continue                                      # the linear scan never loses below N: nothing to compare there
+            tids = np.sort(rng.choice(N, S, replace=False)).astype(np.int64)
+            if batched:
+                t_lin = _median_seconds(lambda: e.impl_cpp.query_linear_batch(Q, 1, tids))
+                t_ivf = _median_seconds(lambda: e.impl_cpp.query_ivf_batch(Q, 1, tids, L))
+            else:
+                t_lin = _median_seconds(lambda: e.impl_cpp.query_linear(Q[0], 1, tids))
+                t_ivf = _median_seconds(lambda: e.impl_cpp.query_ivf(Q[0], 1, tids, L))
+            picked, other = (t_lin, t_ivf) if e._use_linear(S, L, batched=batched) else (t_ivf, t_lin)
+            assert picked <= 1.25 * other, "%s model at |S|=%d (threshold %.0f): picked side %.1f us, other %.1f us" % (
+                name, S, thr, picked * 1e6, other * 1e6)
+
+
+def test_crossover_model_fit_on_a_synthetic_engine():
+    """CPU: the model's search and fit against an engine whose costs are known in closed form (linear = a |S|, inverted index =
+    c + b L): the crossover (c + b L) / a must be recovered, it rises with L, and the batched / single models are independent."""
+    import time
+
+    class _Costed(object):
+        verbose = False
+
+        def __init__(self, N, a, b, c):
+            self.N, self.nlist, self.a, self.b, self.c = N, 100, a, b, c
+
+        def _burn(self, seconds):
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                pass
+
+        def query_linear(self, q, topk, tids):
+            self._burn(self.a * len(tids))
+            return [0], [0.0]
+
+        def query_ivf(self, q, topk, tids, L):
+            self._burn(self.c + self.b * L)
+            return [0], [0.0]
+
+    class _Idx(object):
+        verbose = False
+
+        def __init__(self, impl):
+            self.impl_cpp, self.N = impl, impl.N
+
+        L0 = 100
+
+        def _multiple_of_L0_covering_topk(self, k):
+            return 100 * (k // 100 + 1)
+
+    from rii_amd.api import CrossoverModel
+    impl = _Costed(N=100_000, a=2e-8, b=1e-7, c=1e-4)          # crossover |S|* = (1e-4 + 1e-7 L) / 2e-8 = 5000 + 5 L
+    f = CrossoverModel(_Idx(impl), np.zeros((6, 4), np.float32), rounds=6).fit()
+    for L in (100, 400, 1600):
+        assert 0.6 * (5000 + 5 * L) <= f(L) <= 1.6 * (5000 + 5 * L), (L, f(L))
+    assert f(1600) >= f(100)
