@@ -3,25 +3,37 @@
 D=128, M=32, Ks=256, batch=1024, top-1 linear ADC scan) on N MI355X GPUs of one node.
 
 A step = one pass of the hot path (distance-table build + scan + top-k) over one batch of 1024 queries per GPU, inputs
-and outputs resident in HBM.  N > 1: one process per GPU (torchrun).  linear / ivf / subset: the index is replicated and
-every rank owns a different 1024-query batch (weak scaling); query sharding has no exchange step, so `value` carries no
-collective and the line adds `with_gather` = the same loop with the all-gather of every rank's (ids, dists) rows over
-RCCL/xGMI inside the timed region.  deep (configs[4] shape): the database is sharded, every rank scans its shard for the
-same batch and the timed region holds the all-gather + (dist, id) merge.  Rank 0 prints ONE JSON line.
+and outputs resident in HBM.  ONE JSON line from rank 0:
 
-Extra objects on the line:
-  roofline      the dominant kernel (fscan_mx_kernel / fscan_kernel for the linear scans, ivf_fused_kernel for the inverted index) timed by
-                HIP events recorded around each of its launches in the timed region, against the resource that binds it:
-                the LDS table-gather rate for the scans (157.3 TB/s = ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz), HBM
-                for the inverted index and the single-query Deep scan.  `hbm` inside it holds the counter traffic.
-  host_call     the same step through the host-pointer C ABI (H2D of the queries + D2H of ids/dists included: SURVEY 8d)
-  cpu_baseline  the real reference build (oracle/_ref; else the C oracle) on this box's host cores, same index and
-                queries, with `ids_match_gpu`; rank 0, N=1 only.
+  value / ms_per_step   the named workload, K timed steps (weak scaling: every rank owns a different 1024-query batch over a
+                        replicated index; query sharding has no exchange step, so `value` carries no collective)
+  roofline              the dominant kernel timed by HIP events attached to each of its dispatches inside the timed region,
+                        against the resource that binds it (LDS row-gather rate for the scans, the issue/latency floor of
+                        ivf_fused_kernel for the inverted index, HBM for the single-query Deep scan)
+  cpu_baseline          the real reference build (oracle/_ref; else the C oracle) on this box's host cores, same index and
+                        queries, with `ids_match_gpu`; rank 0, N=1 only
+  others                (default invocation, N=1) EVERY other BASELINE config measured in the same process: configs[2] `ivf`,
+                        configs[3] `subset` and `subset_ivf` on the same index, configs[0] `readme_n10k` (single-query latency)
+                        and a configs[4]-shaped `deep_shard` (D=96, M=16, 16 M codes) -- each with ms_per_step, dominant-kernel
+                        time, roofline.frac against its own binding resource, and cpu_baseline + ids_match_gpu
+  strong                (N > 1) BASELINE's "batch=1024 at 1/2/4/8 GPU": the SAME global batch of 1024 split over the ranks --
+                        `query_sharded` (index replicated, rows all-gathered inside the timed region) and `db_sharded` (codes
+                        split N ways, every rank answers the whole batch on its shard: all-gather + device merge inside the
+                        timed region, through rii_amd.dist.DbShardedIndex)
+  with_gather           (N > 1, or N = 1 under torchrun) the weak loop with the RCCL all-gather of the result rows inside
+  host_call / uninstrumented / fresh_queries / pipelined: the same step through the host-pointer C ABI; without any timing
+                        event; over 8 distinct batches; alternating on two HIP streams.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks
+(`python -m torch.distributed.run --nproc-per-node N`, rendezvous on 127.0.0.1); under torchrun it is one rank.
+`--workload deep`: configs[4] shape, --n-base codes PER GPU, database sharded, through DbShardedIndex (device merge, no host sync).
 `--latency`: one call per step with fresh queries and a synchronisation per call (the reference's usage pattern).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +44,7 @@ sys.path.insert(0, ROOT)
 
 LDS_PEAK_GBPS = 157286.4         # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X guide, LDS table)
 HBM_PEAK_GBPS = 8000.0
+N_CU, N_SIMD, CLK_GHZ = 256, 1024, 2.4
 
 
 def parse():
@@ -52,6 +65,10 @@ def parse():
                     help="skip the extra measurement with a different query batch every step")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra two-stream measurement (reported beside `value`, never as it)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the `others` object (the other BASELINE configs measured in the same process)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurements")
+    ap.add_argument("--deep-shard", type=int, default=16_000_000, help="codes of the `others.deep_shard` measurement")
     ap.add_argument("--latency", action="store_true",
                     help="per-call latency: fresh queries every call, one synchronisation per call (use with --batch 1)")
     ap.add_argument("--lut-mode", default="exact", choices=["exact", "mfma"])
@@ -65,36 +82,34 @@ def parse():
     return ap.parse_args()
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` typed directly: become the launcher of N ranks (what the driver does with torchrun)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the reference itself (oracle/_ref) on the host cores, same index, same queries
 # --------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(workload, eng, cw, codes, queries, topk, tids, L, arch_hint):
+def cpu_baseline(kind_of_search, what, ref_engine_factory, queries, topk, tids, L, budget_s=6.0, thread_settings=None):
     """The reference's own path, one query per call (it has no batch entry point): QueryLinear is OpenMP-parallel over
     N (src/rii.h:213,222), QueryIvf single-threaded (rii.h:244-326).  OpenMP's default thread count (all hardware
     threads) is not the reference's best setting on a many-core host, so a few counts are timed on a bounded sample and
-    the BEST is reported with `cores` = the threads it used.  For the inverted-index workloads the reference receives the
-    GPU engine's centres and posting lists through its own py::pickle set-state (src/main.cpp:39-52)."""
+    the BEST is reported with `cores` = the threads it used.  Returns (object, list of id lists of the longest sample)."""
     import ctypes
-    from oracle import oracle as O
-    ref, arch, flav = O.load_reference()
+    ref_e, kind, flav = ref_engine_factory()
     E = np.array([], np.int64)
     tids = E if tids is None else tids
-    ivf = workload in ("ivf", "subset-ivf")
-    if ref is not None:
-        kind = "reference"
-        if ivf:
-            ref_e = ref.RiiCpp.__new__(ref.RiiCpp)
-            ref_e.__setstate__(eng.__getstate__())
-        else:
-            ref_e = ref.RiiCpp(cw, False)
-            ref_e.add_codes(codes, False)
-    else:
-        kind = "port"
-        ref_e = O.OracleRii(cw, False, simd_arch=arch_hint)
-        ref_e.add_codes(codes, False)
-        if ivf:
-            ref_e.centers = np.array(eng.coarse_centers, np.uint8)
-            ref_e._lists = eng.posting_lists
+    ivf = kind_of_search == "ivf"
 
     def call(q):
         return ref_e.query_ivf(q, topk, tids, L) if ivf else ref_e.query_linear(q, topk, tids)
@@ -104,7 +119,9 @@ def cpu_baseline(workload, eng, cw, codes, queries, topk, tids, L, arch_hint):
     except OSError:
         gomp = None
     ncpu = os.cpu_count() or 1
-    settings = [1] if ivf else (sorted({ncpu, min(ncpu, 64), min(ncpu, 16), min(ncpu, 8)}, reverse=True) if gomp else [ncpu])
+    if thread_settings is None:
+        thread_settings = [ncpu, 64, 16, 8]
+    settings = [1] if ivf else (sorted({min(ncpu, t) for t in thread_settings}, reverse=True) if gomp else [ncpu])
     tried, best, ids_full = [], None, None
     for nthr in settings:
         if gomp:
@@ -114,7 +131,7 @@ def cpu_baseline(workload, eng, cw, codes, queries, topk, tids, L, arch_hint):
         for q in queries[:4]:
             call(q)
         per = (time.perf_counter() - t0) / 4
-        n = int(min(len(queries), max(8, 6.0 / max(per, 1e-6))))      # ~6 s of CPU work per setting
+        n = int(min(len(queries), max(8, budget_s / max(per, 1e-6))))     # ~budget_s of CPU work per setting
         t0 = time.perf_counter()
         res = [call(q)[0] for q in queries[:n]]
         dt = time.perf_counter() - t0
@@ -123,11 +140,40 @@ def cpu_baseline(workload, eng, cw, codes, queries, topk, tids, L, arch_hint):
             ids_full = res
         if best is None or n / dt > best[0]:
             best = (n / dt, nthr, n)
-    what = {"linear": "full %d-code linear scan" % codes.shape[0], "subset": "linear scan of %d target ids" % len(tids),
-            "ivf": "inverted index nlist=1024 L=%d" % L, "subset-ivf": "inverted index nlist=1024 L=%d over %d target ids" % (L, len(tids))}
     return {"value": best[0], "unit": "queries/s", "ms_per_query": 1e3 / best[0], "cores": best[1], "kind": kind,
             "sample": "one query per call, %s, top-%d%s; thread counts tried: %s"
-                      % (what[workload], topk, (", build flavour " + flav) if ref is not None else "", "; ".join(tried))}, ids_full
+                      % (what, topk, (", build flavour " + flav) if flav else "", "; ".join(tried))}, ids_full
+
+
+def reference_factory(eng, cw, codes, arch_hint, ivf):
+    """-> callable building the CPU engine: the real reference (kind "reference") when oracle/_ref loads, else the C oracle
+    ("port").  For the inverted index it receives the GPU engine's centres and posting lists through its own py::pickle
+    set-state (src/main.cpp:39-52)."""
+    def make():
+        from oracle import oracle as O
+        ref, arch, flav = O.load_reference()
+        if ref is not None:
+            if ivf:
+                e = ref.RiiCpp.__new__(ref.RiiCpp)
+                e.__setstate__(eng.__getstate__())
+            else:
+                e = ref.RiiCpp(cw, False)
+                e.add_codes(codes, False)
+            return e, "reference", flav
+        e = O.OracleRii(cw, False, simd_arch=arch_hint)
+        e.add_codes(codes, False)
+        if ivf:
+            e.centers = np.array(eng.coarse_centers, np.uint8)
+            e._lists = eng.posting_lists
+        return e, "port", None
+    return make
+
+
+def ids_match(res_ids, res_cnt, cpu_res):
+    n = len(cpu_res)
+    if res_cnt is not None:
+        return bool(all(list(res_ids[b, :int(res_cnt[b])]) == list(cpu_res[b]) for b in range(n))), n
+    return bool(all(list(res_ids[b]) == list(cpu_res[b]) for b in range(n))), n
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -140,21 +186,20 @@ def profile_table(name):
         return {}
 
 
-def filter_kernel_name(args, M):
-    return "fscan_mx_kernel" if (args.scan_mx and M in (16, 32, 64)) else "fscan_kernel"
+def filter_kernel_name(scan_mx, M):
+    return "fscan_mx_kernel" if (scan_mx and M in (16, 32, 64)) else "fscan_kernel"
 
 
-def workload_key(args, n_scanned):
-    key = "%s/scan_mode=%d/M=%d/N=%d/B=%d" % (args.workload, args.scan_mode, args.M if args.workload != "deep" else 16,
-                                              n_scanned, args.batch)
-    if args.scan_mode == 1 and not args.scan_mx:
+def workload_key(workload, scan_mode, scan_mx, M, n_scanned, batch, topk):
+    key = "%s/scan_mode=%d/M=%d/N=%d/B=%d" % (workload, scan_mode, M, n_scanned, batch)
+    if scan_mode == 1 and not scan_mx:
         key += "/scan_mx=0"
-    if args.topk != 1:
-        key += "/topk=%d" % args.topk
+    if topk != 1:
+        key += "/topk=%d" % topk
     return key
 
 
-def roofline_scan(args, kernel_name, B, n_codes, M, Ks, avg_s, launches, steps, byte_tables, pmc_key):
+def roofline_scan(kernel_name, B, n_codes, M, Ks, avg_s, launches, steps, byte_tables, fmt_bytes, pmc_key):
     """Linear scans: the binding resource is the LDS table gather -- every (query, code, m) lookup reads one table entry
     (1 byte from the filter's byte tables, 4 bytes from the exact fp32 tables) out of LDS; the code bytes themselves are
     shared by the whole batch through L2/LDS, so HBM sees ~N*M bytes per launch, not B*N*M."""
@@ -163,10 +208,7 @@ def roofline_scan(args, kernel_name, B, n_codes, M, Ks, avg_s, launches, steps, 
     achieved = lookups * entry / avg_s / 1e9 if avg_s > 0 else 0.0
     pmc = profile_table("pmc.json").get(pmc_key, {})
     traffic = profile_table("traffic.json").get(pmc_key, {}).get("hbm_bytes_per_launch")
-    # codes once (fscan_kernel's formatted copy of the M = 16 / 32 shapes holds 2 bytes per code byte; fscan_mx_kernel's is a
-    # permutation of the code bytes) + the tables staged
-    fmt = 2 if (byte_tables and M in (16, 32) and Ks == 256 and not args.scan_mx) else 1      # (M = 64: plain or permuted code bytes)
-    floor = n_codes * M * fmt + B * M * Ks * entry
+    floor = n_codes * M * fmt_bytes + B * M * Ks * entry       # the code stream once + the tables staged
     hbm = {"algorithmic_bytes_per_launch": lookups, "compulsory_floor_bytes": floor, "traffic_bytes": traffic,
            "achieved": (traffic / avg_s / 1e9) if (traffic and avg_s > 0) else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     if hbm["achieved"] is not None:
@@ -174,13 +216,16 @@ def roofline_scan(args, kernel_name, B, n_codes, M, Ks, avg_s, launches, steps, 
     return {"bound": "lds-gather", "kernel": kernel_name, "achieved": achieved, "peak": LDS_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / LDS_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": launches,
             "launches_per_step": launches / max(steps, 1), "table_lookups_per_launch": lookups, "entry_bytes": entry,
-            "conflict_frac": pmc.get("lds_conflict_frac"), "lds_busy": pmc.get("lds_busy"), "valu_busy": pmc.get("valu_busy"),
-            "mfma_busy": pmc.get("mfma_busy"), "shader_clock_ghz": pmc.get("shader_clock_ghz"),
             "hbm": hbm,
-            "note": "achieved = table-entry bytes gathered from LDS per second (B*N*M lookups x entry_bytes / kernel time); "
-                    "peak = conflict-free ds_read_b128 rate at the nominal 2.4 GHz; conflict_frac = SQ_LDS_BANK_CONFLICT / "
-                    "SQ_LDS_IDX_ACTIVE, lds_busy / valu_busy / mfma_busy = busy cycles over the launch's shader cycles, from the "
-                    "rocprofv3 --pmc passes of the same command (profiles/)"}
+            # NOT measured in this run: the rocprofv3 --pmc passes of the same command, kept under profiles/ (a kernel change
+            # moves `frac` above, measured live, but not these until the profiles are retaken)
+            "counters_from_profiles": {"source": pmc.get("source"), "conflict_frac": pmc.get("lds_conflict_frac"),
+                                       "lds_busy": pmc.get("lds_busy"), "valu_busy": pmc.get("valu_busy"),
+                                       "mfma_busy": pmc.get("mfma_busy"), "shader_clock_ghz": pmc.get("shader_clock_ghz"),
+                                       "wave_wait_frac": pmc.get("wave_wait_frac"), "wave_active_frac": pmc.get("wave_active_frac")},
+            "note": "achieved = table-entry bytes gathered from LDS per second (B*N*M lookups x entry_bytes / kernel time, the "
+                    "kernel time from HIP events on its dispatches in the timed region); peak = conflict-free ds_read_b128 "
+                    "rate at the nominal 2.4 GHz"}
 
 
 def roofline_hbm(kernel_name, alg_bytes, avg_s, launches, steps, traffic):
@@ -188,6 +233,29 @@ def roofline_hbm(kernel_name, alg_bytes, avg_s, launches, steps, traffic):
     return {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": avg_s * 1e3, "launches": launches, "launches_per_step": launches / max(steps, 1)}
+
+
+def roofline_ivf(B, nlist, M, Ks, Ds, w, mean_len, L, avg_s, launches, steps, traffic):
+    """ivf_fused_kernel's working set (codebook 128 KiB, centres nlist*M, the visited lists' codes) lives in L2 / Infinity Cache,
+    so HBM does not bind it; neither does the LDS array (profiles/r02_ivf_pmc.json: 28 % busy).  What the kernel has to issue
+    per query is fixed by the algorithm: M*Ks table entries built (Ds subtract + Ds multiply + Ds-1 add each), (nlist + L) * M
+    table lookups with one fp32 add each, i.e. a floor of VALU instruction issues; `achieved` = those issues per second against
+    the chip's VALU issue rate (one wave64 instruction per 4 cycles per SIMD).  The HBM-form figure of SURVEY 8(d) is kept in
+    `hbm_form` for continuity."""
+    per_q = M * Ks * (3 * Ds - 1) + (nlist + L) * M * 2          # lane-operations: table build + (address, add) per lookup
+    insts = B * per_q / 64.0                                    # wave64 instructions
+    peak = N_SIMD * CLK_GHZ * 1e9 / 4.0                          # wave instructions per second, whole chip
+    achieved = insts / avg_s if avg_s > 0 else 0.0
+    alg = B * (nlist * M + w * mean_len * 4 + L * M)
+    return {"bound": "valu-issue", "kernel": "ivf_fused_kernel", "achieved": achieved / 1e9, "peak": peak / 1e9,
+            "unit": "G wave-instructions/s", "frac": achieved / peak, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
+            "launches": launches, "launches_per_step": launches / max(steps, 1),
+            "algorithmic_lane_ops_per_query": per_q,
+            "hbm_form": {"algorithmic_bytes_per_launch": alg, "achieved": alg / avg_s / 1e9 if avg_s > 0 else 0.0,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (alg / avg_s / 1e9 / HBM_PEAK_GBPS) if avg_s > 0 else 0.0},
+            "note": "one block per query: table build + coarse scoring + candidate scan are dependent phases of ~2.7 k vector "
+                    "instructions per wave; the floor counted here is the arithmetic the algorithm cannot avoid (no address "
+                    "arithmetic, no selection): frac = that floor over the chip's issue rate"}
 
 
 def timed_loop(fn, steps, barrier):
@@ -199,11 +267,188 @@ def timed_loop(fn, steps, barrier):
     return time.perf_counter() - t0
 
 
+DOMINANT = ("scan", "ivf_fused", "ivf_scan")
+OTHER_KERNELS = ("lut", "quant", "rerank", "kth", "tie", "select", "gather", "ivf_exact", "ivf_coarse", "ivf_plan", "ivf_scan",
+                 "ivf_select")
+
+
+def measure(eng, step, steps, warmup, barrier, sync):
+    """warm-up, K timed steps with ONLY the dominant kernel carrying HIP events (attached to its dispatch: engine option
+    `timing` = 2), then a short untimed pass with events around every launch for the other kernels' shares."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    eng.set_option("timing", 2)
+    eng.timing_reset()
+    elapsed = timed_loop(step, steps, barrier)
+    eng.set_option("timing", 0)
+    dom = {kn: eng.timing_read(kn) for kn in DOMINANT}
+    eng.timing_reset()
+    eng.set_option("timing", 1)
+    n_break = max(3, min(steps, 10))
+    for _ in range(n_break):
+        step()
+    sync()
+    eng.set_option("timing", 0)
+    shares = {}
+    for kn in OTHER_KERNELS:
+        ms_, n_ = eng.timing_read(kn)
+        if n_:
+            shares[kn + "_ms_per_step"] = ms_ / n_break
+    eng.timing_reset()
+    return elapsed, dom, shares
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# `others`: the other BASELINE configs, measured in the same process (rank 0, N = 1)
+# --------------------------------------------------------------------------------------------------------------------
+def sift_workload(name, eng, args, torch, dev, stream, q_dev, cw, codes, barrier, arch, N, M, Ks, Ds, B, topk):
+    """One of configs[2] / configs[3] on the SIFT1M-shaped index the main measurement used: `ivf`, `subset`, `subset_ivf`."""
+    ivf = name in ("ivf", "subset_ivf")
+    S, L, d_tids, h_tids = 0, 0, 0, None
+    nlist = 1024
+    if ivf:
+        if eng.nlist != nlist:
+            eng.reconfigure(nlist, 5)
+        L = int(np.round(N / nlist))
+    if name in ("subset", "subset_ivf"):
+        h_tids = np.sort(np.random.default_rng(7).choice(N, min(100_000, N), replace=False)).astype(np.int64)
+        tids = torch.from_numpy(h_tids).to(dev)
+        S, d_tids = tids.numel(), tids.data_ptr()
+    out_ids = torch.empty((B, topk), dtype=torch.int64, device=dev)
+    out_d = torch.empty((B, topk), dtype=torch.float32, device=dev)
+    out_cnt = torch.empty((B,), dtype=torch.int64, device=dev)
+
+    def step():
+        if ivf:
+            eng.query_ivf_dev(q_dev.data_ptr(), B, topk, d_tids, S, L, out_ids.data_ptr(), out_d.data_ptr(), out_cnt.data_ptr(), stream)
+        else:
+            eng.query_linear_dev(q_dev.data_ptr(), B, topk, d_tids, S, out_ids.data_ptr(), out_d.data_ptr(), stream)
+
+    elapsed, dom, shares = measure(eng, step, args.steps, max(args.warmup, 2), barrier, torch.cuda.synchronize)
+    res_ids = out_ids.cpu().numpy().copy()
+    res_cnt = out_cnt.cpu().numpy().copy() if ivf else None
+    k_ms, k_n = dom["ivf_fused" if ivf else "scan"]
+    avg_s = (k_ms / max(args.steps, 1)) * 1e-3
+    n_scanned = S if name == "subset" else N
+    if ivf:
+        w = min(nlist, int(np.round(L * nlist / (S if S else N))) + 3)
+        key = workload_key(name.replace("_", "-"), args.scan_mode, args.scan_mx, M, N, B, topk)
+        roof = roofline_ivf(B, nlist, M, Ks, Ds, w, N // nlist, L, avg_s, k_n, args.steps,
+                            profile_table("traffic.json").get(key, {}).get("hbm_bytes_per_launch"))
+    else:
+        filt = bool(args.scan_mode and (topk > 1 or B >= eng.get_option("fast_min_batch")))
+        key = workload_key(name, args.scan_mode, args.scan_mx, M, n_scanned, B, topk)
+        roof = roofline_scan(filter_kernel_name(args.scan_mx, M) if filt else "scan_kernel", B, n_scanned, M, Ks, avg_s, k_n,
+                             args.steps, filt, 1 if args.scan_mx or not filt else 2, key)
+    roof.update(shares)
+    obj = {"config": "SIFT1M-shaped %s, D=128 M=%d Ks=256, N=%d, batch=%d, topk=%d%s%s"
+                     % (name, M, N, B, topk, (", nlist=%d L=%d" % (nlist, L)) if L else "", (", |target_ids|=%d" % S) if S else ""),
+           "value": B * args.steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / args.steps * 1e3,
+           "kernel": roof["kernel"], "kernel_ms": avg_s * 1e3, "roofline": roof}
+    if not args.no_cpu_baseline:
+        what = {"ivf": "inverted index nlist=%d L=%d" % (nlist, L), "subset": "linear scan of %d target ids" % S,
+                "subset_ivf": "inverted index nlist=%d L=%d over %d target ids" % (nlist, L, S)}[name]
+        cb, cpu_res = cpu_baseline("ivf" if ivf else "linear", what, reference_factory(eng, cw, codes, arch, ivf),
+                                   q_dev.cpu().numpy(), topk, h_tids, L, budget_s=3.0)
+        cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, res_cnt, cpu_res)
+        obj["cpu_baseline"] = cb
+    return obj
+
+
+def readme_workload(args, torch, dev, arch):
+    """configs[0]: the README example (N=10k, D=128, M=32, Ks=256, uniform random vectors; nlist = sqrt(N) = 100, topk = 3),
+    ONE query per call through the host-pointer C ABI with a synchronisation per call -- the reference's own usage pattern --
+    beside the reference on the host cores."""
+    from rii_amd import RiiGpu
+    from rii_amd import bench_data as bd
+    rng = np.random.default_rng(0)
+    N, D, M, Ks = 10_000, 128, 32, 256
+    X = rng.random((N, D)).astype(np.float32)
+    Q = rng.random((256, D)).astype(np.float32)
+    cw = bd.train_pq(X[:5000], M, Ks, iters=5, seed=123, device=dev)
+    codes = bd.encode_pq(X, cw, device=dev)
+    eng = RiiGpu(cw, False, simd_arch=arch, device=dev.index)
+    eng.add_codes(codes, False)
+    eng.reconfigure(100, 5)
+    topk, L = 3, 100
+    E = np.array([], np.int64)
+    out = {"config": "README example: N=10k D=128 M=32 Ks=256, nlist=100, ONE query per call (host pointers, one synchronisation "
+                     "per call), topk=%d, L=%d" % (topk, L)}
+    for name in ("linear", "ivf"):
+        call = (lambda q: eng.query_ivf(q, topk, E, L)) if name == "ivf" else (lambda q: eng.query_linear(q, topk, E))
+        for q in Q[:20]:
+            call(q)
+        ts, res = [], []
+        for q in Q:
+            t0 = time.perf_counter()
+            r = call(q)
+            ts.append(time.perf_counter() - t0)
+            res.append(r[0])
+        ts = np.array(ts) * 1e3
+        o = {"p50_ms": float(np.percentile(ts, 50)), "p99_ms": float(np.percentile(ts, 99)), "value": 1e3 / float(np.mean(ts)),
+             "unit": "queries/s"}
+        if not args.no_cpu_baseline:
+            cb, cpu_res = cpu_baseline(name, "README index, %s" % name, reference_factory(eng, cw, codes, arch, name == "ivf"),
+                                       Q, topk, None, L, budget_s=1.0, thread_settings=[os.cpu_count() or 1, 8, 1])
+            cb["ids_match_gpu"] = bool(all(list(res[b]) == list(cpu_res[b]) for b in range(len(cpu_res))))
+            cb["queries_compared"] = len(cpu_res)
+            o["cpu_baseline"] = cb
+        out[name] = o
+    out["note"] = ("latency-bound: 3 short dependent launches + pinned H2D/D2H + one synchronisation; no roofline applies (the "
+                   "index is 320 KB)")
+    return out
+
+
+def deep_shard_workload(args, torch, dev, arch, barrier):
+    """configs[4] per-GPU shape at a size that fits the default run: D=96, M=16, Ks=256 (Ds=6), --deep-shard codes of uniform
+    random bytes (throughput only: no recall), batch 1024, top-1, one GPU = one shard."""
+    from rii_amd import RiiGpu
+    from rii_amd import bench_data as bd
+    B, M, Ks, D = args.batch, 16, 256, 96
+    n = args.deep_shard
+    _, train, query = bd.sift_like(n_base=1, n_train=50_000, n_query=B, D=D, seed=99)
+    cw = bd.train_pq(train, M, Ks, iters=5, seed=123, device=dev)
+    codes = np.random.default_rng(1000).integers(0, 256, size=(n, M), dtype=np.uint8)
+    eng = RiiGpu(cw, False, simd_arch=arch, device=dev.index)
+    eng.add_codes(codes, False)
+    for k in ("scan_mode", "scan_order", "scan_mx"):
+        eng.set_option(k, getattr(args, k))
+    q = torch.from_numpy(np.ascontiguousarray(query[:B])).to(dev)
+    out_ids = torch.empty((B, 1), dtype=torch.int64, device=dev)
+    out_d = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.query_linear_dev(q.data_ptr(), B, 1, 0, 0, out_ids.data_ptr(), out_d.data_ptr(), stream)
+
+    steps = max(3, min(args.steps, 10))
+    elapsed, dom, shares = measure(eng, step, steps, 2, barrier, torch.cuda.synchronize)
+    k_ms, k_n = dom["scan"]
+    avg_s = (k_ms / steps) * 1e-3
+    filt = bool(args.scan_mode and B >= eng.get_option("fast_min_batch"))
+    roof = roofline_scan(filter_kernel_name(args.scan_mx, M) if filt else "scan_kernel", B, n, M, Ks, avg_s, k_n, steps, filt,
+                         1 if args.scan_mx or not filt else 2, workload_key("deep", args.scan_mode, args.scan_mx, M, n, B, 1))
+    roof.update(shares)
+    obj = {"config": "Deep1B-shaped shard: D=96 M=16 Ks=256, %d codes on one GPU, batch=%d, topk=1" % (n, B),
+           "value": B * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+           "kernel": roof["kernel"], "kernel_ms": avg_s * 1e3, "roofline": roof}
+    if not args.no_cpu_baseline:
+        res_ids = out_ids.cpu().numpy().copy()
+        cb, cpu_res = cpu_baseline("linear", "full %d-code linear scan (M=16)" % n, reference_factory(eng, cw, codes, arch, False),
+                                   query[:B], 1, None, 0, budget_s=3.0, thread_settings=[64, 16])
+        cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, None, cpu_res)
+        obj["cpu_baseline"] = cb
+    del eng
+    return obj
+
+
 # --------------------------------------------------------------------------------------------------------------------
 def main_deep(args, world, rank, local, dev, arch):
     """Deep1B-shaped database sharding (BASELINE configs[4]): D=96, M=16, Ks=256; every rank holds --n-base codes
-    (uniform random bytes: throughput only, so no recall), all ranks answer the SAME batch on their shard, global id =
-    shard offset + local id, results all-gathered over RCCL and merged on the device under the (dist, id) rule."""
+    (uniform random bytes: throughput only, so no recall), all ranks answer the SAME batch on their shard through
+    rii_amd.dist.DbShardedIndex: engine -> record -> RCCL all-gather -> device merge (per-rank id offsets added by the merge
+    kernel), no host synchronisation in the step."""
     import torch
     import torch.distributed as dist
     from rii_amd import RiiGpu
@@ -223,63 +468,45 @@ def main_deep(args, world, rank, local, dev, arch):
     del codes
     topk = args.topk
     q = torch.from_numpy(np.ascontiguousarray(query[:B])).to(dev)
-    out_ids = torch.empty((B, topk), dtype=torch.int64, device=dev)
-    out_d = torch.empty((B, topk), dtype=torch.float32, device=dev)
-    side = torch.cuda.Stream(device=dev)      # engine kernels, RCCL calls and the merge are ordered on ONE torch stream
-    torch.cuda.set_stream(side)
-    stream = side.cuda_stream
-    offset = rank * n_shard
-    merged = [None]
     use_dist = dist.is_initialized()
+    idx = rd.DbShardedIndex(eng, rank * n_shard, (rank + 1) * n_shard)
+    idx.all_starts()
+    merged = [None]
 
     def step():
-        eng.query_linear_dev(q.data_ptr(), B, topk, 0, 0, out_ids.data_ptr(), out_d.data_ptr(), stream)
-        merged[0] = rd.allgather_merge_topk(out_ids, out_d, topk, id_offset=offset)
+        merged[0] = idx.query_linear_batch(q, topk)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # inside the timed region only the dominant kernel carries HIP events (2 records per step); the other kernels' shares
-    # come from a short untimed pass afterwards (events around every launch cost ~10 % of a 0.4 ms step)
-    eng.set_option("timing", 2)
-    eng.timing_reset()
-    elapsed = timed_loop(step, args.steps, barrier)
-    eng.set_option("timing", 0)
-    dom = {kn: eng.timing_read(kn) for kn in ("scan", "ivf_fused", "ivf_scan")}
-    eng.timing_reset()
-    eng.set_option("timing", 1)
-    n_break = max(3, min(args.steps, 10))
-    for _ in range(n_break):
-        step()
-    torch.cuda.synchronize()
-    eng.set_option("timing", 0)
+    elapsed, dom, shares = measure(eng, step, args.steps, args.warmup, barrier, torch.cuda.synchronize)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     k_ms, k_n = dom["scan"]
     if rank == 0:
         avg_s = (k_ms / max(args.steps, 1)) * 1e-3
         filt = bool(args.scan_mode and (topk > 1 or B >= eng.get_option("fast_min_batch")))
-        key = workload_key(args, n_shard)
+        key = workload_key("deep", args.scan_mode, args.scan_mx, M, n_shard, B, topk)
         if B == 1:
             roof = roofline_hbm("scan_kernel", n_shard * M, avg_s, k_n, args.steps,
                                 profile_table("traffic.json").get(key, {}).get("hbm_bytes_per_launch"))
         else:
-            roof = roofline_scan(args, filter_kernel_name(args, M) if filt else "scan_kernel", B, n_shard, M, Ks, avg_s, k_n, args.steps,
-                                 filt, key)
+            roof = roofline_scan(filter_kernel_name(args.scan_mx, M) if filt else "scan_kernel", B, n_shard, M, Ks, avg_s, k_n,
+                                 args.steps, filt, 1 if args.scan_mx or not filt else 2, key)
+        roof.update(shares)
         print(json.dumps({
             "metric": "queries/sec", "value": B * args.steps / elapsed, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Deep1B-shaped linear ADC scan, D=96 M=16 Ks=256, %d codes per GPU (database sharded, "
                                    "%d codes total), batch=%d, topk=%d" % (n_shard, n_shard * world, B, topk),
-                       "global_batch": B, "parallelism": "database-sharded x%d, RCCL all-gather + device (dist,id) merge in the timed region" % world,
+                       "global_batch": B,
+                       "parallelism": "database-sharded x%d through rii_amd.dist.DbShardedIndex: RCCL all-gather + device (dist,id) "
+                                      "merge in the timed region, no host synchronisation per step" % world,
                        "scan_mode": "byte-table filter + exact fp32 re-rank" if args.scan_mode else "exact fp32 scan"},
             "recall_at_1": None, "roofline": roof}))
     if use_dist:
@@ -288,6 +515,8 @@ def main_deep(args, world, rank, local, dev, arch):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
     from rii_amd import RiiGpu, host_simd_arch
@@ -306,7 +535,9 @@ def main():
             local = int(os.environ.get("RII_BENCH_DEVICE", "0"))
         torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (got WORLD_SIZE=%d)" % (args.gpus, world)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` directly, or under "
+                         "`python -m torch.distributed.run --nproc-per-node N`)" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, M, Ks, D = args.batch, args.M, 256, 128
@@ -394,51 +625,89 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(*vals):
+        if not use_dist:
+            return vals
+        t = torch.tensor(list(vals), dtype=torch.float64, device="cpu" if host_coll else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return tuple(float(x) for x in t)
+
     if args.latency:
         return main_latency(args, eng, t_q, run, ivf, topk, h_tids, L, rank, world, dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # inside the timed region only the dominant kernel carries HIP events (2 records per step); the other kernels' shares
-    # come from a short untimed pass afterwards (events around every launch cost ~10 % of a 0.4 ms step)
-    eng.set_option("timing", 2)
-    eng.timing_reset()
-    elapsed = timed_loop(step, args.steps, barrier)
-    eng.set_option("timing", 0)
-    dom = {kn: eng.timing_read(kn) for kn in ("scan", "ivf_fused", "ivf_scan")}
-    eng.timing_reset()
-    eng.set_option("timing", 1)
-    n_break = max(3, min(args.steps, 10))
-    for _ in range(n_break):
-        step()
-    torch.cuda.synchronize()
-    eng.set_option("timing", 0)
+    elapsed, dom, extra = measure(eng, step, args.steps, args.warmup, barrier, torch.cuda.synchronize)
     res_ids = out_ids.cpu().numpy().copy()
     res_cnt = out_cnt.cpu().numpy().copy() if ivf else None
+    # the same K steps with no timing event at all (twice): what the events attached to the dominant kernel's dispatches cost,
+    # and how stable a K-step sample is
+    plain = [timed_loop(step, args.steps, barrier) for _ in range(2)]
     elapsed_g = None
     if use_dist:
         for _ in range(args.warmup):
             step_gather()
         elapsed_g = timed_loop(step_gather, args.steps, barrier)
-        cdev = "cpu" if host_coll else dev
-        t = torch.tensor([elapsed, elapsed_g], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_g = float(t[0].item()), float(t[1].item())
+        elapsed, elapsed_g, plain[0], plain[1] = max_over_ranks(elapsed, elapsed_g, plain[0], plain[1])
         allq = gathered[0][0]                        # the gathered batch really is every rank's rows, in rank order
         assert allq.shape[0] == B * world and torch.equal(allq[rank * B:(rank + 1) * B].to(out_ids.device), out_ids)
+
+    # ---------------- strong scaling: BASELINE's "batch=1024 at 1/2/4/8 GPU" -- ONE global batch split over the ranks ----------------
+    strong = None
+    if use_dist and not args.no_strong:
+        strong = {}
+        Qg = t_q[:B].contiguous()                    # the same global batch on every rank
+        Qs = Qg.cpu().numpy() if host_coll else Qg   # (gloo: host engines' surface)
+        tids_np = h_tids if (host_coll or not S) else tids
+        qidx = rd.QueryShardedIndex(eng)
+        res_q = [None]
+
+        def step_strong_q():
+            if ivf:
+                res_q[0] = qidx.query_ivf_batch(Qs, topk, tids_np, L)
+            else:
+                res_q[0] = qidx.query_linear_batch(Qs, topk, tids_np)
+
+        for _ in range(max(args.warmup, 1)):
+            step_strong_q()
+        e_q, = max_over_ranks(timed_loop(step_strong_q, args.steps, barrier))
+        run(Qg)                                      # every row equals the single-engine answer for that row
+        torch.cuda.synchronize()
+        ok_q = bool(torch.equal(torch.as_tensor(res_q[0][0]).to(dev), out_ids))
+        strong["query_sharded"] = {"value": B * args.steps / e_q, "unit": "queries/s", "ms_per_step": e_q / args.steps * 1e3,
+                                   "global_batch": B, "rows_per_rank": [rd.shard_range(B, r, world)[1] - rd.shard_range(B, r, world)[0]
+                                                                          for r in range(world)],
+                                   "results_match_single_engine": ok_q,
+                                   "what": "index replicated, rank r answers its slice of the global batch, ONE all-gather of the "
+                                           "packed result rows inside the timed region (QueryShardedIndex)"}
+        if not ivf and S == 0:
+            s0, s1 = rd.shard_range(N, rank, world)
+            eng_s = RiiGpu(cw, False, simd_arch=arch, device=local)
+            eng_s.add_codes(codes[s0:s1], False)
+            for k in ("scan_mode", "scan_order", "scan_mx"):
+                eng_s.set_option(k, getattr(args, k))
+            didx = rd.DbShardedIndex(eng_s, s0, s1)
+            didx.all_starts()
+            res_d = [None]
+
+            def step_strong_d():
+                res_d[0] = didx.query_linear_batch(Qs, topk)
+
+            for _ in range(max(args.warmup, 1)):
+                step_strong_d()
+            e_d, = max_over_ranks(timed_loop(step_strong_d, args.steps, barrier))
+            ok_d = bool(torch.equal(torch.as_tensor(res_d[0][0]).to(dev), out_ids) and torch.equal(torch.as_tensor(res_d[0][1]).to(dev), out_d))
+            strong["db_sharded"] = {"value": B * args.steps / e_d, "unit": "queries/s", "ms_per_step": e_d / args.steps * 1e3,
+                                    "global_batch": B, "codes_per_rank": s1 - s0, "results_match_single_engine": ok_d,
+                                    "what": "codes split into contiguous id ranges, every rank answers the whole batch on its shard, "
+                                            "ONE all-gather + device (dist, id) merge inside the timed region (DbShardedIndex: "
+                                            "rii_merge_topk_ex_dev, no host synchronisation for top-1)"}
+            del didx, eng_s
+        run(my_q)
+        torch.cuda.synchronize()
 
     kernel = "scan"
     if ivf:
         kernel = "ivf_fused" if eng.get_option("ivf_fused") else "ivf_scan"
     k_ms, k_n = dom[kernel]
-    extra = {}
-    for kn in ("lut", "quant", "rerank", "kth", "tie", "select", "gather", "ivf_exact", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select"):
-        if kn == kernel:
-            continue
-        ms_, n_ = eng.timing_read(kn)
-        if n_:
-            extra[kn + "_ms_per_step"] = ms_ / n_break
     recall = bd.recall_at_r(res_ids, my_gt, 1)
     if use_dist:
         r = torch.tensor([recall], dtype=torch.float64, device="cpu" if host_coll else dev)
@@ -530,18 +799,15 @@ def main():
         qps = B * world * args.steps / elapsed
         n_scanned = S if args.workload == "subset" else N
         avg_s = (k_ms / max(args.steps, 1)) * 1e-3          # top-k runs the scan kernel twice per step: charged together
-        key = workload_key(args, n_scanned)
+        key = workload_key(args.workload, args.scan_mode, args.scan_mx, M, n_scanned, B, topk)
         if ivf:
-            # coarse codes + visited posting ids + L gathered codes per query
             w = min(1024, int(np.round(L * 1024 / (S if S else N))) + 3)
-            alg = B * (1024 * M + w * (N // 1024) * 4 + L * M)
-            roof = roofline_hbm("ivf_fused_kernel", alg, avg_s, k_n, args.steps,
+            roof = roofline_ivf(B, 1024, M, Ks, D // M, w, N // 1024, L, avg_s, k_n, args.steps,
                                 profile_table("traffic.json").get(key, {}).get("hbm_bytes_per_launch"))
-            roof["note"] = ("latency-bound random 32-byte gathers: algorithmic bytes = B*(nlist*M + w*mean_list_len*4 + L*M)")
         else:
             filt = bool(args.scan_mode and (topk > 1 or B >= eng.get_option("fast_min_batch")))
-            roof = roofline_scan(args, filter_kernel_name(args, M) if filt else "scan_kernel", B, n_scanned, M, Ks, avg_s, k_n, args.steps,
-                                 filt, key)
+            roof = roofline_scan(filter_kernel_name(args.scan_mx, M) if filt else "scan_kernel", B, n_scanned, M, Ks, avg_s, k_n,
+                                 args.steps, filt, 1 if args.scan_mx or not filt else 2, key)
         roof.update(extra)
         line = {
             "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
@@ -552,17 +818,24 @@ def main():
                                       (", |target_ids|=%d" % S) if S else ""),
                        "global_batch": B * world,
                        "parallelism": "query-sharded x%d, index replicated; value: no exchange step (results stay with the "
-                                      "owning rank), with_gather: RCCL all-gather of the result rows in the timed region" % world,
+                                      "owning rank), with_gather: RCCL all-gather of the result rows in the timed region; "
+                                      "strong: ONE global batch of %d split over the ranks" % (world, B),
                        "lut_mode": args.lut_mode, "simd_order": arch,
                        "scan_mode": "8-bit filter + exact fp32 re-rank" if args.scan_mode else "exact fp32 scan"},
             "recall_at_1": recall,
             "roofline": roof,
+            "uninstrumented": {"ms_per_step": [p_ / args.steps * 1e3 for p_ in plain],
+                               "value": B * world * args.steps / min(plain), "unit": "queries/s",
+                               "what": "the same K steps twice more with no timing event in the stream (`value`'s loop carries two "
+                                       "events on the dominant kernel's dispatch, which the roofline needs)"},
         }
         if elapsed_g is not None:
             line["with_gather"] = {"ms_per_step": elapsed_g / args.steps * 1e3, "value": B * world * args.steps / elapsed_g,
                                    "unit": "queries/s", "backend": dist.get_backend(),
                                    "collective": "all_gather of %d B per rank (ids int64 + dists f32), device tensors" % (B * topk * 12),
                                    "collective_share": max(0.0, 1.0 - elapsed / elapsed_g)}
+        if strong:
+            line["strong"] = strong
         if host is not None:
             line["host_call"] = host
         if fresh is not None:
@@ -570,15 +843,23 @@ def main():
         if pipe is not None:
             line["pipelined"] = pipe
         if world == 1 and not args.no_cpu_baseline:
-            cb, cpu_res = cpu_baseline(args.workload, eng, cw, codes, my_q.cpu().numpy(), topk, h_tids, L, arch)
-            n = len(cpu_res)
-            if ivf:
-                ok = all(list(res_ids[b, :int(res_cnt[b])]) == list(cpu_res[b]) for b in range(n))
-            else:
-                ok = all(list(res_ids[b]) == list(cpu_res[b]) for b in range(n))
-            cb["ids_match_gpu"] = bool(ok)
-            cb["queries_compared"] = n
+            what = {"linear": "full %d-code linear scan" % N, "subset": "linear scan of %d target ids" % S,
+                    "ivf": "inverted index nlist=1024 L=%d" % L, "subset-ivf": "inverted index nlist=1024 L=%d over %d target ids" % (L, S)}
+            cb, cpu_res = cpu_baseline("ivf" if ivf else "linear", what[args.workload], reference_factory(eng, cw, codes, arch, ivf),
+                                       my_q.cpu().numpy(), topk, h_tids, L)
+            cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, res_cnt, cpu_res)
             line["cpu_baseline"] = cb
+        # every other BASELINE config in the same process (default invocation only: the SIFT-shaped legs reuse this index)
+        if world == 1 and not use_dist and not args.no_others and args.workload == "linear" and topk == 1:
+            others = {}
+            t_oth = time.perf_counter()
+            for name in ("subset", "ivf", "subset_ivf"):            # (reconfigure happens once, before the two ivf legs)
+                others[name] = sift_workload(name, eng, args, torch, dev, stream, my_q, cw, codes, barrier, arch, N, M, Ks, D // M, B, topk)
+            others["readme_n10k"] = readme_workload(args, torch, dev, arch)
+            if args.deep_shard > 0:
+                others["deep_shard"] = deep_shard_workload(args, torch, dev, arch, barrier)
+            others["seconds_spent"] = time.perf_counter() - t_oth
+            line["others"] = others
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

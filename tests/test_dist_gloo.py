@@ -585,7 +585,8 @@ def test_nccl_world1_device_resident_sharding():
 @pytest.mark.gpu
 def test_bench_runs_under_torchrun_world1_with_rccl():
     """bench.py launched the way the driver launches N > 1 (env rendezvous, backend nccl), at world size 1: the timed
-    all-gather (`with_gather`) runs over RCCL and the line keeps the contract's keys."""
+    all-gather (`with_gather`) and both strong-scaling forms (QueryShardedIndex / DbShardedIndex: engine -> RCCL -> device merge)
+    run over RCCL and the line keeps the contract's keys."""
     import json
     import subprocess
     import sys
@@ -596,25 +597,23 @@ def test_bench_runs_under_torchrun_world1_with_rccl():
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "with_gather", "host_call"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "with_gather", "host_call", "strong", "uninstrumented"):
         assert key in line, key
     assert line["with_gather"]["backend"] == "nccl" and line["with_gather"]["ms_per_step"] > 0
     assert 0 < line["roofline"]["frac"] <= 1.0
+    for form in ("query_sharded", "db_sharded"):
+        assert line["strong"][form]["ms_per_step"] > 0 and line["strong"][form]["results_match_single_engine"] is True, line["strong"]
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_launched_like_the_driver():
-    """bench.py under `python -m torch.distributed.run --nproc-per-node 2` (the driver's N > 1 launch), both ranks on the one
-    GPU of the test box with the collectives on gloo: the N > 1 control flow (broadcast of the inputs, per-rank batches,
-    timed all-gather, MAX over ranks, one JSON line from rank 0)."""
+def _bench_two_ranks(cmd_prefix, extra_env):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RII_BENCH_BACKEND="gloo", RII_BENCH_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--n-base", "100000", "--no-cpu-baseline"]
+    env = dict(os.environ, RII_BENCH_BACKEND="gloo", RII_BENCH_DEVICE="0", **extra_env)
+    env.pop("WORLD_SIZE", None)
+    cmd = cmd_prefix(sys.executable, os.path.join(root, "bench.py")) + ["--gpus", "2", "--steps", "2", "--warmup", "1", "--n-base",
+                                                                        "100000", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -622,6 +621,48 @@ def test_bench_two_ranks_launched_like_the_driver():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2048 and line["scaling"] == "weak"
     assert line["with_gather"]["ms_per_step"] > 0 and line["value"] > 0
+    # strong scaling: ONE global batch of 1024 over the two ranks, both decompositions, answers equal to the single engine's
+    st = line["strong"]
+    assert st["query_sharded"]["rows_per_rank"] == [512, 512] and st["query_sharded"]["results_match_single_engine"] is True
+    assert st["db_sharded"]["codes_per_rank"] == 50000 and st["db_sharded"]["results_match_single_engine"] is True
+    assert st["query_sharded"]["ms_per_step"] > 0 and st["db_sharded"]["ms_per_step"] > 0
+    return line
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_launched_like_the_driver():
+    """bench.py under `python -m torch.distributed.run --nproc-per-node 2` (the driver's N > 1 launch), both ranks on the one
+    GPU of the test box with the collectives on gloo: the N > 1 control flow (broadcast of the inputs, per-rank batches,
+    timed all-gather, MAX over ranks, weak AND strong scaling, one JSON line from rank 0)."""
+    _bench_two_ranks(lambda py, bench: [py, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                        "127.0.0.1", "--master-port", str(_free_port()), bench], {})
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_typed_directly_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py becomes the launcher (round 2 asserted)."""
+    _bench_two_ranks(lambda py, bench: [py, bench], {})
+
+
+def test_bench_self_launch_command_line(monkeypatch):
+    """CPU: the launcher bench.py builds for `--gpus N` typed directly (no GPU needed to check the command)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
 
 
 def test_merge_topk_canonical_rule():
