@@ -98,7 +98,7 @@ struct ScratchSet {
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
         s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
-        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident;
+        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident, s_big;
     bool have_ident = false;    // s_ident = [count | 0 .. 63]: work list of rii_linear_tie_emit_dev (every query of the call is "flagged")
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
@@ -122,7 +122,7 @@ struct ScratchSet {
                           &s_keys_b, &s_assign, &s_coarse_d, &s_coarse_i, &s_cum, &s_ncand, &s_nvis, &s_cand_i, &s_cand_d,
                           &s_bitmap, &s_fids, &s_flen, &s_hist, &s_cnt, &s_sample, &s_qlut, &s_slack, &s_cand, &s_cand_cnt,
                           &s_flag, &s_segmin, &s_thr16, &s_gthr, &s_qc, &s_flag_list, &s_tie_list, &s_tie_hid, &s_tie_hd,
-                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident};
+                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident, &s_big};
         for (DevBuf *b : bufs) b->release();
         if (sort_temp) (void) hipFree(sort_temp);
         sort_temp = nullptr; sort_temp_bytes = 0;
@@ -773,6 +773,15 @@ int filter_lists_by_targets(rii_engine *e, const int64_t *d_tids, int64_t S, hip
     return RII_OK;
 }
 
+// scratch of ivf_exact_big_kernel: one slice per block of its persistent grid, at most ~256 MiB in total
+int ensure_big_scratch(rii_engine *e, int nlist, int64_t L, int64_t B, int *grid)
+{
+    const size_t per = ivf_exact_big_scratch(nlist, L);
+    int64_t g = std::min<int64_t>(std::min<int64_t>(B, 256), std::max<int64_t>(1, ((int64_t) 256 << 20) / (int64_t) per));
+    *grid = (int) g;
+    return e->s_big.ensure(per * (size_t) g);
+}
+
 int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
                   int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st,
                   int32_t *d_flag_defer = nullptr)
@@ -828,6 +837,9 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     p.cum = e->s_cum.as<int32_t>(); p.ncand = e->s_ncand.as<int32_t>(); p.nvis = e->s_nvis.as<int32_t>();
     p.cand_id = e->s_cand_i.as<int32_t>(); p.cand_dist = e->s_cand_d.as<float>(); p.cand_stride = stride;
     const bool fused = e->ivf_fused && ivf_fused_supported(e->M, e->Ks, (int) nlist, w, topk);
+    // a shape outside the fused kernel (w > 32 next to a large nlist, topk >= 1023): every query through the big exact kernel;
+    // option ivf_fused = 0 keeps selecting the one-lane emulation kernels (tests)
+    const bool big_all = !fused && e->ivf_fused && ivf_exact_big_supported(e->M, e->Ks, w, topk);
     RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
     p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
     const bool defer = fused && d_flag_defer && bc >= B;       // one launch group: the caller inspects the flags itself
@@ -874,7 +886,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
                 e->ivf_has_deferred = true;
                 return RII_OK;
             }
-        } else {
+        } else if (!big_all) {
             ScopedTimer t(e, "ivf_coarse", st);
             HIP_TRY(launch_ivf_coarse(p, st));
         }
@@ -882,6 +894,13 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             // flagged queries: exact std::partial_sort emulation with every working set in LDS
             ScopedTimer t(e, "ivf_exact", st);
             HIP_TRY(launch_ivf_exact_lds(p, st));
+        } else if ((fused || big_all) && ivf_exact_big_supported(e->M, e->Ks, w, topk)) {
+            // nlist or L past the LDS kernel's limits: sequences in global scratch, heaps in LDS -- for the flagged queries of the
+            // fused kernel, or for every query when the fused kernel does not cover the shape (its flag array is then NULL)
+            int grid = 0;
+            RII_TRY(ensure_big_scratch(e, (int) nlist, L, p.B, &grid));
+            ScopedTimer t(e, "ivf_exact", st);
+            HIP_TRY(launch_ivf_exact_big(p, e->s_big.p, grid, st));
         } else {
             { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
             { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
@@ -899,6 +918,11 @@ int ivf_run_deferred_fallback(rii_engine *e, hipStream_t st)
     if (ivf_exact_lds_supported(p.M, p.Ks, p.nlist, p.L)) {
         ScopedTimer t(e, "ivf_exact", st);
         HIP_TRY(launch_ivf_exact_lds(p, st));
+    } else if (ivf_exact_big_supported(p.M, p.Ks, p.w, p.topk)) {
+        int grid = 0;
+        RII_TRY(ensure_big_scratch(e, p.nlist, p.L, p.B, &grid));
+        ScopedTimer t(e, "ivf_exact", st);
+        HIP_TRY(launch_ivf_exact_big(p, e->s_big.p, grid, st));
     } else {
         { ScopedTimer t(e, "ivf_plan", st); HIP_TRY(launch_ivf_plan(p, st)); }
         { ScopedTimer t(e, "ivf_scan", st); HIP_TRY(launch_ivf_scan(p, st)); }
@@ -1425,7 +1449,7 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
                                     int32_t *d_out_nloc, int64_t *d_out_counts, void *stream)
 {
     if (rows <= 0) rows = topk + 1;
-    if (rows > 4096) return set_err(RII_ERR_INVALID, "rows=%d: at most 4096 output rows per query", rows);
+    if (rows > ivf_shard_max_L()) return set_err(RII_ERR_INVALID, "rows=%d: at most %d output rows per query", rows, ivf_shard_max_L());
     if (!e || B < 0 || (B > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_pos || !d_out_nloc || !d_out_counts)) ||
         !d_glen || G < 1 || rank < 0 || rank >= G || (S > 0 && !d_tids) || S < 0)
         return set_err(RII_ERR_INVALID, "bad arguments");
@@ -1438,8 +1462,14 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
     if (topk < 1 || (int64_t) topk > L || L > N_global || (S_global != 0 && ((int64_t) topk > S_global || S_global > N_global)))
         return set_err(RII_ERR_INVALID, "need topk <= L <= N and topk <= len(target_ids) <= N on the whole database "
                                         "(topk=%d, L=%lld, N=%lld, S=%lld)", topk, (long long) L, (long long) N_global, (long long) S_global);
-    if (!ivf_shard_supported(e->M, e->Ks, (int) nlist, L))
-        return set_err(RII_ERR_UNSUPPORTED, "sharded inverted index: nlist=%lld and L=%lld must both be <= 4096", (long long) nlist, (long long) L);
+    // w of src/rii.h:266-277 from the global sizes
+    const double wd = (S_global == 0) ? std::round((double) L * (double) nlist / (double) N_global)
+                                      : std::round((double) L * (double) nlist / (double) S_global);
+    int64_t w = (int64_t) (size_t) wd + 3;
+    if (nlist < w) w = nlist;
+    if (!ivf_shard_supported(e->M, e->Ks, (int) nlist, L, w))
+        return set_err(RII_ERR_UNSUPPORTED, "sharded inverted index: L=%lld must be <= %d (candidate keys are sorted in LDS)%s",
+                       (long long) L, ivf_shard_max_L(), nlist > 4096 ? "; nlist > 4096 additionally needs w <= 1024" : "");
     if (B == 0) return RII_OK;
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     RII_TRY(begin_on(e, st));
@@ -1451,13 +1481,12 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
         pl_ids = e->s_fids.as<int32_t>();
         list_len = e->s_flen.as<int32_t>();
     }
-    // w of src/rii.h:266-277 from the global sizes
-    const double wd = (S_global == 0) ? std::round((double) L * (double) nlist / (double) N_global)
-                                      : std::round((double) L * (double) nlist / (double) S_global);
-    int64_t w = (int64_t) (size_t) wd + 3;
-    if (nlist < w) w = nlist;
-    for (int64_t b0 = 0; b0 < B && r == RII_OK; b0 += kMaxBatch) {
-        const int64_t cur = std::min<int64_t>(kMaxBatch, B - b0);
+    // nlist past the LDS limit: coarse order + cumulative counts of a query in global scratch, <= 256 MiB per launch
+    const size_t per_q = ivf_shard_scratch_per_query((int) nlist);
+    const int64_t step = per_q ? std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, ((int64_t) 256 << 20) / (int64_t) per_q)) : kMaxBatch;
+    if (r == RII_OK && per_q) r = e->s_big.ensure(per_q * (size_t) std::min<int64_t>(step, B));
+    for (int64_t b0 = 0; b0 < B && r == RII_OK; b0 += step) {
+        const int64_t cur = std::min<int64_t>(step, B - b0);
         const int64_t D = (int64_t) e->M * e->Ds;
         r = build_lut(e, d_queries + b0 * D, cur, st, false, 1);
         if (r != RII_OK) break;
@@ -1465,7 +1494,7 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
         if (launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
                              e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
                              d_out_ids + b0 * rows, d_out_dists + b0 * rows, d_out_pos + b0 * rows,
-                             d_out_nloc + b0, d_out_counts + b0, st) != hipSuccess)
+                             d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st) != hipSuccess)
             r = set_err(RII_ERR_HIP, "ivf_shard_kernel launch failed");
     }
     const std::string msg = g_err;
@@ -1477,7 +1506,7 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
 RII_API int rii_ivf_shard_replay_dev(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
                                      float *d_out_dists, void *stream)
 {
-    if (!d_gathered || G < 1 || nf < 0 || rows < 1 || rows > 4096 || topk < 1 || topk > rows || (nf > 0 && (!d_out_ids || !d_out_dists)))
+    if (!d_gathered || G < 1 || nf < 0 || rows < 1 || rows > ivf_shard_max_L() || topk < 1 || topk > rows || (nf > 0 && (!d_out_ids || !d_out_dists)))
         return set_err(RII_ERR_INVALID, "bad arguments");
     HIP_TRY(launch_shard_replay(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, (hipStream_t) stream));
     return RII_OK;

@@ -20,7 +20,8 @@
 
 namespace riiamd {
 
-constexpr int kShardMax = 4096;          // nlist and L of the sharded path (working sets live in LDS)
+constexpr int kShardMaxNlistLds = 4096;  // coarse (distance, list) pairs in LDS up to here; above: global scratch, heap in LDS
+constexpr int kShardMaxL = 8192;         // candidate keys of a query are sorted in LDS
 
 struct ShardArgs {
     const uint8_t *codes; int M, Ks;
@@ -31,8 +32,12 @@ struct ShardArgs {
     int topk; int64_t L; int64_t w;
     int rows;                            // output rows per query: topk + 1, or L (every owned candidate: tie replay)
     int64_t *out_ids; float *out_dists; int32_t *out_pos; int32_t *out_nloc; int64_t *out_counts;
+    unsigned char *scratch; size_t per_block;      // BIG: [nlist] pq64 + [nlist + 1] int32 per block
 };
 
+// BIG (nlist above kShardMaxNlistLds -- the reference's default sqrt(N) is 11 k lists at a 125 M-code shard): the coarse order and
+// the cumulative counts live in global scratch, the heap of the coarse std::partial_sort (w entries) in LDS
+template <bool BIG>
 __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -42,9 +47,13 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     const int64_t b = blockIdx.x;
     float *lds = reinterpret_cast<float *>(smem);
     unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
-    pq64_t *s_coarse = reinterpret_cast<pq64_t *>(base);              // [nlist]   (coarse distance, list id), sorted in place
-    int32_t *s_cum = reinterpret_cast<int32_t *>(s_coarse + nlist);   // [nlist+1] cumulative GLOBAL candidate counts
-    int32_t *s_misc = s_cum + (nlist + 1);                            // [4]
+    const int ncoarse = BIG ? (int) p.w : nlist;                      // entries of the coarse sequence kept in LDS
+    pq64_t *s_head = reinterpret_cast<pq64_t *>(base);                // [ncoarse] (coarse distance, list id)
+    int32_t *s_cum_lds = reinterpret_cast<int32_t *>(s_head + ncoarse);   // !BIG: [nlist+1] cumulative GLOBAL candidate counts
+    int32_t *s_misc = s_cum_lds + (BIG ? 0 : (nlist + 1));            // [4]
+    unsigned char *mine = BIG ? p.scratch + p.per_block * blockIdx.x : nullptr;
+    pq64_t *s_coarse = BIG ? reinterpret_cast<pq64_t *>(mine) : s_head;                           // the whole order, [nlist]
+    int32_t *s_cum = BIG ? reinterpret_cast<int32_t *>(mine + (size_t) nlist * 8) : s_cum_lds;   // [nlist + 1]
     unsigned long long *s_key = reinterpret_cast<unsigned long long *>(
         smem + ((reinterpret_cast<unsigned char *>(s_misc + 4) - smem + 15) & ~(size_t) 15));      // [pow2 >= L]
 
@@ -53,10 +62,19 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
         for (int i = tid; i < MK; i += 256) lds[i] = src[i];
     }
     __syncthreads();
-    for (int c = tid; c < nlist; c += 256)                                            // src/rii.h:262-264
-        s_coarse[c] = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
+    for (int c = tid; c < nlist; c += 256) {                                          // src/rii.h:262-264
+        const pq64_t e = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
+        if (BIG && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
+    }
     __syncthreads();
-    if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);                   // src/rii.h:279-280 (wave 0)
+    if constexpr (BIG) {
+        if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);
+        __syncthreads();
+        for (int c = tid; c < (int) p.w; c += 256) s_coarse[c] = s_head[c];
+        __syncthreads();
+    } else {
+        if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);               // src/rii.h:279-280 (wave 0)
+    }
     if (tid == 0) {
         long long cnt = 0;
         int nv = 0;
@@ -186,32 +204,40 @@ hipError_t launch_shard_replay(const void *d_gathered, int G, int64_t nf, int ro
     return hipGetLastError();
 }
 
-static size_t shard_smem(int M, int Ks, int nlist, int64_t L)
+static bool shard_big(int nlist) { return nlist > kShardMaxNlistLds; }
+static size_t shard_smem(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
     size_t n2 = 64;
     while ((int64_t) n2 < L) n2 <<= 1;
-    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 + 16 + 16 + n2 * 8;
+    const size_t coarse = shard_big(nlist) ? (size_t) w * 8 : (size_t) nlist * 8 + (size_t) (nlist + 1) * 4;
+    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + coarse + 16 + 16 + n2 * 8;
 }
-bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L)
+bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
-    return nlist <= kShardMax && L <= kShardMax && shard_smem(M, Ks, nlist, L) <= (size_t) 160 * 1024 - 512;
+    if (L > kShardMaxL) return false;
+    if (shard_big(nlist) && w > kWhSplitMaxHeap) return false;
+    return shard_smem(M, Ks, nlist, L, w) <= (size_t) 160 * 1024 - 512;
 }
+int ivf_shard_max_L() { return kShardMaxL; }
+// BIG: bytes of global scratch per query of a launch, and how many queries one launch may take
+size_t ivf_shard_scratch_per_query(int nlist) { return shard_big(nlist) ? ((size_t) nlist * 12 + 4 + 63) / 64 * 64 : 0; }
 
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
-                            int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st)
+                            int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     ShardArgs a;
     a.codes = d_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.centers = d_centers; a.nlist = nlist; a.pl_off = d_pl_off;
     a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w; a.rows = rows;
     a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_pos = d_out_pos; a.out_nloc = d_out_nloc; a.out_counts = d_out_counts;
-    const size_t smem = shard_smem(M, Ks, nlist, L);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_shard_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    a.scratch = static_cast<unsigned char *>(d_scratch); a.per_block = ivf_shard_scratch_per_query(nlist);
+    const size_t smem = shard_smem(M, Ks, nlist, L, w);
+    auto kern = shard_big(nlist) ? ivf_shard_kernel<true> : ivf_shard_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ivf_shard_kernel, dim3((unsigned) B), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a);
     return hipGetLastError();
 }
 

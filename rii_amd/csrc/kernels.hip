@@ -701,7 +701,10 @@ __device__ __forceinline__ float adc_lds_wide(const float *lds, const uint4 (&cv
 
 // Instantiated per (top-1 / top-k, Ds == 4 / generic): the all-in-one kernel was 63 KB of code -- the size of the instruction
 // cache two CUs share -- of which a top-1, Ds = 4 query runs a fraction.
-template <bool TOP1, bool DS4, bool LSEL = false>
+// GDIST: the coarse scores of the query live in global scratch (p.coarse_dist, L2-resident: 4 nlist bytes) instead of LDS -- the
+// form for nlist above kFusedMaxNlist (the reference's default nlist = sqrt(N) is 11 k at a 125 M-code shard and 31.6 k at 1e9
+// codes: rii/rii.py:143); the selection rounds stream them from there.  Same code otherwise.
+template <bool TOP1, bool DS4, bool LSEL = false, bool GDIST = false>
 __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -715,13 +718,15 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     int *s_misc = s_cum + (SC + 2);                                                      // [4]: ncand, nv, flag
     int *s_len = s_misc + 4;                                                             // [SC + 2] lengths of the selected lists ...
     int *s_poff = s_len + (SC + 2);                                                      // [SC + 2] ... and their offsets, in visiting order
-    float *s_dist = reinterpret_cast<float *>(s_poff + (SC + 2));                        // [nlist] coarse scores; LSEL: later the
-    uint32_t *s_cd = reinterpret_cast<uint32_t *>(s_dist);                               //   candidates' orderable distances [<= L]
+    float *s_region = reinterpret_cast<float *>(s_poff + (SC + 2));                      // [nlist] coarse scores; LSEL: later the
+    uint32_t *s_cd = reinterpret_cast<uint32_t *>(s_region);                             //   candidates' orderable distances [<= L]
     // top-k > 1: key buffer behind that region (LSEL: p.kcap keys of the final sort; else the streaming buffer), 16-byte aligned
-    const int region = LSEL ? (p.nlist > (int) p.L ? p.nlist : (int) p.L) : p.nlist;
+    const int nreg = GDIST ? 0 : p.nlist;
+    const int region = LSEL ? (nreg > (int) p.L ? nreg : (int) p.L) : nreg;
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(
-        smem + ((reinterpret_cast<unsigned char *>(s_dist + region) - smem + 15) & ~(size_t) 15));
+        smem + ((reinterpret_cast<unsigned char *>(s_region + region) - smem + 15) & ~(size_t) 15));
     const int64_t bl = blockIdx.x;
+    float *s_dist = GDIST ? (p.coarse_dist + bl * (int64_t) p.nlist) : s_region;
     const int tid = threadIdx.x;
     const int nlist = p.nlist;
     const int w = (int) p.w;
@@ -848,7 +853,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     if (s_misc[2]) {
         // flagged: hand the coarse scores and the table (layout [b][M*Ks], QT == 1) to the exact-emulation kernels
         for (int c = tid; c < nlist; c += blockDim.x) {
-            p.coarse_dist[bl * nlist + c] = s_dist[c];
+            if constexpr (!GDIST) p.coarse_dist[bl * nlist + c] = s_dist[c];
             p.coarse_id[bl * nlist + c] = c;
         }
         if (p.queries) {
@@ -1108,7 +1113,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         __syncthreads();
         if (s_misc[2]) {          // ties at the cut, found only now: same hand-over as above
             for (int c = tid; c < nlist; c += blockDim.x) {
-                p.coarse_dist[bl * nlist + c] = s_dist[c];
+                if constexpr (!GDIST) p.coarse_dist[bl * nlist + c] = s_dist[c];
                 p.coarse_id[bl * nlist + c] = c;
             }
             if (p.queries) {
@@ -1140,24 +1145,33 @@ static int ivf_fused_kcap(int topk)
     while (c < 2 * (topk + 1)) c <<= 1;
     return c;
 }
-static size_t ivf_fused_smem(int M, int Ks, int nlist, int sel_cap, int topk, int64_t L, bool lsel)
+static size_t ivf_fused_smem(int M, int Ks, int nlist, int sel_cap, int topk, int64_t L, bool lsel, bool gdist = false)
 {
     const size_t head = (((size_t) M * Ks * sizeof(float) + 15) & ~(size_t) 15) + (size_t) sel_cap * 8 + 16 + (size_t) (sel_cap + 2) * 4 + 16 +
                         (size_t) (sel_cap + 2) * 8;
-    const size_t region = (size_t) (lsel ? std::max<int64_t>(nlist, L) : nlist) * 4 + 32;
+    const int64_t nreg = gdist ? 0 : nlist;
+    const size_t region = (size_t) (lsel ? std::max<int64_t>(nreg, L) : nreg) * 4 + 32;
     const size_t keys = topk > 1 ? (lsel ? (size_t) ivf_fused_kcap(topk) * 8 : (size_t) (kRrBuf + 2) * 8) : 0;
     return head + region + keys;
 }
 int ivf_fused_sel_cap(int nlist, int64_t w);
+// coarse scores in LDS while they fit next to the table (nlist <= kFusedMaxNlist), else in global scratch -- that form needs the
+// w + 1 selection rounds (w <= kFusedMaxW): the all-keys sort of larger w would not fit either
+static bool ivf_fused_gdist(int M, int Ks, int nlist, int64_t w, int topk)
+{
+    return nlist > kFusedMaxNlist || ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk, 0, false) > (size_t) 160 * 1024;
+}
 static bool ivf_fused_lsel(int M, int Ks, int nlist, int64_t w, int topk, int64_t L)
 {
-    return topk > 1 && L <= kFusedSelMaxL && ivf_fused_kcap(topk) <= 2048 && ivf_exact_lds_supported(M, Ks, nlist, L) &&
-           ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk, L, true) <= (size_t) 160 * 1024;
+    const bool gd = ivf_fused_gdist(M, Ks, nlist, w, topk);
+    return topk > 1 && L <= kFusedSelMaxL && ivf_fused_kcap(topk) <= 2048 &&
+           ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk, L, true, gd) <= (size_t) 160 * 1024;
 }
 bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk)
 {
-    return nlist <= kFusedMaxNlist && topk + 1 <= kRrBuf / 2 &&
-           ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk, 0, false) <= (size_t) 160 * 1024;
+    if (topk + 1 > kRrBuf / 2) return false;
+    if (!ivf_fused_gdist(M, Ks, nlist, w, topk)) return true;
+    return w <= kFusedMaxW && ivf_fused_smem(M, Ks, nlist, kFusedMaxW + 2, topk, 0, false, true) <= (size_t) 160 * 1024;
 }
 int ivf_fused_sel_cap(int nlist, int64_t w)
 {
@@ -1167,22 +1181,28 @@ int ivf_fused_sel_cap(int nlist, int64_t w)
     return c;
 }
 
-hipError_t launch_ivf_fused(const IvfParams &p0, hipStream_t st)
+template <bool GD> static hipError_t launch_ivf_fused_t(const IvfParams &p, bool lsel, size_t smem, hipStream_t st)
 {
-    if (p0.B == 0) return hipSuccess;
-    IvfParams p = p0;
-    const bool lsel = ivf_fused_lsel(p.M, p.Ks, p.nlist, p.w, p.topk, p.L);
-    p.kcap = lsel ? ivf_fused_kcap(p.topk) : 0;
-    const size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk, p.L, lsel);
     const bool top1 = p.topk == 1, ds4 = p.Ds == 4;
-    auto kern = top1 ? (ds4 ? ivf_fused_kernel<true, true> : ivf_fused_kernel<true, false>)
-                     : lsel ? (ds4 ? ivf_fused_kernel<false, true, true> : ivf_fused_kernel<false, false, true>)
-                            : (ds4 ? ivf_fused_kernel<false, true> : ivf_fused_kernel<false, false>);
+    auto kern = top1 ? (ds4 ? ivf_fused_kernel<true, true, false, GD> : ivf_fused_kernel<true, false, false, GD>)
+                     : lsel ? (ds4 ? ivf_fused_kernel<false, true, true, GD> : ivf_fused_kernel<false, false, true, GD>)
+                            : (ds4 ? ivf_fused_kernel<false, true, false, GD> : ivf_fused_kernel<false, false, false, GD>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) smem);
     if (e != hipSuccess) return e;
     launch_timed(kern, dim3((unsigned) p.B), dim3(256), smem, st, p);
     return hipGetLastError();
+}
+
+hipError_t launch_ivf_fused(const IvfParams &p0, hipStream_t st)
+{
+    if (p0.B == 0) return hipSuccess;
+    IvfParams p = p0;
+    const bool gd = ivf_fused_gdist(p.M, p.Ks, p.nlist, p.w, p.topk);
+    const bool lsel = ivf_fused_lsel(p.M, p.Ks, p.nlist, p.w, p.topk, p.L);
+    p.kcap = lsel ? ivf_fused_kcap(p.topk) : 0;
+    const size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk, p.L, lsel, gd);
+    return gd ? launch_ivf_fused_t<true>(p, lsel, smem, st) : launch_ivf_fused_t<false>(p, lsel, smem, st);
 }
 
 // final re-ranking (src/rii.h:312-319): std::partial_sort over the candidates in traversal order
@@ -1308,6 +1328,106 @@ hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st)
     if (e != hipSuccess) return e;
     const unsigned grid = p.flag_list ? (unsigned) std::min<int64_t>(p.B, 256) : (unsigned) p.B;
     hipLaunchKernelGGL(ivf_exact_lds_kernel, dim3(grid), dim3(256), smem, st, p);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// The same exact emulation for shapes whose working sets do not fit LDS (nlist or L above kExactLdsMax): the (distance, list) and
+// (distance, position) sequences live in global scratch (one slice per block of the persistent grid), only the HEAP of each
+// std::partial_sort -- its first `middle` entries: w lists, topk candidates -- is in LDS, and the library's __heap_select streams
+// the rest from memory (rii_device.h: wh_partial_sort_split).  Same moves as the reference, any nlist <= N and any L <= N;
+// w, topk <= kWhSplitMaxHeap.
+// ===================================================================================================
+__global__ __launch_bounds__(256) void ivf_exact_big_kernel(IvfParams p, unsigned char *scratch, size_t per_block, int hcap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nflag = p.flag_list ? *p.nflag : (int) p.B;
+    const int MK = p.M * p.Ks, nlist = p.nlist, tid = threadIdx.x;
+    const int w = (int) p.w, k = p.topk;
+    float *lds = reinterpret_cast<float *>(smem);
+    pq64_t *s_head = reinterpret_cast<pq64_t *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));      // [hcap] the heap of the running sort
+    int32_t *s_misc = reinterpret_cast<int32_t *>(s_head + hcap);                                      // [4]
+    unsigned char *mine = scratch + per_block * blockIdx.x;
+    pq64_t *gco = reinterpret_cast<pq64_t *>(mine);                     // [nlist] (coarse distance, list), in the reference's order afterwards
+    pq64_t *gcand = gco + nlist;                                        // [L]     (distance, traversal position)
+    int32_t *gcum = reinterpret_cast<int32_t *>(gcand + p.L);           // [nlist + 1]
+    int32_t *gcid = gcum + (nlist + 1);                                 // [L]     id of the candidate at a traversal position
+    for (int fi = blockIdx.x; fi < nflag; fi += gridDim.x) {
+        const int64_t bl = p.flag_list ? p.flag_list[fi] : fi;
+        if (!p.flag_list && p.flag && !p.flag[bl]) continue;
+        __syncthreads();                                   // the previous query's LDS contents are dead from here on
+        stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
+        __syncthreads();
+        for (int c = tid; c < nlist; c += blockDim.x) {                                  // src/rii.h:262-264
+            const pq64_t e = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
+            if (c < w) s_head[c] = e; else gco[c] = e;
+        }
+        __syncthreads();
+        if (tid < 64) wh_partial_sort_split(s_head, gco + w, w, nlist, tid);            // src/rii.h:279-280 (wave 0)
+        __syncthreads();
+        for (int c = tid; c < w; c += blockDim.x) gco[c] = s_head[c];                    // the whole order in one array
+        __syncthreads();
+        if (tid == 0) {
+            long long cnt = 0;
+            int nv = 0;
+            bool finished = false;
+            for (int c = 0; c < nlist; ++c) {                                            // src/rii.h:286-321
+                const long long len = p.list_len[pq64_id(gco[c])];
+                gcum[c] = (int) cnt;
+                if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+                cnt += len;
+                if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+            }
+            if (!finished) { cnt = 0; nv = 0; }
+            gcum[nv] = (int) cnt;
+            s_misc[0] = (int) cnt; s_misc[1] = nv;
+        }
+        __syncthreads();
+        const int ncand = s_misc[0], nv = s_misc[1];
+        if (ncand == 0) {
+            if (tid == 0) p.out_counts[bl] = 0;                                          // src/rii.h:324-325
+            continue;
+        }
+        for (int pos = tid; pos < ncand; pos += blockDim.x) {
+            int lo = 0, hi = nv;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (gcum[mid] <= pos) lo = mid; else hi = mid;
+            }
+            const int no = (int) pq64_id(gco[lo]);
+            const int32_t id = p.pl_ids[p.pl_off[no] + (pos - gcum[lo])];
+            const pq64_t e = pq64_make(exact_adist(lds, p.codes + (size_t) id * p.M, p.M, p.Ks), (uint32_t) pos);
+            if (pos < k) s_head[pos] = e; else gcand[pos] = e;
+            gcid[pos] = id;
+        }
+        __syncthreads();
+        if (tid < 64) wh_partial_sort_split(s_head, gcand + k, k, ncand, tid);          // src/rii.h:312-313 (wave 0)
+        if (tid == 0) p.out_counts[bl] = k;
+        __syncthreads();
+        for (int j = tid; j < k; j += blockDim.x) {
+            const pq64_t e = s_head[j];
+            p.out_ids[bl * k + j] = gcid[pq64_id(e)];
+            p.out_dists[bl * k + j] = pq64_dist(e);
+        }
+    }
+}
+
+bool ivf_exact_big_supported(int M, int Ks, int64_t w, int topk)
+{
+    const int64_t hcap = std::max<int64_t>(w, topk);
+    return hcap <= kWhSplitMaxHeap && (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) hcap * 8 + 64 <= (size_t) 160 * 1024;
+}
+size_t ivf_exact_big_scratch(int nlist, int64_t L) { return ((size_t) nlist * 12 + (size_t) L * 12 + 4 + 63) / 64 * 64; }
+hipError_t launch_ivf_exact_big(const IvfParams &p, void *d_scratch, int grid, hipStream_t st)
+{
+    if (p.B == 0) return hipSuccess;
+    const int hcap = (int) std::max<int64_t>(p.w, p.topk);
+    const size_t smem = (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15) + (size_t) hcap * 8 + 64;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_exact_big_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_exact_big_kernel, dim3((unsigned) grid), dim3(256), smem, st, p, static_cast<unsigned char *>(d_scratch),
+                       ivf_exact_big_scratch(p.nlist, p.L), hcap);
     return hipGetLastError();
 }
 

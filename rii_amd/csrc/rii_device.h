@@ -444,6 +444,46 @@ __device__ __forceinline__ void wh_partial_sort(pq64_t *h, int middle, int n, in
     }
 }
 
+// The same over a sequence that does not fit LDS: entries [0, middle) -- the heap -- live at `head` (LDS), entries [middle, n) at
+// `tail[i - middle]` (global memory).  __heap_select only ever READS a tail entry once, at its own step, and writes the evicted heap
+// top back into that very slot (__pop_heap(first, middle, i)); nothing reads a tail slot again before the call returns, so the tail
+// needs no ordering beyond the caller's barrier afterwards.  middle <= 2 * 64 * kWhMaxWords + 1 (the caller checks).
+template <int NW>
+__device__ __forceinline__ void wh_partial_sort_split_t(pq64_t *head, pq64_t *tail, int middle, int n, int lane)
+{
+    if (middle >= 2)
+        for (int parent = (middle - 2) / 2; parent >= 0; --parent) wh_adjust_heap<NW>(head, parent, middle, wh_uniform(head[parent]), lane);
+    if (middle > 0) {
+        pq64_t topv = wh_uniform(head[0]);
+        for (int i0 = middle; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const pq64_t e = i < n ? tail[i - middle] : ~0ull;
+            unsigned long long m = __ballot(i < n && pq64_less(e, topv));
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const pq64_t ej = wh_readlane(e, j);
+                if (pq64_less(ej, topv)) {
+                    if (lane == 0) tail[i0 + j - middle] = topv;
+                    topv = wh_adjust_heap<NW>(head, 0, middle, ej, lane);
+                }
+            }
+        }
+    }
+    pq64_t top = middle > 0 ? wh_uniform(head[0]) : 0ull;
+    for (int len = middle - 1; len >= 1; --len) {
+        const pq64_t v = wh_uniform(head[len]);
+        if (lane == 0) head[len] = top;
+        top = wh_adjust_heap<NW>(head, 0, len, v, lane);
+    }
+}
+constexpr int kWhSplitMaxHeap = 2 * 64 * kWhMaxWords;
+__device__ __forceinline__ void wh_partial_sort_split(pq64_t *head, pq64_t *tail, int middle, int n, int lane)
+{
+    if (middle <= 129) wh_partial_sort_split_t<1>(head, tail, middle, n, lane);
+    else wh_partial_sort_split_t<kWhMaxWords>(head, tail, middle, n, lane);
+}
+
 // single operations for callers that run the phases themselves (tieorder.hip); k <= 2 * 64 * kWhMaxWords
 __device__ __forceinline__ pq64_t wh_adjust_top(pq64_t *h, int len, pq64_t v, int lane)        // returns the new top
 {

@@ -121,6 +121,10 @@ hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_select(const IvfParams &p, hipStream_t st);
 bool ivf_exact_lds_supported(int M, int Ks, int nlist, int64_t L);
 hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st);
+// shapes past the LDS kernel's limits: sequences in global scratch, heaps in LDS (any nlist, any L; w, topk <= 1024)
+bool ivf_exact_big_supported(int M, int Ks, int64_t w, int topk);
+size_t ivf_exact_big_scratch(int nlist, int64_t L);          // bytes per block of the grid
+hipError_t launch_ivf_exact_big(const IvfParams &p, void *d_scratch, int grid, hipStream_t st);
 hipError_t launch_bitmap_set(const int64_t *d_tids, int64_t S, uint32_t *d_bitmap, hipStream_t st);
 hipError_t launch_filter_lists(const int64_t *d_pl_off, const int32_t *d_pl_ids, int nlist,
                                const uint32_t *d_bitmap, int32_t *d_fids, int32_t *d_flen, hipStream_t st);
@@ -195,11 +199,13 @@ hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc
                                   int32_t *d_flag_list, int *d_nflag, hipStream_t st);
 
 // ivfshard.hip: inverted-index search over a database-sharded index (global stop rule from all-gathered list lengths)
-bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L);
+bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w);
+int ivf_shard_max_L();
+size_t ivf_shard_scratch_per_query(int nlist);       // global scratch per query of a launch (0: everything fits LDS)
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
-                            int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st);
+                            int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st);
 hipError_t launch_shard_replay(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
                                float *d_out_dists, hipStream_t st);
 

@@ -129,7 +129,11 @@ class _OracleShard(_OracleBatch):
                 return acc
             coarse = np.zeros(nlist, pair)
             coarse["id"] = np.arange(nlist)
-            coarse["dist"] = [adist(o.centers[c]) for c in range(nlist)]
+            cacc = np.zeros(nlist, np.float32)               # sequential fp32 adds over m, all centres at once
+            cen = np.asarray(o.centers)
+            for m in range(o.M):
+                cacc = (cacc + dt[m, cen[:, m]]).astype(np.float32)
+            coarse["dist"] = cacc
             O.lib().oracle_partial_sort(coarse.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(w), ctypes.c_size_t(nlist))
             c_cnt, finished, mine = 0, False, []
             for c in range(nlist):
@@ -261,16 +265,19 @@ class _GpuBatch(object):
         return ri.cpu().numpy(), rd.cpu().numpy()
 
 
-def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties=False):
+def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties=False, nlist=40):
     """Database-sharded inverted index against the single-index oracle on the concatenated database, incl. target ids,
     ranks without targets, stale lists (tail walk into the unsorted coarse order, `not found`)."""
     from oracle import oracle as O
     N = codes.shape[0]
     s, e = rd.shard_range(N, rank, world)
-    trainer = O.OracleRii(cw, False, simd_arch="avx512")
-    trainer.add_codes(codes, False)
-    trainer.reconfigure(40, 3)
-    centers = np.array(trainer.coarse_centers, np.uint8)
+    if nlist == 40:
+        trainer = O.OracleRii(cw, False, simd_arch="avx512")
+        trainer.add_codes(codes, False)
+        trainer.reconfigure(40, 3)
+        centers = np.array(trainer.coarse_centers, np.uint8)
+    else:                # many lists (past the LDS limits of the sharded kernel): random codes as centres, duplicates included
+        centers = np.ascontiguousarray(codes[np.random.default_rng(17).integers(0, N, nlist)])
     Q = qs[:6]
     E = np.array([], np.int64)
     n_tied = 0
@@ -282,7 +289,7 @@ def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties
         full = O.OracleRii(cw, False, simd_arch="avx512")
         full.add_codes(codes, False)
         full.centers = centers
-        full._lists = [[] for _ in range(40)]
+        full._lists = [[] for _ in range(nlist)]
         for r in range(world):
             rs, re_ = rd.shard_range(N, r, world)
             sh = _OracleShard(cw, codes[rs:re_])
@@ -294,6 +301,8 @@ def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties
         sub = np.sort(rng.choice(N, 400, replace=False)).astype(np.int64)
         low = np.sort(rng.choice(N // 2 - 10, 9, replace=False)).astype(np.int64)        # targets on rank 0 only
         cases = [(1, 75, None), (1, 400, None), (5, 300, None), (3, 3, None), (10, N, None), (7, 200, sub), (2, 9, low), (1, 40, low)]
+        if nlist != 40:
+            cases = [(1, 3, None), (4, 60, None), (2, N, None), (3, 30, sub)]
         if stale:
             cases += [(20, 100, None), (20, 40, None), (3, 30, None), (12, 50, None), (1, 51, None)]
         n_empty = 0
@@ -420,6 +429,9 @@ def _worker(rank, world, port, q, use_gpu=False):
         qs2 = np.round(rng.random((6, 32)) * 3).astype(np.float32)
         n_tied = _check_sharded_ivf(rd, rank, world, cw2, codes2, qs2, _GpuBatch if use_gpu else _OracleShard, use_gpu, ties=True)
         assert n_tied > 0
+        # nlist = 5000 (above the LDS limit of the sharded kernel: coarse order in global scratch, heap in LDS) and L up to N
+        _check_sharded_ivf(rd, rank, world, cw2, np.concatenate([codes2] * 5)[:7001], qs2, _GpuBatch if use_gpu else _OracleShard, use_gpu,
+                           ties=True, nlist=5000)
         q.put((rank, "ok"))
     except Exception as ex:                                   # noqa: BLE001
         import traceback

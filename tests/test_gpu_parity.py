@@ -101,6 +101,47 @@ def test_gpu_vs_oracle_linear_ivf_batch(shape):
                 assert_same_result((ids[b, :n], d[b, :n]), want, "ivf k=%d L=%d S=%d b=%d" % (topk, L, len(tids), b))
 
 
+@pytest.mark.parametrize("nlist", [5000, 20000, 3000])
+def test_gpu_ivf_many_lists_and_large_L_vs_oracle(nlist):
+    """Shapes past the LDS working sets of round 2 (nlist <= 4096, L <= 4096): the reference's default nlist = sqrt(N) is 11 k at
+    a 125 M-code shard and 31.6 k at 1e9 codes (rii/rii.py:143), its SIFT1M benchmark runs L = 5000
+    (examples/benchmark/ann_methods.py:19).  Fused kernel with the coarse scores in global scratch (w <= 32), the exact kernel
+    with sequences in global scratch and heaps in LDS (flagged queries, and every query when w > 32), strict ids / distances /
+    counts against the oracle on the same centres and lists; duplicated codes and duplicated centres force exact ties."""
+    from rii_amd import RiiGpu
+    arch = "avx512"
+    N, M, Ks, Ds = 100_000, 8, 256, 4
+    cw, codes, qs = make_problem(1234 + nlist, M, Ks, Ds, N, "sift", dup=N // 20)
+    rng = np.random.default_rng(nlist)
+    centers = np.ascontiguousarray(codes[rng.integers(0, N, nlist)])          # random codes as centres (some twice: tied coarse distances)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    g.add_codes(codes, False)
+    g.set_coarse_centers(centers)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    o.add_codes(codes, False)
+    o.set_coarse_centers(centers)
+    assert g.posting_lists == o.posting_lists
+    sub = np.sort(rng.choice(N, N // 9, replace=False)).astype(np.int64)
+    Q = qs[:10]
+    L0 = max(1, int(np.round(N / nlist)))
+    cases = [(1, L0, E), (1, 5000, E), (5, 5000, E), (50, 200, E), (3, 8192, E), (2, 40, sub), (1, 5000, sub), (10, 20000, E), (1, N, E)]
+    n_tied = 0
+    for topk, L, tids in cases:
+        ids, d, cnt = g.query_ivf_batch(Q, topk, tids, L)
+        for b in range(Q.shape[0]):
+            wi, wd = o.query_ivf(Q[b], topk, tids, L)
+            n = int(cnt[b])
+            assert_same_result((ids[b, :n], d[b, :n]), (wi, wd), "nlist=%d k=%d L=%d S=%d b=%d" % (nlist, topk, L, len(tids), b))
+            n_tied += int(len(set(np.asarray(wd).tolist())) < len(wd))
+    assert n_tied > 0
+    # the one-lane emulation kernels (option ivf_fused = 0) must agree too: they stay the fallback for w or topk above 1024
+    g.set_option("ivf_fused", 0)
+    ids, d, cnt = g.query_ivf_batch(Q[:3], 5, E, 300)
+    g.set_option("ivf_fused", 1)
+    for b in range(3):
+        assert_same_result((ids[b, :int(cnt[b])], d[b, :int(cnt[b])]), o.query_ivf(Q[b], 5, E, 300), "emulation kernels b=%d" % b)
+
+
 def test_gpu_ivf_empty_and_tail_vs_oracle():
     from rii_amd import RiiGpu
     arch = "avx512"
