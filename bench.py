@@ -272,9 +272,40 @@ OTHER_KERNELS = ("lut", "quant", "rerank", "kth", "tie", "select", "gather", "iv
                  "ivf_select")
 
 
-def measure(eng, step, steps, warmup, barrier, sync):
-    """warm-up, K timed steps with ONLY the dominant kernel carrying HIP events (attached to its dispatch: engine option
-    `timing` = 2), then a short untimed pass with events around every launch for the other kernels' shares."""
+PREHEAT_S = 0.15
+
+
+def preheat(step, sync, seconds=PREHEAT_S):
+    """The MI355X ramps its shader clock over the first ~30 ms of sustained load (tools/clock_ramp.py, profiles/r03_clock_ramp.json:
+    0.415 -> 0.381 -> 0.366 -> 0.359 -> 0.356 ms per step over consecutive 20-step loops from idle, and back up after 1 s of
+    idling), so W = 5 warm-up steps (2 ms) followed by K = 20 timed steps (8 ms) would time the ramp, not the kernel.  Untimed steps
+    for `seconds` of wall time bring the chip to its steady state first; the W warm-up steps and the K timed steps follow as the
+    contract says.  Returns the number of steps issued."""
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            step()
+        sync()
+        n += 8
+    return n
+
+
+def preheat_count(step, sync, count):
+    """The same by step count: for steps that hold a collective (every rank must issue the same number of them)."""
+    for _ in range(count):
+        step()
+    sync()
+    return count
+
+
+def measure(eng, step, steps, warmup, barrier, sync, heat=True):
+    """pre-heat (clock ramp), W warm-up steps, K timed steps with ONLY the dominant kernel carrying HIP events (attached to its
+    dispatch: engine option `timing` = 2), then a short untimed pass with events around every launch for the other kernels' shares."""
+    if heat is True:
+        preheat(step, sync)
+    elif heat:
+        preheat_count(step, sync, int(heat))
     for _ in range(warmup):
         step()
     barrier()
@@ -481,7 +512,9 @@ def main_deep(args, world, rank, local, dev, arch):
             dist.barrier()
         torch.cuda.synchronize()
 
-    elapsed, dom, shares = measure(eng, step, args.steps, args.warmup, barrier, torch.cuda.synchronize)
+    # (the step holds a collective: pre-heat by step count, the same on every rank)
+    elapsed, dom, shares = measure(eng, step, args.steps, args.warmup, barrier, torch.cuda.synchronize,
+                                   heat=max(8, min(200, int(0.15 / max(1e-4, 2e-10 * n_shard * B / 1024.0)))))
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -635,6 +668,11 @@ def main():
     if args.latency:
         return main_latency(args, eng, t_q, run, ivf, topk, h_tids, L, rank, world, dev)
 
+    # first exactly what the contract's wording gives from an idle GPU (W warm-up + K timed steps, clocks still ramping) ...
+    for _ in range(args.warmup):
+        step()
+    cold = timed_loop(step, args.steps, barrier)
+    # ... then the steady state: pre-heat, W warm-up steps, K timed steps (this is `value`)
     elapsed, dom, extra = measure(eng, step, args.steps, args.warmup, barrier, torch.cuda.synchronize)
     res_ids = out_ids.cpu().numpy().copy()
     res_cnt = out_cnt.cpu().numpy().copy() if ivf else None
@@ -643,10 +681,11 @@ def main():
     plain = [timed_loop(step, args.steps, barrier) for _ in range(2)]
     elapsed_g = None
     if use_dist:
+        preheat_count(step_gather, torch.cuda.synchronize, 100)
         for _ in range(args.warmup):
             step_gather()
         elapsed_g = timed_loop(step_gather, args.steps, barrier)
-        elapsed, elapsed_g, plain[0], plain[1] = max_over_ranks(elapsed, elapsed_g, plain[0], plain[1])
+        elapsed, elapsed_g, plain[0], plain[1], cold = max_over_ranks(elapsed, elapsed_g, plain[0], plain[1], cold)
         allq = gathered[0][0]                        # the gathered batch really is every rank's rows, in rank order
         assert allq.shape[0] == B * world and torch.equal(allq[rank * B:(rank + 1) * B].to(out_ids.device), out_ids)
 
@@ -666,6 +705,7 @@ def main():
             else:
                 res_q[0] = qidx.query_linear_batch(Qs, topk, tids_np)
 
+        preheat_count(step_strong_q, torch.cuda.synchronize, 100)
         for _ in range(max(args.warmup, 1)):
             step_strong_q()
         e_q, = max_over_ranks(timed_loop(step_strong_q, args.steps, barrier))
@@ -691,6 +731,7 @@ def main():
             def step_strong_d():
                 res_d[0] = didx.query_linear_batch(Qs, topk)
 
+            preheat_count(step_strong_d, torch.cuda.synchronize, 100)
             for _ in range(max(args.warmup, 1)):
                 step_strong_d()
             e_d, = max_over_ranks(timed_loop(step_strong_d, args.steps, barrier))
@@ -741,6 +782,7 @@ def main():
             run(pool[it_f[0] % len(pool)])
             it_f[0] += 1
 
+        preheat(step_fresh, torch.cuda.synchronize, 0.05)
         for _ in range(max(args.warmup, 1)):
             step_fresh()
         fe = timed_loop(step_fresh, args.steps, barrier)
@@ -777,6 +819,7 @@ def main():
             run_rep(reps[it[0] & 1])
             it[0] += 1
 
+        preheat(step_pipe, torch.cuda.synchronize, 0.05)
         for _ in range(2 * max(args.warmup, 1)):
             step_pipe()
         pe = timed_loop(step_pipe, args.steps, barrier)
@@ -824,6 +867,11 @@ def main():
                        "scan_mode": "8-bit filter + exact fp32 re-rank" if args.scan_mode else "exact fp32 scan"},
             "recall_at_1": recall,
             "roofline": roof,
+            "preheat": {"seconds": PREHEAT_S, "what": "untimed steps before the W warm-up steps: the shader clock ramps over the first ~30 ms "
+                                                        "of sustained load (profiles/r03_clock_ramp.json); `value` is the steady state",
+                        "cold_start_ms_per_step": cold / args.steps * 1e3,
+                        "cold_start_value": B * world * args.steps / cold,
+                        "cold_start_what": "W warm-up + K timed steps issued right after the index build, before any pre-heat"},
             "uninstrumented": {"ms_per_step": [p_ / args.steps * 1e3 for p_ in plain],
                                "value": B * world * args.steps / min(plain), "unit": "queries/s",
                                "what": "the same K steps twice more with no timing event in the stream (`value`'s loop carries two "

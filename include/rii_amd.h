@@ -118,7 +118,7 @@ int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk
  * ({}, {}) (identical on every rank).  Merging the G records under (distance, position) gives the reference's answer for
  * top-1 and for top-k whenever the k+1 smallest distances are pairwise different.  S_global / N_global: sizes of the whole
  * target set / database (they fix `w`, src/rii.h:266-277).  Any nlist <= N (above 4096 lists the coarse order of a
- * query lives in global scratch and w must be <= 1024); L <= 8192 (the candidate keys of a query are sorted in LDS). */
+ * query lives in global scratch); L <= 8192 (the candidate keys of a query are sorted in LDS). */
 int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64_t S, int64_t S_global, int32_t *d_out_len,
                              void *stream);
 int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,

@@ -1468,8 +1468,8 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
     int64_t w = (int64_t) (size_t) wd + 3;
     if (nlist < w) w = nlist;
     if (!ivf_shard_supported(e->M, e->Ks, (int) nlist, L, w))
-        return set_err(RII_ERR_UNSUPPORTED, "sharded inverted index: L=%lld must be <= %d (candidate keys are sorted in LDS)%s",
-                       (long long) L, ivf_shard_max_L(), nlist > 4096 ? "; nlist > 4096 additionally needs w <= 1024" : "");
+        return set_err(RII_ERR_UNSUPPORTED, "sharded inverted index: L=%lld must be <= %d (the candidate keys of a query are sorted in LDS)",
+                       (long long) L, ivf_shard_max_L());
     if (B == 0) return RII_OK;
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     RII_TRY(begin_on(e, st));

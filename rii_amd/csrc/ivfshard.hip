@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     const int64_t b = blockIdx.x;
     float *lds = reinterpret_cast<float *>(smem);
     unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
-    const int ncoarse = BIG ? (int) p.w : nlist;                      // entries of the coarse sequence kept in LDS
+    const bool w_lds = p.w <= kWhSplitMaxHeap;                        // BIG: the heap of the coarse sort in LDS (walked by a wave)
+    const int ncoarse = BIG ? (w_lds ? (int) p.w : 0) : nlist;        // entries of the coarse sequence kept in LDS
     pq64_t *s_head = reinterpret_cast<pq64_t *>(base);                // [ncoarse] (coarse distance, list id)
     int32_t *s_cum_lds = reinterpret_cast<int32_t *>(s_head + ncoarse);   // !BIG: [nlist+1] cumulative GLOBAL candidate counts
     int32_t *s_misc = s_cum_lds + (BIG ? 0 : (nlist + 1));            // [4]
@@ -64,13 +65,17 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     __syncthreads();
     for (int c = tid; c < nlist; c += 256) {                                          // src/rii.h:262-264
         const pq64_t e = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
-        if (BIG && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
+        if (BIG && w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
     }
     __syncthreads();
     if constexpr (BIG) {
-        if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);
-        __syncthreads();
-        for (int c = tid; c < (int) p.w; c += 256) s_coarse[c] = s_head[c];
+        if (w_lds) {
+            if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);
+            __syncthreads();
+            for (int c = tid; c < (int) p.w; c += 256) s_coarse[c] = s_head[c];
+        } else if (tid == 0) {
+            pq64_partial_sort(s_coarse, (long) p.w, (long) nlist);    // deeper heap than the wave code covers: one lane, global memory
+        }
         __syncthreads();
     } else {
         if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);               // src/rii.h:279-280 (wave 0)
@@ -209,13 +214,12 @@ static size_t shard_smem(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
     size_t n2 = 64;
     while ((int64_t) n2 < L) n2 <<= 1;
-    const size_t coarse = shard_big(nlist) ? (size_t) w * 8 : (size_t) nlist * 8 + (size_t) (nlist + 1) * 4;
+    const size_t coarse = shard_big(nlist) ? (size_t) (w <= kWhSplitMaxHeap ? w : 0) * 8 : (size_t) nlist * 8 + (size_t) (nlist + 1) * 4;
     return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + coarse + 16 + 16 + n2 * 8;
 }
 bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
     if (L > kShardMaxL) return false;
-    if (shard_big(nlist) && w > kWhSplitMaxHeap) return false;
     return shard_smem(M, Ks, nlist, L, w) <= (size_t) 160 * 1024 - 512;
 }
 int ivf_shard_max_L() { return kShardMaxL; }

@@ -1336,7 +1336,7 @@ hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st)
 // (distance, position) sequences live in global scratch (one slice per block of the persistent grid), only the HEAP of each
 // std::partial_sort -- its first `middle` entries: w lists, topk candidates -- is in LDS, and the library's __heap_select streams
 // the rest from memory (rii_device.h: wh_partial_sort_split).  Same moves as the reference, any nlist <= N and any L <= N;
-// w, topk <= kWhSplitMaxHeap.
+// a heap deeper than the wave code covers (w or topk above kWhSplitMaxHeap) is walked by one lane over the global array.
 // ===================================================================================================
 __global__ __launch_bounds__(256) void ivf_exact_big_kernel(IvfParams p, unsigned char *scratch, size_t per_block, int hcap)
 {
@@ -1358,14 +1358,19 @@ __global__ __launch_bounds__(256) void ivf_exact_big_kernel(IvfParams p, unsigne
         __syncthreads();                                   // the previous query's LDS contents are dead from here on
         stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
         __syncthreads();
+        const bool w_lds = w <= kWhSplitMaxHeap, k_lds = k <= kWhSplitMaxHeap;          // heap in LDS, walked by a wave
         for (int c = tid; c < nlist; c += blockDim.x) {                                  // src/rii.h:262-264
             const pq64_t e = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
-            if (c < w) s_head[c] = e; else gco[c] = e;
+            if (w_lds && c < w) s_head[c] = e; else gco[c] = e;
         }
         __syncthreads();
-        if (tid < 64) wh_partial_sort_split(s_head, gco + w, w, nlist, tid);            // src/rii.h:279-280 (wave 0)
-        __syncthreads();
-        for (int c = tid; c < w; c += blockDim.x) gco[c] = s_head[c];                    // the whole order in one array
+        if (w_lds) {
+            if (tid < 64) wh_partial_sort_split(s_head, gco + w, w, nlist, tid);        // src/rii.h:279-280 (wave 0)
+            __syncthreads();
+            for (int c = tid; c < w; c += blockDim.x) gco[c] = s_head[c];                // the whole order in one array
+        } else if (tid == 0) {
+            pq64_partial_sort(gco, w, nlist);                                            // one lane, global memory: correct, slow
+        }
         __syncthreads();
         if (tid == 0) {
             long long cnt = 0;
@@ -1397,31 +1402,39 @@ __global__ __launch_bounds__(256) void ivf_exact_big_kernel(IvfParams p, unsigne
             const int no = (int) pq64_id(gco[lo]);
             const int32_t id = p.pl_ids[p.pl_off[no] + (pos - gcum[lo])];
             const pq64_t e = pq64_make(exact_adist(lds, p.codes + (size_t) id * p.M, p.M, p.Ks), (uint32_t) pos);
-            if (pos < k) s_head[pos] = e; else gcand[pos] = e;
+            if (k_lds && pos < k) s_head[pos] = e; else gcand[pos] = e;
             gcid[pos] = id;
         }
         __syncthreads();
-        if (tid < 64) wh_partial_sort_split(s_head, gcand + k, k, ncand, tid);          // src/rii.h:312-313 (wave 0)
+        if (k_lds) {
+            if (tid < 64) wh_partial_sort_split(s_head, gcand + k, k, ncand, tid);      // src/rii.h:312-313 (wave 0)
+        } else if (tid == 0) {
+            pq64_partial_sort(gcand, k, ncand);
+        }
         if (tid == 0) p.out_counts[bl] = k;
         __syncthreads();
         for (int j = tid; j < k; j += blockDim.x) {
-            const pq64_t e = s_head[j];
+            const pq64_t e = k_lds ? s_head[j] : gcand[j];
             p.out_ids[bl * k + j] = gcid[pq64_id(e)];
             p.out_dists[bl * k + j] = pq64_dist(e);
         }
     }
 }
 
+static int ivf_exact_big_hcap(int64_t w, int topk)
+{
+    const int64_t a = w <= kWhSplitMaxHeap ? w : 0, b = topk <= kWhSplitMaxHeap ? topk : 0;
+    return (int) std::max<int64_t>(std::max<int64_t>(a, b), 1);
+}
 bool ivf_exact_big_supported(int M, int Ks, int64_t w, int topk)
 {
-    const int64_t hcap = std::max<int64_t>(w, topk);
-    return hcap <= kWhSplitMaxHeap && (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) hcap * 8 + 64 <= (size_t) 160 * 1024;
+    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) ivf_exact_big_hcap(w, topk) * 8 + 64 <= (size_t) 160 * 1024;
 }
 size_t ivf_exact_big_scratch(int nlist, int64_t L) { return ((size_t) nlist * 12 + (size_t) L * 12 + 4 + 63) / 64 * 64; }
 hipError_t launch_ivf_exact_big(const IvfParams &p, void *d_scratch, int grid, hipStream_t st)
 {
     if (p.B == 0) return hipSuccess;
-    const int hcap = (int) std::max<int64_t>(p.w, p.topk);
+    const int hcap = ivf_exact_big_hcap(p.w, p.topk);
     const size_t smem = (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15) + (size_t) hcap * 8 + 64;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_exact_big_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
