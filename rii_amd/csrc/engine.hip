@@ -110,6 +110,8 @@ struct ScratchSet {
     int flag_parity = 0;        // which of the two flagged-query counters the next inverted-index launch group uses
     int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
+    bool qlut_quarter = false;  // ... as quarter tables (qlut_fused_kernel): fscan_mx_kernel interleaves them while staging
+    bool lut_valid = true;      // s_lut holds the exact fp32 tables of the current batch (false: only the byte tables were built)
     int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)
     // `last_stream`/`order_ev` chain this lane's users when successive calls on it come from different streams
     hipStream_t last_stream = nullptr;
@@ -145,6 +147,7 @@ struct rii_engine : ScratchSet {
     int cand_cap = 4096;        // candidate slots per query for the re-rank stage (lower bound; grows for small batches)
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
+    int fused_tables = 1;       // option "fused_tables": 1 = qlut_fused_kernel + table-free top-1 re-rank (round 3), 0 = the two-launch tile path
     int ivf_force_exact = 0;    // tests: the fused kernel flags every query, so the exact LDS kernel answers all of them
     int timing = 0;
     hipStream_t stream = nullptr;
@@ -352,8 +355,9 @@ int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
     return RII_OK;
 }
 
+// need_fp32 = false: the caller only needs the byte tables of the filter (top-1 over a shape whose re-rank works from the codebook)
 int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, bool want_quant = false, int qt = 0,
-              bool alloc_only = false)
+              bool alloc_only = false, bool need_fp32 = true)
 {
     if (qt <= 0) qt = e->QT;
     const size_t tiles = (size_t) ((B + qt - 1) / qt);
@@ -361,6 +365,8 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
     e->lut_qt = qt;
     if (alloc_only) return RII_OK;
     e->qlut_ready = false;
+    e->qlut_quarter = false;
+    e->lut_valid = true;
     if (want_quant && e->lut_mode == RII_LUT_EXACT && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
         const int qr = fastscan_rows(e->M, e->Ks);
         RII_TRY(e->s_qlut.ensure((size_t) ((B + qr - 1) / qr) * e->M * e->Ks * qr));
@@ -368,6 +374,20 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
         RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
         RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
         RII_TRY(e->s_gthr.ensure((size_t) B * sizeof(uint32_t)));
+        if (e->fused_tables && qlut_fused_supported(e->M, e->Ks, e->Ds, e->scan_mx)) {
+            // one launch: exact entries in registers -> per-query step by a block-local reduction -> quarter tables (+ the fp32
+            // table only when somebody reads it)
+            const bool fp32 = need_fp32 || !rerank_direct_supported(e->M, e->Ks, e->Ds);
+            RII_TRY(e->s_qlut.ensure(qlut_fused_bytes(B, e->M)));
+            ScopedTimer t(e, "lut", st);
+            HIP_TRY(launch_qlut_fused(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ds, fp32 ? e->s_lut.as<float>() : nullptr,
+                                      e->s_qlut.as<uint32_t>(), e->s_slack.as<int32_t>(), e->s_cand_cnt.as<unsigned int>(),
+                                      e->s_gthr.as<uint32_t>(), st));
+            e->qlut_ready = true;
+            e->qlut_quarter = true;
+            e->lut_valid = fp32;
+            return RII_OK;
+        }
         if (lut_tile_supported(e->M, e->Ks, e->Ds, e->scan_mx)) {         // by tile: exact table, extrema, rotated byte rows, slack
             RII_TRY(e->s_lohi.ensure((size_t) B * e->M * 2 * sizeof(float)));
             ScopedTimer t(e, "lut", st);
@@ -616,9 +636,16 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                     HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
-                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st));
+                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0));
                 }
                 ScopedTimer t(e, "rerank", st);
+                if (!e->lut_valid) {     // no fp32 table was written: distances of the candidates straight from the codebook
+                    HIP_TRY(launch_rerank_top1_direct(d_rr, n_codes, e->M, e->Ds, d_queries, e->d_codewords.as<float>(),
+                                                      e->s_slack.as<int32_t>(), e->s_cand.as<unsigned long long>(),
+                                                      e->s_cand_cnt.as<unsigned int>(), cap, d_remap, B, d_out_ids, d_out_dists, topk,
+                                                      indirect, st));
+                    return RII_OK;
+                }
                 HIP_TRY(launch_rerank_top1(d_rr, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
                                            e->s_slack.as<int32_t>(), e->s_cand.as<unsigned long long>(),
                                            e->s_cand_cnt.as<unsigned int>(), cap, d_remap, d_perm, B, d_out_ids, d_out_dists, topk,
@@ -633,7 +660,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride,
-                                     e->scan_mx, st));
+                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0));
             }
             {
                 ScopedTimer t(e, "kth", st);
@@ -644,7 +671,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
-                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st));
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0));
             }
             RII_TRY(tie_list_reset(e, B, st));
             {
@@ -659,7 +686,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
     }
     // the exhaustive kernels read the tile-interleaved layout: re-lay the tables out if they are in another one
     const int qt = exact_tile_for(e, B, topk);
-    if (e->lut_qt != qt) RII_TRY(build_lut(e, d_queries, B, st, false, qt));
+    if (e->lut_qt != qt || !e->lut_valid) RII_TRY(build_lut(e, d_queries, B, st, false, qt));
     sp.lut = e->s_lut.as<float>();
     sp.QT = qt;
     if (S) RII_TRY(gather_plain(e, d_remap, S, st, &d_codes));
@@ -752,7 +779,7 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
     }
     {
         const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
-        RII_TRY(build_lut(e, d_queries, B, st, !small_top1, small_top1 ? exact_tile_for(e, B, topk) : 0));
+        RII_TRY(build_lut(e, d_queries, B, st, !small_top1, small_top1 ? exact_tile_for(e, B, topk) : 0, false, /*need_fp32=*/topk > 1));
     }
     return scan_topk(e, d_queries, B, topk, S ? d_tids : nullptr, S, d_out_ids, d_out_dists, st);
 }
@@ -1667,6 +1694,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->ivf_fused = value ? 1 : 0;
     } else if (k == "ivf_force_exact") {
         e->ivf_force_exact = value ? 1 : 0;
+    } else if (k == "fused_tables") {
+        e->fused_tables = value ? 1 : 0;
     } else if (k == "scan_order") {
         e->scan_order = value ? 1 : 0;
     } else if (k == "scan_mx") {
@@ -1702,6 +1731,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "cand_cap") return e->cand_cap;
     if (k == "ivf_fused") return e->ivf_fused;
     if (k == "ivf_force_exact") return e->ivf_force_exact;
+    if (k == "fused_tables") return e->fused_tables;
     if (k == "scan_order") return e->scan_order;
     if (k == "lanes") return e->lanes;
     if (k == "scan_mx") return e->scan_mx;

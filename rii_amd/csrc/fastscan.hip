@@ -438,7 +438,7 @@ hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, in
     if (n1 <= n0) return hipSuccess;
     if (mx) {              // fscan_mx_kernel's order: whole groups of 16 codes, starting at the group n0 falls into
         n0 = n0 / 16 * 16;
-        const int64_t tot = ((n1 + 15) / 16 * 16 - n0) * M;
+        const int64_t tot = ((n1 + 15) / 16 * 16 - n0) * M / 4;         // one thread per output dword
         const int nb = (int) std::min<int64_t>((tot + 255) / 256, 16384);
         hipLaunchKernelGGL(fcodes_mx_format_kernel, dim3(nb), dim3(256), 0, st, d_codes, d_ids, n0, n1, M,
                            reinterpret_cast<uint8_t *>(d_out));
@@ -670,6 +670,152 @@ __global__ __launch_bounds__(256) void qlut_tile_quant8_kernel(const float *__re
     dst[tid] = s_rows[tid];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE launch for the tables of the matrix-core filter (round 3; M = 16 / 32, Ks = 256, Ds = 4 / 2): grid (tile of 16 queries,
+// quarter of the tile), 1024 threads.  The 16 waves of a block cover ALL M subspaces (MW per wave) for the quarter's four queries,
+// so the per-query quantisation step -- a maximum over every subspace -- is a block-local reduction and nothing has to travel
+// through global memory between "build" and "quantise":
+//   codewords of the wave's subspaces in registers (as lut_tile_build_kernel) -> the 32 exact entries of a thread stay in
+//   registers -> min / max per (query, subspace) by wave shuffles -> LDS -> step, reciprocal, slack per query -> levels
+//   c = floor((t - lo) / delta + 1/2) (the same fp32 expression as qlut_tile_quant_kernel: identical bytes) -> the four queries'
+//   levels of an entry packed into ONE dword, stored coalesced as a "quarter table" [tile][quarter][m][ks] u32.
+// fscan_mx_kernel scatters the four quarter tables of its tile into the 16-byte rotated rows while staging them (a wave writes 256
+// contiguous LDS bytes per ds_write_b32: conflict-free).  The exact fp32 table goes to global memory only when somebody will read
+// it (top-k re-rank, tie order); the top-1 re-rank rebuilds what it needs from the codebook (rerank_top1_direct_kernel).
+// Cost at the bench shape: 256 blocks, 128 KiB of codebook (L2) in and 32 KiB out per block, no 32 MB fp32 round trip.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename Vec, int MW>          // float4: Ds = 4, float2: Ds = 2; MW = subspaces per wave (M = 16 MW)
+__global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restrict__ queries, int64_t B,
+                                                          const float *__restrict__ codewords, float *__restrict__ lut,
+                                                          uint32_t *__restrict__ qlut4, int32_t *__restrict__ slack,
+                                                          unsigned int *__restrict__ cand_cnt, uint32_t *__restrict__ gthr)
+{
+    constexpr int M = 16 * MW;
+    constexpr int Ds = (int) (sizeof(Vec) / sizeof(float));
+    constexpr int MK = M * 256;
+    __shared__ float s_lo[4][M], s_hi[4][M];
+    __shared__ float s_inv[4];
+    const int64_t tile = blockIdx.x;
+    const int quarter = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int m0 = wave * MW;
+    const Vec *cw4 = reinterpret_cast<const Vec *>(codewords);
+    Vec cv[MW][4];
+#pragma unroll
+    for (int s_ = 0; s_ < MW; ++s_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv[s_][e] = cw4[(m0 + s_) * 256 + lane + 64 * e];
+    float t[4][MW][4], lo[4][MW], hi[4][MW];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int64_t b = tile * 16 + quarter * 4 + jj;
+        const Vec *q4 = reinterpret_cast<const Vec *>(queries + (b < B ? b : 0) * (int64_t) (M * Ds));
+#pragma unroll
+        for (int s_ = 0; s_ < MW; ++s_) {
+            const Vec qm = q4[m0 + s_];
+            lo[jj][s_] = INFINITY; hi[jj][s_] = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = fvec_l2sqr_vec(qm, cv[s_][e]);
+                t[jj][s_][e] = v;
+                lo[jj][s_] = fminf(lo[jj][s_], v);
+                hi[jj][s_] = fmaxf(hi[jj][s_], v);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int s_ = 0; s_ < MW; ++s_) {
+                lo[jj][s_] = fminf(lo[jj][s_], __shfl_xor(lo[jj][s_], off));
+                hi[jj][s_] = fmaxf(hi[jj][s_], __shfl_xor(hi[jj][s_], off));
+            }
+    if (lane == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int s_ = 0; s_ < MW; ++s_) { s_lo[jj][m0 + s_] = lo[jj][s_]; s_hi[jj][m0 + s_] = hi[jj][s_]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * 32) {          // 32 lanes per query: range and |lo| + |hi| over the M subspaces
+        const int j = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+        const int64_t b = tile * 16 + quarter * 4 + j;
+        float range = 0.f;
+        double dmax = 0.0;
+        for (int m = l32; m < M; m += 32) {
+            range = fmaxf(range, s_hi[j][m] - s_lo[j][m]);
+            dmax += fabs((double) s_lo[j][m]) + fabs((double) s_hi[j][m]);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            range = fmaxf(range, __shfl_xor(range, off));
+            dmax += __shfl_xor(dmax, off);
+        }
+        if (l32 == 0) {
+            float d = range / (float) kFsLevels;
+            if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
+            const float delta = d * 1.000001f;
+            s_inv[j] = 1.0f / delta;
+            if (b < B) {                 // the per-query state of the filter stage (see qlut_tile_quant_kernel for the slack)
+                const double eps = (double) M * 1.1920928955078125e-07 * dmax;
+                double sl = (double) M * (1.0 + 1e-4) + 2.0 * eps / (double) delta;
+                sl = sl * (1.0 + 1e-9) + 2.0;
+                slack[b] = (sl >= 0.0 && sl < 60000.0) ? (int32_t) sl : 60000;
+                if (cand_cnt) cand_cnt[b] = 0u;
+                if (gthr) gthr[b] = 0xffffffffu;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *dst = qlut4 + ((size_t) tile * 4 + quarter) * MK;
+#pragma unroll
+    for (int s_ = 0; s_ < MW; ++s_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t w = 0u;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int64_t b = tile * 16 + quarter * 4 + jj;
+                uint32_t c = 0u;
+                if (b < B) {
+                    const float x = floorf((t[jj][s_][e] - lo[jj][s_]) * s_inv[jj] + 0.5f);
+                    c = (x >= (float) kFsLevels) ? (uint32_t) kFsLevels : (x > 0.f ? (uint32_t) x : 0u);
+                }
+                w |= c << (8 * jj);
+            }
+            dst[(m0 + s_) * 256 + lane + 64 * e] = w;
+        }
+    if (lut) {                            // the exact table, plain [b][M*Ks]: only for the callers that read it (top-k, tie order)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int64_t b = tile * 16 + quarter * 4 + jj;
+            if (b < B)
+#pragma unroll
+                for (int s_ = 0; s_ < MW; ++s_)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lut[(size_t) b * MK + (m0 + s_) * 256 + lane + 64 * e] = t[jj][s_][e];
+        }
+    }
+}
+
+bool qlut_fused_supported(int M, int Ks, int Ds, int mx) { return mx && Ks == 256 && (M == 16 || M == 32) && (Ds == 4 || Ds == 2) && fs_rot_supported(M, Ks, mx); }
+size_t qlut_fused_bytes(int64_t B, int M) { return (size_t) ((B + 15) / 16) * 4 * M * 256 * 4; }
+hipError_t launch_qlut_fused(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ds, float *d_lut_or_null,
+                             uint32_t *d_qlut4, int32_t *d_slack, unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    const dim3 grid((unsigned) ((B + 15) / 16), 4), block(1024);
+    if (M == 32 && Ds == 4) hipLaunchKernelGGL((qlut_fused_kernel<float4, 2>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr);
+    else if (M == 16 && Ds == 4) hipLaunchKernelGGL((qlut_fused_kernel<float4, 1>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr);
+    else if (M == 32 && Ds == 2) hipLaunchKernelGGL((qlut_fused_kernel<float2, 2>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr);
+    else if (M == 16 && Ds == 2) hipLaunchKernelGGL((qlut_fused_kernel<float2, 1>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 bool lut_tile_supported(int M, int Ks, int Ds, int mx);
 hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ds, float *d_lut,
                                        float *d_lohi, uint8_t *d_qlut, int32_t *d_slack, unsigned int *d_cand_cnt,
@@ -741,6 +887,7 @@ struct FsArgs {
     const uint32_t *thr16;         // MODE 2: [B] fixed thresholds (candidate <=> a < thr16[b])
     uint32_t *gthr;                // MODE 0: [B] thresholds shared by all chunk-blocks of a tile (pre-set to 0xffff)
     int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
+    int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
 };
 
 // MODE 0: top-1, thresholds adapt to the block's running minimum.  MODE 1 / 2: the two passes of top-k (k > 1):
@@ -1381,22 +1528,28 @@ __host__ __device__ __forceinline__ int fs_mx_subspace(int g, int col, int t)
 __global__ __launch_bounds__(256) void fcodes_mx_format_kernel(const uint8_t *__restrict__ codes, const int64_t *__restrict__ ids,
                                                                int64_t n0, int64_t n1, int M, uint8_t *__restrict__ out)
 {
-    const int T = M / 4;
+    // one thread per output DWORD (four consecutive lookups of a lane): one id load and four bytes of one code row per thread,
+    // coalesced 4-byte stores (a thread per byte cost 13 us per 100 k gathered codes: subset search pays this per batch)
+    const int T = M / 4, TW = T / 4;                        // lookups / dwords per lane and group
     const int64_t n1p = (n1 + 15) / 16 * 16;
-    const int64_t total = (n1p - n0) * M;
+    const int64_t total = (n1p - n0) * M / 4;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out + (size_t) n0 * M);
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
-        // consecutive threads write consecutive lookups: i = ((group * 64 + lane) * T + t) relative to n0's group
-        const int t = (int) (i % T);
-        const int64_t gl = i / T;
+        const int u = (int) (i % TW);                       // dword u of the lane: lookups 4u .. 4u + 3
+        const int64_t gl = i / TW;
         const int lane = (int) (gl & 63);
         const int64_t n = n0 + (gl >> 6) * 16 + (lane & 15);
-        const int m = (M == 64) ? fs_mx_subspace64(lane >> 4, lane & 15, t) : fs_mx_subspace(lane >> 4, lane & 15, t);
-        uint32_t ks = 0;
+        uint32_t w = 0u;
         if (n < n1) {
-            const int64_t src = ids ? ids[n] : n;
-            ks = codes[(size_t) src * M + m];
+            const uint8_t *row = codes + (size_t) (ids ? ids[n] : n) * M;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = 4 * u + j;
+                const int m = (M == 64) ? fs_mx_subspace64(lane >> 4, lane & 15, t) : fs_mx_subspace(lane >> 4, lane & 15, t);
+                w |= (uint32_t) row[m] << (8 * j);
+            }
         }
-        out[(size_t) n0 * M + i] = (uint8_t) ks;
+        out32[i] = w;
     }
 }
 
@@ -1651,9 +1804,28 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(smem + lut_bytes + 64);                  // [16] staged, [16] global bases
     unsigned long long *s_lcand = reinterpret_cast<unsigned long long *>(smem + lut_bytes + 64 + QR * 8);
     {
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
-        uint4 *d4 = reinterpret_cast<uint4 *>(smem);
-        for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
+        if (QR == 16 && p.quarter) {
+            // four quarter tables (one dword = the levels of four queries for one (m, ks)) -> 16-byte rotated rows.  Lane =
+            // (slot = m mod 16, quarter): the 64 lanes of a wave write the 64 dwords of 16 consecutive rows (one ks, one half) --
+            // 256 contiguous LDS bytes per ds_write_b32, conflict-free; each lane reads 64 contiguous bytes (16 ks) of its
+            // quarter table per unit.
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(p.qlut) + (size_t) tile * 4 * M * 256;
+            const int slot = tid & 15, qq = (tid >> 4) & 3;
+            for (int unit = tid >> 6; unit < M; unit += kFsThreads >> 6) {          // unit = (half, block of 16 ks): M / 16 x 16 of them
+                const int h = unit >> 4, ks0 = (unit & 15) * 16;
+                const uint4 *sp = reinterpret_cast<const uint4 *>(src + ((size_t) qq * M + 16 * h + slot) * 256 + ks0);
+                const uint4 v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3];
+                uint32_t *d = reinterpret_cast<uint32_t *>(smem + ((size_t) h * 4096 + (size_t) ks0 * 16 + slot) * 16 + qq * 4);
+                d[0 * 64] = v0.x; d[1 * 64] = v0.y; d[2 * 64] = v0.z; d[3 * 64] = v0.w;
+                d[4 * 64] = v1.x; d[5 * 64] = v1.y; d[6 * 64] = v1.z; d[7 * 64] = v1.w;
+                d[8 * 64] = v2.x; d[9 * 64] = v2.y; d[10 * 64] = v2.z; d[11 * 64] = v2.w;
+                d[12 * 64] = v3.x; d[13 * 64] = v3.y; d[14 * 64] = v3.z; d[15 * 64] = v3.w;
+            }
+        } else {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * lut_bytes);
+            uint4 *d4 = reinterpret_cast<uint4 *>(smem);
+            for (size_t i = tid; i < lut_bytes / 16; i += kFsThreads) d4[i] = s4[i];
+        }
         if (tid < 16) {
             // queries past the end of the batch (last tile) and the unused rows of an 8-query tile get threshold 0: they never hit
             const int b = tile * QR + tid;
@@ -1983,12 +2155,13 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st)
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter)
 {
     // d_codes: formatted lookups (launch_fcodes_format, same `mx`) for fs_rot_supported shapes, the plain codes otherwise
     if (B == 0 || n_codes == 0) return hipSuccess;
     const bool rot = fs_rot_supported(M, Ks, mx);
     FsArgs a;
+    a.quarter = quarter;
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
@@ -2174,6 +2347,117 @@ __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
         p.out_ids[b * p.topk] = (k == ~0ull) ? -1 : (p.remap ? p.remap[idx] : (int64_t) idx);
         p.out_dists[b * p.topk] = (k == ~0ull) ? INFINITY : __uint_as_float(f32_unorderable((uint32_t) (k >> 32)));
     }
+}
+
+// The same without a table in global memory (round 3): the candidates of a query (~150 of 1 M codes at the bench shape) touch at
+// most cnt * M of the M * Ks table entries, and each entry is one fvec_L2sqr of the query's sub-vector with a codeword of the L2-
+// resident codebook -- the very expression the table kernels evaluate, so the distances are bit-identical.  One thread per
+// candidate, eight codeword loads in flight per thread, additions in the reference's m order.  Saves the 32 MB fp32 table the
+// table kernel would write and this kernel would read back per 1024-query batch.  Ks = 256, M a multiple of 8, Ds = 4 / 2.
+template <typename Vec>
+__global__ __launch_bounds__(256) void rerank_top1_direct_kernel(RrArgs p, const float *__restrict__ queries,
+                                                                 const float *__restrict__ codewords)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int Ds = (int) (sizeof(Vec) / sizeof(float));
+    float *lds = reinterpret_cast<float *>(smem);                    // [M * 256] exact table: built only if the candidates overflowed
+    const int MK = p.M * 256;
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(smem + (size_t) MK * 4);
+    Vec *s_q = reinterpret_cast<Vec *>(red + 2);                     // [M] the query's sub-vectors
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const Vec *cw = reinterpret_cast<const Vec *>(codewords);
+    if (tid < p.M) s_q[tid] = reinterpret_cast<const Vec *>(queries + b * (int64_t) (p.M * Ds))[tid];
+    if (tid == 0) { red[0] = ~0ull; red[1] = ~0ull; }
+    __syncthreads();
+    const unsigned int cnt = p.cand_count[b];
+    unsigned long long best = ~0ull;
+    if (cnt <= (unsigned int) p.cap) {
+        const unsigned long long *cand = p.cand + (size_t) b * p.cap;
+        unsigned long long amin = ~0ull;
+        for (unsigned int i = tid; i < cnt; i += blockDim.x) {
+            const unsigned long long a = cand[i] >> 32;
+            amin = a < amin ? a : amin;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(amin, off);
+            amin = o < amin ? o : amin;
+        }
+        if ((tid & 63) == 0) atomicMin(&red[0], amin);
+        __syncthreads();
+        const unsigned long long lim = red[0] + (unsigned long long) (uint32_t) p.slack[b];
+        for (unsigned int i = tid; i < cnt; i += blockDim.x) {
+            const unsigned long long c = cand[i];
+            if ((c >> 32) > lim) continue;
+            const uint32_t n = (uint32_t) (c & 0xffffffffu);
+            const uint2 *code = reinterpret_cast<const uint2 *>(p.codes + (size_t) (p.indirect ? (int64_t) p.remap[n] : (int64_t) n) * p.M);
+            float dist = 0.f;
+            for (int m0 = 0; m0 < p.M; m0 += 8) {
+                const uint2 wd = code[m0 >> 3];
+                Vec cv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t ks = ((j < 4 ? wd.x : wd.y) >> (8 * (j & 3))) & 0xffu;
+                    cv[j] = cw[(m0 + j) * 256 + ks];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dist = __fadd_rn(dist, fvec_l2sqr_vec(s_q[m0 + j], cv[j]));
+            }
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(dist)) << 32) | n;
+            best = key < best ? key : best;
+        }
+    } else {
+        // the candidate buffer overflowed (e.g. thousands of duplicated nearest codes): exact table in LDS, every code scanned
+        for (int i = tid; i < MK; i += blockDim.x) lds[i] = fvec_l2sqr_vec(s_q[i >> 8], cw[i]);
+        __syncthreads();
+        for (int64_t n = tid; n < p.n_codes; n += blockDim.x) {
+            const float d = exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[n] : (int64_t) n) * p.M, p.M, 256);
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | (uint32_t) n;
+            best = key < best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0 && best != ~0ull) atomicMin(&red[1], best);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long k = red[1];
+        const uint32_t idx = (uint32_t) (k & 0xffffffffu);
+        p.out_ids[b * p.topk] = (k == ~0ull) ? -1 : (p.remap ? p.remap[idx] : (int64_t) idx);
+        p.out_dists[b * p.topk] = (k == ~0ull) ? INFINITY : __uint_as_float(f32_unorderable((uint32_t) (k >> 32)));
+    }
+}
+
+bool rerank_direct_supported(int M, int Ks, int Ds) { return Ks == 256 && (M % 8) == 0 && M <= 64 && (Ds == 4 || Ds == 2); }
+hipError_t launch_rerank_top1_direct(const uint8_t *d_codes, int64_t n_codes, int M, int Ds, const float *d_queries,
+                                     const float *d_codewords, const int32_t *d_slack, const unsigned long long *d_cand,
+                                     const unsigned int *d_cand_count, int cap, const int64_t *d_remap, int64_t B,
+                                     int64_t *d_out_ids, float *d_out_dists, int topk, int indirect, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    RrArgs a;
+    a.indirect = indirect;
+    a.perm = nullptr;
+    a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = 256; a.lut = nullptr; a.QT = 1; a.slack = d_slack;
+    a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.remap = d_remap; a.out_ids = d_out_ids;
+    a.out_dists = d_out_dists; a.topk = topk;
+    const size_t smem = (size_t) M * 256 * sizeof(float) + 16 + (size_t) M * 16;
+    if (Ds == 4) {
+        auto kern = rerank_top1_direct_kernel<float4>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, d_queries, d_codewords);
+    } else {
+        auto kern = rerank_top1_direct_kernel<float2>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, d_queries, d_codewords);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, int QT,

@@ -338,10 +338,14 @@ def test_gpu_filter_rerank_overflow_falls_back_exactly():
     Q = np.stack([q, qs[0], qs[1]]).astype(np.float32)
     g.set_option("cand_cap", 64)
     g.set_option("fast_min_batch", 0)
-    i1, d1 = g.query_linear_batch(Q, 1, None)
+    assert g.get_option("fused_tables") == 1
+    i1, d1 = g.query_linear_batch(Q, 1, None)            # default: table-free re-rank (it builds its table in LDS on overflow)
+    g.set_option("fused_tables", 0)
+    i2, d2 = g.query_linear_batch(Q, 1, None)            # round 2's path: re-rank from the fp32 table in global memory
     g.set_option("scan_mode", 0)
     i0, d0 = g.query_linear_batch(Q, 1, None)
     assert i0[0, 0] == 4999 and np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
+    assert np.array_equal(i2, i0) and np.array_equal(d2.view(np.uint32), d0.view(np.uint32))
 
 
 def test_gpu_ivf_fused_equals_emulation_path():
@@ -592,15 +596,16 @@ def test_alternating_streams_share_scratch_safely():
         assert np.array_equal(ib.cpu().numpy(), want_b[0]) and np.array_equal(db.cpu().numpy(), want_b[1])
 
 
-@pytest.mark.parametrize("M", [32, 16, 64])
-def test_matrix_core_scan_equals_vector_scan(M):
+@pytest.mark.parametrize("M,Ds", [(32, 4), (16, 4), (64, 2), (32, 2), (16, 2)])
+def test_matrix_core_scan_equals_vector_scan(M, Ds):
     """fscan_mx_kernel (option scan_mx = 1, default: table bytes summed by v_smfmac) against fscan_kernel (scan_mx = 0) and the
     exhaustive scan: identical ids and distances for top-1, top-k and subset search; sizes that end inside a group of 16
     codes, inside a 1024-code trip, below one trip and below one group; appends that re-format a partial last group; exact
     duplicates in the database (ties)."""
     from rii_amd import RiiGpu
     rng = np.random.default_rng(4100 + M)
-    Ds = 2 if M == 64 else 4                 # M = 64: the reference's own benchmark shape (D = 128), tables built by tile for Ds = 2
+    # M = 64, Ds = 2: the reference's own benchmark shape (D = 128).  M = 16 / 32: the tables come from qlut_fused_kernel (one
+    # launch, quarter tables) and top-1 is re-ranked from the codebook; option fused_tables = 0 selects round 2's two-launch path
     cw = rng.random((M, 256, Ds)).astype(np.float32)
     N = 70000 + 13
     codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
@@ -611,15 +616,17 @@ def test_matrix_core_scan_equals_vector_scan(M):
 
     def both(topk, tids=None):
         out = []
-        for mx, mode in ((1, 1), (0, 1), (1, 0)):
+        for mx, mode, ft in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)):
             g.set_option("scan_mx", mx)
             g.set_option("scan_mode", mode)
+            g.set_option("fused_tables", ft)
             out.append(g.query_linear_batch(qs, topk, tids))
         g.set_option("scan_mx", 1)
         g.set_option("scan_mode", 1)
-        a, b, c = out
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (topk, g.N)
-        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), (topk, g.N)
+        g.set_option("fused_tables", 1)
+        a = out[0]
+        for o_ in out[1:]:
+            assert np.array_equal(a[0], o_[0]) and np.array_equal(a[1], o_[1]), (topk, g.N)
         return a
 
     sizes = [7, 16, 100, 1024, 1500, 5000, 33000 + 5, 66000 + 9, N]          # cumulative appends
