@@ -360,6 +360,7 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
               bool alloc_only = false, bool need_fp32 = true)
 {
     if (qt <= 0) qt = e->QT;
+    if (qt <= 0) qt = 1;                  // wide tables (widetab.hip): plain [b][M*Ks] in global memory
     const size_t tiles = (size_t) ((B + qt - 1) / qt);
     RII_TRY(e->s_lut.ensure(tiles * (size_t) e->M * e->Ks * qt * sizeof(float)));
     e->lut_qt = qt;
@@ -757,26 +758,64 @@ int check_query_args(const rii_engine *e, int64_t B, int topk, int64_t S)
     if (S < 0 || S > e->N) return set_err(RII_ERR_INVALID, "S=%lld must satisfy S <= N (src/rii.h:220)", (long long) S);
     if (S != 0 && (int64_t) topk > S)
         return set_err(RII_ERR_INVALID, "topk=%d must be <= len(target_ids)=%lld (src/rii.h:219)", topk, (long long) S);
-    if (e->QT == 0)
-        return set_err(RII_ERR_UNSUPPORTED, "M*Ks=%d tables do not fit the 160 KiB LDS", e->M * e->Ks);
     return RII_OK;
 }
 
 constexpr int64_t kMaxBatch = 8192;       // queries per internal pass: bounds the table scratch (32 KiB fp32 per query)
+constexpr int64_t kMaxBatchWide = 1024;   // ... of the wide-table shapes (up to 256 KiB per query)
+
+// Linear search of a shape whose one-query table does not fit LDS (QT == 0; widetab.hip): exact fp32 tables in global memory,
+// one packed key per (query, code), segmented sort -> canonical (dist, id) order, exact ties replayed over the key rows.
+int query_linear_wide(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_remap, int64_t S,
+                      int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+{
+    const int64_t n_codes = S ? S : e->N;
+    RII_TRY(build_lut(e, d_queries, B, st, false, 1));
+    const int64_t budget_keys = (int64_t) 1 << 27;                 // 1 GiB per key buffer
+    int64_t bc = std::max<int64_t>(1, std::min<int64_t>(B, budget_keys / std::max<int64_t>(n_codes, 1)));
+    while (bc > 1 && bc * n_codes >= ((int64_t) 1 << 31)) --bc;
+    if (bc * n_codes >= ((int64_t) 1 << 31))
+        return set_err(RII_ERR_UNSUPPORTED, "wide-table search over %lld codes exceeds the sort path's 2^31 key limit", (long long) n_codes);
+    RII_TRY(e->s_keys_a.ensure((size_t) bc * n_codes * sizeof(unsigned long long)));
+    RII_TRY(e->s_keys_b.ensure((size_t) bc * n_codes * sizeof(unsigned long long)));
+    for (int64_t b0 = 0; b0 < B; b0 += bc) {
+        const int64_t cur = std::min<int64_t>(bc, B - b0);
+        {
+            ScopedTimer t(e, "scan", st);
+            HIP_TRY(launch_scan_wide(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, e->s_lut.as<float>(), d_remap, (int) b0, (int) cur,
+                                     e->s_keys_a.as<unsigned long long>(), st));
+        }
+        ScopedTimer t(e, "select", st);
+        HIP_TRY(segmented_sort_keys(e->s_keys_a.as<unsigned long long>(), e->s_keys_b.as<unsigned long long>(), cur, n_codes,
+                                    &e->sort_temp, &e->sort_temp_bytes, st));
+        HIP_TRY(launch_gather_sorted_topk(e->s_keys_b.as<unsigned long long>(), cur, n_codes, topk, d_remap, d_out_ids + b0 * topk,
+                                          d_out_dists + b0 * topk, st));
+        if (topk > 1) {
+            RII_TRY(tie_list_reset(e, cur, st));
+            HIP_TRY(launch_sorted_tie_flag(e->s_keys_b.as<unsigned long long>(), cur, n_codes, topk, e->s_tie_list.as<int32_t>() + 1,
+                                           e->s_tie_list.as<int>(), st));
+            HIP_TRY(launch_tie_rows(e->s_keys_a.as<unsigned long long>(), n_codes, b0, cur, e->s_tie_list.as<int32_t>() + 1,
+                                    e->s_tie_list.as<int>(), topk, d_remap, d_out_ids, d_out_dists, st));
+        }
+    }
+    return RII_OK;
+}
 
 int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
                      int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
     if (B == 0) return RII_OK;
-    if (B > kMaxBatch) {
+    const int64_t maxb = e->QT ? kMaxBatch : kMaxBatchWide;
+    if (B > maxb) {
         const int64_t D = (int64_t) e->M * e->Ds;
-        for (int64_t b0 = 0; b0 < B; b0 += kMaxBatch) {
-            const int64_t cur = std::min<int64_t>(kMaxBatch, B - b0);
+        for (int64_t b0 = 0; b0 < B; b0 += maxb) {
+            const int64_t cur = std::min<int64_t>(maxb, B - b0);
             RII_TRY(query_linear_dev(e, d_queries + b0 * D, cur, topk, d_tids, S, d_out_ids + b0 * topk,
                                      d_out_dists + b0 * topk, st));
         }
         return RII_OK;
     }
+    if (e->QT == 0) return query_linear_wide(e, d_queries, B, topk, S ? d_tids : nullptr, S, d_out_ids, d_out_dists, st);
     {
         const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
         RII_TRY(build_lut(e, d_queries, B, st, !small_top1, small_top1 ? exact_tile_for(e, B, topk) : 0, false, /*need_fp32=*/topk > 1));
@@ -815,10 +854,11 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
 {
     e->ivf_has_deferred = false;
     if (B == 0) return RII_OK;
-    if (B > kMaxBatch) {
+    const int64_t maxb = e->QT ? kMaxBatch : kMaxBatchWide;
+    if (B > maxb) {
         const int64_t D = (int64_t) e->M * e->Ds;
-        for (int64_t b0 = 0; b0 < B; b0 += kMaxBatch) {
-            const int64_t cur = std::min<int64_t>(kMaxBatch, B - b0);
+        for (int64_t b0 = 0; b0 < B; b0 += maxb) {
+            const int64_t cur = std::min<int64_t>(maxb, B - b0);
             RII_TRY(query_ivf_dev(e, d_queries + b0 * D, cur, topk, d_tids, S, L, d_out_ids + b0 * topk,
                                   d_out_dists + b0 * topk, d_out_counts + b0, st));
         }
@@ -866,7 +906,8 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     const bool fused = e->ivf_fused && ivf_fused_supported(e->M, e->Ks, (int) nlist, w, topk);
     // a shape outside the fused kernel (w > 32 next to a large nlist, topk >= 1023): every query through the big exact kernel;
     // option ivf_fused = 0 keeps selecting the one-lane emulation kernels (tests)
-    const bool big_all = !fused && e->ivf_fused && ivf_exact_big_supported(e->M, e->Ks, w, topk);
+    // (a shape whose table does not fit LDS at all -- QT == 0, widetab.hip -- has no other inverted-index kernel)
+    const bool big_all = !fused && (e->ivf_fused || e->QT == 0) && ivf_exact_big_supported(e->M, e->Ks, w, topk);
     RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
     p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
     const bool defer = fused && d_flag_defer && bc >= B;       // one launch group: the caller inspects the flags itself
@@ -1170,7 +1211,6 @@ RII_API int rii_reconfigure(rii_engine *e, int nlist, int iter)
     if (nlist <= 0 || (int64_t) nlist > e->N)
         return set_err(RII_ERR_INVALID, "reconfigure: need 0 < nlist=%d <= N=%lld (src/rii.h:110-111)", nlist, (long long) e->N);
     if (iter < 0) return set_err(RII_ERR_INVALID, "iter must be >= 0");
-    if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
     const int M = e->M, Ks = e->Ks;
     const size_t len = (size_t) std::min<int64_t>(e->N, (int64_t) nlist * 100);
     if (e->verbose) printf("The number of vectors used for training of coarse centers: %zu\n", len);
@@ -1640,13 +1680,12 @@ RII_API int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *ou
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
     RII_TRY(begin_on(e, e->stream));
-    if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
     if (B == 0) return RII_OK;
     RII_TRY(stage_inputs(e, queries, B, nullptr, 0, 1));
     RII_TRY(build_lut(e, e->s_queries.as<float>(), B, e->stream));          // tile-interleaved (QT) layout
     const size_t bytes = (size_t) B * e->M * e->Ks * sizeof(float);
     RII_TRY(e->s_keys_a.ensure(bytes));
-    HIP_TRY(launch_lut_untile(e->s_lut.as<float>(), B, e->M, e->Ks, e->QT, e->s_keys_a.as<float>(), e->stream));
+    HIP_TRY(launch_lut_untile(e->s_lut.as<float>(), B, e->M, e->Ks, e->lut_qt, e->s_keys_a.as<float>(), e->stream));
     HIP_TRY(hipMemcpyAsync(out, e->s_keys_a.p, bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return RII_OK;

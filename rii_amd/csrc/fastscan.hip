@@ -2393,16 +2393,19 @@ __global__ __launch_bounds__(256) void rerank_top1_direct_kernel(RrArgs p, const
             const uint32_t n = (uint32_t) (c & 0xffffffffu);
             const uint2 *code = reinterpret_cast<const uint2 *>(p.codes + (size_t) (p.indirect ? (int64_t) p.remap[n] : (int64_t) n) * p.M);
             float dist = 0.f;
-            for (int m0 = 0; m0 < p.M; m0 += 8) {
-                const uint2 wd = code[m0 >> 3];
-                Vec cv[8];
+            for (int m0 = 0; m0 < p.M; m0 += 16) {                   // 16 codeword loads in flight per thread: one or two round trips per code
+                const uint2 wa = code[m0 >> 3];
+                const uint2 wb = (m0 + 8 < p.M) ? code[(m0 >> 3) + 1] : make_uint2(0u, 0u);
+                const uint32_t wd[4] = {wa.x, wa.y, wb.x, wb.y};
+                Vec cv[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t ks = ((j < 4 ? wd.x : wd.y) >> (8 * (j & 3))) & 0xffu;
-                    cv[j] = cw[(m0 + j) * 256 + ks];
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t ks = (wd[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    cv[j] = cw[(m0 + j < p.M ? m0 + j : 0) * 256 + ks];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dist = __fadd_rn(dist, fvec_l2sqr_vec(s_q[m0 + j], cv[j]));
+                for (int j = 0; j < 16; ++j)
+                    if (m0 + j < p.M) dist = __fadd_rn(dist, fvec_l2sqr_vec(s_q[m0 + j], cv[j]));
             }
             const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(dist)) << 32) | n;
             best = key < best ? key : best;

@@ -1338,14 +1338,16 @@ hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st)
 // the rest from memory (rii_device.h: wh_partial_sort_split).  Same moves as the reference, any nlist <= N and any L <= N;
 // a heap deeper than the wave code covers (w or topk above kWhSplitMaxHeap) is walked by one lane over the global array.
 // ===================================================================================================
+// GTAB: the query's table does not fit LDS at all (M * Ks * 4 B > 144 KiB, widetab.hip): it is read from global memory (L2).
+template <bool GTAB>
 __global__ __launch_bounds__(256) void ivf_exact_big_kernel(IvfParams p, unsigned char *scratch, size_t per_block, int hcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nflag = p.flag_list ? *p.nflag : (int) p.B;
     const int MK = p.M * p.Ks, nlist = p.nlist, tid = threadIdx.x;
     const int w = (int) p.w, k = p.topk;
-    float *lds = reinterpret_cast<float *>(smem);
-    pq64_t *s_head = reinterpret_cast<pq64_t *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));      // [hcap] the heap of the running sort
+    float *lds_tab = reinterpret_cast<float *>(smem);
+    pq64_t *s_head = reinterpret_cast<pq64_t *>(smem + (GTAB ? 0 : (((size_t) MK * 4 + 15) & ~(size_t) 15)));   // [hcap] the heap of the running sort
     int32_t *s_misc = reinterpret_cast<int32_t *>(s_head + hcap);                                      // [4]
     unsigned char *mine = scratch + per_block * blockIdx.x;
     pq64_t *gco = reinterpret_cast<pq64_t *>(mine);                     // [nlist] (coarse distance, list), in the reference's order afterwards
@@ -1356,7 +1358,8 @@ __global__ __launch_bounds__(256) void ivf_exact_big_kernel(IvfParams p, unsigne
         const int64_t bl = p.flag_list ? p.flag_list[fi] : fi;
         if (!p.flag_list && p.flag && !p.flag[bl]) continue;
         __syncthreads();                                   // the previous query's LDS contents are dead from here on
-        stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds);
+        if constexpr (!GTAB) stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds_tab);
+        const float *lds = GTAB ? p.lut + (size_t) (p.b0 + bl) * MK : lds_tab;        // (GTAB: plain [b][M*Ks] tables, QT == 1)
         __syncthreads();
         const bool w_lds = w <= kWhSplitMaxHeap, k_lds = k <= kWhSplitMaxHeap;          // heap in LDS, walked by a wave
         for (int c = tid; c < nlist; c += blockDim.x) {                                  // src/rii.h:262-264
@@ -1428,6 +1431,7 @@ static int ivf_exact_big_hcap(int64_t w, int topk)
 }
 bool ivf_exact_big_supported(int M, int Ks, int64_t w, int topk)
 {
+    if (lut_tile_for(M, Ks) == 0) return true;             // table read from global memory: only the heaps use LDS
     return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) ivf_exact_big_hcap(w, topk) * 8 + 64 <= (size_t) 160 * 1024;
 }
 size_t ivf_exact_big_scratch(int nlist, int64_t L) { return ((size_t) nlist * 12 + (size_t) L * 12 + 4 + 63) / 64 * 64; }
@@ -1435,11 +1439,12 @@ hipError_t launch_ivf_exact_big(const IvfParams &p, void *d_scratch, int grid, h
 {
     if (p.B == 0) return hipSuccess;
     const int hcap = ivf_exact_big_hcap(p.w, p.topk);
-    const size_t smem = (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15) + (size_t) hcap * 8 + 64;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_exact_big_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    const bool gtab = lut_tile_for(p.M, p.Ks) == 0;
+    const size_t smem = (gtab ? 0 : (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15)) + (size_t) hcap * 8 + 64;
+    auto kern = gtab ? ivf_exact_big_kernel<true> : ivf_exact_big_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ivf_exact_big_kernel, dim3((unsigned) grid), dim3(256), smem, st, p, static_cast<unsigned char *>(d_scratch),
+    hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(256), smem, st, p, static_cast<unsigned char *>(d_scratch),
                        ivf_exact_big_scratch(p.nlist, p.L), hcap);
     return hipGetLastError();
 }
@@ -1614,6 +1619,7 @@ hipError_t launch_assign(const uint8_t *d_codes, int64_t num, int M, int Ks, con
 {
     if (num == 0) return hipSuccess;
     const int QT = lut_tile_for(M, Ks);
+    if (QT == 0) return launch_assign_wide(d_codes, num, M, Ks, d_symtab, d_centers, nlist, d_assign, st);
     if (QT == 4) return launch_assign_t<4>(d_codes, num, M, Ks, d_symtab, d_centers, nlist, d_assign, st);
     if (QT == 2) return launch_assign_t<2>(d_codes, num, M, Ks, d_symtab, d_centers, nlist, d_assign, st);
     return launch_assign_t<1>(d_codes, num, M, Ks, d_symtab, d_centers, nlist, d_assign, st);

@@ -229,6 +229,14 @@ hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, in
                              float *d_out_dists, int64_t *d_out_payload, hipStream_t st, const int64_t *id_offsets = nullptr,
                              int tie_cols = 0, int32_t *d_out_tie = nullptr, int32_t *d_out_any = nullptr);
 
+// widetab.hip: shapes whose one-query table does not fit LDS (lut_tile_for() == 0): tables stay in global memory
+hipError_t launch_scan_wide(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, const int64_t *d_remap,
+                            int b0, int bc, unsigned long long *d_keys, hipStream_t st);
+hipError_t launch_tie_rows(unsigned long long *d_keys, int64_t n_codes, int64_t b0, int64_t bc, const int32_t *d_flag_list, const int *d_nflag,
+                           int topk, const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st);
+hipError_t launch_assign_wide(const uint8_t *d_codes, int64_t num, int M, int Ks, const float *d_symtab, const uint8_t *d_centers, int nlist,
+                              int32_t *d_assign, hipStream_t st);
+
 // scanorder.hip: LDS-friendly scan order for the filter stage (perm[pos] = code id, codes gathered in that order)
 bool scan_order_supported(int M, int Ks);
 hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, int rows, int64_t win0, int32_t *d_perm,

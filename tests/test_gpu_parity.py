@@ -142,6 +142,48 @@ def test_gpu_ivf_many_lists_and_large_L_vs_oracle(nlist):
         assert_same_result((ids[b, :int(cnt[b])], d[b, :int(cnt[b])]), o.query_ivf(Q[b], 5, E, 300), "emulation kernels b=%d" % b)
 
 
+@pytest.mark.parametrize("M,Ks,Ds", [(160, 256, 1), (256, 256, 1), (200, 256, 2)])
+def test_gpu_wide_tables_vs_oracle(M, Ks, Ds):
+    """Shapes whose one-query table (M * Ks * 4 B = 160 .. 256 KiB) does not fit the LDS budget -- legal in the reference (any
+    M <= D, Ks <= 256: rii/rii.py:35, src/rii.h:361-373), refused by round 2's engine.  Tables in global memory (widetab.hip):
+    DTable, linear search for every topk incl. exact ties and target ids, reconfigure / coarse assignment, the inverted index."""
+    from rii_amd import RiiGpu
+    arch = "avx512"
+    N = 3000
+    cw, codes, qs = make_problem(900 + M, M, Ks, Ds, N, "sift", dup=400)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    assert g.get_option("lut_tile") == 0                       # no table tile fits LDS
+    g.add_codes(codes, False); o.add_codes(codes, False)
+    Q = qs[:9]
+    lut = g.dtable(Q[:3])
+    for b in range(3):
+        assert np.array_equal(lut[b].view(np.uint32), O.dtable(cw, Q[b], arch).view(np.uint32))
+    rng = np.random.default_rng(M)
+    sub = np.sort(rng.choice(N, N // 5, replace=False)).astype(np.int64)
+    n_tied = 0
+    for topk in (1, 6, 64, 1500):
+        for tids in (E, sub):
+            if len(tids) and topk > len(tids):
+                continue
+            ids, d = g.query_linear_batch(Q, topk, tids)
+            for b in range(Q.shape[0]):
+                wi, wd = o.query_linear(Q[b], topk, tids)
+                assert_same_result((ids[b], d[b]), (wi, wd), "wide linear M=%d k=%d S=%d b=%d" % (M, topk, len(tids), b))
+                n_tied += int(len(set(np.asarray(wd).tolist())) < len(wd))
+    assert n_tied > 0
+    g.reconfigure(30, 3); o.reconfigure(30, 3)
+    assert g.coarse_centers == o.coarse_centers and g.posting_lists == o.posting_lists
+    g.add_codes(codes[:100], True); o.add_codes(codes[:100], True)
+    assert g.posting_lists == o.posting_lists
+    for topk, L in ((1, 100), (5, 100), (3, 3), (20, 900), (2, N)):
+        for tids in (E, sub):
+            ids, d, cnt = g.query_ivf_batch(Q, topk, tids, L)
+            for b in range(Q.shape[0]):
+                n = int(cnt[b])
+                assert_same_result((ids[b, :n], d[b, :n]), o.query_ivf(Q[b], topk, tids, L), "wide ivf M=%d k=%d L=%d S=%d b=%d" % (M, topk, L, len(tids), b))
+
+
 def test_gpu_ivf_empty_and_tail_vs_oracle():
     from rii_amd import RiiGpu
     arch = "avx512"
