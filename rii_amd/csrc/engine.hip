@@ -173,6 +173,7 @@ struct rii_engine : ScratchSet {
     int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
     int scan_mx = 1;            // option "scan_mx": 1 = rotated shapes scan with fscan_mx_kernel (its own lookup order), 0 = fscan_kernel
+    int scan_dual = 1;          // option "scan_dual": M = 16 keeps two 16-query tiles per scan block (fscan_mx_dual_kernel)
     int64_t scan_cov = 0;       // codes [0, scan_cov) are final (whole windows)
     int64_t scan_N = -1;        // N the order was last completed for
     bool have_symtab = false, have_cnorm = false, lists_dirty = true;
@@ -548,7 +549,8 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
     if (e->scan_mode == 1 && !small_top1 && fastscan_supported(e->M, e->Ks) && topk <= rerank_topk_max_k()) {
         // stage 0: quantise the tables; stage 1: byte-table scan -> candidates; stage 2: exact re-rank
         const int qr = fastscan_rows(e->M, e->Ks);
-        const int64_t tiles = (B + qr - 1) / qr;
+        const int qpb = fscan_queries_per_block(e->M, e->Ks, e->scan_mx, e->scan_dual);     // queries one scan block answers
+        const int64_t tiles = (B + qpb - 1) / qpb;                                          // scan blocks per chunk
         int64_t c = e->scan_chunks;
         if (c <= 0) {
             // one block per CU at a time (LDS), all blocks equally long: the scan takes ceil(tiles * c / n_cu) rounds, each
@@ -616,7 +618,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 }
             }
             const uint8_t *d_rr = d_perm ? d_scan : d_codes_idx;       // the re-rank reads the code at the scan position
-            RII_TRY(e->s_qlut.ensure((size_t) tiles * e->M * e->Ks * qr));
+            RII_TRY(e->s_qlut.ensure((size_t) ((B + qr - 1) / qr) * e->M * e->Ks * qr));
             RII_TRY(e->s_slack.ensure((size_t) B * sizeof(int32_t)));
             RII_TRY(e->s_cand.ensure((size_t) B * cap * sizeof(unsigned long long)));
             RII_TRY(e->s_cand_cnt.ensure((size_t) B * sizeof(unsigned int)));
@@ -637,7 +639,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                     HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
-                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0));
+                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual));
                 }
                 ScopedTimer t(e, "rerank", st);
                 if (!e->lut_valid) {     // no fp32 table was written: distances of the candidates straight from the codebook
@@ -661,7 +663,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride,
-                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0));
+                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual));
             }
             {
                 ScopedTimer t(e, "kth", st);
@@ -672,7 +674,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
-                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0));
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual));
             }
             RII_TRY(tie_list_reset(e, B, st));
             {
@@ -1742,6 +1744,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         RII_TRY(begin_exclusive(e));
         e->scan_mx = value ? 1 : 0;
         e->fc_cov = 0;                  // the formatted lookups are laid out per kernel
+    } else if (k == "scan_dual") {
+        e->scan_dual = value ? 1 : 0;
     } else if (k == "lanes") {
         if (value != 1 && value != 2) return set_err(RII_ERR_INVALID, "lanes must be 1 or 2");
         HIP_TRY(hipSetDevice(e->device));
@@ -1774,6 +1778,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "scan_order") return e->scan_order;
     if (k == "lanes") return e->lanes;
     if (k == "scan_mx") return e->scan_mx;
+    if (k == "scan_dual") return e->scan_dual;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;

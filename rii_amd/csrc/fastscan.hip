@@ -888,6 +888,7 @@ struct FsArgs {
     uint32_t *gthr;                // MODE 0: [B] thresholds shared by all chunk-blocks of a tile (pre-set to 0xffff)
     int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
     int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
+    int dual = 0;                  // M = 16: two 16-query tiles per block (fscan_mx_dual_kernel)
 };
 
 // MODE 0: top-1, thresholds adapt to the block's running minimum.  MODE 1 / 2: the two passes of top-k (k > 1):
@@ -2114,6 +2115,329 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     }
 }
 
+// =====================================================================================================================
+// fscan_mx_dual_kernel: M = 16 with TWO 16-query tiles resident (round 3).  The byte tables of 16 queries are 64 KiB at M = 16, so
+// fscan_mx_kernel<4> leaves half of the LDS unused and keeps only 8 row reads in flight per wave (two register sets of 4 rows):
+// 0.50 - 0.56 of the LDS row rate against 0.65 for M = 32.  Here a block holds the tables of tiles 2y and 2y + 1 (128 KiB: the
+// second tile 64 KiB above the first, which is exactly the `half` bit of the row address), every lane turns each of its four
+// code bytes into TWO row addresses -- the same v_perm_b32 with a second per-lane constant -- and the eight rows of a group go
+// through the matrix core as two pairs of instructions with separate accumulators.  The pipeline is the M = 32 one (two register
+// sets of 8 rows, 16 reads in flight); one fetch of the lookups serves 32 queries, so the shard is streamed B / 32 times
+// instead of B / 16: half the HBM traffic of the Deep1B-shaped scan.  Thresholds: 32 words in LDS.
+// =====================================================================================================================
+__device__ __forceinline__ void fs_mx_issue_hot_dual(uint32_t w, const uint32_t (&C)[8], v4i_t (&r)[8])
+{
+    fs_mx_issue2<0>(w, C[0], C[1], r[0], r[1]);
+    fs_mx_issue2<2>(w, C[2], C[3], r[2], r[3]);
+    fs_mx_issue2<0>(w, C[4], C[5], r[4], r[5]);
+    fs_mx_issue2<2>(w, C[6], C[7], r[6], r[7]);
+}
+// rows r[0..3] -> tile A's sums, r[4..7] -> tile B's; every pair of registers is refilled with the rows of the group two ahead
+// (lookups wn) right behind the instruction that consumed it
+__device__ __forceinline__ void fs_mx_reduce_refill_dual(v4i_t (&r)[8], uint32_t wn, const uint32_t (&C)[8], const v4i_t &spa, int spidx,
+                                                         const v4i_t &zero, v4i_t &accA, v4i_t &accB)
+{
+    accA = zero;
+    {
+        const v8i_t b = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        accA = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, accA, spidx, 0, 0);
+        fs_mx_issue2<0>(wn, C[0], C[1], r[0], r[1]);
+    }
+    {
+        const v8i_t b = __builtin_shufflevector(r[2], r[3], 0, 1, 2, 3, 4, 5, 6, 7);
+        accA = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, accA, spidx, 0, 0);
+        fs_mx_issue2<2>(wn, C[2], C[3], r[2], r[3]);
+    }
+    accB = zero;
+    {
+        const v8i_t b = __builtin_shufflevector(r[4], r[5], 0, 1, 2, 3, 4, 5, 6, 7);
+        accB = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, accB, spidx, 0, 0);
+        fs_mx_issue2<0>(wn, C[4], C[5], r[4], r[5]);
+    }
+    {
+        const v8i_t b = __builtin_shufflevector(r[6], r[7], 0, 1, 2, 3, 4, 5, 6, 7);
+        accB = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, accB, spidx, 0, 0);
+        fs_mx_issue2<2>(wn, C[6], C[7], r[6], r[7]);
+    }
+}
+
+// grid = (chunks, ceil(B / 32)), 1024 threads
+template <int MODE>
+__global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
+{
+    constexpr int M = 16, NQ = 32;
+    constexpr size_t tile_bytes = (size_t) M * 256 * 16;               // 64 KiB: one tile's rotated byte rows
+    constexpr size_t lut_bytes = 2 * tile_bytes;
+    typedef uint32_t W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, tile2 = blockIdx.y;                   // this block: tiles 2 tile2, 2 tile2 + 1 = queries 32 tile2 .. + 31
+    const int qbase = tile2 * NQ;
+    uint32_t *s_thr = reinterpret_cast<uint32_t *>(smem + lut_bytes);                       // [32]
+    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(smem + lut_bytes + NQ * 4);              // [32] staged, [32] global bases
+    unsigned long long *s_lcand = reinterpret_cast<unsigned long long *>(smem + lut_bytes + NQ * 4 + NQ * 8);
+    {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t tile = 2 * (int64_t) tile2 + u;
+            unsigned char *dstb = smem + u * tile_bytes;
+            if (tile * 16 >= p.B) {                                     // no second tile (odd tile count): all-zero rows, thresholds 0
+                uint4 *d4 = reinterpret_cast<uint4 *>(dstb);
+                for (size_t i = tid; i < tile_bytes / 16; i += kFsThreads) d4[i] = make_uint4(0u, 0u, 0u, 0u);
+            } else if (p.quarter) {                                     // quarter tables -> rotated rows (see fscan_mx_kernel)
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(p.qlut) + (size_t) tile * 4 * M * 256;
+                const int slot = tid & 15, qq = (tid >> 4) & 3;
+                for (int unit = tid >> 6; unit < M; unit += kFsThreads >> 6) {
+                    const int ks0 = unit * 16;
+                    const uint4 *sp = reinterpret_cast<const uint4 *>(src + ((size_t) qq * M + slot) * 256 + ks0);
+                    const uint4 v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3];
+                    uint32_t *d = reinterpret_cast<uint32_t *>(dstb + ((size_t) ks0 * 16 + slot) * 16 + qq * 4);
+                    d[0 * 64] = v0.x; d[1 * 64] = v0.y; d[2 * 64] = v0.z; d[3 * 64] = v0.w;
+                    d[4 * 64] = v1.x; d[5 * 64] = v1.y; d[6 * 64] = v1.z; d[7 * 64] = v1.w;
+                    d[8 * 64] = v2.x; d[9 * 64] = v2.y; d[10 * 64] = v2.z; d[11 * 64] = v2.w;
+                    d[12 * 64] = v3.x; d[13 * 64] = v3.y; d[14 * 64] = v3.z; d[15 * 64] = v3.w;
+                }
+            } else {
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(p.qlut + (size_t) tile * tile_bytes);
+                uint4 *d4 = reinterpret_cast<uint4 *>(dstb);
+                for (size_t i = tid; i < tile_bytes / 16; i += kFsThreads) d4[i] = s4[i];
+            }
+        }
+        if (tid < NQ) {
+            const int b = qbase + tid;
+            const bool live = b < p.B;
+            uint32_t t = live ? 0xffffu : 0u;
+            if constexpr (MODE == 2) t = live ? p.thr16[b] : 0u;
+            s_thr[tid] = t;
+        }
+        if (tid < 2 * NQ) s_lcnt[tid] = 0u;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, col = lane & 15, gq = lane >> 4;      // this lane judges queries 4 gq .. + 3 of both tiles
+    v4i_t spa;
+    int spidx;
+    uint32_t C[8];
+    fs_mx_pattern(col, spa, spidx);
+    {
+        uint32_t C4[4];
+        fs_mx_consts<4>(lane, C4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { C[t] = C4[t]; C[4 + t] = C4[t] | 0x10000u; }      // tile B: 64 KiB above tile A
+    }
+    const int64_t c_begin = (int64_t) blockIdx.x * p.chunk_len;         // a multiple of 1024
+    int64_t c_end = c_begin + p.chunk_len;
+    if (c_end > p.n_codes) c_end = p.n_codes;
+    const int64_t span = c_end > c_begin ? c_end - c_begin : 0;
+    const int full = (int) (span / kFsThreads);
+    const int tail_groups = (int) ((span - (int64_t) full * kFsThreads + 15) / 16);
+    const W *fc = reinterpret_cast<const W *>(p.codes) + (size_t) (c_begin / 16) * 64 + lane;
+
+    auto emit = [&](int q, uint32_t a, uint32_t t, uint32_t n) {
+        const int b = qbase + q;
+        if (b >= p.B) return;
+        if constexpr (MODE == 0) {
+            const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
+            if (nt < t) {
+                atomicMin(&s_thr[q], nt);
+                atomicMin(&p.gthr[b], nt);
+            }
+        }
+        const unsigned long long rec = ((unsigned long long) a << 32) | n;
+        bool staged = false;
+        if (p.lcap > 0) {
+            const unsigned int lp = atomicAdd(&s_lcnt[q], 1u);
+            if (lp < (unsigned int) p.lcap) { s_lcand[(size_t) q * p.lcap + lp] = rec; staged = true; }
+        }
+        if (!staged) {
+            const unsigned int pos = atomicAdd(&p.cand_count[b], 1u);
+            if (pos < (unsigned int) p.cap) p.cand[(size_t) b * p.cap + pos] = rec;
+        }
+    };
+    auto judge = [&](const v4i_t &acc, const v4i_t &thr, uint32_t n, int qoff) {
+        const bool h0 = acc[0] < thr[0], h1 = acc[1] < thr[1], h2 = acc[2] < thr[2], h3 = acc[3] < thr[3];
+        if (h0 | h1 | h2 | h3) {
+            uint32_t mask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
+            while (mask) {
+                const int r = __ffs((int) mask) - 1;
+                mask &= mask - 1u;
+                const int a = r == 0 ? acc[0] : r == 1 ? acc[1] : r == 2 ? acc[2] : acc[3];
+                const int t = r == 0 ? thr[0] : r == 1 ? thr[1] : r == 2 ? thr[2] : thr[3];
+                emit(qoff + 4 * gq + r, (uint32_t) a, (uint32_t) t, n);
+            }
+        }
+    };
+    v4i_t keepA = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff}, keepB = keepA;
+    auto take_min = [&](v4i_t &keep, const v4i_t &acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[r] = acc[r] < keep[r] ? acc[r] : keep[r];
+    };
+    auto publish = [&](const v4i_t &keep, int qoff) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int v = keep[r];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const int o = __shfl_xor(v, off);
+                v = o < v ? o : v;
+            }
+            const int q = qoff + 4 * gq + r, b = qbase + q;
+            if (col == 0 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[q], fs_thr_of((uint32_t) v, (uint32_t) p.slack[b]));
+        }
+    };
+    auto adopt = [&](bool first) {
+        if (MODE == 0 && tid < NQ) {
+            const int b = qbase + tid;
+            if (b < p.B) {
+                const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (first) {
+                    const uint32_t mine = s_thr[tid];
+                    if (mine < g) atomicMin(&p.gthr[b], mine);
+                }
+                atomicMin(&s_thr[tid], g);
+            }
+        }
+    };
+    auto slow_group = [&](int64_t gi, bool minima) {
+        const W w = fc[(size_t) gi * 64];
+        v4i_t r[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t addr = __builtin_amdgcn_perm(C[t], w, fs_mx_sel(t & 3));
+            r[t] = *(fs_lds_row_t) (uintptr_t) addr;
+        }
+        v4i_t accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+            const v8i_t ba = __builtin_shufflevector(r[t], r[t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+            accA = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, ba, accA, spidx, 0, 0);
+            const v8i_t bb = __builtin_shufflevector(r[4 + t], r[5 + t], 0, 1, 2, 3, 4, 5, 6, 7);
+            accB = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, bb, accB, spidx, 0, 0);
+        }
+        const int64_t n = c_begin + gi * 16 + col;
+        if (n >= c_end) { accA = v4i_t{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff}; accB = accA; }
+        if (minima) { take_min(keepA, accA); take_min(keepB, accB); }
+        else {
+            const v4i_t thrA = *reinterpret_cast<const v4i_t *>(s_thr + 4 * gq), thrB = *reinterpret_cast<const v4i_t *>(s_thr + 16 + 4 * gq);
+            judge(accA, thrA, (uint32_t) n, 0);
+            judge(accB, thrB, (uint32_t) n, 16);
+        }
+    };
+    auto tail = [&](bool minima) {
+        for (int gi = wave; gi < tail_groups; gi += kFsThreads / 64) slow_group((int64_t) full * 64 + gi, minima);
+    };
+    if constexpr (MODE == 0) {
+        if (full > 0) {
+            for (int j = 0; j < 4; ++j) slow_group(wave * 4 + j, true);
+        } else {
+            tail(true);
+        }
+        publish(keepA, 0);
+        publish(keepB, 16);
+        __syncthreads();
+        adopt(true);
+        __syncthreads();
+    }
+    const int step = (MODE == 1) ? p.sample_stride : 1;
+    const int ntrip = (MODE == 1) ? (full + step - 1) / step : full;
+    auto trip_of = [&](int k) { return (MODE == 0) ? (k + 1 < full ? k + 1 : 0) : k * step; };
+    if (ntrip > 0) {
+        v4i_t zero4 = {0, 0, 0, 0};
+        asm volatile("" : "+v"(zero4));
+        const W *pw = fc + (size_t) wave * 4 * 64;
+        auto trip_ptr = [&](int k) { return pw + (size_t) trip_of(k < ntrip ? k : ntrip - 1) * 64 * 64; };
+        v4i_t ra[8], rb[8];
+        W q[4];
+        constexpr int S = 64 * (int) sizeof(W);
+        {
+            const W *p0 = trip_ptr(0), *p1 = trip_ptr(1);
+            const W g0 = p0[0], g1 = p0[64];
+            fs_mx_issue_hot_dual(g0, C, ra);
+            fs_mx_issue_hot_dual(g1, C, rb);
+            fs_mx_load<2 * S>(q[2], p0);
+            fs_mx_load<3 * S>(q[3], p0);
+            fs_mx_load<0>(q[0], p1);
+            fs_mx_load<S>(q[1], p1);
+        }
+        const uint32_t thr_addr = (uint32_t) (lut_bytes + 16 * gq);
+        v4i_t thrA, thrB;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(thrA), "=&v"(thrB) : "v"(thr_addr));
+        for (int k = 0; k < ntrip; ++k) {
+            const int it = trip_of(k);
+            const W *pn = trip_ptr(k + 1), *pnn = trip_ptr(k + 2);
+            const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;
+            v4i_t accA, accB;
+            fs_mx_vmwait<3>(q[2]);
+            fs_mx_wait<8>(ra);                                    // group 0 (the 8 younger reads are group 1's)
+            fs_mx_reduce_refill_dual(ra, q[2], C, spa, spidx, zero4, accA, accB);
+            fs_mx_load<2 * S>(q[2], pn);
+            if (MODE == 1) { take_min(keepA, accA); take_min(keepB, accB); } else { judge(accA, thrA, n, 0); judge(accB, thrB, n, 16); }
+            fs_mx_vmwait<3>(q[3]);
+            fs_mx_wait<8>(rb);                                    // group 1
+            fs_mx_reduce_refill_dual(rb, q[3], C, spa, spidx, zero4, accA, accB);
+            fs_mx_load<3 * S>(q[3], pn);
+            if (MODE == 1) { take_min(keepA, accA); take_min(keepB, accB); } else { judge(accA, thrA, n + 16, 0); judge(accB, thrB, n + 16, 16); }
+            // thresholds: re-read once per trip into the live registers (any mix of old and new words is a valid set)
+            if constexpr (MODE == 0) {
+                asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thrA) : "v"(thr_addr));
+                asm volatile("ds_read_b128 %0, %1 offset:64 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thrB) : "v"(thr_addr));
+            }
+            fs_mx_vmwait<3>(q[0]);
+            fs_mx_wait<(MODE == 0) ? 10 : 8>(ra);                 // group 2 (younger: group 3's rows and the two threshold reads)
+            fs_mx_reduce_refill_dual(ra, q[0], C, spa, spidx, zero4, accA, accB);
+            fs_mx_load<0>(q[0], pnn);
+            if (MODE == 1) { take_min(keepA, accA); take_min(keepB, accB); } else { judge(accA, thrA, n + 32, 0); judge(accB, thrB, n + 32, 16); }
+            fs_mx_vmwait<3>(q[1]);
+            fs_mx_wait<8>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
+            fs_mx_reduce_refill_dual(rb, q[1], C, spa, spidx, zero4, accA, accB);
+            fs_mx_load<S>(q[1], pnn);
+            if (MODE == 1) { take_min(keepA, accA); take_min(keepB, accB); } else { judge(accA, thrA, n + 48, 0); judge(accB, thrB, n + 48, 16); }
+            adopt(false);
+        }
+        fs_mx_wait<0>(ra);
+        fs_mx_wait<0>(rb);
+        fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
+    }
+    tail(MODE == 1);
+
+    if (MODE == 0 && p.lcap > 0) {
+        __syncthreads();
+        if (tid < NQ) {
+            const int b = qbase + tid;
+            const unsigned int c = min(s_lcnt[tid], (unsigned int) p.lcap);
+            s_lcnt[NQ + tid] = (c && b < p.B) ? atomicAdd(&p.cand_count[b], c) : 0u;
+        }
+        __syncthreads();
+        for (int q = tid >> 6; q < NQ; q += kFsThreads >> 6) {        // one wave per query
+            const int b = qbase + q;
+            const unsigned int c = min(s_lcnt[q], (unsigned int) p.lcap), base = s_lcnt[NQ + q];
+            for (unsigned int i = tid & 63; i < c; i += 64)
+                if (base + i < (unsigned int) p.cap) p.cand[(size_t) b * p.cap + base + i] = s_lcand[(size_t) q * p.lcap + i];
+        }
+    }
+    if constexpr (MODE == 1) {
+        const size_t G = (size_t) gridDim.x * kFsMxSeg;
+        const size_t seg = (size_t) blockIdx.x * kFsMxSeg + wave * 16 + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bA = qbase + 4 * gq + r, bB = bA + 16;
+            if (bA < p.B) p.segmin[(size_t) bA * G + seg] = (uint16_t) (keepA[r] > 0xffff ? 0xffff : keepA[r]);
+            if (bB < p.B) p.segmin[(size_t) bB * G + seg] = (uint16_t) (keepB[r] > 0xffff ? 0xffff : keepB[r]);
+        }
+    }
+}
+
+template <int MODE> static hipError_t launch_fscan_mx_dual_t(const FsArgs &a, int chunks, hipStream_t st)
+{
+    const size_t tab = (size_t) 2 * 16 * 256 * 16 + 32 * 4 + 32 * 8;
+    FsArgs b = a;
+    b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) 32 * 8));
+    const size_t smem = tab + (size_t) 32 * 8 * b.lcap;
+    auto kern = fscan_mx_dual_kernel<MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    launch_timed(kern, dim3(chunks, (a.B + 31) / 32), dim3(kFsThreads), smem, st, b);
+    return hipGetLastError();
+}
+
 template <int T, int MODE, int QR = 16> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
     const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8;
@@ -2132,6 +2456,7 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
     const int qr = fastscan_rows(a.M, a.Ks);
     const int tiles = (a.B + qr - 1) / qr;
     if (rot && mx) {
+        if (a.M == 16 && a.dual) return launch_fscan_mx_dual_t<MODE>(a, chunks, st);
         if (a.M == 16) return launch_fscan_mx_t<4, MODE>(a, chunks, tiles, st);
         if (a.M == 32) return launch_fscan_mx_t<8, MODE>(a, chunks, tiles, st);
         if (a.M == 64) return launch_fscan_mx_t<16, MODE, 8>(a, chunks, tiles, st);
@@ -2155,13 +2480,14 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter)
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter, int dual)
 {
     // d_codes: formatted lookups (launch_fcodes_format, same `mx`) for fs_rot_supported shapes, the plain codes otherwise
     if (B == 0 || n_codes == 0) return hipSuccess;
     const bool rot = fs_rot_supported(M, Ks, mx);
     FsArgs a;
     a.quarter = quarter;
+    a.dual = (dual && mx && M == 16 && rot) ? 1 : 0;
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
@@ -2172,6 +2498,10 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     return launch_fscan_mode<0>(a, chunks, rot, mx != 0, st);
 }
 
+int fscan_queries_per_block(int M, int Ks, int mx, int dual)
+{
+    return (dual && mx && M == 16 && fs_rot_supported(M, Ks, mx)) ? 32 : fastscan_rows(M, Ks);
+}
 int fscan_mx_subspace(int M, int lane, int t)
 {
     return M == 64 ? fs_mx_subspace64(lane >> 4, lane & 15, t) : fs_mx_subspace(lane >> 4, lane & 15, t);

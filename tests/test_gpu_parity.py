@@ -658,17 +658,25 @@ def test_matrix_core_scan_equals_vector_scan(M, Ds):
 
     def both(topk, tids=None):
         out = []
-        for mx, mode, ft in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)):
+        # (scan_mx, scan_mode, fused_tables, scan_dual): default; vector-ALU filter; exhaustive scan; round 2's two-launch tables;
+        # M = 16 with one tile per block instead of two (fscan_mx_kernel<4> instead of fscan_mx_dual_kernel)
+        for mx, mode, ft, dual in ((1, 1, 1, 1), (0, 1, 1, 1), (1, 0, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0), (1, 1, 0, 0)):
             g.set_option("scan_mx", mx)
             g.set_option("scan_mode", mode)
             g.set_option("fused_tables", ft)
+            g.set_option("scan_dual", dual)
             out.append(g.query_linear_batch(qs, topk, tids))
         g.set_option("scan_mx", 1)
         g.set_option("scan_mode", 1)
         g.set_option("fused_tables", 1)
+        g.set_option("scan_dual", 1)
         a = out[0]
         for o_ in out[1:]:
             assert np.array_equal(a[0], o_[0]) and np.array_equal(a[1], o_[1]), (topk, g.N)
+        # an odd number of 16-query tiles (the last two-tile block of the M = 16 kernel holds one live tile) and a ragged last tile
+        for nq in (40, 33):
+            x = g.query_linear_batch(qs[:nq], topk, tids)
+            assert np.array_equal(x[0], a[0][:nq]) and np.array_equal(x[1], a[1][:nq]), (topk, g.N, nq)
         return a
 
     sizes = [7, 16, 100, 1024, 1500, 5000, 33000 + 5, 66000 + 9, N]          # cumulative appends

@@ -27,7 +27,7 @@ def asm_path():
 def test_no_instruction_touches_a_register_with_a_load_in_flight(asm_path):
     t = _tool()
     funcs = t.split_functions(asm_path)
-    names = [n for n in funcs if "fscan_mx_kernel" in n or "fscan_kernel" in n]
+    names = [n for n in funcs if "fscan_mx_kernel" in n or "fscan_mx_dual_kernel" in n or "fscan_kernel" in n]
     assert len(names) >= 30                      # every (shape, mode) instance of both kernels
     for n in names:
         probs, ninst = t.check_function(n, funcs[n])

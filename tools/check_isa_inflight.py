@@ -33,6 +33,9 @@ VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LABEL = re.compile(r"^(\.LBB\d+_\d+):")
 BRANCH = re.compile(r"^\s*s_(cbranch_\w+|branch)\s+(\.LBB\d+_\d+)")
 LOAD_VM = re.compile(r"^(global_load|buffer_load|flat_load|scratch_load)")
+# gfx9 has no separate store counter: stores and atomics sit in the same vmcnt queue as the loads (the compiler counts its spill
+# stores when it picks a vmcnt(N)); they carry no destination register unless they return a value
+STORE_VM = re.compile(r"^(global_store|buffer_store|flat_store|scratch_store|global_atomic|buffer_atomic|flat_atomic)")
 LGKM = re.compile(r"^(ds_|s_load|s_buffer_load)")
 OK_MARK = "rii:inflight-ok"
 
@@ -175,6 +178,9 @@ def check_function(name, lines):
         bad = touched & st.pending()
         if bad and report and not ok:
             problems.append((i, body, sorted(bad)))
+        if STORE_VM.match(mnem):
+            returns = "atomic" in mnem and (" sc0" in body or " glc" in body)
+            st.vm.append(frozenset(dest_regs(ops)) if returns else frozenset())
         return st
 
     st = State()
@@ -213,7 +219,7 @@ def main():
         asm, args = args[1], args[2:]
     if asm is None:
         asm = compile_asm()
-    subs = args or ["fscan_mx_kernel", "fscan_kernel"]
+    subs = args or ["fscan_mx_kernel", "fscan_mx_dual_kernel", "fscan_kernel"]
     funcs = split_functions(asm)
     total, bad = 0, 0
     for name, lines in sorted(funcs.items()):
