@@ -69,6 +69,8 @@ def parse():
                     help="skip the `others` object (the other BASELINE configs measured in the same process)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurements")
     ap.add_argument("--deep-shard", type=int, default=16_000_000, help="codes of the `others.deep_shard` measurement")
+    ap.add_argument("--preheat", type=float, default=0.15,
+                    help="seconds of untimed steps before the W warm-up steps (clock ramp; 0 under rocprofv3 counter passes)")
     ap.add_argument("--latency", action="store_true",
                     help="per-call latency: fresh queries every call, one synchronisation per call (use with --batch 1)")
     ap.add_argument("--lut-mode", default="exact", choices=["exact", "mfma"])
@@ -275,13 +277,14 @@ OTHER_KERNELS = ("lut", "quant", "rerank", "kth", "tie", "select", "gather", "iv
 PREHEAT_S = 0.15
 
 
-def preheat(step, sync, seconds=PREHEAT_S):
+def preheat(step, sync, seconds=None):
     """The MI355X ramps its shader clock over the first ~30 ms of sustained load (tools/clock_ramp.py, profiles/r03_clock_ramp.json:
     0.415 -> 0.381 -> 0.366 -> 0.359 -> 0.356 ms per step over consecutive 20-step loops from idle, and back up after 1 s of
     idling), so W = 5 warm-up steps (2 ms) followed by K = 20 timed steps (8 ms) would time the ramp, not the kernel.  Untimed steps
     for `seconds` of wall time bring the chip to its steady state first; the W warm-up steps and the K timed steps follow as the
     contract says.  Returns the number of steps issued."""
     n = 0
+    seconds = PREHEAT_S if seconds is None else min(seconds, PREHEAT_S)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(8):
@@ -293,6 +296,8 @@ def preheat(step, sync, seconds=PREHEAT_S):
 
 def preheat_count(step, sync, count):
     """The same by step count: for steps that hold a collective (every rank must issue the same number of them)."""
+    if PREHEAT_S <= 0:
+        return 0
     for _ in range(count):
         step()
     sync()
@@ -547,7 +552,9 @@ def main_deep(args, world, rank, local, dev, arch):
 
 
 def main():
+    global PREHEAT_S
     args = parse()
+    PREHEAT_S = max(0.0, args.preheat)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     import torch

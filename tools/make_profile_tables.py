@@ -26,6 +26,11 @@ def main():
            "valu_busy": c["SQ_INSTS_VALU"] * 4.0 / n_simd / cycles,
            "lds_cycles_per_read": c["SQ_LDS_IDX_ACTIVE"] / c["SQ_INSTS_LDS"],
            "valu_insts": c["SQ_INSTS_VALU"], "lds_insts": c["SQ_INSTS_LDS"], "gpu_cycles": cycles}
+    if c.get("SQ_WAVE_CYCLES"):                                # wave-state split (all in the SQ's 4-cycle units)
+        pmc["wave_wait_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]            # parked in s_waitcnt
+        pmc["wave_wait_inst_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]  # waiting to issue (any pipe)
+        pmc["wave_wait_inst_lds_frac"] = c.get("SQ_WAIT_INST_LDS", 0.0) / c["SQ_WAVE_CYCLES"]
+        pmc["wave_active_frac"] = c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
     if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
         pmc["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / n_simd / cycles
         pmc["mfma_insts"] = c.get("SQ_INSTS_MFMA")

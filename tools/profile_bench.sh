@@ -10,10 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
 OUT=gpurun_out/prof_summary; RAW=/tmp/rii_prof_raw
 mkdir -p $OUT; rm -rf $RAW; mkdir -p $RAW
-KREGEX='scan_order|scan_kernel|lut_build|ivf_|assign_kernel|finalize|fscan|rerank|lut_quant|gather_codes|linear_tie|qlut'
-BENCH="python bench.py --no-cpu-baseline --no-host-call $*"
+KREGEX='scan_order|scan_kernel|lut_build|ivf_|assign_kernel|finalize|fscan|rerank|lut_quant|gather_codes|linear_tie|qlut|fcodes|merge_topk'
+BENCH="python bench.py --no-cpu-baseline --no-host-call --no-others --no-fresh --no-pipelined $*"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/kt -o kt -- $BENCH --steps 10 --warmup 2 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $RAW/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/kt -o kt -- $BENCH --steps 10 --warmup 2 --preheat 0.05 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $RAW/kt.err
 python tools/summarize_prof.py stats $RAW/kt > $OUT/${TAG}_kernel_stats.txt
 
 i=0
@@ -21,7 +21,7 @@ for CTRS in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLE
             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE" \
             "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
   i=$((i+1))
-  rocprofv3 --pmc $CTRS --kernel-include-regex "$KREGEX" --output-format csv -d $RAW/pmc$i -o pmc -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $RAW/pmc$i.err
+  rocprofv3 --pmc $CTRS --kernel-include-regex "$KREGEX" --output-format csv -d $RAW/pmc$i -o pmc -- $BENCH --steps 3 --warmup 1 --preheat 0 > /dev/null 2> $RAW/pmc$i.err
 done
 python tools/summarize_prof.py pmc $RAW/pmc* > $OUT/${TAG}_pmc_counters.txt
 python tools/summarize_prof.py pmcjson $RAW/pmc* > $OUT/${TAG}_pmc.json
