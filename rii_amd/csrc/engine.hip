@@ -110,6 +110,7 @@ struct ScratchSet {
     int flag_parity = 0;        // which of the two flagged-query counters the next inverted-index launch group uses
     int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
+    int qlut_levels = 63;       // quantisation levels of the byte tables of the current batch (255: signed bytes, fscan_mx_* only)
     bool qlut_quarter = false;  // ... as quarter tables (qlut_fused_kernel): fscan_mx_kernel interleaves them while staging
     bool lut_valid = true;      // s_lut holds the exact fp32 tables of the current batch (false: only the byte tables were built)
     int64_t last_fs_B = 0;      // batch size of the last filter + re-rank call (debug counters)
@@ -147,6 +148,7 @@ struct rii_engine : ScratchSet {
     int cand_cap = 4096;        // candidate slots per query for the re-rank stage (lower bound; grows for small batches)
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
+    int table_levels = 255;     // option "table_levels": 63 or 255 quantisation levels of the fused tables (qlut_fused_kernel)
     int fused_tables = 1;       // option "fused_tables": 1 = qlut_fused_kernel + table-free top-1 re-rank (round 3), 0 = the two-launch tile path
     int ivf_force_exact = 0;    // tests: the fused kernel flags every query, so the exact LDS kernel answers all of them
     int timing = 0;
@@ -368,6 +370,7 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
     if (alloc_only) return RII_OK;
     e->qlut_ready = false;
     e->qlut_quarter = false;
+    e->qlut_levels = 63;
     e->lut_valid = true;
     if (want_quant && e->lut_mode == RII_LUT_EXACT && e->scan_mode == 1 && fastscan_supported(e->M, e->Ks)) {
         const int qr = fastscan_rows(e->M, e->Ks);
@@ -384,9 +387,10 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
             ScopedTimer t(e, "lut", st);
             HIP_TRY(launch_qlut_fused(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ds, fp32 ? e->s_lut.as<float>() : nullptr,
                                       e->s_qlut.as<uint32_t>(), e->s_slack.as<int32_t>(), e->s_cand_cnt.as<unsigned int>(),
-                                      e->s_gthr.as<uint32_t>(), st));
+                                      e->s_gthr.as<uint32_t>(), e->table_levels, st));
             e->qlut_ready = true;
             e->qlut_quarter = true;
+            e->qlut_levels = e->table_levels;
             e->lut_valid = fp32;
             return RII_OK;
         }
@@ -639,7 +643,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                     HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
-                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual));
+                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual, e->qlut_levels));
                 }
                 ScopedTimer t(e, "rerank", st);
                 if (!e->lut_valid) {     // no fp32 table was written: distances of the candidates straight from the codebook
@@ -663,18 +667,18 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride,
-                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual));
+                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual, e->qlut_levels));
             }
             {
                 ScopedTimer t(e, "kth", st);
-                HIP_TRY(launch_kth_threshold(e->s_segmin.as<uint16_t>(), G, B, topk, fastscan_max_sum(e->M),
+                HIP_TRY(launch_kth_threshold(e->s_segmin.as<uint16_t>(), G, B, topk, fastscan_max_sum(e->M, e->qlut_levels),
                                              e->s_slack.as<int32_t>(), e->s_thr16.as<uint32_t>(), st));
             }
             {
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
-                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual));
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual, e->qlut_levels));
             }
             RII_TRY(tie_list_reset(e, B, st));
             {
@@ -1737,6 +1741,9 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->ivf_force_exact = value ? 1 : 0;
     } else if (k == "fused_tables") {
         e->fused_tables = value ? 1 : 0;
+    } else if (k == "table_levels") {
+        if (value != 63 && value != 255) return set_err(RII_ERR_INVALID, "table_levels must be 63 or 255");
+        e->table_levels = (int) value;
     } else if (k == "scan_order") {
         e->scan_order = value ? 1 : 0;
     } else if (k == "scan_mx") {
@@ -1775,6 +1782,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_fused") return e->ivf_fused;
     if (k == "ivf_force_exact") return e->ivf_force_exact;
     if (k == "fused_tables") return e->fused_tables;
+    if (k == "table_levels") return e->table_levels;
     if (k == "scan_order") return e->scan_order;
     if (k == "lanes") return e->lanes;
     if (k == "scan_mx") return e->scan_mx;

@@ -684,7 +684,29 @@ __global__ __launch_bounds__(256) void qlut_tile_quant8_kernel(const float *__re
 // it (top-k re-rank, tie order); the top-1 re-rank rebuilds what it needs from the codebook (rerank_top1_direct_kernel).
 // Cost at the bench shape: 256 blocks, 128 KiB of codebook (L2) in and 32 KiB out per block, no 32 MB fp32 round trip.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename Vec, int MW>          // float4: Ds = 4, float2: Ds = 2; MW = subspaces per wave (M = 16 MW)
+// LEVELS = 63: the byte tables every filter kernel understands.  LEVELS = 255 (fscan_mx_* only): the matrix core adds SIGNED bytes
+// without carries, so a table entry may use the whole byte -- stored as level - 128, the scan starts its accumulator at 128 M
+// instead of 0 -- and the quantisation step is 4x finer: ~4x fewer codes fall within the proven slack of the running minimum
+// (fewer trips through the scan's divergent candidate path, fewer candidates for the re-rank).  Rounding: the level is off the real
+// quotient by at most 1/2 + 6.1e-5 (three fp32 roundings of values below 256), so Rhi - Rlo <= M delta (1 + 1.3e-4).
+// wave-wide min / max on the DPP path (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast 15 / 31 across the rows): six
+// VALU instructions per value and no LDS round trip; __shfl_xor compiles to ds_bpermute_b32 -- 96 dependent LDS operations for the 16
+// extrema of a thread here.  The result is valid in LANE 63.
+template <bool MAX> __device__ __forceinline__ float fs_wave_extremum_l63(float v)
+{
+    const int ident = MAX ? (int) 0xff800000u : 0x7f800000;             // -inf / +inf: lanes without a source keep their value
+#define RII_STEP(CTRL, ROWS)                                                                                             \
+    {                                                                                                                    \
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(ident, __float_as_int(v), CTRL, ROWS, 0xf, false));   \
+        v = MAX ? fmaxf(v, o) : fminf(v, o);                                                                             \
+    }
+    RII_STEP(0x111, 0xf) RII_STEP(0x112, 0xf) RII_STEP(0x114, 0xf) RII_STEP(0x118, 0xf)       // row_shr:1, 2, 4, 8
+    RII_STEP(0x142, 0xa) RII_STEP(0x143, 0xc)                                                  // row_bcast:15 (rows 1, 3), row_bcast:31 (rows 2, 3)
+#undef RII_STEP
+    return v;
+}
+
+template <typename Vec, int MW, int LEVELS>          // float4: Ds = 4, float2: Ds = 2; MW = subspaces per wave (M = 16 MW)
 __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restrict__ queries, int64_t B,
                                                           const float *__restrict__ codewords, float *__restrict__ lut,
                                                           uint32_t *__restrict__ qlut4, int32_t *__restrict__ slack,
@@ -725,21 +747,17 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int s_ = 0; s_ < MW; ++s_) {
-                lo[jj][s_] = fminf(lo[jj][s_], __shfl_xor(lo[jj][s_], off));
-                hi[jj][s_] = fmaxf(hi[jj][s_], __shfl_xor(hi[jj][s_], off));
-            }
-    if (lane == 0) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int s_ = 0; s_ < MW; ++s_) { s_lo[jj][m0 + s_] = lo[jj][s_]; s_hi[jj][m0 + s_] = hi[jj][s_]; }
-    }
+        for (int s_ = 0; s_ < MW; ++s_) {
+            const float l = fs_wave_extremum_l63<false>(lo[jj][s_]), h = fs_wave_extremum_l63<true>(hi[jj][s_]);
+            if (lane == 63) { s_lo[jj][m0 + s_] = l; s_hi[jj][m0 + s_] = h; }
+        }
     __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)                      // every lane needs its subspaces' minima for the levels
+#pragma unroll
+        for (int s_ = 0; s_ < MW; ++s_) lo[jj][s_] = s_lo[jj][m0 + s_];
     if (threadIdx.x < 4 * 32) {          // 32 lanes per query: range and |lo| + |hi| over the M subspaces
         const int j = threadIdx.x >> 5, l32 = threadIdx.x & 31;
         const int64_t b = tile * 16 + quarter * 4 + j;
@@ -755,13 +773,13 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
             dmax += __shfl_xor(dmax, off);
         }
         if (l32 == 0) {
-            float d = range / (float) kFsLevels;
+            float d = range / (float) LEVELS;
             if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
             const float delta = d * 1.000001f;
             s_inv[j] = 1.0f / delta;
             if (b < B) {                 // the per-query state of the filter stage (see qlut_tile_quant_kernel for the slack)
                 const double eps = (double) M * 1.1920928955078125e-07 * dmax;
-                double sl = (double) M * (1.0 + 1e-4) + 2.0 * eps / (double) delta;
+                double sl = (double) M * (1.0 + (LEVELS > 63 ? 2e-4 : 1e-4)) + 2.0 * eps / (double) delta;
                 sl = sl * (1.0 + 1e-9) + 2.0;
                 slack[b] = (sl >= 0.0 && sl < 60000.0) ? (int32_t) sl : 60000;
                 if (cand_cnt) cand_cnt[b] = 0u;
@@ -782,8 +800,9 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
                 uint32_t c = 0u;
                 if (b < B) {
                     const float x = floorf((t[jj][s_][e] - lo[jj][s_]) * s_inv[jj] + 0.5f);
-                    c = (x >= (float) kFsLevels) ? (uint32_t) kFsLevels : (x > 0.f ? (uint32_t) x : 0u);
+                    c = (x >= (float) LEVELS) ? (uint32_t) LEVELS : (x > 0.f ? (uint32_t) x : 0u);
                 }
+                if (LEVELS > 127) c ^= 0x80u;            // stored as the signed byte (level - 128); dead queries: -128, never judged
                 w |= c << (8 * jj);
             }
             dst[(m0 + s_) * 256 + lane + 64 * e] = w;
@@ -804,15 +823,18 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
 bool qlut_fused_supported(int M, int Ks, int Ds, int mx) { return mx && Ks == 256 && (M == 16 || M == 32) && (Ds == 4 || Ds == 2) && fs_rot_supported(M, Ks, mx); }
 size_t qlut_fused_bytes(int64_t B, int M) { return (size_t) ((B + 15) / 16) * 4 * M * 256 * 4; }
 hipError_t launch_qlut_fused(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ds, float *d_lut_or_null,
-                             uint32_t *d_qlut4, int32_t *d_slack, unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st)
+                             uint32_t *d_qlut4, int32_t *d_slack, unsigned int *d_cand_cnt, uint32_t *d_gthr, int levels, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     const dim3 grid((unsigned) ((B + 15) / 16), 4), block(1024);
-    if (M == 32 && Ds == 4) hipLaunchKernelGGL((qlut_fused_kernel<float4, 2>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr);
-    else if (M == 16 && Ds == 4) hipLaunchKernelGGL((qlut_fused_kernel<float4, 1>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr);
-    else if (M == 32 && Ds == 2) hipLaunchKernelGGL((qlut_fused_kernel<float2, 2>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr);
-    else if (M == 16 && Ds == 2) hipLaunchKernelGGL((qlut_fused_kernel<float2, 1>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr);
+#define RII_QF(VEC, MW, LV) hipLaunchKernelGGL((qlut_fused_kernel<VEC, MW, LV>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr)
+    if (levels != 63 && levels != 255) return hipErrorInvalidValue;
+    if (M == 32 && Ds == 4) { if (levels == 255) RII_QF(float4, 2, 255); else RII_QF(float4, 2, 63); }
+    else if (M == 16 && Ds == 4) { if (levels == 255) RII_QF(float4, 1, 255); else RII_QF(float4, 1, 63); }
+    else if (M == 32 && Ds == 2) { if (levels == 255) RII_QF(float2, 2, 255); else RII_QF(float2, 2, 63); }
+    else if (M == 16 && Ds == 2) { if (levels == 255) RII_QF(float2, 1, 255); else RII_QF(float2, 1, 63); }
     else return hipErrorInvalidValue;
+#undef RII_QF
     return hipGetLastError();
 }
 
@@ -889,6 +911,7 @@ struct FsArgs {
     int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
     int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
     int dual = 0;                  // M = 16: two 16-query tiles per block (fscan_mx_dual_kernel)
+    int bias = 0;                  // fscan_mx_*: initial value of the accumulators (128 M for tables of signed bytes = 255 levels, else 0)
 };
 
 // MODE 0: top-1, thresholds adapt to the block's running minimum.  MODE 1 / 2: the two passes of top-k (k > 1):
@@ -1469,7 +1492,7 @@ int fastscan_rows(int M, int Ks)
     return 0;
 }
 bool fastscan_supported(int M, int Ks) { return fastscan_rows(M, Ks) != 0; }
-int fastscan_max_sum(int M) { return M * kFsLevels; }
+int fastscan_max_sum(int M, int levels) { return M * (levels > 0 ? levels : kFsLevels); }
 
 // shapes with the conflict-free rotated layout: whole groups of G = 16 subspaces (the lanes of a ds_read_b128 service
 // group) and Ks = 256 (the (half, ks, slot) lookup value fits 16 bits)
@@ -1674,9 +1697,9 @@ template <int PENDING> __device__ __forceinline__ void fs_mx_wait(v4i_t (&r)[4])
 {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(PENDING));
 }
-template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce(const v4i_t (&r)[T], const v4i_t &spa, int spidx)
+template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce(const v4i_t (&r)[T], const v4i_t &spa, int spidx, int bias = 0)
 {
-    v4i_t acc = {0, 0, 0, 0};
+    v4i_t acc = {bias, bias, bias, bias};
 #pragma unroll
     for (int t = 0; t < T; t += 2) {
         const v8i_t b = __builtin_shufflevector(r[t], r[t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -1803,8 +1826,11 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     constexpr size_t lut_bytes = (size_t) M * 256 * QR;
     uint32_t *s_thr = reinterpret_cast<uint32_t *>(smem + lut_bytes);                       // [16]
     uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(smem + lut_bytes + 64);                  // [16] staged, [16] global bases
-    unsigned long long *s_lcand = reinterpret_cast<unsigned long long *>(smem + lut_bytes + 64 + QR * 8);
+    uint32_t *s_slk = reinterpret_cast<uint32_t *>(smem + lut_bytes + 64 + QR * 8);          // [16] the queries' slacks (the candidate path
+                                                                                             //      read them from global memory: ~1 us each)
+    unsigned long long *s_lcand = reinterpret_cast<unsigned long long *>(smem + lut_bytes + 64 + QR * 8 + 64);
     {
+        if (tid < 16) s_slk[tid] = (tid < QR && tile * QR + tid < p.B) ? (uint32_t) p.slack[tile * QR + tid] : 0u;
         if (QR == 16 && p.quarter) {
             // four quarter tables (one dword = the levels of four queries for one (m, ks)) -> 16-byte rotated rows.  Lane =
             // (slot = m mod 16, quarter): the 64 lanes of a wave write the 64 dwords of 16 consecutive rows (one ks, one half) --
@@ -1862,7 +1888,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
         const int b = tile * QR + q;
         if (b >= p.B) return;
         if constexpr (MODE == 0) {
-            const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
+            const uint32_t nt = fs_thr_of(a, s_slk[q]);
             if (nt < t) {
                 atomicMin(&s_thr[q], nt);
                 atomicMin(&p.gthr[b], nt);       // let the other chunks of this tile prune with it too
@@ -1911,7 +1937,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
             }
             const int b = tile * QR + 4 * gq + r;
             if (col == 0 && 4 * gq + r < QR && v != 0x7fffffff && b < p.B)
-                atomicMin(&s_thr[4 * gq + r], fs_thr_of((uint32_t) v, (uint32_t) p.slack[b]));
+                atomicMin(&s_thr[4 * gq + r], fs_thr_of((uint32_t) v, s_slk[4 * gq + r]));
         }
     };
     auto load_thr = [&]() { return *reinterpret_cast<const v4i_t *>(s_thr + 4 * gq); };
@@ -1936,7 +1962,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
         if constexpr (QR == 16) {
             v4i_t r[T];
             fs_mx_issue<T>(w, C, r);
-            acc = fs_mx_reduce<T>(r, spa, spidx);
+            acc = fs_mx_reduce<T>(r, spa, spidx, p.bias);
         } else {
             acc = fs_mx_group8_slow(w, C, spa, spidx);
         }
@@ -1974,7 +2000,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     if (ntrip > 0) {
         // a zero accumulator kept in registers: the matrix instruction accumulates in place, and built from a literal the
         // compiler clears it with six moves per group instead of two
-        v4i_t zero4 = {0, 0, 0, 0};
+        v4i_t zero4 = {p.bias, p.bias, p.bias, p.bias};       // (128 M when the table bytes are signed: see qlut_fused_kernel)
         asm volatile("" : "+v"(zero4));
         // Per wave the groups form one sequence g = 4 * trip + j.  Two register sets of T rows alternate (even / odd groups);
         // while group g runs through the matrix core, the rows of g + 1 are in flight and those of g + 2 are being issued into
@@ -2174,8 +2200,10 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
     const int qbase = tile2 * NQ;
     uint32_t *s_thr = reinterpret_cast<uint32_t *>(smem + lut_bytes);                       // [32]
     uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(smem + lut_bytes + NQ * 4);              // [32] staged, [32] global bases
-    unsigned long long *s_lcand = reinterpret_cast<unsigned long long *>(smem + lut_bytes + NQ * 4 + NQ * 8);
+    uint32_t *s_slk = reinterpret_cast<uint32_t *>(smem + lut_bytes + NQ * 4 + NQ * 8);      // [32] the queries' slacks
+    unsigned long long *s_lcand = reinterpret_cast<unsigned long long *>(smem + lut_bytes + NQ * 4 + NQ * 8 + NQ * 4);
     {
+        if (tid < NQ) s_slk[tid] = (qbase + tid < p.B) ? (uint32_t) p.slack[qbase + tid] : 0u;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t tile = 2 * (int64_t) tile2 + u;
@@ -2235,7 +2263,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
         const int b = qbase + q;
         if (b >= p.B) return;
         if constexpr (MODE == 0) {
-            const uint32_t nt = fs_thr_of(a, (uint32_t) p.slack[b]);
+            const uint32_t nt = fs_thr_of(a, s_slk[q]);
             if (nt < t) {
                 atomicMin(&s_thr[q], nt);
                 atomicMin(&p.gthr[b], nt);
@@ -2280,7 +2308,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
                 v = o < v ? o : v;
             }
             const int q = qoff + 4 * gq + r, b = qbase + q;
-            if (col == 0 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[q], fs_thr_of((uint32_t) v, (uint32_t) p.slack[b]));
+            if (col == 0 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[q], fs_thr_of((uint32_t) v, s_slk[q]));
         }
     };
     auto adopt = [&](bool first) {
@@ -2304,7 +2332,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             const uint32_t addr = __builtin_amdgcn_perm(C[t], w, fs_mx_sel(t & 3));
             r[t] = *(fs_lds_row_t) (uintptr_t) addr;
         }
-        v4i_t accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+        v4i_t accA = {p.bias, p.bias, p.bias, p.bias}, accB = accA;
 #pragma unroll
         for (int t = 0; t < 4; t += 2) {
             const v8i_t ba = __builtin_shufflevector(r[t], r[t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -2340,7 +2368,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
     const int ntrip = (MODE == 1) ? (full + step - 1) / step : full;
     auto trip_of = [&](int k) { return (MODE == 0) ? (k + 1 < full ? k + 1 : 0) : k * step; };
     if (ntrip > 0) {
-        v4i_t zero4 = {0, 0, 0, 0};
+        v4i_t zero4 = {p.bias, p.bias, p.bias, p.bias};
         asm volatile("" : "+v"(zero4));
         const W *pw = fc + (size_t) wave * 4 * 64;
         auto trip_ptr = [&](int k) { return pw + (size_t) trip_of(k < ntrip ? k : ntrip - 1) * 64 * 64; };
@@ -2427,7 +2455,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
 
 template <int MODE> static hipError_t launch_fscan_mx_dual_t(const FsArgs &a, int chunks, hipStream_t st)
 {
-    const size_t tab = (size_t) 2 * 16 * 256 * 16 + 32 * 4 + 32 * 8;
+    const size_t tab = (size_t) 2 * 16 * 256 * 16 + 32 * 4 + 32 * 8 + 32 * 4;
     FsArgs b = a;
     b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) 32 * 8));
     const size_t smem = tab + (size_t) 32 * 8 * b.lcap;
@@ -2440,7 +2468,7 @@ template <int MODE> static hipError_t launch_fscan_mx_dual_t(const FsArgs &a, in
 
 template <int T, int MODE, int QR = 16> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
-    const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8;
+    const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8 + 64;
     FsArgs b = a;
     b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) QR * 8));
     const size_t smem = tab + (size_t) QR * 8 * b.lcap;
@@ -2480,7 +2508,7 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter, int dual)
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter, int dual, int levels)
 {
     // d_codes: formatted lookups (launch_fcodes_format, same `mx`) for fs_rot_supported shapes, the plain codes otherwise
     if (B == 0 || n_codes == 0) return hipSuccess;
@@ -2488,6 +2516,7 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     FsArgs a;
     a.quarter = quarter;
     a.dual = (dual && mx && M == 16 && rot) ? 1 : 0;
+    a.bias = levels > 127 ? 128 * M : 0;
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;

@@ -156,16 +156,16 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter = 0, int dual = 0);
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter = 0, int dual = 0, int levels = 63);
 // queries per block of the filter scan: 32 when the M = 16 shape runs two tiles per block (option scan_dual), else fastscan_rows()
 int fscan_queries_per_block(int M, int Ks, int mx, int dual);
-int fastscan_max_sum(int M);
+int fastscan_max_sum(int M, int levels = 0);      // largest quantised sum: M x levels (0 = the default 63)
 // round 3: the tables of the matrix-core filter in ONE launch (quarter tables, d_lut_or_null = also the exact fp32 table), and
 // the top-1 re-rank that needs no table in global memory
 bool qlut_fused_supported(int M, int Ks, int Ds, int mx);
 size_t qlut_fused_bytes(int64_t B, int M);
 hipError_t launch_qlut_fused(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ds, float *d_lut_or_null,
-                             uint32_t *d_qlut4, int32_t *d_slack, unsigned int *d_cand_cnt, uint32_t *d_gthr, hipStream_t st);
+                             uint32_t *d_qlut4, int32_t *d_slack, unsigned int *d_cand_cnt, uint32_t *d_gthr, int levels, hipStream_t st);
 bool rerank_direct_supported(int M, int Ks, int Ds);
 hipError_t launch_rerank_top1_direct(const uint8_t *d_codes, int64_t n_codes, int M, int Ds, const float *d_queries,
                                      const float *d_codewords, const int32_t *d_slack, const unsigned long long *d_cand,
