@@ -189,7 +189,9 @@ def profile_table(name):
 
 
 def filter_kernel_name(scan_mx, M):
-    return "fscan_mx_kernel" if (scan_mx and M in (16, 32, 64)) else "fscan_kernel"
+    if scan_mx and M == 16:
+        return "fscan_mx_dual_kernel"          # two 16-query tiles per block (engine option scan_dual, default on)
+    return "fscan_mx_kernel" if (scan_mx and M in (32, 64)) else "fscan_kernel"
 
 
 def workload_key(workload, scan_mode, scan_mx, M, n_scanned, batch, topk):

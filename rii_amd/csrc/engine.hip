@@ -1742,7 +1742,7 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
     } else if (k == "fused_tables") {
         e->fused_tables = value ? 1 : 0;
     } else if (k == "table_levels") {
-        if (value != 63 && value != 255) return set_err(RII_ERR_INVALID, "table_levels must be 63 or 255");
+        if (value != 63 && value != 127 && value != 255) return set_err(RII_ERR_INVALID, "table_levels must be 63, 127 or 255");
         e->table_levels = (int) value;
     } else if (k == "scan_order") {
         e->scan_order = value ? 1 : 0;

@@ -828,12 +828,14 @@ hipError_t launch_qlut_fused(const float *d_queries, int64_t B, const float *d_c
     if (B == 0) return hipSuccess;
     const dim3 grid((unsigned) ((B + 15) / 16), 4), block(1024);
 #define RII_QF(VEC, MW, LV) hipLaunchKernelGGL((qlut_fused_kernel<VEC, MW, LV>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr)
-    if (levels != 63 && levels != 255) return hipErrorInvalidValue;
-    if (M == 32 && Ds == 4) { if (levels == 255) RII_QF(float4, 2, 255); else RII_QF(float4, 2, 63); }
-    else if (M == 16 && Ds == 4) { if (levels == 255) RII_QF(float4, 1, 255); else RII_QF(float4, 1, 63); }
-    else if (M == 32 && Ds == 2) { if (levels == 255) RII_QF(float2, 2, 255); else RII_QF(float2, 2, 63); }
-    else if (M == 16 && Ds == 2) { if (levels == 255) RII_QF(float2, 1, 255); else RII_QF(float2, 1, 63); }
+    if (levels != 63 && levels != 127 && levels != 255) return hipErrorInvalidValue;
+#define RII_QF3(VEC, MW) { if (levels == 255) RII_QF(VEC, MW, 255); else if (levels == 127) RII_QF(VEC, MW, 127); else RII_QF(VEC, MW, 63); }
+    if (M == 32 && Ds == 4) RII_QF3(float4, 2)
+    else if (M == 16 && Ds == 4) RII_QF3(float4, 1)
+    else if (M == 32 && Ds == 2) RII_QF3(float2, 2)
+    else if (M == 16 && Ds == 2) RII_QF3(float2, 1)
     else return hipErrorInvalidValue;
+#undef RII_QF3
 #undef RII_QF
     return hipGetLastError();
 }

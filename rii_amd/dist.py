@@ -45,13 +45,15 @@ def shard_range(N, rank, world_size):
 
 def _comm_device(like=None):
     """Where the exchanged tensors live: HBM under "nccl"; host memory under "gloo"; with no process group at all (a single
-    engine) wherever the caller's tensor already is."""
+    engine) wherever the caller's tensor already is (default: the current GPU when there is one)."""
     if dist.is_available() and dist.is_initialized():
         if dist.get_backend() == "nccl":
             return torch.device("cuda", torch.cuda.current_device())
         return torch.device("cpu")
     if isinstance(like, torch.Tensor):
         return like.device
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
 
 
@@ -207,7 +209,13 @@ def allgather_query_shards(local_ids, local_dists, group=None, local_counts=None
 
 
 def _is_device_engine(engine):
-    return hasattr(engine, "query_linear_dev") and _comm_device().type == "cuda"
+    """Device-resident path: a HIP engine whose exchange tensors live in HBM -- under "nccl", or with no process group at all (a
+    single engine on its own GPU); under "gloo" the collectives run on host tensors and the engine's host-pointer surface is used."""
+    if not hasattr(engine, "query_linear_dev"):
+        return False
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_backend() == "nccl"
+    return torch.cuda.is_available()
 
 
 class DbShardedIndex(object):

@@ -677,6 +677,38 @@ def test_bench_self_launch_command_line(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
 
 
+@pytest.mark.gpu
+def test_single_engine_without_process_group_and_bench_deep():
+    """No process group at all (one engine, one GPU): the sharding classes stay device-resident (engine -> record -> merge kernel),
+    and `bench.py --workload deep` (configs[4] shape through DbShardedIndex) runs as typed at N = 1."""
+    import json
+    import subprocess
+    import sys
+    from rii_amd import RiiGpu
+    from rii_amd import dist as rd
+    assert not dist.is_initialized()
+    M, Ks, Ds, N = 16, 256, 6, 5003
+    cw, codes, qs = make_problem(8, M, Ks, Ds, N, "unit", dup=300)
+    g = RiiGpu(cw, False, simd_arch="avx512", device=0)
+    g.add_codes(codes, False)
+    full = _OracleBatch(cw, codes)
+    idx = rd.DbShardedIndex(g, 0, N)
+    Q = torch.from_numpy(qs[:9]).cuda()
+    for topk in (1, 4, 40):
+        gi, gd = idx.query_linear_batch(Q, topk)
+        wi, wd = full.query_linear_batch(qs[:9], topk)
+        assert gi.is_cuda and np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+    gi, gd = rd.QueryShardedIndex(g).query_linear_batch(Q, 3)
+    assert gi.is_cuda and np.array_equal(gi.cpu().numpy(), full.query_linear_batch(qs[:9], 3)[0])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "deep", "--n-base", "2000000", "--steps", "3",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["kernel"] == "fscan_mx_dual_kernel" and 0 < line["roofline"]["frac"] <= 1.0
+
+
 def test_merge_topk_canonical_rule():
     from rii_amd.dist import merge_topk
     ids = torch.tensor([[7, 3, 9, 1, 5]], dtype=torch.int64)

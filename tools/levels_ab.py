@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""A/B of the fused tables' quantisation levels (engine option table_levels: 63 / 127 / 255) on the bench shape: step time, kernel
+times, candidates per query; ids must not change."""
+import sys, json, time, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rii_amd import RiiGpu
+from rii_amd import bench_data as bd
+dev = torch.device("cuda", 0)
+N, B, M = 1_000_000, 1024, 32
+base, train, query = bd.sift_like(n_base=N, n_train=100_000, n_query=B)
+cw = bd.train_pq(train, M, 256, iters=10, seed=123, device=dev)
+codes = bd.encode_pq(base, cw, device=dev)
+eng = RiiGpu(cw, False, device=0); eng.add_codes(codes, False)
+q = torch.from_numpy(np.ascontiguousarray(query[:B])).to(dev)
+oi = torch.empty((B, 1), dtype=torch.int64, device=dev); od = torch.empty((B, 1), dtype=torch.float32, device=dev)
+st = torch.cuda.Stream(); torch.cuda.set_stream(st)
+def step(b=B): eng.query_linear_dev(q.data_ptr(), b, 1, 0, 0, oi.data_ptr(), od.data_ptr(), st.cuda_stream)
+out, ref = {}, None
+for lv in (63, 127, 255, 63, 127, 255):
+    for b in (1024, 128):
+        eng.set_option("table_levels", lv)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.3: step(b); torch.cuda.synchronize()
+        cand = eng.get_option("cand_total")
+        eng.set_option("timing", 1); eng.timing_reset()
+        K = 50
+        for _ in range(K): step(b)
+        torch.cuda.synchronize()
+        tm = {k: round(eng.timing_read(k)[0] / K, 5) for k in ("scan", "lut", "rerank")}
+        eng.set_option("timing", 0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(K): step(b)
+        torch.cuda.synchronize(); el0 = (time.perf_counter() - t0) / K
+        ids = oi[:b].cpu().numpy().copy()
+        if ref is None: ref = ids
+        out.setdefault("levels%d_B%d" % (lv, b), []).append({"ms_plain": round(el0 * 1e3, 5), "kernels_ms": tm, "cand_per_query": cand / b, "ids_equal": bool((ids == ref[:b]).all())})
+print(json.dumps(out))
