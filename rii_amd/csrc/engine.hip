@@ -148,7 +148,10 @@ struct rii_engine : ScratchSet {
     int cand_cap = 4096;        // candidate slots per query for the re-rank stage (lower bound; grows for small batches)
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
-    int table_levels = 255;     // option "table_levels": 63 or 255 quantisation levels of the fused tables (qlut_fused_kernel)
+    // option "table_levels": quantisation levels of the fused tables (qlut_fused_kernel).  Measured at the bench shape (tools/levels_ab.py,
+    // profiles/r03_levels_ab.json): 63 -> 124 candidates per query, 127 -> 40, 255 -> 20; the scan itself is 3 % SLOWER with 255 (signed
+    // bytes: more switching in the matrix core under a power-limited clock), so 127 -- non-negative bytes, no bias -- is the default.
+    int table_levels = 127;
     int fused_tables = 1;       // option "fused_tables": 1 = qlut_fused_kernel + table-free top-1 re-rank (round 3), 0 = the two-launch tile path
     int ivf_force_exact = 0;    // tests: the fused kernel flags every query, so the exact LDS kernel answers all of them
     int timing = 0;

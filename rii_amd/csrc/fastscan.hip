@@ -1944,16 +1944,19 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     };
     auto load_thr = [&]() { return *reinterpret_cast<const v4i_t *>(s_thr + 4 * gq); };
     // adopt thresholds published by the blocks scanning the other chunks for the same queries (stale = a few more candidates)
-    auto adopt = [&](bool first) {
-        if (MODE == 0 && tid < QR) {
-            const int b = tile * QR + tid;
+    // `turn`: the wave that does it this time.  The global load stalls the wave that issues it for an L2 round trip (its lookups
+    // in flight are drained by the wait); taking turns spreads that over the 16 waves instead of making wave 0 the block's straggler.
+    auto adopt = [&](bool first, int turn = 0) {
+        const int q = tid & 63;
+        if (MODE == 0 && (tid >> 6) == (turn & 15) && q < QR) {
+            const int b = tile * QR + q;
             if (b < p.B) {
                 const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (first) {
-                    const uint32_t mine = s_thr[tid];
+                    const uint32_t mine = s_thr[q];
                     if (mine < g) atomicMin(&p.gthr[b], mine);
                 }
-                atomicMin(&s_thr[tid], g);
+                atomicMin(&s_thr[q], g);
             }
         }
     };
@@ -2056,7 +2059,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx, zero4);
                 fs_mx_load<S>(q[1], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
-                adopt(false);
+                adopt(false, k + 1);
             }
             fs_mx_wait<0>(ra);            // the rows and lookups fetched past the last trip are never used, but must have landed
             fs_mx_wait<0>(rb);
@@ -2109,7 +2112,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 acc = fs_mx_group8<12>(r, q[0], C, spa, spidx, zero4);          // group 3; refills = next trip's group 0
                 fs_mx_load<0>(q[0], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
-                adopt(false);
+                adopt(false, k + 1);
             }
             fs_mx_wait8<0>(r[0], r[1], r[2], r[3]);       // everything fetched past the last trip has landed
             fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
@@ -2313,16 +2316,17 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             if (col == 0 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[q], fs_thr_of((uint32_t) v, s_slk[q]));
         }
     };
-    auto adopt = [&](bool first) {
-        if (MODE == 0 && tid < NQ) {
-            const int b = qbase + tid;
+    auto adopt = [&](bool first, int turn = 0) {                       // (the waves take turns: see fscan_mx_kernel)
+        const int q = tid & 63;
+        if (MODE == 0 && (tid >> 6) == (turn & 15) && q < NQ) {
+            const int b = qbase + q;
             if (b < p.B) {
                 const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (first) {
-                    const uint32_t mine = s_thr[tid];
+                    const uint32_t mine = s_thr[q];
                     if (mine < g) atomicMin(&p.gthr[b], mine);
                 }
-                atomicMin(&s_thr[tid], g);
+                atomicMin(&s_thr[q], g);
             }
         }
     };
@@ -2420,7 +2424,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             fs_mx_reduce_refill_dual(rb, q[1], C, spa, spidx, zero4, accA, accB);
             fs_mx_load<S>(q[1], pnn);
             if (MODE == 1) { take_min(keepA, accA); take_min(keepB, accB); } else { judge(accA, thrA, n + 48, 0); judge(accB, thrB, n + 48, 16); }
-            adopt(false);
+            adopt(false, k + 1);
         }
         fs_mx_wait<0>(ra);
         fs_mx_wait<0>(rb);

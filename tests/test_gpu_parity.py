@@ -660,9 +660,9 @@ def test_matrix_core_scan_equals_vector_scan(M, Ds):
         out = []
         # (scan_mx, scan_mode, fused_tables, scan_dual): default; vector-ALU filter; exhaustive scan; round 2's two-launch tables;
         # M = 16 with one tile per block instead of two (fscan_mx_kernel<4> instead of fscan_mx_dual_kernel)
-        # last column: quantisation levels of the fused tables (255 = signed bytes, accumulators start at 128 M; default)
-        for mx, mode, ft, dual, lv in ((1, 1, 1, 1, 255), (0, 1, 1, 1, 255), (1, 0, 1, 1, 255), (1, 1, 0, 1, 255), (1, 1, 1, 0, 255),
-                                       (1, 1, 0, 0, 255), (1, 1, 1, 1, 63), (1, 1, 1, 0, 63)):
+        # last column: quantisation levels of the fused tables (127 = default; 255 = signed bytes, accumulators start at 128 M)
+        for mx, mode, ft, dual, lv in ((1, 1, 1, 1, 127), (0, 1, 1, 1, 127), (1, 0, 1, 1, 127), (1, 1, 0, 1, 127), (1, 1, 1, 0, 127),
+                                       (1, 1, 0, 0, 127), (1, 1, 1, 1, 63), (1, 1, 1, 0, 63), (1, 1, 1, 1, 255), (1, 1, 1, 0, 255)):
             g.set_option("scan_mx", mx)
             g.set_option("scan_mode", mode)
             g.set_option("fused_tables", ft)
@@ -673,7 +673,7 @@ def test_matrix_core_scan_equals_vector_scan(M, Ds):
         g.set_option("scan_mode", 1)
         g.set_option("fused_tables", 1)
         g.set_option("scan_dual", 1)
-        g.set_option("table_levels", 255)
+        g.set_option("table_levels", 127)
         a = out[0]
         for o_ in out[1:]:
             assert np.array_equal(a[0], o_[0]) and np.array_equal(a[1], o_[1]), (topk, g.N)
