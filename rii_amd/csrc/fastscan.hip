@@ -913,6 +913,7 @@ struct FsArgs {
     int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
     int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
     int dual = 0;                  // M = 16: two 16-query tiles per block (fscan_mx_dual_kernel)
+    int adopt_rr = 1;              // fscan_mx_*: the waves take turns adopting the other chunks' thresholds (0: wave 0 every trip)
     int bias = 0;                  // fscan_mx_*: initial value of the accumulators (128 M for tables of signed bytes = 255 levels, else 0)
 };
 
@@ -2059,7 +2060,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx, zero4);
                 fs_mx_load<S>(q[1], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
-                adopt(false, k + 1);
+                adopt(false, p.adopt_rr ? k + 1 : 0);
             }
             fs_mx_wait<0>(ra);            // the rows and lookups fetched past the last trip are never used, but must have landed
             fs_mx_wait<0>(rb);
@@ -2112,7 +2113,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 acc = fs_mx_group8<12>(r, q[0], C, spa, spidx, zero4);          // group 3; refills = next trip's group 0
                 fs_mx_load<0>(q[0], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
-                adopt(false, k + 1);
+                adopt(false, p.adopt_rr ? k + 1 : 0);
             }
             fs_mx_wait8<0>(r[0], r[1], r[2], r[3]);       // everything fetched past the last trip has landed
             fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
@@ -2424,7 +2425,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             fs_mx_reduce_refill_dual(rb, q[1], C, spa, spidx, zero4, accA, accB);
             fs_mx_load<S>(q[1], pnn);
             if (MODE == 1) { take_min(keepA, accA); take_min(keepB, accB); } else { judge(accA, thrA, n + 48, 0); judge(accB, thrB, n + 48, 16); }
-            adopt(false, k + 1);
+            adopt(false, p.adopt_rr ? k + 1 : 0);
         }
         fs_mx_wait<0>(ra);
         fs_mx_wait<0>(rb);
@@ -2521,8 +2522,9 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     const bool rot = fs_rot_supported(M, Ks, mx);
     FsArgs a;
     a.quarter = quarter;
-    a.dual = (dual && mx && M == 16 && rot) ? 1 : 0;
+    a.dual = ((dual & 1) && mx && M == 16 && rot) ? 1 : 0;
     a.bias = levels > 127 ? 128 * M : 0;
+    a.adopt_rr = (dual >> 8) & 1;               // (bit 8 of `dual`: engine option adopt_rr)
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
