@@ -178,7 +178,7 @@ struct rii_engine : ScratchSet {
     int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
     int scan_mx = 1;            // option "scan_mx": 1 = rotated shapes scan with fscan_mx_kernel (its own lookup order), 0 = fscan_kernel
-    int adopt_rr = 1;           // option "adopt_rr": the waves of a scan block take turns adopting the shared thresholds
+    int adopt_rr = 0;           // option "adopt_rr": 1 = the waves of a scan block take turns adopting the shared thresholds (measured: no gain at B = 1024, 4 % slower at B = 128: tools/opt_ab.py)
     int scan_dual = 1;          // option "scan_dual": M = 16 keeps two 16-query tiles per scan block (fscan_mx_dual_kernel)
     int64_t scan_cov = 0;       // codes [0, scan_cov) are final (whole windows)
     int64_t scan_N = -1;        // N the order was last completed for

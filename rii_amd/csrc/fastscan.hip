@@ -913,7 +913,7 @@ struct FsArgs {
     int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
     int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
     int dual = 0;                  // M = 16: two 16-query tiles per block (fscan_mx_dual_kernel)
-    int adopt_rr = 1;              // fscan_mx_*: the waves take turns adopting the other chunks' thresholds (0: wave 0 every trip)
+    int adopt_rr = 0;              // fscan_mx_*: 1 = the waves take turns adopting the other chunks' thresholds (0: wave 0 every trip)
     int bias = 0;                  // fscan_mx_*: initial value of the accumulators (128 M for tables of signed bytes = 255 levels, else 0)
 };
 
