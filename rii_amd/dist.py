@@ -67,16 +67,21 @@ class _engine_stream(object):
 
     def __enter__(self):
         dev = torch.cuda.current_device()
+        self.outer = torch.cuda.current_stream()
+        self.direct = self.outer.cuda_stream != 0      # the caller already works on an explicit stream: use it, no fences
+        if self.direct:
+            return self.outer.cuda_stream
         if dev not in _SIDE:
             _SIDE[dev] = torch.cuda.Stream(device=dev)
         self.side = _SIDE[dev]
-        self.outer = torch.cuda.current_stream()
         self.side.wait_stream(self.outer)
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self.side.cuda_stream
 
     def __exit__(self, *exc):
+        if self.direct:
+            return False
         self.ctx.__exit__(*exc)
         self.outer.wait_stream(self.side)
         return False
@@ -586,12 +591,27 @@ class QueryShardedIndex(object):
             q = _as_tensor(Q, torch.float32, dev)[s:e].contiguous()
             t = None if target_ids is None or len(target_ids) == 0 else _as_tensor(target_ids, torch.int64, dev)
             with _engine_stream() as sh:
-                ids = torch.empty((n, topk), dtype=torch.int64, device=dev)
-                d = torch.empty((n, topk), dtype=torch.float32, device=dev)
-                if n:
-                    self.engine.query_linear_dev(q.data_ptr(), n, topk, t.data_ptr() if t is not None else 0,
-                                                 0 if t is None else t.numel(), ids.data_ptr(), d.data_ptr(), sh)
-                out = allgather_query_shards(ids, d, self.group, rows=rows)
+                nmax = int(max(rows))
+                if min(rows) == nmax:
+                    # even split (the usual case): the engine writes ids and distances straight into this rank's record, ONE
+                    # all-gather, and the two outputs are one strided copy each out of the gathered buffer
+                    nid = nmax * topk * 8
+                    rec_bytes = (nmax * topk * 12 + 15) // 16 * 16
+                    rec = torch.empty(rec_bytes, dtype=torch.uint8, device=dev)
+                    if n:
+                        self.engine.query_linear_dev(q.data_ptr(), n, topk, t.data_ptr() if t is not None else 0,
+                                                     0 if t is None else t.numel(), rec.data_ptr(), rec.data_ptr() + nid, sh)
+                    g = _all_gather_bytes(rec, self.group)
+                    wg = g.shape[0]
+                    out = (g[:, :nid].view(torch.int64).reshape(wg * nmax, topk),
+                           g[:, nid:nid + nmax * topk * 4].view(torch.float32).reshape(wg * nmax, topk))
+                else:
+                    ids = torch.empty((n, topk), dtype=torch.int64, device=dev)
+                    d = torch.empty((n, topk), dtype=torch.float32, device=dev)
+                    if n:
+                        self.engine.query_linear_dev(q.data_ptr(), n, topk, t.data_ptr() if t is not None else 0,
+                                                     0 if t is None else t.numel(), ids.data_ptr(), d.data_ptr(), sh)
+                    out = allgather_query_shards(ids, d, self.group, rows=rows)
             return _handoff(*out)
         else:
             Qh = np.asarray(Q)
