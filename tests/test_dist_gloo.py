@@ -709,6 +709,35 @@ def test_single_engine_without_process_group_and_bench_deep():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["kernel"] == "fscan_mx_dual_kernel" and 0 < line["roofline"]["frac"] <= 1.0
 
 
+@pytest.mark.gpu
+def test_bench_default_line_carries_every_baseline_config():
+    """`python bench.py` (default workload, N = 1; sizes cut down for the test): the line keeps the contract's keys and `others` holds
+    every other BASELINE config with its roofline and a reference baseline whose ids match the GPU's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OMP_NUM_THREADS")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--n-base", "200000", "--steps", "3", "--warmup", "1",
+                          "--deep-shard", "400000", "--preheat", "0.02"], env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "others", "preheat", "uninstrumented"):
+        assert key in line, key
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["cpu_baseline"]["ids_match_gpu"] is True
+    assert line["roofline"]["bound"] == "lds-gather" and 0 < line["roofline"]["frac"] <= 1.0 and "counters_from_profiles" in line["roofline"]
+    oth = line["others"]
+    for name in ("subset", "ivf", "subset_ivf", "deep_shard"):
+        o = oth[name]
+        assert o["ms_per_step"] > 0 and o["kernel_ms"] > 0 and 0 < o["roofline"]["frac"] <= 1.0, name
+        assert o["cpu_baseline"]["ids_match_gpu"] is True and o["cpu_baseline"]["queries_compared"] > 0, name
+    assert oth["ivf"]["roofline"]["bound"] == "valu-issue" and oth["deep_shard"]["kernel"] == "fscan_mx_dual_kernel"
+    for name in ("linear", "ivf"):
+        r = oth["readme_n10k"][name]
+        assert r["p50_ms"] > 0 and r["cpu_baseline"]["ids_match_gpu"] is True
+
+
 def test_merge_topk_canonical_rule():
     from rii_amd.dist import merge_topk
     ids = torch.tensor([[7, 3, 9, 1, 5]], dtype=torch.int64)
