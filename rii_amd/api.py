@@ -7,7 +7,7 @@ Structure: the argument policy of a search lives in `_SearchPlan` (one place for
 linear-vs-inverted-index crossover is learnt by `CrossoverModel` (the engine timed like the reference times its CPU path,
 rii/rii.py:403-486 -- same idea, same `threshold(L)` contract: an `np.poly1d`).  Two models are kept: `threshold` (one query
 per call: what `query` experiences, the reference's attribute) and `threshold_batch` (a batch per call: per-query cost is
-~100x lower there and the crossover sits elsewhere), used by `query_batch(method="auto")`.
+~100x lower there and the crossover sits elsewhere), used by `query_batch(method="auto")`; both are fitted by `reconfigure`.
 """
 import copy
 import time
@@ -129,7 +129,9 @@ class Rii(object):
         self.impl_cpp.reconfigure(nlist, iter)
         probes = self.fine_quantizer.decode(self.codes[:min(100, self.N)])
         self.threshold = estimate_best_threshold_function(e=self, queries=probes)
-        self.threshold_batch = None            # learnt on the first query_batch(method="auto") (engines with a batch entry point)
+        self.threshold_batch = None
+        if hasattr(self.impl_cpp, "query_linear_batch"):       # engines with a batch entry point: the batched crossover as well
+            self.threshold_batch = CrossoverModel(self, self.fine_quantizer.decode(self.codes[:min(256, self.N)]), batched=True).fit()
 
     def add_configure(self, vecs, nlist=None, iter=5):
         self.add(vecs=vecs, update_posting_lists=False)

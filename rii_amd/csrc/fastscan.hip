@@ -758,36 +758,37 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
     for (int jj = 0; jj < 4; ++jj)                      // every lane needs its subspaces' minima for the levels
 #pragma unroll
         for (int s_ = 0; s_ < MW; ++s_) lo[jj][s_] = s_lo[jj][m0 + s_];
-    if (threadIdx.x < 4 * 32) {          // 32 lanes per query: range and |lo| + |hi| over the M subspaces
+    double my_dmax = 0.0;
+    float my_delta = 0.f;
+    if (threadIdx.x < 4 * 32) {          // 32 lanes per query: the range over the M subspaces -> step and reciprocal
         const int j = threadIdx.x >> 5, l32 = threadIdx.x & 31;
-        const int64_t b = tile * 16 + quarter * 4 + j;
         float range = 0.f;
-        double dmax = 0.0;
         for (int m = l32; m < M; m += 32) {
             range = fmaxf(range, s_hi[j][m] - s_lo[j][m]);
-            dmax += fabs((double) s_lo[j][m]) + fabs((double) s_hi[j][m]);
+            my_dmax += fabs((double) s_lo[j][m]) + fabs((double) s_hi[j][m]);
         }
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-            range = fmaxf(range, __shfl_xor(range, off));
-            dmax += __shfl_xor(dmax, off);
-        }
-        if (l32 == 0) {
-            float d = range / (float) LEVELS;
-            if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
-            const float delta = d * 1.000001f;
-            s_inv[j] = 1.0f / delta;
-            if (b < B) {                 // the per-query state of the filter stage (see qlut_tile_quant_kernel for the slack)
-                const double eps = (double) M * 1.1920928955078125e-07 * dmax;
-                double sl = (double) M * (1.0 + (LEVELS > 63 ? 2e-4 : 1e-4)) + 2.0 * eps / (double) delta;
-                sl = sl * (1.0 + 1e-9) + 2.0;
-                slack[b] = (sl >= 0.0 && sl < 60000.0) ? (int32_t) sl : 60000;
-                if (cand_cnt) cand_cnt[b] = 0u;
-                if (gthr) gthr[b] = 0xffffffffu;
-            }
-        }
+        for (int off = 16; off > 0; off >>= 1) range = fmaxf(range, __shfl_xor(range, off));
+        float d = range / (float) LEVELS;
+        if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
+        my_delta = d * 1.000001f;
+        if (l32 == 0) s_inv[j] = 1.0f / my_delta;
     }
     __syncthreads();
+    if (threadIdx.x < 4 * 32) {          // the per-query state of the filter stage, OFF the critical path of the other waves (double math)
+        const int j = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+        const int64_t b = tile * 16 + quarter * 4 + j;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) my_dmax += __shfl_xor(my_dmax, off);
+        if (l32 == 0 && b < B) {         // (see qlut_tile_quant_kernel for the slack)
+            const double eps = (double) M * 1.1920928955078125e-07 * my_dmax;
+            double sl = (double) M * (1.0 + (LEVELS > 63 ? 2e-4 : 1e-4)) + 2.0 * eps / (double) my_delta;
+            sl = sl * (1.0 + 1e-9) + 2.0;
+            slack[b] = (sl >= 0.0 && sl < 60000.0) ? (int32_t) sl : 60000;
+            if (cand_cnt) cand_cnt[b] = 0u;
+            if (gthr) gthr[b] = 0xffffffffu;
+        }
+    }
     uint32_t *dst = qlut4 + ((size_t) tile * 4 + quarter) * MK;
 #pragma unroll
     for (int s_ = 0; s_ < MW; ++s_)
