@@ -736,18 +736,20 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         // table built in place (exact fvec_L2sqr order): no global round trip for the common case
         const float *q = p.queries + (p.b0 + bl) * (int64_t) (p.M * p.Ds);
         if constexpr (DS4) {
-            // 8 independent 16-byte codeword loads in flight per thread (the block has nothing else to hide them behind)
+            // 16 independent 16-byte codeword loads in flight per thread (the block has nothing else to hide them behind; this phase
+            // is at the start of the kernel, where few other values are live: 8 in flight meant four dependent L2 round trips for
+            // the M = 32 table, 16 mean two)
             const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
             const float4 *q4 = reinterpret_cast<const float4 *>(q);
-            for (int i0 = tid; i0 < MK; i0 += 256 * 8) {
-                float4 cv[8];
+            for (int i0 = tid; i0 < MK; i0 += 256 * 16) {
+                float4 cv[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int i = i0 + u * 256;
                     cv[u] = i < MK ? cw4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int i = i0 + u * 256;
                     if (i < MK) lds[i] = fvec_l2sqr_ds4v(q4[i / p.Ks], cv[u]);
                 }
