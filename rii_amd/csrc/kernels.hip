@@ -718,7 +718,9 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     int *s_misc = s_cum + (SC + 2);                                                      // [4]: ncand, nv, flag
     int *s_len = s_misc + 4;                                                             // [SC + 2] lengths of the selected lists ...
     int *s_poff = s_len + (SC + 2);                                                      // [SC + 2] ... and their offsets, in visiting order
-    float *s_region = reinterpret_cast<float *>(s_poff + (SC + 2));                      // [nlist] coarse scores; LSEL: later the
+    unsigned long long *s_wsel = reinterpret_cast<unsigned long long *>(                  // [4][kFusedMaxW + 1] the waves' own picks
+        smem + ((reinterpret_cast<unsigned char *>(s_poff + (SC + 2)) - smem + 7) & ~(size_t) 7));
+    float *s_region = reinterpret_cast<float *>(s_wsel + 4 * (kFusedMaxW + 1));           // [nlist] coarse scores; LSEL: later the
     uint32_t *s_cd = reinterpret_cast<uint32_t *>(s_region);                             //   candidates' orderable distances [<= L]
     // top-k > 1: key buffer behind that region (LSEL: p.kcap keys of the final sort; else the streaming buffer), 16-byte aligned
     const int nreg = GDIST ? 0 : p.nlist;
@@ -816,24 +818,41 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             s_sel[c] = c < nlist ? (((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c) : ~0ull;
         rr_bitonic_sort(s_sel, tid, SC);
     }
-    for (int r = 0; r < rounds && rounds <= kFusedMaxW + 1; ++r) {
-        if (tid == 0) s_red[0] = ~0ull;
-        __syncthreads();
-        unsigned long long best = ~0ull;
-        for (int c = tid; c < nlist; c += blockDim.x) {
-            const unsigned long long key =
-                ((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c;
-            if ((r == 0 || key > last) && key < best) best = key;
+    if (rounds <= kFusedMaxW + 1) {
+        // Two levels, two barriers (round 2: w + 1 block-wide arg-min rounds with three barriers each, all of them exposed latency
+        // in a block that has nothing else to run).  (a) Every wave extracts the `rounds` smallest keys among the lists its lanes
+        // own, in ascending order, with wave-wide DPP minima (no LDS, no barrier) -- the w + 1 smallest keys of the block are among
+        // the 4 x rounds found this way; (b) wave 0 extracts the `rounds` smallest of those the same way.
+
+        const int wv = tid >> 6, ln = tid & 63;
+        for (int r = 0; r < rounds; ++r) {
+            unsigned long long best = ~0ull;
+            for (int c = tid; c < nlist; c += blockDim.x) {
+                const unsigned long long key =
+                    ((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c;
+                if ((r == 0 || key > last) && key < best) best = key;
+            }
+            last = wave_min_u64(best);                                         // ~0 when this wave's lists are exhausted
+            if (ln == 0) s_wsel[wv * (kFusedMaxW + 1) + r] = last;
         }
+        __syncthreads();
+        if (wv == 0) {
+            unsigned long long cand[3];                                        // 4 x 33 = 132 keys at most: up to three per lane
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(best, off);
-            best = o < best ? o : best;
+            for (int u = 0; u < 3; ++u) {
+                const int i = ln + 64 * u;                                     // i = wave * rounds + r
+                cand[u] = i < 4 * rounds ? s_wsel[(i / rounds) * (kFusedMaxW + 1) + (i % rounds)] : ~0ull;
+            }
+            unsigned long long prev = 0ull;
+            for (int r = 0; r < rounds; ++r) {
+                unsigned long long best = ~0ull;
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if ((r == 0 || cand[u] > prev) && cand[u] < best) best = cand[u];
+                prev = wave_min_u64(best);
+                if (ln == 0) s_sel[r] = prev;
+            }
         }
-        if ((tid & 63) == 0 && best != ~0ull) atomicMin(&s_red[0], best);
-        __syncthreads();
-        last = s_red[0];
-        if (tid == 0) s_sel[r] = last;
         __syncthreads();
     }
     for (int c = tid; c < (w < nlist ? w : nlist); c += blockDim.x) {      // lengths / offsets of the lists the walk may visit
@@ -1164,7 +1183,7 @@ static int ivf_fused_kcap(int topk)
 static size_t ivf_fused_smem(int M, int Ks, int nlist, int sel_cap, int topk, int64_t L, bool lsel, bool gdist = false)
 {
     const size_t head = (((size_t) M * Ks * sizeof(float) + 15) & ~(size_t) 15) + (size_t) sel_cap * 8 + 16 + (size_t) (sel_cap + 2) * 4 + 16 +
-                        (size_t) (sel_cap + 2) * 8;
+                        (size_t) (sel_cap + 2) * 8 + 8 + (size_t) 4 * (kFusedMaxW + 1) * 8;
     const int64_t nreg = gdist ? 0 : nlist;
     const size_t region = (size_t) (lsel ? std::max<int64_t>(nreg, L) : nreg) * 4 + 32;
     const size_t keys = topk > 1 ? (lsel ? (size_t) ivf_fused_kcap(topk) * 8 : (size_t) (kRrBuf + 2) * 8) : 0;
@@ -1187,7 +1206,7 @@ bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk)
 {
     if (topk + 1 > kRrBuf / 2) return false;
     if (!ivf_fused_gdist(M, Ks, nlist, w, topk)) return true;
-    return w <= kFusedMaxW && ivf_fused_smem(M, Ks, nlist, kFusedMaxW + 2, topk, 0, false, true) <= (size_t) 160 * 1024;
+    return w <= kFusedMaxW && ivf_fused_smem(M, Ks, nlist, ivf_fused_sel_cap(nlist, w), topk, 0, false, true) <= (size_t) 160 * 1024;
 }
 int ivf_fused_sel_cap(int nlist, int64_t w)
 {

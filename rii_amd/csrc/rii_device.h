@@ -141,6 +141,29 @@ __device__ __forceinline__ size_t lut_index(int64_t b, int i, int MK, int QT)
 }
 
 
+// wave-wide minimum of a packed 64-bit key (hi = orderable distance, lo = index) on the DPP path -- row_shr 1, 2, 4, 8 inside each
+// row of 16 lanes, then row_bcast 15 / 31 across the rows: six VALU instructions per 32-bit half and no LDS round trip
+// (__shfl_xor compiles to ds_bpermute_b32).  Returns the minimum in EVERY lane (read back from lane 63).
+__device__ __forceinline__ uint32_t wave_min_u32_l63(uint32_t v)
+{
+#define RII_MIN_STEP(CTRL, ROWS)                                                                              \
+    {                                                                                                         \
+        const uint32_t o = (uint32_t) __builtin_amdgcn_update_dpp((int) 0xffffffffu, (int) v, CTRL, ROWS, 0xf, false); \
+        v = o < v ? o : v;                                                                                    \
+    }
+    RII_MIN_STEP(0x111, 0xf) RII_MIN_STEP(0x112, 0xf) RII_MIN_STEP(0x114, 0xf) RII_MIN_STEP(0x118, 0xf)
+    RII_MIN_STEP(0x142, 0xa) RII_MIN_STEP(0x143, 0xc)
+#undef RII_MIN_STEP
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long key)
+{
+    const uint32_t hi = (uint32_t) (key >> 32);
+    const uint32_t mh = wave_min_u32_l63(hi);
+    const uint32_t ml = wave_min_u32_l63(hi == mh ? (uint32_t) (key & 0xffffffffu) : 0xffffffffu);
+    return ((unsigned long long) mh << 32) | ml;
+}
+
 // ---- block-local streaming top-k support (256 threads): LDS key buffer + bitonic sort ----
 constexpr int kRrBuf = 2048;             // LDS key buffer; supports topk <= kRrBuf / 2
 
