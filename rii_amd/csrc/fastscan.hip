@@ -914,6 +914,7 @@ struct FsArgs {
     int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
     int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
     int dual = 0;                  // M = 16: two 16-query tiles per block (fscan_mx_dual_kernel)
+    int prio = 0;                  // fscan_mx_kernel: 1 = s_setprio 1 for the younger half of the block's waves, 2 = for the older half
     int adopt_rr = 0;              // fscan_mx_*: 1 = the waves take turns adopting the other chunks' thresholds (0: wave 0 every trip)
     int bias = 0;                  // fscan_mx_*: initial value of the accumulators (128 M for tables of signed bytes = 255 levels, else 0)
 };
@@ -2004,6 +2005,8 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     const int step = (MODE == 1) ? p.sample_stride : 1;
     const int ntrip = (MODE == 1) ? (full + step - 1) / step : full;
     auto trip_of = [&](int k) { return (MODE == 0) ? (k + 1 < full ? k + 1 : 0) : k * step; };
+    if (p.prio == 1 && wave >= 8) __builtin_amdgcn_s_setprio(1);        // (experiment: MI355X guide, "static priority for the younger half")
+    if (p.prio == 2 && wave < 8) __builtin_amdgcn_s_setprio(1);
     if (ntrip > 0) {
         // a zero accumulator kept in registers: the matrix instruction accumulates in place, and built from a literal the
         // compiler clears it with six moves per group instead of two
@@ -2526,6 +2529,7 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     a.dual = ((dual & 1) && mx && M == 16 && rot) ? 1 : 0;
     a.bias = levels > 127 ? 128 * M : 0;
     a.adopt_rr = (dual >> 8) & 1;               // (bit 8 of `dual`: engine option adopt_rr)
+    a.prio = (dual >> 9) & 3;                   // (bits 9-10: engine option scan_prio)
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
