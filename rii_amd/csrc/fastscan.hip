@@ -800,8 +800,11 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
                 const int64_t b = tile * 16 + quarter * 4 + jj;
                 uint32_t c = 0u;
                 if (b < B) {
-                    const float x = floorf((t[jj][s_][e] - lo[jj][s_]) * s_inv[jj] + 0.5f);
-                    c = (x >= (float) LEVELS) ? (uint32_t) LEVELS : (x > 0.f ? (uint32_t) x : 0u);
+                    // x >= 1/2 always (t >= lo), so floor = the truncating conversion (which saturates and sends NaN to 0), then one
+                    // clamp: the same level as floorf + a two-sided clamp in half the instructions (this kernel is VALU-bound:
+                    // 1011 instructions per wave, four waves per SIMD)
+                    const float x = (t[jj][s_][e] - lo[jj][s_]) * s_inv[jj] + 0.5f;
+                    c = min(__float2uint_rz(x), (uint32_t) LEVELS);
                 }
                 if (LEVELS > 127) c ^= 0x80u;            // stored as the signed byte (level - 128); dead queries: -128, never judged
                 w |= c << (8 * jj);
@@ -2746,19 +2749,24 @@ __global__ __launch_bounds__(256) void rerank_top1_direct_kernel(RrArgs p, const
     unsigned long long best = ~0ull;
     if (cnt <= (unsigned int) p.cap) {
         const unsigned long long *cand = p.cand + (size_t) b * p.cap;
-        unsigned long long amin = ~0ull;
-        for (unsigned int i = tid; i < cnt; i += blockDim.x) {
-            const unsigned long long a = cand[i] >> 32;
-            amin = a < amin ? a : amin;
-        }
+        // candidates emitted under early (loose) thresholds can be pruned with the final minimum of the quantised sums -- worth a
+        // pass over the list and a barrier only when there is more than one candidate per thread (40 per query at the bench shape)
+        unsigned long long lim = ~0ull;
+        if (cnt > blockDim.x) {
+            unsigned long long amin = ~0ull;
+            for (unsigned int i = tid; i < cnt; i += blockDim.x) {
+                const unsigned long long a = cand[i] >> 32;
+                amin = a < amin ? a : amin;
+            }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(amin, off);
-            amin = o < amin ? o : amin;
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(amin, off);
+                amin = o < amin ? o : amin;
+            }
+            if ((tid & 63) == 0) atomicMin(&red[0], amin);
+            __syncthreads();
+            lim = red[0] + (unsigned long long) (uint32_t) p.slack[b];
         }
-        if ((tid & 63) == 0) atomicMin(&red[0], amin);
-        __syncthreads();
-        const unsigned long long lim = red[0] + (unsigned long long) (uint32_t) p.slack[b];
         for (unsigned int i = tid; i < cnt; i += blockDim.x) {
             const unsigned long long c = cand[i];
             if ((c >> 32) > lim) continue;
