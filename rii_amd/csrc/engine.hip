@@ -178,6 +178,7 @@ struct rii_engine : ScratchSet {
     int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
     int scan_mx = 1;            // option "scan_mx": 1 = rotated shapes scan with fscan_mx_kernel (its own lookup order), 0 = fscan_kernel
+    int warm_groups = 4;        // option "warm_groups" (1..4): groups per wave of a chunk's first trip that seed the thresholds
     int scan_prio = 0;          // option "scan_prio": 1 / 2 = s_setprio 1 for the younger / older half of a scan block's waves (experiment)
     int adopt_rr = 0;           // option "adopt_rr": 1 = the waves of a scan block take turns adopting the shared thresholds (measured: no gain at B = 1024, 4 % slower at B = 128: tools/opt_ab.py)
     int scan_dual = 1;          // option "scan_dual": M = 16 keeps two 16-query tiles per scan block (fscan_mx_dual_kernel)
@@ -648,7 +649,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                     HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
-                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9), e->qlut_levels));
+                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9) | ((e->warm_groups - 1) << 11), e->qlut_levels));
                 }
                 ScopedTimer t(e, "rerank", st);
                 if (!e->lut_valid) {     // no fp32 table was written: distances of the candidates straight from the codebook
@@ -672,7 +673,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride,
-                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9), e->qlut_levels));
+                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9) | ((e->warm_groups - 1) << 11), e->qlut_levels));
             }
             {
                 ScopedTimer t(e, "kth", st);
@@ -683,7 +684,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
-                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9), e->qlut_levels));
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9) | ((e->warm_groups - 1) << 11), e->qlut_levels));
             }
             RII_TRY(tie_list_reset(e, B, st));
             {
@@ -1758,6 +1759,9 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->fc_cov = 0;                  // the formatted lookups are laid out per kernel
     } else if (k == "scan_dual") {
         e->scan_dual = value ? 1 : 0;
+    } else if (k == "warm_groups") {
+        if (value < 1 || value > 4) return set_err(RII_ERR_INVALID, "warm_groups must be 1..4");
+        e->warm_groups = (int) value;
     } else if (k == "scan_prio") {
         e->scan_prio = (int) (value & 3);
     } else if (k == "adopt_rr") {
@@ -1798,6 +1802,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "scan_dual") return e->scan_dual;
     if (k == "adopt_rr") return e->adopt_rr;
     if (k == "scan_prio") return e->scan_prio;
+    if (k == "warm_groups") return e->warm_groups;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;

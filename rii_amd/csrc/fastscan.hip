@@ -917,6 +917,7 @@ struct FsArgs {
     int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
     int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
     int dual = 0;                  // M = 16: two 16-query tiles per block (fscan_mx_dual_kernel)
+    int warm_groups = 4;           // fscan_mx_*: groups per wave of the chunk's first trip whose minima become the first thresholds
     int prio = 0;                  // fscan_mx_kernel: 1 = s_setprio 1 for the younger half of the block's waves, 2 = for the older half
     int adopt_rr = 0;              // fscan_mx_*: 1 = the waves take turns adopting the other chunks' thresholds (0: wave 0 every trip)
     int bias = 0;                  // fscan_mx_*: initial value of the accumulators (128 M for tables of signed bytes = 255 levels, else 0)
@@ -1992,7 +1993,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     if constexpr (MODE == 0) {
         if (full > 0) {
             const v4i_t none = {0, 0, 0, 0};
-            for (int j = 0; j < 4; ++j) slow_group(wave * 4 + j, true, none);
+            for (int j = 0; j < p.warm_groups; ++j) slow_group(wave * 4 + j, true, none);      // (1 .. 4 of the first trip's groups)
         } else {
             tail(true);
         }
@@ -2368,7 +2369,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
     };
     if constexpr (MODE == 0) {
         if (full > 0) {
-            for (int j = 0; j < 4; ++j) slow_group(wave * 4 + j, true);
+            for (int j = 0; j < p.warm_groups; ++j) slow_group(wave * 4 + j, true);
         } else {
             tail(true);
         }
@@ -2533,6 +2534,7 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     a.bias = levels > 127 ? 128 * M : 0;
     a.adopt_rr = (dual >> 8) & 1;               // (bit 8 of `dual`: engine option adopt_rr)
     a.prio = (dual >> 9) & 3;                   // (bits 9-10: engine option scan_prio)
+    a.warm_groups = ((dual >> 11) & 3) + 1;     // (bits 11-12: engine option warm_groups - 1)
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
