@@ -11,6 +11,7 @@ import importlib.util
 import os
 import subprocess
 import sys
+import threading
 
 import numpy as np
 
@@ -119,8 +120,10 @@ def _lib():
         "rii_get_codes": (c_int, [c_vp, u8p]),
         "rii_get_coarse_centers": (c_int, [c_vp, u8p]),
         "rii_get_posting_lists": (c_int, [c_vp, i64p, i32p]),
-        "rii_query_linear": (c_int, [c_vp, f32p, c_i64, c_int, i64p, c_i64, i64p, f32p]),
-        "rii_query_ivf": (c_int, [c_vp, f32p, c_i64, c_int, i64p, c_i64, c_i64, i64p, f32p, i64p]),
+        # the host-pointer query calls take plain addresses: ndarray.ctypes.data_as(POINTER(...)) costs 2.4 us per argument,
+        # a quarter of a one-query call's latency
+        "rii_query_linear": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
+        "rii_query_ivf": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
         "rii_query_linear_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
         "rii_query_ivf_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
         "rii_ivf_list_lengths_dev": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
@@ -203,6 +206,11 @@ def _ptr(a, ct):
     return a.ctypes.data_as(ctypes.POINTER(ct))
 
 
+def _addr(a):
+    """Address of a contiguous ndarray's first element (None for an empty one) for a c_void_p parameter."""
+    return a.ctypes.data if a.size else None
+
+
 def _check(rc):
     if rc != 0:
         msg = _lib().rii_last_error().decode("utf-8", "replace")
@@ -248,6 +256,8 @@ class RiiGpu(object):
         _check(_lib().rii_create(_ptr(cw, ctypes.c_float), M, Ks, Ds, int(verbose), SIMD[self._simd], self._device,
                                  ctypes.byref(h)))
         self._h = h
+        self._D = M * Ds
+        self._tl = threading.local()          # per-thread buffers of the one-query calls
 
     def __del__(self):
         try:
@@ -303,25 +313,22 @@ class RiiGpu(object):
 
     # ---- batched entry points (NEW) ----
     def query_linear_batch(self, queries, topk, target_ids=None):
-        Q = self._as_query_batch(queries, self.M * self.Ds)
+        Q = self._as_query_batch(queries, self._D)
         t = self._as_tids(target_ids)
         B = Q.shape[0]
         ids = np.empty((B, topk), np.int64)
         d = np.empty((B, topk), np.float32)
-        _check(_lib().rii_query_linear(self._h, _ptr(Q, ctypes.c_float), B, int(topk), _ptr(t, ctypes.c_int64), t.size,
-                                       _ptr(ids, ctypes.c_int64), _ptr(d, ctypes.c_float)))
+        _check(_lib().rii_query_linear(self._h, _addr(Q), B, int(topk), _addr(t), t.size, _addr(ids), _addr(d)))
         return ids, d
 
     def query_ivf_batch(self, queries, topk, target_ids, L):
-        Q = self._as_query_batch(queries, self.M * self.Ds)
+        Q = self._as_query_batch(queries, self._D)
         t = self._as_tids(target_ids)
         B = Q.shape[0]
         ids = np.empty((B, topk), np.int64)
         d = np.empty((B, topk), np.float32)
         cnt = np.empty(B, np.int64)
-        _check(_lib().rii_query_ivf(self._h, _ptr(Q, ctypes.c_float), B, int(topk), _ptr(t, ctypes.c_int64), t.size,
-                                    int(L), _ptr(ids, ctypes.c_int64), _ptr(d, ctypes.c_float),
-                                    _ptr(cnt, ctypes.c_int64)))
+        _check(_lib().rii_query_ivf(self._h, _addr(Q), B, int(topk), _addr(t), t.size, int(L), _addr(ids), _addr(d), _addr(cnt)))
         return ids, d, cnt
 
     def query_linear_dev(self, d_queries, B, topk, d_tids, S, d_out_ids, d_out_dists, stream=0):
@@ -349,20 +356,61 @@ class RiiGpu(object):
                                               d_out_dists, d_out_pos, d_out_nloc, d_out_counts, stream or None))
 
     # ---- main.cpp:17-27: one query per call, python lists out ----
-    def query_linear(self, query, topk, target_ids):
+    # The reference is called this way (README.md:84-140), so the wrapper's own cost counts: per-thread staging and output buffers
+    # with their addresses cached (an ndarray's .ctypes costs a microsecond per use), one ctypes call.
+    _SINGLE_MAX_TOPK = 4096
+
+    def _single(self, topk):
+        tl = self._tl
+        try:
+            q = tl.q
+        except AttributeError:
+            qa = np.empty((1, self._D), np.float32)
+            q = tl.q = (qa, qa.ctypes.data)
+            tl.out = {}
+        o = tl.out.get(topk)
+        if o is None:
+            if len(tl.out) >= 32:
+                tl.out.clear()
+            ids, d, cnt = np.empty((1, topk), np.int64), np.empty((1, topk), np.float32), np.empty(1, np.int64)
+            o = tl.out[topk] = (ids, d, cnt, ids.ctypes.data, d.ctypes.data, cnt.ctypes.data)
+        return q, o
+
+    def _single_query(self, query):
         q = np.asarray(query)
         if q.ndim != 1:
             raise ValueError("query must be 1-D")
-        ids, d = self.query_linear_batch(q.reshape(1, -1), topk, target_ids)
-        return ids[0].tolist(), [float(x) for x in d[0]]
+        if q.dtype != np.float32:
+            raise TypeError("query must be float32 (py::arg(\"query\").noconvert(), src/main.cpp:18)")
+        if q.shape[0] != self._D:
+            raise ValueError("queries must have shape (B, D=%d)" % self._D)
+        return q
+
+    def query_linear(self, query, topk, target_ids):
+        q = self._single_query(query)
+        topk = int(topk)
+        if not 1 <= topk <= self._SINGLE_MAX_TOPK:
+            ids, d = self.query_linear_batch(q.reshape(1, -1), topk, target_ids)
+            return ids[0].tolist(), d[0].tolist()
+        t = self._as_tids(target_ids)
+        (qa, qp), (ids, d, _, pi, pd, _) = self._single(topk)
+        qa[0] = q
+        _check(_lib().rii_query_linear(self._h, qp, 1, topk, _addr(t), t.size, pi, pd))
+        return ids[0].tolist(), d[0].tolist()
 
     def query_ivf(self, query, topk, target_ids, L):
-        q = np.asarray(query)
-        if q.ndim != 1:
-            raise ValueError("query must be 1-D")
-        ids, d, cnt = self.query_ivf_batch(q.reshape(1, -1), topk, target_ids, L)
+        q = self._single_query(query)
+        topk = int(topk)
+        if not 1 <= topk <= self._SINGLE_MAX_TOPK:
+            ids, d, cnt = self.query_ivf_batch(q.reshape(1, -1), topk, target_ids, L)
+            n = int(cnt[0])
+            return ids[0, :n].tolist(), d[0, :n].tolist()
+        t = self._as_tids(target_ids)
+        (qa, qp), (ids, d, cnt, pi, pd, pc) = self._single(topk)
+        qa[0] = q
+        _check(_lib().rii_query_ivf(self._h, qp, 1, topk, _addr(t), t.size, int(L), pi, pd, pc))
         n = int(cnt[0])
-        return ids[0, :n].tolist(), [float(x) for x in d[0, :n]]
+        return ids[0, :n].tolist(), d[0, :n].tolist()
 
     def dtable(self, queries):
         Q = self._as_query_batch(np.atleast_2d(queries), self.M * self.Ds)

@@ -178,6 +178,7 @@ struct rii_engine : ScratchSet {
     int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
     int scan_mx = 1;            // option "scan_mx": 1 = rotated shapes scan with fscan_mx_kernel (its own lookup order), 0 = fscan_kernel
+    int small_topk = 1;         // option "small_topk": a small batch over a small index in one launch after the tables (smalltopk.hip)
     int warm_groups = 4;        // option "warm_groups" (1..4): groups per wave of a chunk's first trip that seed the thresholds
     int scan_prio = 0;          // option "scan_prio": 1 / 2 = s_setprio 1 for the younger / older half of a scan block's waves (experiment)
     int adopt_rr = 0;           // option "adopt_rr": 1 = the waves of a scan block take turns adopting the shared thresholds (measured: no gain at B = 1024, 4 % slower at B = 128: tools/opt_ab.py)
@@ -828,6 +829,18 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
         return RII_OK;
     }
     if (e->QT == 0) return query_linear_wide(e, d_queries, B, topk, S ? d_tids : nullptr, S, d_out_ids, d_out_dists, st);
+    {
+        // small index, small batch (the reference's README pattern: one query per call, N ~ 10^4, topk = 3): the exact
+        // distances of all codes of a query fit LDS -- tables, selection and the tie order in ONE launch (smalltopk.hip)
+        const int64_t n_codes = S ? S : e->N;
+        if (e->small_topk && B < e->fast_min_batch && small_topk_supported(e->M, e->Ks, n_codes, topk)) {
+            RII_TRY(build_lut(e, d_queries, B, st, false, 1));
+            ScopedTimer t(e, "scan", st, true);
+            HIP_TRY(launch_small_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, e->s_lut.as<float>(), B, topk, S ? d_tids : nullptr,
+                                      d_out_ids, d_out_dists, st));
+            return RII_OK;
+        }
+    }
     {
         const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
         RII_TRY(build_lut(e, d_queries, B, st, !small_top1, small_top1 ? exact_tile_for(e, B, topk) : 0, false, /*need_fp32=*/topk > 1));
@@ -1759,6 +1772,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->fc_cov = 0;                  // the formatted lookups are laid out per kernel
     } else if (k == "scan_dual") {
         e->scan_dual = value ? 1 : 0;
+    } else if (k == "small_topk") {
+        e->small_topk = value ? 1 : 0;
     } else if (k == "warm_groups") {
         if (value < 1 || value > 4) return set_err(RII_ERR_INVALID, "warm_groups must be 1..4");
         e->warm_groups = (int) value;
@@ -1803,6 +1818,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "adopt_rr") return e->adopt_rr;
     if (k == "scan_prio") return e->scan_prio;
     if (k == "warm_groups") return e->warm_groups;
+    if (k == "small_topk") return e->small_topk;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;

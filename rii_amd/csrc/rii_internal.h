@@ -231,6 +231,11 @@ hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, in
                              float *d_out_dists, int64_t *d_out_payload, hipStream_t st, const int64_t *id_offsets = nullptr,
                              int tie_cols = 0, int32_t *d_out_tie = nullptr, int32_t *d_out_any = nullptr);
 
+// smalltopk.hip: a small batch over a small index, one launch (tables in s_lut, plain layout)
+bool small_topk_supported(int M, int Ks, int64_t n, int topk);
+hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int64_t B, int topk,
+                             const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st);
+
 // widetab.hip: shapes whose one-query table does not fit LDS (lut_tile_for() == 0): tables stay in global memory
 hipError_t launch_scan_wide(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, const int64_t *d_remap,
                             int b0, int bc, unsigned long long *d_keys, hipStream_t st);

@@ -1,0 +1,249 @@
+// smalltopk.hip -- QueryLinear (src/rii.h:195-242) for a SMALL index and a SMALL batch, in one launch after the tables (gfx950, round 3).
+//
+// The reference's own usage pattern is one query per call on an index of ~10^4 codes (README.md:84-140: N = 10 000, topk = 3).  The
+// batched top-k path spends eight launches there (tables, two filter passes, k-th threshold, re-rank, three tie-order kernels): 90 us
+// per call against 97 us for the reference on one CPU core.  Here one block per query holds the query's exact table AND the exact
+// distance of every code, in index order, in LDS -- the reference's `scores` array -- and
+//   1. bounds the (k+1)-th smallest distance from above with a 256-bin histogram of the occupied range (refined bin by bin only
+//      while more than 2048 keys lie under the bound), sorts the few keys up to it under (dist, id);
+//   2. if no two of the k+1 smallest distances are bit-equal that IS std::partial_sort's answer;
+//   3. else one wave replays std::partial_sort (rii_device.h: wh_partial_sort) over the array itself -- the library's algorithm on the
+//      library's input, move for move.
+// n <= (160 KiB - table - 19.5 KiB) / 8 codes (13 800 at M = 32, Ks = 256), batches below the filter's crossover (fast_min_batch).
+#include "rii_internal.h"
+#include "rii_device.h"
+#include <algorithm>
+
+namespace riiamd {
+
+constexpr int kStThreads = 1024;
+constexpr int kStBuf = 2048;                 // keys up to the bound that are sorted (more: exact ties galore -> replay)
+constexpr int kStRank = 256;                 // up to this many keys are sorted by counting
+
+struct SmallArgs {
+    const uint8_t *codes; int64_t n; int M, Ks;
+    const float *lut;                        // plain [b][M * Ks]
+    const int64_t *remap;                    // subset search: index i stands for the code remap[i] (ids translated on output), or NULL
+    int topk;
+    int64_t *out_ids; float *out_dists;
+};
+
+// ascending bitonic sort of n (a power of two) 64-bit keys in LDS by all threads of the block
+__device__ __forceinline__ void st_bitonic(unsigned long long *buf, int tid, int n)
+{
+    for (int size = 2; size <= n; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < n / 2; t += kStThreads) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool up = ((i & size) == 0);
+                const unsigned long long x = buf[i], y = buf[j];
+                if ((x > y) == up) { buf[i] = y; buf[j] = x; }
+            }
+        }
+    __syncthreads();
+}
+
+// one code row of NV * 16 bytes in registers; the sum in m order (RiiCpp::ADist, src/rii.h:386-394)
+template <int NV>
+__device__ __forceinline__ float st_adist(const float *lds, const uint4 (&w)[NV], int Ks)
+{
+    float d = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const uint32_t x[4] = {w[v].x, w[v].y, w[v].z, w[v].w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d = __fadd_rn(d, lds[(v * 16 + j) * Ks + ((x[j >> 2] >> (8 * (j & 3))) & 0xffu)]);
+    }
+    return d;
+}
+
+// NV > 0: M == 16 * NV, code rows loaded as NV 16-byte words, two codes per trip (the loads of both in flight before the first
+// lookup: one block on one CU is latency-bound).  NV == 0: any M.
+template <int NV>
+__global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int MK = p.M * p.Ks, tid = threadIdx.x, lane = tid & 63, n = (int) p.n, k = p.topk;
+    float *lds = reinterpret_cast<float *>(smem);
+    pq64_t *s_key = reinterpret_cast<pq64_t *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));     // [n] (distance, index), index order
+    unsigned long long *s_buf = s_key + n;                                                           // [kStBuf] keys up to the bound
+    unsigned long long *s_out = s_buf + kStBuf;                                                      // [kStRank] rank-sorted
+    unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_out + kStRank);                        // [256]
+    unsigned int *s_ctl = s_hist + 256;                                                              // [8]
+    const int64_t b = blockIdx.x;
+    {
+        const float *src = p.lut + (size_t) b * MK;
+        if ((MK & 3) == 0) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(lds);
+            for (int i = tid; i < MK / 4; i += kStThreads) d4[i] = s4[i];
+        } else {
+            for (int i = tid; i < MK; i += kStThreads) lds[i] = src[i];
+        }
+        if (tid == 0) { s_ctl[0] = 0xffffffffu; s_ctl[1] = 0u; s_ctl[5] = 0u; }
+    }
+    __syncthreads();
+    uint32_t umin = 0xffffffffu, umax = 0u;
+    if constexpr (NV > 0) {
+        for (int i = tid; i < n; i += 2 * kStThreads) {
+            const int i2 = i + kStThreads < n ? i + kStThreads : i;
+            const int64_t r1 = p.remap ? p.remap[i] : (int64_t) i, r2 = p.remap ? p.remap[i2] : (int64_t) i2;
+            const uint4 *row1 = reinterpret_cast<const uint4 *>(p.codes + (size_t) r1 * (NV * 16));
+            const uint4 *row2 = reinterpret_cast<const uint4 *>(p.codes + (size_t) r2 * (NV * 16));
+            uint4 w1[NV], w2[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { w1[v] = row1[v]; w2[v] = row2[v]; }
+            const pq64_t e1 = pq64_make(st_adist<NV>(lds, w1, p.Ks), (uint32_t) i);
+            const pq64_t e2 = pq64_make(st_adist<NV>(lds, w2, p.Ks), (uint32_t) i2);
+            s_key[i] = e1;
+            s_key[i2] = e2;                            // i2 == i past the end: the same key again
+            const uint32_t u1 = (uint32_t) (e1 >> 32), u2 = (uint32_t) (e2 >> 32);
+            umin = u1 < umin ? u1 : umin; umin = u2 < umin ? u2 : umin;
+            umax = u1 > umax ? u1 : umax; umax = u2 > umax ? u2 : umax;
+        }
+    } else {
+        for (int i = tid; i < n; i += kStThreads) {
+            const uint8_t *code = p.codes + (size_t) (p.remap ? p.remap[i] : (int64_t) i) * p.M;
+            const pq64_t e = pq64_make(exact_adist(lds, code, p.M, p.Ks), (uint32_t) i);              // RiiCpp::ADist, m order
+            s_key[i] = e;
+            const uint32_t u = (uint32_t) (e >> 32);
+            umin = u < umin ? u : umin;
+            umax = u > umax ? u : umax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t a = (uint32_t) __shfl_xor((int) umin, off), c = (uint32_t) __shfl_xor((int) umax, off);
+        umin = a < umin ? a : umin;
+        umax = c > umax ? c : umax;
+    }
+    if (lane == 0) { atomicMin(&s_ctl[0], umin); atomicMax(&s_ctl[1], umax); }
+    __syncthreads();
+    // ---- a bound T with k+1 <= #{distance <= T} <= kStBuf: 256-bin histograms over the occupied range, refined bin by bin
+    //      (typically ONE pass: the bin holding the (k+1)-th smallest of 10^4 distances has a handful of keys below it) ----
+    const uint32_t k1 = (uint32_t) (k + 1 < n ? k + 1 : n);
+    uint32_t lo = s_ctl[0], T;
+    int shift;
+    {
+        const uint32_t span = s_ctl[1] - lo;
+        const int bits = span ? 32 - __clz((int) span) : 0;
+        shift = bits > 8 ? bits - 8 : 0;
+    }
+    uint32_t below = 0u;                              // keys under lo
+    for (;;) {
+        __syncthreads();
+        if (tid < 256) s_hist[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n; i += kStThreads) {
+            const uint32_t u = (uint32_t) (s_key[i] >> 32);
+            if (u >= lo && ((u - lo) >> shift) < 256u) atomicAdd(&s_hist[(u - lo) >> shift], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t c0 = s_hist[4 * lane], c1 = s_hist[4 * lane + 1], c2 = s_hist[4 * lane + 2], c3 = s_hist[4 * lane + 3];
+            const uint32_t sum = c0 + c1 + c2 + c3;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t) __shfl_up((int) incl, off);
+                if (lane >= off) incl += t;
+            }
+            const uint32_t need = k1 - below, excl = incl - sum;
+            if (excl < need && need <= incl) {        // exactly one lane: the pass's keys number at least `need`
+                uint32_t before = excl, cnt = c0;
+                int bin = 4 * lane;
+                if (before + cnt < need) { before += cnt; cnt = c1; ++bin; }
+                if (before + cnt < need) { before += cnt; cnt = c2; ++bin; }
+                if (before + cnt < need) { before += cnt; cnt = c3; ++bin; }
+                s_ctl[2] = (uint32_t) bin; s_ctl[3] = before; s_ctl[4] = cnt;
+            }
+        }
+        __syncthreads();
+        const uint32_t bin = s_ctl[2], before = below + s_ctl[3], through = before + s_ctl[4];
+        const uint32_t base = lo + (bin << shift);
+        if (through <= (uint32_t) kStBuf || shift == 0) { T = base + ((1u << shift) - 1u); break; }
+        below = before;
+        lo = base;
+        shift = shift > 8 ? shift - 8 : 0;
+    }
+    for (int i0 = 0; i0 < n; i0 += kStThreads) {                    // keys up to the bound, appended wave by wave
+        const int i = i0 + tid;
+        const pq64_t e = i < n ? s_key[i] : ~0ull;
+        const bool keep = i < n && (uint32_t) (e >> 32) <= T;
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            unsigned int at0 = 0u;
+            if (lane == 0) at0 = atomicAdd(&s_ctl[5], (unsigned int) __popcll(bal));
+            at0 = (unsigned int) __shfl((int) at0, 0);
+            const unsigned int at = at0 + (unsigned int) __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && at < (unsigned int) kStBuf) s_buf[at] = e;
+        }
+    }
+    __syncthreads();
+    const unsigned int nkeep = s_ctl[5];
+    int tie = nkeep > (unsigned int) kStBuf ? 1 : 0;
+    const unsigned long long *res = s_buf;
+    if (!tie) {
+        if (nkeep <= (unsigned int) kStRank) {
+            // few keys: every key counts the keys under it ((dist, index) pairs are distinct) -- no barrier ladder
+            if (tid < (int) nkeep) {
+                const unsigned long long mine = s_buf[tid];
+                unsigned int rank = 0u;
+                for (unsigned int j = 0; j < nkeep; ++j) rank += s_buf[j] < mine ? 1u : 0u;
+                s_out[rank] = mine;
+            }
+            res = s_out;
+            __syncthreads();
+        } else {
+            int nsort = 512;
+            while (nsort < (int) nkeep) nsort <<= 1;
+            for (int i = tid; i < nsort; i += kStThreads)
+                if ((unsigned int) i >= nkeep) s_buf[i] = ~0ull;
+            st_bitonic(s_buf, tid, nsort);                           // (dist, index): the canonical order when nothing ties
+        }
+        for (int j = tid; j + 1 < (int) k1; j += kStThreads)
+            if ((res[j] >> 32) == (res[j + 1] >> 32)) tie = 1;
+    }
+    if (__syncthreads_or(tie)) {
+        // two of the k+1 smallest distances are bit-equal: the answer is whatever std::partial_sort (src/rii.h:234-235) makes of
+        // the scores in index order -- replay it on the array itself
+        if (tid < 64) wh_partial_sort(s_key, k, n, tid);
+        __syncthreads();
+        res = s_key;
+    }
+    for (int j = tid; j < k; j += kStThreads) {
+        const pq64_t e = res[j];
+        const uint32_t idx = pq64_id(e);
+        p.out_ids[b * k + j] = p.remap ? p.remap[idx] : (int64_t) idx;
+        p.out_dists[b * k + j] = pq64_dist(e);
+    }
+}
+
+static size_t small_topk_smem(int M, int Ks, int64_t n)
+{
+    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) n * 8 + (size_t) (kStBuf + kStRank) * 8 + 256 * 4 + 32;
+}
+bool small_topk_supported(int M, int Ks, int64_t n, int topk)
+{
+    return n >= 2 && topk >= 1 && topk <= n && topk + 1 <= kStBuf / 2 && small_topk_smem(M, Ks, n) <= (size_t) 160 * 1024 - 512;
+}
+hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int64_t B, int topk,
+                             const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    SmallArgs a;
+    a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.remap = d_remap; a.topk = topk; a.out_ids = d_out_ids; a.out_dists = d_out_dists;
+    const size_t smem = small_topk_smem(M, Ks, n);
+    void (*kern)(SmallArgs) = small_topk_kernel<0>;
+    if (M == 16) kern = small_topk_kernel<1>;
+    else if (M == 32) kern = small_topk_kernel<2>;
+    else if (M == 48) kern = small_topk_kernel<3>;
+    else if (M == 64) kern = small_topk_kernel<4>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(kStThreads), smem, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace riiamd

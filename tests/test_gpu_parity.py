@@ -484,6 +484,48 @@ def test_gpu_linear_topk_tie_order_vs_oracle(case):
     assert n_tied > 0, "the case was meant to produce exactly tied distances inside the top-k"
 
 
+@pytest.mark.parametrize("case", [(32, 256, 4, 10000, "sift", 400), (32, 256, 4, 12288, "unit", 0), (16, 256, 6, 9000, "unit", 3000),
+                                  (8, 16, 2, 4000, "round", 0), (4, 8, 3, 700, "round", 0), (64, 256, 2, 2000, "unit", 100)])
+def test_gpu_small_index_topk_one_launch_vs_oracle(case):
+    """A small batch on a small index (the reference's README pattern: N = 10 000, topk = 3, one query per call):
+    the one-launch path (smalltopk.hip) against the oracle AND against the general path (option small_topk = 0), exactly tied
+    distances (duplicated codes, integer-valued tables), subsets, k == n and k just below the path's limit included."""
+    from rii_amd import RiiGpu
+    M, Ks, Ds, N, scale, dup = case
+    if scale == "round":
+        rng = np.random.default_rng(N)
+        cw = np.round(rng.random((M, Ks, Ds)) * 3.0).astype(np.float32)
+        qs = np.round(rng.random((16, M * Ds)) * 3.0).astype(np.float32)
+        codes = rng.integers(0, Ks, size=(N, M), dtype=np.uint8)
+    else:
+        cw, codes, qs = make_problem(N + M, M, Ks, Ds, N, scale, dup=dup)
+    rng = np.random.default_rng(N + 1)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False); o.add_codes(codes, False)
+    assert g.get_option("small_topk") == 1
+    sub = rng.permutation(N)[:N // 3].astype(np.int64)            # unsorted subset: positions, not ids, break ties
+    n_tied = 0
+    for topk in [k for k in (1, 2, 3, 10, 100, 1023) if k <= N // 3] + ([N] if N <= 1023 else []):
+        for tids in (E, sub):
+            if len(tids) and topk > len(tids):
+                continue
+            for B in (1, 5):
+                g.set_option("small_topk", 1)
+                ids, d = g.query_linear_batch(qs[:B], topk, tids)
+                g.set_option("small_topk", 0)
+                ids0, d0 = g.query_linear_batch(qs[:B], topk, tids)
+                for b in range(B):
+                    want = o.query_linear(qs[b], topk, tids)
+                    what = "small topk k=%d S=%d B=%d b=%d" % (topk, len(tids), B, b)
+                    assert_same_result((ids[b], d[b]), want, what)
+                    assert_same_result((ids0[b], d0[b]), want, what + " (general path)")
+                    n_tied += int(len(np.unique(np.asarray(want[1]))) < topk)
+    g.set_option("small_topk", 1)
+    if dup or scale == "round":
+        assert n_tied > 0, "the case was meant to produce exactly tied distances inside the top-k"
+
+
 def test_gpu_large_batch_is_chunked_transparently():
     """B above the internal pass size (8192 queries) is processed in slices with identical per-row results."""
     from rii_amd import RiiGpu
