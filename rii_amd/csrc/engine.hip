@@ -98,7 +98,7 @@ struct ScratchSet {
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
         s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
-        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident, s_big;
+        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident, s_big, s_small_done;
     bool have_ident = false;    // s_ident = [count | 0 .. 63]: work list of rii_linear_tie_emit_dev (every query of the call is "flagged")
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
@@ -125,7 +125,7 @@ struct ScratchSet {
                           &s_keys_b, &s_assign, &s_coarse_d, &s_coarse_i, &s_cum, &s_ncand, &s_nvis, &s_cand_i, &s_cand_d,
                           &s_bitmap, &s_fids, &s_flen, &s_hist, &s_cnt, &s_sample, &s_qlut, &s_slack, &s_cand, &s_cand_cnt,
                           &s_flag, &s_segmin, &s_thr16, &s_gthr, &s_qc, &s_flag_list, &s_tie_list, &s_tie_hid, &s_tie_hd,
-                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident, &s_big};
+                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident, &s_big, &s_small_done};
         for (DevBuf *b : bufs) b->release();
         if (sort_temp) (void) hipFree(sort_temp);
         sort_temp = nullptr; sort_temp_bytes = 0;
@@ -834,10 +834,18 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
         // distances of all codes of a query fit LDS -- tables, selection and the tie order in ONE launch (smalltopk.hip)
         const int64_t n_codes = S ? S : e->N;
         if (e->small_topk && B < e->fast_min_batch && small_topk_supported(e->M, e->Ks, n_codes, topk)) {
-            RII_TRY(build_lut(e, d_queries, B, st, false, 1));
-            ScopedTimer t(e, "scan", st, true);
-            HIP_TRY(launch_small_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, e->s_lut.as<float>(), B, topk, S ? d_tids : nullptr,
-                                      d_out_ids, d_out_dists, st));
+            const bool own_tables = e->lut_mode == RII_LUT_EXACT;       // matrix-core tables come from their own kernel
+            if (!own_tables) RII_TRY(build_lut(e, d_queries, B, st, false, 1));
+            e->lut_valid = false;                                        // s_lut does not hold this batch's tables
+            RII_TRY(e->s_keys_a.ensure(std::max<size_t>(small_topk_scratch(n_codes, B), 16)));
+            if (e->s_small_done.cap < (size_t) kMaxBatch * sizeof(unsigned int)) {
+                RII_TRY(e->s_small_done.ensure((size_t) kMaxBatch * sizeof(unsigned int)));
+                HIP_TRY(hipMemsetAsync(e->s_small_done.p, 0, (size_t) kMaxBatch * sizeof(unsigned int), st));   // once: the kernel leaves zeros
+            }
+            ScopedTimer t(e, "scan", st);
+            HIP_TRY(launch_small_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, own_tables ? nullptr : e->s_lut.as<float>(), d_queries,
+                                      e->d_codewords.as<float>(), e->Ds, e->arch, B, topk, S ? d_tids : nullptr,
+                                      e->s_keys_a.as<unsigned long long>(), e->s_small_done.as<unsigned int>(), d_out_ids, d_out_dists, st));
             return RII_OK;
         }
     }
@@ -1399,24 +1407,32 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
         HIP_TRY(hipStreamSynchronize(st));
         return RII_OK;
     }
-    RII_TRY(ensure_pin(e, q_bytes + out_bytes));
-    RII_TRY(e->s_queries.ensure(std::max<size_t>(q_bytes, 16)));
+    // target ids of a small call ride in the same pinned block and the same H2D copy as the queries (a copy from the caller's
+    // pageable array is staged and synchronised by the runtime: +15 us on a 40 us call)
+    const size_t t_bytes = (size_t) S * sizeof(int64_t);
+    const size_t q_pad = (q_bytes + 15) & ~(size_t) 15;
+    const bool pack_tids = S > 0 && q_pad + t_bytes + out_bytes <= kPinLimit;
+    const size_t in_bytes = pack_tids ? q_pad + t_bytes : q_pad;
+    RII_TRY(ensure_pin(e, in_bytes + out_bytes));
+    RII_TRY(e->s_queries.ensure(std::max<size_t>(in_bytes, 16)));
     RII_TRY(e->s_out_pack.ensure(std::max<size_t>(out_bytes, 16)));
-    RII_TRY(e->s_tids.ensure(std::max<size_t>((size_t) S * sizeof(int64_t), 16)));
+    if (!pack_tids) RII_TRY(e->s_tids.ensure(std::max<size_t>(t_bytes, 16)));
     unsigned char *pin = static_cast<unsigned char *>(e->h_pin);
     memcpy(pin, queries, q_bytes);
-    HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, q_bytes, hipMemcpyHostToDevice, st));
-    if (S) HIP_TRY(hipMemcpyAsync(e->s_tids.p, tids, (size_t) S * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (pack_tids) memcpy(pin + q_pad, tids, t_bytes);
+    HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, pack_tids ? in_bytes : q_bytes, hipMemcpyHostToDevice, st));
+    if (S && !pack_tids) HIP_TRY(hipMemcpyAsync(e->s_tids.p, tids, t_bytes, hipMemcpyHostToDevice, st));
+    const int64_t *d_tids_in = pack_tids ? reinterpret_cast<const int64_t *>(e->s_queries.as<unsigned char>() + q_pad) : e->s_tids.as<int64_t>();
     unsigned char *dp = e->s_out_pack.as<unsigned char>();
     int64_t *d_ids = reinterpret_cast<int64_t *>(dp);
     int64_t *d_cnt = reinterpret_cast<int64_t *>(dp + ids_bytes);
     int32_t *d_flag = reinterpret_cast<int32_t *>(dp + ids_bytes + c_bytes);
     float *d_d = reinterpret_cast<float *>(dp + ids_bytes + c_bytes + f_bytes);
     if (ivf)
-        RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, L, d_ids, d_d, d_cnt, st, d_flag));
+        RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S, L, d_ids, d_d, d_cnt, st, d_flag));
     else
-        RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, e->s_tids.as<int64_t>(), S, d_ids, d_d, st));
-    unsigned char *pout = pin + q_bytes;
+        RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S, d_ids, d_d, st));
+    unsigned char *pout = pin + in_bytes;
     HIP_TRY(hipMemcpyAsync(pout, dp, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (ivf && e->ivf_has_deferred) {

@@ -231,10 +231,16 @@ hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, in
                              float *d_out_dists, int64_t *d_out_payload, hipStream_t st, const int64_t *id_offsets = nullptr,
                              int tie_cols = 0, int32_t *d_out_tie = nullptr, int32_t *d_out_any = nullptr);
 
-// smalltopk.hip: a small batch over a small index, one launch (tables in s_lut, plain layout)
+// smalltopk.hip: a small batch over a small index, one launch
+// d_lut == NULL: every block builds its exact table from d_queries and the codebook itself (no table launch).
+// small_topk_slices() > 1: the codes of a query are scored by that many blocks; d_keys = small_topk_scratch() bytes, d_done = B
+// counters that are zero between launches (zeroed once by the caller, put back by the kernel).
 bool small_topk_supported(int M, int Ks, int64_t n, int topk);
-hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int64_t B, int topk,
-                             const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st);
+int small_topk_slices(int64_t n, int64_t B);
+size_t small_topk_scratch(int64_t n, int64_t B);
+hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, const float *d_queries,
+                             const float *d_codewords, int Ds, int arch, int64_t B, int topk, const int64_t *d_remap,
+                             unsigned long long *d_keys, unsigned int *d_done, int64_t *d_out_ids, float *d_out_dists, hipStream_t st);
 
 // widetab.hip: shapes whose one-query table does not fit LDS (lut_tile_for() == 0): tables stay in global memory
 hipError_t launch_scan_wide(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, const int64_t *d_remap,

@@ -1,4 +1,4 @@
-// smalltopk.hip -- QueryLinear (src/rii.h:195-242) for a SMALL index and a SMALL batch, in one launch after the tables (gfx950, round 3).
+// smalltopk.hip -- QueryLinear (src/rii.h:195-242) for a SMALL index and a SMALL batch, in ONE launch, tables included (gfx950, round 3).
 //
 // The reference's own usage pattern is one query per call on an index of ~10^4 codes (README.md:84-140: N = 10 000, topk = 3).  The
 // batched top-k path spends eight launches there (tables, two filter passes, k-th threshold, re-rank, three tie-order kernels): 90 us
@@ -22,10 +22,14 @@ constexpr int kStRank = 256;                 // up to this many keys are sorted 
 
 struct SmallArgs {
     const uint8_t *codes; int64_t n; int M, Ks;
-    const float *lut;                        // plain [b][M * Ks]
+    const float *lut;                        // plain [b][M * Ks], or NULL: the block builds its table itself from
+    const float *queries, *codewords;        //   queries [b][M * Ds] and the codebook (RiiCpp::DTable, src/rii.h:361-373)
+    int Ds, arch;                            //   with the fvec_L2sqr flavour `arch` (src/distance.h:117-252)
     const int64_t *remap;                    // subset search: index i stands for the code remap[i] (ids translated on output), or NULL
     int topk;
     int64_t *out_ids; float *out_dists;
+    unsigned long long *gkeys;               // gridDim.x > 1: [b][n] keys of all slices (the last block to finish selects)
+    unsigned int *done;                      // [b] blocks of the query that have stored their slice; back to 0 when the launch ends
 };
 
 // ascending bitonic sort of n (a power of two) 64-bit keys in LDS by all threads of the block
@@ -58,8 +62,10 @@ __device__ __forceinline__ float st_adist(const float *lds, const uint4 (&w)[NV]
     return d;
 }
 
-// NV > 0: M == 16 * NV, code rows loaded as NV 16-byte words, two codes per trip (the loads of both in flight before the first
-// lookup: one block on one CU is latency-bound).  NV == 0: any M.
+// NV > 0: M == 16 * NV, code rows loaded as NV 16-byte words.  NV == 0: any M.
+// One block of 1024 threads per (slice, query).  Everything here is a chain of dependent memory round trips (~1 us each at one block
+// per CU), so every phase issues all its loads before it uses any: the code rows of a thread's first codes are requested BEFORE the
+// table is built, the codebook entries of a thread eight at a time, the keys of the other slices eight at a time.
 template <int NV>
 __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
 {
@@ -71,8 +77,47 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
     unsigned long long *s_out = s_buf + kStBuf;                                                      // [kStRank] rank-sorted
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_out + kStRank);                        // [256]
     unsigned int *s_ctl = s_hist + 256;                                                              // [8]
-    const int64_t b = blockIdx.x;
-    {
+    const int64_t b = blockIdx.y;
+    const int G = (int) gridDim.x;
+    const int per = (n + G - 1) / G;                                   // slice of this block
+    const int s_lo = (int) blockIdx.x * per < n ? (int) blockIdx.x * per : n, s_hi = s_lo + per < n ? s_lo + per : n;
+    pq64_t *dst = G > 1 ? p.gkeys + (size_t) b * n : s_key;
+    constexpr int PRE = NV == 0 ? 0 : NV <= 2 ? 4 : 2;                 // codes per thread requested before the table exists
+    uint4 pre[PRE * NV + 1];
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) {
+            const int i = s_lo + tid + c * kStThreads, ic = i < s_hi ? i : n - 1;
+            const int64_t r = p.remap ? p.remap[ic] : (int64_t) ic;
+            const uint4 *row = reinterpret_cast<const uint4 *>(p.codes + (size_t) r * (NV * 16));
+#pragma unroll
+            for (int v = 0; v < NV; ++v) pre[c * NV + v] = row[v];
+        }
+    }
+    if (tid == 0) { s_ctl[0] = 0xffffffffu; s_ctl[1] = 0u; s_ctl[5] = 0u; }
+    if (!p.lut && p.Ds == 4) {
+        // RiiCpp::DTable (src/rii.h:361-373), Ds == 4: straight-line fvec_L2sqr, identical for the three SIMD flavours
+        const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
+        const float4 *q4 = reinterpret_cast<const float4 *>(p.queries + (size_t) b * p.M * 4);
+        const int sh = (p.Ks & (p.Ks - 1)) == 0 ? __ffs(p.Ks) - 1 : -1;
+        for (int i0 = 0; i0 < MK; i0 += 8 * kStThreads) {
+            float4 cv[8], qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * kStThreads + tid, ic = idx < MK ? idx : MK - 1;
+                cv[u] = cw4[ic];
+                qv[u] = q4[sh >= 0 ? ic >> sh : ic / p.Ks];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * kStThreads + tid;
+                if (idx < MK) lds[idx] = fvec_l2sqr_ds4v(qv[u], cv[u]);
+            }
+        }
+    } else if (!p.lut) {
+        const float *q = p.queries + (size_t) b * p.M * p.Ds;
+        for (int i = tid; i < MK; i += kStThreads) lds[i] = fvec_l2sqr_any(q + (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
+    } else {
         const float *src = p.lut + (size_t) b * MK;
         if ((MK & 3) == 0) {
             const float4 *s4 = reinterpret_cast<const float4 *>(src);
@@ -81,13 +126,26 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
         } else {
             for (int i = tid; i < MK; i += kStThreads) lds[i] = src[i];
         }
-        if (tid == 0) { s_ctl[0] = 0xffffffffu; s_ctl[1] = 0u; s_ctl[5] = 0u; }
     }
     __syncthreads();
     uint32_t umin = 0xffffffffu, umax = 0u;
     if constexpr (NV > 0) {
-        for (int i = tid; i < n; i += 2 * kStThreads) {
-            const int i2 = i + kStThreads < n ? i + kStThreads : i;
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) {
+            const int i = s_lo + tid + c * kStThreads;
+            uint4 w[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) w[v] = pre[c * NV + v];
+            if (i < s_hi) {
+                const pq64_t e = pq64_make(st_adist<NV>(lds, w, p.Ks), (uint32_t) i);                 // RiiCpp::ADist, m order
+                dst[i] = e;
+                const uint32_t u = (uint32_t) (e >> 32);
+                umin = u < umin ? u : umin;
+                umax = u > umax ? u : umax;
+            }
+        }
+        for (int i = s_lo + tid + PRE * kStThreads; i < s_hi; i += 2 * kStThreads) {                   // the rest two at a time
+            const int i2 = i + kStThreads < s_hi ? i + kStThreads : i;
             const int64_t r1 = p.remap ? p.remap[i] : (int64_t) i, r2 = p.remap ? p.remap[i2] : (int64_t) i2;
             const uint4 *row1 = reinterpret_cast<const uint4 *>(p.codes + (size_t) r1 * (NV * 16));
             const uint4 *row2 = reinterpret_cast<const uint4 *>(p.codes + (size_t) r2 * (NV * 16));
@@ -96,20 +154,53 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
             for (int v = 0; v < NV; ++v) { w1[v] = row1[v]; w2[v] = row2[v]; }
             const pq64_t e1 = pq64_make(st_adist<NV>(lds, w1, p.Ks), (uint32_t) i);
             const pq64_t e2 = pq64_make(st_adist<NV>(lds, w2, p.Ks), (uint32_t) i2);
-            s_key[i] = e1;
-            s_key[i2] = e2;                            // i2 == i past the end: the same key again
+            dst[i] = e1;
+            dst[i2] = e2;                              // i2 == i past the end: the same key again
             const uint32_t u1 = (uint32_t) (e1 >> 32), u2 = (uint32_t) (e2 >> 32);
             umin = u1 < umin ? u1 : umin; umin = u2 < umin ? u2 : umin;
             umax = u1 > umax ? u1 : umax; umax = u2 > umax ? u2 : umax;
         }
     } else {
-        for (int i = tid; i < n; i += kStThreads) {
+        for (int i = s_lo + tid; i < s_hi; i += kStThreads) {
             const uint8_t *code = p.codes + (size_t) (p.remap ? p.remap[i] : (int64_t) i) * p.M;
             const pq64_t e = pq64_make(exact_adist(lds, code, p.M, p.Ks), (uint32_t) i);              // RiiCpp::ADist, m order
-            s_key[i] = e;
+            dst[i] = e;
             const uint32_t u = (uint32_t) (e >> 32);
             umin = u < umin ? u : umin;
             umax = u > umax ? u : umax;
+        }
+    }
+    if (G > 1) {
+        // the slices of a query run on G CUs; the LAST block to store its slice gathers all keys into its LDS and selects.
+        // Release / acquire at device scope around the counter (the slices sit in different XCDs' L2s).
+        __syncthreads();                               // the block's keys are written (workgroup scope) ...
+        if (tid == 0) {
+            __threadfence();                           // ... and released to the device by ONE wave (an L2 write-back each)
+            s_ctl[6] = atomicAdd(&p.done[b], 1u);
+            __threadfence();
+        }
+        __syncthreads();
+        if (s_ctl[6] != (unsigned int) (G - 1)) return;
+        if (tid == 0) p.done[b] = 0u;                  // nobody else looks at it before the next launch
+        umin = 0xffffffffu; umax = 0u;
+        const pq64_t *src = p.gkeys + (size_t) b * n;
+        for (int i0 = 0; i0 < n; i0 += 8 * kStThreads) {
+            pq64_t e[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * kStThreads + tid;
+                e[u] = __hip_atomic_load(src + (i < n ? i : n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past this XCD's L2
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * kStThreads + tid;
+                if (i < n) {
+                    s_key[i] = e[u];
+                    const uint32_t x = (uint32_t) (e[u] >> 32);
+                    umin = x < umin ? x : umin;
+                    umax = x > umax ? x : umax;
+                }
+            }
         }
     }
 #pragma unroll
@@ -228,12 +319,22 @@ bool small_topk_supported(int M, int Ks, int64_t n, int topk)
 {
     return n >= 2 && topk >= 1 && topk <= n && topk + 1 <= kStBuf / 2 && small_topk_smem(M, Ks, n) <= (size_t) 160 * 1024 - 512;
 }
-hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int64_t B, int topk,
-                             const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+int small_topk_slices(int64_t n, int64_t B)
+{
+    // one code per thread where the chip has the CUs for it (256 of them, one block each: 160 KiB of LDS)
+    const int64_t by_n = (n + kStThreads - 1) / kStThreads, by_b = 256 / std::max<int64_t>(B, 1);
+    return (int) std::max<int64_t>(1, std::min<int64_t>(16, std::min(by_n, by_b)));
+}
+size_t small_topk_scratch(int64_t n, int64_t B) { return small_topk_slices(n, B) > 1 ? (size_t) B * n * 8 : 0; }
+
+hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, const float *d_queries,
+                             const float *d_codewords, int Ds, int arch, int64_t B, int topk, const int64_t *d_remap,
+                             unsigned long long *d_keys, unsigned int *d_done, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
     SmallArgs a;
-    a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.remap = d_remap; a.topk = topk; a.out_ids = d_out_ids; a.out_dists = d_out_dists;
+    a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch;
+    a.remap = d_remap; a.topk = topk; a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.gkeys = d_keys; a.done = d_done;
     const size_t smem = small_topk_smem(M, Ks, n);
     void (*kern)(SmallArgs) = small_topk_kernel<0>;
     if (M == 16) kern = small_topk_kernel<1>;
@@ -242,7 +343,7 @@ hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, c
     else if (M == 64) kern = small_topk_kernel<4>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(kStThreads), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned) small_topk_slices(n, B), (unsigned) B), dim3(kStThreads), smem, st, a);
     return hipGetLastError();
 }
 

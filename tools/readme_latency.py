@@ -31,6 +31,7 @@ sub = np.sort(rng.choice(N, 3000, replace=False)).astype(np.int64)
 legs = {"linear top-1": lambda q: eng.query_linear(q, 1, E),
         "linear top-%d" % a.topk: lambda q: eng.query_linear(q, a.topk, E),
         "linear top-%d, 3000 target ids" % a.topk: lambda q: eng.query_linear(q, a.topk, sub),
+        "linear top-%d, 100 target ids" % a.topk: lambda q: eng.query_linear(q, a.topk, sub[:100]),
         "ivf top-%d L=100" % a.topk: lambda q: eng.query_ivf(q, a.topk, E, 100),
         "ivf top-%d L=100, 3000 target ids" % a.topk: lambda q: eng.query_ivf(q, a.topk, sub, 100)}
 for name, call in legs.items():
@@ -45,4 +46,16 @@ for name, call in legs.items():
         call(q)
         ts.append(time.perf_counter() - t0)
     ts = np.array(ts) * 1e6
-    print("%-40s p10 %6.1f  p50 %6.1f  p90 %6.1f us" % (name, np.percentile(ts, 10), np.percentile(ts, 50), np.percentile(ts, 90)))
+    eng.set_option("timing", 1); eng.timing_reset()
+    for q in Q[:50]:
+        call(q)
+    ks = {}
+    for key in ("lut", "scan", "finalize", "ivf_fused", "ivf_exact", "bitmap", "filter_lists"):
+        try:
+            ms, cnt = eng.timing_read(key)
+        except Exception:
+            continue
+        if cnt:
+            ks[key] = round(ms / cnt * 1e3, 1)
+    eng.set_option("timing", 0)
+    print("%-40s p10 %6.1f  p50 %6.1f  p90 %6.1f us   kernels (us, HIP events): %s" % (name, np.percentile(ts, 10), np.percentile(ts, 50), np.percentile(ts, 90), ks))
