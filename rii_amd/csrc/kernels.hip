@@ -1002,20 +1002,12 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 if (id[u] >= 0) s_cd[p0 + u * 256] = f32_orderable(__float_as_uint(dist[u]));
         }
         unsigned int &s_cnt = *reinterpret_cast<unsigned int *>(&s_red[0]);
-        uint32_t T = 0u;                                   // largest value with fewer than k1 distances below it = the k1-th smallest
-        for (int bit = 31; bit >= 0; --bit) {
-            __syncthreads();
-            if (tid == 0) s_cnt = 0u;
-            __syncthreads();
-            const uint32_t mid = T | (1u << bit);
-            int local = 0;
-            for (int i = tid; i < ncand; i += 256) local += s_cd[i] < mid ? 1 : 0;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
-            if ((tid & 63) == 0 && local) atomicAdd(&s_cnt, (unsigned int) local);
-            __syncthreads();
-            if ((int) s_cnt < k1) T = mid;
-        }
+        // a bound on the k1-th smallest distance that leaves at most kcap keys under it: 256-bin histograms of the occupied range
+        // (rii_device.h: block_kth_bound; round 2 bisected the 32 value bits with three barriers a bit).  The waves' list picks and
+        // the selected keys are dead by now: their LDS serves as histogram and control words.
+        __syncthreads();
+        const uint32_t T = block_kth_bound([&](int i) { return s_cd[i]; }, ncand, (uint32_t) k1, (uint32_t) kcap,
+                                           reinterpret_cast<unsigned int *>(s_wsel), reinterpret_cast<unsigned int *>(s_sel));
         __syncthreads();
         if (tid == 0) s_cnt = 0u;
         __syncthreads();
@@ -1035,9 +1027,21 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         const unsigned int nkeep = s_cnt;
         int tie = nkeep > (unsigned int) kcap ? 1 : 0;     // more ties at the cut than the buffer holds: exact path
         if (!tie) {
-            for (int i = tid; i < kcap; i += 256)
-                if ((unsigned int) i >= nkeep) s_buf[i] = ~0ull;
-            rr_bitonic_sort(s_buf, tid, kcap);
+            // up to 256 keys (= the block): every key counts the keys under it ((distance, position) pairs are distinct) and moves
+            // to its rank -- two barriers instead of a bitonic ladder
+            if (nkeep <= 256u) {
+                const unsigned long long mine = tid < (int) nkeep ? s_buf[tid] : ~0ull;
+                unsigned int rank = 0u;
+                if (tid < (int) nkeep)
+                    for (unsigned int j = 0; j < nkeep; ++j) rank += s_buf[j] < mine ? 1u : 0u;
+                __syncthreads();
+                if (tid < (int) nkeep) s_buf[rank] = mine;
+                __syncthreads();
+            } else {
+                for (int i = tid; i < kcap; i += 256)
+                    if ((unsigned int) i >= nkeep) s_buf[i] = ~0ull;
+                rr_bitonic_sort(s_buf, tid, kcap);
+            }
             for (int j = tid; j + 1 < k1; j += 256)
                 if ((s_buf[j] >> 32) == (s_buf[j + 1] >> 32)) tie = 1;
         }

@@ -532,6 +532,77 @@ __device__ __forceinline__ void wh_sort_heap(pq64_t *h, int len0, int lane)
     }
 }
 
+// A bound T for the k1-th smallest of n 32-bit values held by the block (val(i), i < n: an LDS read), found with 256-bin histograms
+// over the occupied range instead of a 32-step bisection (three block barriers per step): k1 <= #{val <= T}, and either
+// #{val <= T} <= cap or T IS the k1-th smallest value.  One histogram pass when the bin of the k1-th smallest value ends at most
+// `cap` values into the order (k1 << n: always); otherwise that bin is split into 256 again.  All threads of the block call it
+// (barriers inside); s_hist = 256 words, s_ctl = 5 words of LDS.  Requires 1 <= k1 <= n.
+template <typename Val>
+__device__ __forceinline__ uint32_t block_kth_bound(Val val, int n, uint32_t k1, uint32_t cap, unsigned int *s_hist, unsigned int *s_ctl)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+    if (tid == 0) { s_ctl[0] = 0xffffffffu; s_ctl[1] = 0u; }
+    uint32_t vmin = 0xffffffffu, vmax = 0u;
+    for (int i = tid; i < n; i += nt) {
+        const uint32_t u = val(i);
+        vmin = u < vmin ? u : vmin;
+        vmax = u > vmax ? u : vmax;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t a = (uint32_t) __shfl_xor((int) vmin, off), c = (uint32_t) __shfl_xor((int) vmax, off);
+        vmin = a < vmin ? a : vmin;
+        vmax = c > vmax ? c : vmax;
+    }
+    __syncthreads();
+    if (lane == 0) { atomicMin(&s_ctl[0], vmin); atomicMax(&s_ctl[1], vmax); }
+    __syncthreads();
+    uint32_t lo = s_ctl[0], below = 0u;               // `below` values lie under lo
+    int shift;
+    {
+        const uint32_t span = s_ctl[1] - lo;
+        const int bits = span ? 32 - __clz((int) span) : 0;
+        shift = bits > 8 ? bits - 8 : 0;              // (val - lo) >> shift < 256 for every value
+    }
+    for (;;) {
+        __syncthreads();
+        if (tid < 256) s_hist[tid] = 0u;
+        if (nt < 256) for (int i = tid + nt; i < 256; i += nt) s_hist[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            const uint32_t u = val(i);
+            if (u >= lo && ((u - lo) >> shift) < 256u) atomicAdd(&s_hist[(u - lo) >> shift], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t c0 = s_hist[4 * lane], c1 = s_hist[4 * lane + 1], c2 = s_hist[4 * lane + 2], c3 = s_hist[4 * lane + 3];
+            const uint32_t sum = c0 + c1 + c2 + c3;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t) __shfl_up((int) incl, off);
+                if (lane >= off) incl += t;
+            }
+            const uint32_t need = k1 - below, excl = incl - sum;
+            if (excl < need && need <= incl) {        // exactly one lane: the pass holds at least `need` values
+                uint32_t before = excl, cnt = c0;
+                int bin = 4 * lane;
+                if (before + cnt < need) { before += cnt; cnt = c1; ++bin; }
+                if (before + cnt < need) { before += cnt; cnt = c2; ++bin; }
+                if (before + cnt < need) { before += cnt; cnt = c3; ++bin; }
+                s_ctl[2] = (uint32_t) bin; s_ctl[3] = before; s_ctl[4] = cnt;
+            }
+        }
+        __syncthreads();
+        const uint32_t bin = s_ctl[2], before = below + s_ctl[3], through = before + s_ctl[4];
+        const uint32_t base = lo + (bin << shift);
+        if (through <= cap || shift == 0) return base + ((1u << shift) - 1u);
+        below = before;
+        lo = base;
+        shift = shift > 8 ? shift - 8 : 0;
+    }
+}
+
 // sequential fp32 ADC (RiiCpp::ADist, src/rii.h:386-394) of one code against a plain [M][Ks] table in LDS
 __device__ __forceinline__ float exact_adist(const float *lds, const uint8_t *code, int M, int Ks)
 {

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
             for (int v = 0; v < NV; ++v) pre[c * NV + v] = row[v];
         }
     }
-    if (tid == 0) { s_ctl[0] = 0xffffffffu; s_ctl[1] = 0u; s_ctl[5] = 0u; }
+    if (tid == 0) s_ctl[5] = 0u;
     if (!p.lut && p.Ds == 4) {
         // RiiCpp::DTable (src/rii.h:361-373), Ds == 4: straight-line fvec_L2sqr, identical for the three SIMD flavours
         const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
@@ -128,7 +128,6 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
         }
     }
     __syncthreads();
-    uint32_t umin = 0xffffffffu, umax = 0u;
     if constexpr (NV > 0) {
 #pragma unroll
         for (int c = 0; c < PRE; ++c) {
@@ -139,9 +138,6 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
             if (i < s_hi) {
                 const pq64_t e = pq64_make(st_adist<NV>(lds, w, p.Ks), (uint32_t) i);                 // RiiCpp::ADist, m order
                 dst[i] = e;
-                const uint32_t u = (uint32_t) (e >> 32);
-                umin = u < umin ? u : umin;
-                umax = u > umax ? u : umax;
             }
         }
         for (int i = s_lo + tid + PRE * kStThreads; i < s_hi; i += 2 * kStThreads) {                   // the rest two at a time
@@ -156,18 +152,12 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
             const pq64_t e2 = pq64_make(st_adist<NV>(lds, w2, p.Ks), (uint32_t) i2);
             dst[i] = e1;
             dst[i2] = e2;                              // i2 == i past the end: the same key again
-            const uint32_t u1 = (uint32_t) (e1 >> 32), u2 = (uint32_t) (e2 >> 32);
-            umin = u1 < umin ? u1 : umin; umin = u2 < umin ? u2 : umin;
-            umax = u1 > umax ? u1 : umax; umax = u2 > umax ? u2 : umax;
         }
     } else {
         for (int i = s_lo + tid; i < s_hi; i += kStThreads) {
             const uint8_t *code = p.codes + (size_t) (p.remap ? p.remap[i] : (int64_t) i) * p.M;
             const pq64_t e = pq64_make(exact_adist(lds, code, p.M, p.Ks), (uint32_t) i);              // RiiCpp::ADist, m order
             dst[i] = e;
-            const uint32_t u = (uint32_t) (e >> 32);
-            umin = u < umin ? u : umin;
-            umax = u > umax ? u : umax;
         }
     }
     if (G > 1) {
@@ -182,7 +172,6 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
         __syncthreads();
         if (s_ctl[6] != (unsigned int) (G - 1)) return;
         if (tid == 0) p.done[b] = 0u;                  // nobody else looks at it before the next launch
-        umin = 0xffffffffu; umax = 0u;
         const pq64_t *src = p.gkeys + (size_t) b * n;
         for (int i0 = 0; i0 < n; i0 += 8 * kStThreads) {
             pq64_t e[8];
@@ -194,70 +183,15 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * kStThreads + tid;
-                if (i < n) {
-                    s_key[i] = e[u];
-                    const uint32_t x = (uint32_t) (e[u] >> 32);
-                    umin = x < umin ? x : umin;
-                    umax = x > umax ? x : umax;
-                }
+                if (i < n) s_key[i] = e[u];
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t a = (uint32_t) __shfl_xor((int) umin, off), c = (uint32_t) __shfl_xor((int) umax, off);
-        umin = a < umin ? a : umin;
-        umax = c > umax ? c : umax;
-    }
-    if (lane == 0) { atomicMin(&s_ctl[0], umin); atomicMax(&s_ctl[1], umax); }
+    // ---- a bound T with k+1 <= #{distance <= T} <= kStBuf: typically ONE histogram pass (the bin holding the (k+1)-th smallest of
+    //      10^4 distances has a handful of keys below it) ----
     __syncthreads();
-    // ---- a bound T with k+1 <= #{distance <= T} <= kStBuf: 256-bin histograms over the occupied range, refined bin by bin
-    //      (typically ONE pass: the bin holding the (k+1)-th smallest of 10^4 distances has a handful of keys below it) ----
     const uint32_t k1 = (uint32_t) (k + 1 < n ? k + 1 : n);
-    uint32_t lo = s_ctl[0], T;
-    int shift;
-    {
-        const uint32_t span = s_ctl[1] - lo;
-        const int bits = span ? 32 - __clz((int) span) : 0;
-        shift = bits > 8 ? bits - 8 : 0;
-    }
-    uint32_t below = 0u;                              // keys under lo
-    for (;;) {
-        __syncthreads();
-        if (tid < 256) s_hist[tid] = 0u;
-        __syncthreads();
-        for (int i = tid; i < n; i += kStThreads) {
-            const uint32_t u = (uint32_t) (s_key[i] >> 32);
-            if (u >= lo && ((u - lo) >> shift) < 256u) atomicAdd(&s_hist[(u - lo) >> shift], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const uint32_t c0 = s_hist[4 * lane], c1 = s_hist[4 * lane + 1], c2 = s_hist[4 * lane + 2], c3 = s_hist[4 * lane + 3];
-            const uint32_t sum = c0 + c1 + c2 + c3;
-            uint32_t incl = sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = (uint32_t) __shfl_up((int) incl, off);
-                if (lane >= off) incl += t;
-            }
-            const uint32_t need = k1 - below, excl = incl - sum;
-            if (excl < need && need <= incl) {        // exactly one lane: the pass's keys number at least `need`
-                uint32_t before = excl, cnt = c0;
-                int bin = 4 * lane;
-                if (before + cnt < need) { before += cnt; cnt = c1; ++bin; }
-                if (before + cnt < need) { before += cnt; cnt = c2; ++bin; }
-                if (before + cnt < need) { before += cnt; cnt = c3; ++bin; }
-                s_ctl[2] = (uint32_t) bin; s_ctl[3] = before; s_ctl[4] = cnt;
-            }
-        }
-        __syncthreads();
-        const uint32_t bin = s_ctl[2], before = below + s_ctl[3], through = before + s_ctl[4];
-        const uint32_t base = lo + (bin << shift);
-        if (through <= (uint32_t) kStBuf || shift == 0) { T = base + ((1u << shift) - 1u); break; }
-        below = before;
-        lo = base;
-        shift = shift > 8 ? shift - 8 : 0;
-    }
+    const uint32_t T = block_kth_bound([&](int i) { return (uint32_t) (s_key[i] >> 32); }, n, k1, (uint32_t) kStBuf, s_hist, s_ctl);
     for (int i0 = 0; i0 < n; i0 += kStThreads) {                    // keys up to the bound, appended wave by wave
         const int i = i0 + tid;
         const pq64_t e = i < n ? s_key[i] : ~0ull;

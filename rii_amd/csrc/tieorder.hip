@@ -216,25 +216,12 @@ __global__ __launch_bounds__(256) void tie_chunk_kth_kernel(TcArgs p)
     const int cnt = (int) ((p.n - s) < kTcChunk ? (p.n - s) : kTcChunk);
     for (int j = tid; j < kTcChunk; j += 256) buf[j] = j < cnt ? f32_orderable(__float_as_uint(tc_dist(p, lds, s + j))) : 0xffffffffu;
     __syncthreads();
-    // k-th smallest of buf[0, cnt): bisection on the 32 value bits (count of values below a pivot), 256 threads
-    __shared__ int s_count;
-    uint32_t lo = 0u, hi = 0xffffffffu;                    // invariant: #(v < lo) < k  <=  #(v <= hi)
+    // k-th smallest of buf[0, cnt), exactly: histograms of the occupied range refined down to single values (cap = 0)
+    __shared__ unsigned int s_hist[256];
+    __shared__ unsigned int s_ctl[8];
     if (cnt < p.topk) { if (tid == 0) p.kth[(size_t) fi * p.nchunks + c] = 0xffffffffu; return; }
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t mid = lo | (1u << bit);             // candidates with this bit set are >= mid
-        if (tid == 0) s_count = 0;
-        __syncthreads();
-        int local = 0;
-        for (int j = tid; j < kTcChunk; j += 256) local += (buf[j] < mid) ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
-        if ((tid & 63) == 0) atomicAdd(&s_count, local);
-        __syncthreads();
-        if (s_count < p.topk) lo = mid;                    // fewer than k values below mid: the k-th smallest is >= mid
-        __syncthreads();
-    }
-    (void) hi;
-    if (tid == 0) p.kth[(size_t) fi * p.nchunks + c] = lo; // largest value v with #(values < v) < k  ==  the k-th smallest
+    const uint32_t kth = block_kth_bound([&](int j) { return buf[j]; }, cnt, (uint32_t) p.topk, 0u, s_hist, s_ctl);
+    if (tid == 0) p.kth[(size_t) fi * p.nchunks + c] = kth;
 }
 
 __global__ __launch_bounds__(256) void tie_chunk_emit_kernel(TcArgs p)
