@@ -435,8 +435,9 @@ def readme_workload(args, torch, dev, arch):
             cb["queries_compared"] = len(cpu_res)
             o["cpu_baseline"] = cb
         out[name] = o
-    out["note"] = ("latency-bound: 3 short dependent launches + pinned H2D/D2H + one synchronisation; no roofline applies (the "
-                   "index is 320 KB)")
+    out["note"] = ("latency-bound: one launch (linear: small_topk_kernel) or three (inverted index) + pinned H2D/D2H + one "
+                   "synchronisation, floor 17-20 us on this box (tools/host_latency_probe.hip); no roofline applies (the index is "
+                   "320 KB)")
     return out
 
 
