@@ -710,52 +710,61 @@ def main():
         Qg = t_q[:B].contiguous()                    # the same global batch on every rank
         Qs = Qg.cpu().numpy() if host_coll else Qg   # (gloo: host engines' surface)
         tids_np = h_tids if (host_coll or not S) else tids
-        qidx = rd.QueryShardedIndex(eng)
-        res_q = [None]
+        # a failure of either form is reported in its object instead of taking the whole line down (the weak-scaling `value`
+        # above is already measured); the same exception on every rank keeps the ranks in step
+        try:
+            qidx = rd.QueryShardedIndex(eng)
+            res_q = [None]
 
-        def step_strong_q():
-            if ivf:
-                res_q[0] = qidx.query_ivf_batch(Qs, topk, tids_np, L)
-            else:
-                res_q[0] = qidx.query_linear_batch(Qs, topk, tids_np)
+            def step_strong_q():
+                if ivf:
+                    res_q[0] = qidx.query_ivf_batch(Qs, topk, tids_np, L)
+                else:
+                    res_q[0] = qidx.query_linear_batch(Qs, topk, tids_np)
 
-        preheat_count(step_strong_q, torch.cuda.synchronize, 100)
-        for _ in range(max(args.warmup, 1)):
-            step_strong_q()
-        e_q, = max_over_ranks(timed_loop(step_strong_q, args.steps, barrier))
-        run(Qg)                                      # every row equals the single-engine answer for that row
-        torch.cuda.synchronize()
-        ok_q = bool(torch.equal(torch.as_tensor(res_q[0][0]).to(dev), out_ids))
-        strong["query_sharded"] = {"value": B * args.steps / e_q, "unit": "queries/s", "ms_per_step": e_q / args.steps * 1e3,
-                                   "global_batch": B, "rows_per_rank": [rd.shard_range(B, r, world)[1] - rd.shard_range(B, r, world)[0]
-                                                                          for r in range(world)],
-                                   "results_match_single_engine": ok_q,
-                                   "what": "index replicated, rank r answers its slice of the global batch, ONE all-gather of the "
-                                           "packed result rows inside the timed region (QueryShardedIndex)"}
-        if not ivf and S == 0:
-            s0, s1 = rd.shard_range(N, rank, world)
-            eng_s = RiiGpu(cw, False, simd_arch=arch, device=local)
-            eng_s.add_codes(codes[s0:s1], False)
-            for k in ("scan_mode", "scan_order", "scan_mx"):
-                eng_s.set_option(k, getattr(args, k))
-            didx = rd.DbShardedIndex(eng_s, s0, s1)
-            didx.all_starts()
-            res_d = [None]
-
-            def step_strong_d():
-                res_d[0] = didx.query_linear_batch(Qs, topk)
-
-            preheat_count(step_strong_d, torch.cuda.synchronize, 100)
+            preheat_count(step_strong_q, torch.cuda.synchronize, 100)
             for _ in range(max(args.warmup, 1)):
-                step_strong_d()
-            e_d, = max_over_ranks(timed_loop(step_strong_d, args.steps, barrier))
-            ok_d = bool(torch.equal(torch.as_tensor(res_d[0][0]).to(dev), out_ids) and torch.equal(torch.as_tensor(res_d[0][1]).to(dev), out_d))
-            strong["db_sharded"] = {"value": B * args.steps / e_d, "unit": "queries/s", "ms_per_step": e_d / args.steps * 1e3,
-                                    "global_batch": B, "codes_per_rank": s1 - s0, "results_match_single_engine": ok_d,
-                                    "what": "codes split into contiguous id ranges, every rank answers the whole batch on its shard, "
-                                            "ONE all-gather + device (dist, id) merge inside the timed region (DbShardedIndex: "
-                                            "rii_merge_topk_ex_dev, no host synchronisation for top-1)"}
-            del didx, eng_s
+                step_strong_q()
+            e_q, = max_over_ranks(timed_loop(step_strong_q, args.steps, barrier))
+            run(Qg)                                      # every row equals the single-engine answer for that row
+            torch.cuda.synchronize()
+            ok_q = bool(torch.equal(torch.as_tensor(res_q[0][0]).to(dev), out_ids))
+            strong["query_sharded"] = {"value": B * args.steps / e_q, "unit": "queries/s", "ms_per_step": e_q / args.steps * 1e3,
+                                       "global_batch": B, "rows_per_rank": [rd.shard_range(B, r, world)[1] - rd.shard_range(B, r, world)[0]
+                                                                              for r in range(world)],
+                                       "results_match_single_engine": ok_q,
+                                       "what": "index replicated, rank r answers its slice of the global batch, ONE all-gather of the "
+                                               "packed result rows inside the timed region (QueryShardedIndex)"}
+        except Exception as ex:                              # noqa: BLE001
+            strong["query_sharded"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if not ivf and S == 0:
+            try:
+                s0, s1 = rd.shard_range(N, rank, world)
+                eng_s = RiiGpu(cw, False, simd_arch=arch, device=local)
+                eng_s.add_codes(codes[s0:s1], False)
+                for k in ("scan_mode", "scan_order", "scan_mx"):
+                    eng_s.set_option(k, getattr(args, k))
+                didx = rd.DbShardedIndex(eng_s, s0, s1)
+                didx.all_starts()
+                res_d = [None]
+
+                def step_strong_d():
+                    res_d[0] = didx.query_linear_batch(Qs, topk)
+
+                preheat_count(step_strong_d, torch.cuda.synchronize, 100)
+                for _ in range(max(args.warmup, 1)):
+                    step_strong_d()
+                e_d, = max_over_ranks(timed_loop(step_strong_d, args.steps, barrier))
+                ok_d = bool(torch.equal(torch.as_tensor(res_d[0][0]).to(dev), out_ids) and torch.equal(torch.as_tensor(res_d[0][1]).to(dev), out_d))
+                strong["db_sharded"] = {"value": B * args.steps / e_d, "unit": "queries/s", "ms_per_step": e_d / args.steps * 1e3,
+                                        "global_batch": B, "codes_per_rank": s1 - s0, "results_match_single_engine": ok_d,
+                                        "what": "codes split into contiguous id ranges, every rank answers the whole batch on its shard, "
+                                                "ONE all-gather + device (dist, id) merge inside the timed region (DbShardedIndex: "
+                                                "rii_merge_topk_ex_dev, no host synchronisation for top-1)"}
+                del didx, eng_s
+            except Exception as ex:                          # noqa: BLE001
+                strong["db_sharded"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
         run(my_q)
         torch.cuda.synchronize()
 
@@ -907,19 +916,29 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             what = {"linear": "full %d-code linear scan" % N, "subset": "linear scan of %d target ids" % S,
                     "ivf": "inverted index nlist=1024 L=%d" % L, "subset-ivf": "inverted index nlist=1024 L=%d over %d target ids" % (L, S)}
-            cb, cpu_res = cpu_baseline("ivf" if ivf else "linear", what[args.workload], reference_factory(eng, cw, codes, arch, ivf),
-                                       my_q.cpu().numpy(), topk, h_tids, L)
-            cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, res_cnt, cpu_res)
+            try:
+                cb, cpu_res = cpu_baseline("ivf" if ivf else "linear", what[args.workload], reference_factory(eng, cw, codes, arch, ivf),
+                                           my_q.cpu().numpy(), topk, h_tids, L)
+                cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, res_cnt, cpu_res)
+            except Exception as ex:                              # noqa: BLE001 -- the measured line above must still be printed
+                cb = {"error": "%s: %s" % (type(ex).__name__, ex)}
             line["cpu_baseline"] = cb
         # every other BASELINE config in the same process (default invocation only: the SIFT-shaped legs reuse this index)
         if world == 1 and not use_dist and not args.no_others and args.workload == "linear" and topk == 1:
             others = {}
             t_oth = time.perf_counter()
+            def guarded(fn, *a):                                 # one failing leg must not take the line (or the other legs) down
+                try:
+                    return fn(*a)
+                except Exception as ex:                              # noqa: BLE001
+                    return {"error": "%s: %s" % (type(ex).__name__, ex)}
+
             for name in ("subset", "ivf", "subset_ivf"):            # (reconfigure happens once, before the two ivf legs)
-                others[name] = sift_workload(name, eng, args, torch, dev, stream, my_q, cw, codes, barrier, arch, N, M, Ks, D // M, B, topk)
-            others["readme_n10k"] = readme_workload(args, torch, dev, arch)
+                others[name] = guarded(sift_workload, name, eng, args, torch, dev, stream, my_q, cw, codes, barrier, arch, N, M, Ks,
+                                       D // M, B, topk)
+            others["readme_n10k"] = guarded(readme_workload, args, torch, dev, arch)
             if args.deep_shard > 0:
-                others["deep_shard"] = deep_shard_workload(args, torch, dev, arch, barrier)
+                others["deep_shard"] = guarded(deep_shard_workload, args, torch, dev, arch, barrier)
             others["seconds_spent"] = time.perf_counter() - t_oth
             line["others"] = others
         print(json.dumps(line))
