@@ -103,6 +103,7 @@ struct ScratchSet {
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     void *h_pin = nullptr;          // pinned host staging for small batches (one H2D + one D2H per call)
+    void *d_pin = nullptr;          // ... as the device sees it (coherent, mapped)
     size_t h_pin_cap = 0;
     DevBuf s_out_pack;              // [ids | counts | flags | dists] of a small batch, copied back in one transfer
     riiamd::IvfParams ivf_deferred; // host-pointer small batches: fallback kernels are launched only if a flag came back set
@@ -178,6 +179,11 @@ struct rii_engine : ScratchSet {
     int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
     int scan_mx = 1;            // option "scan_mx": 1 = rotated shapes scan with fscan_mx_kernel (its own lookup order), 0 = fscan_kernel
+    int host_spin = 1;          // option "host_spin": small host-pointer calls answered by the one-launch kernel get their rows written
+                                // straight into the pinned block and wait on a flag there instead of a D2H copy + stream synchronisation
+    unsigned int *spin_flag = nullptr;   // (set by host_query around the call: device address of the flags in the pinned block)
+    unsigned int spin_seq = 0;
+    bool spin_used = false;
     int small_topk = 1;         // option "small_topk": a small batch over a small index in one launch after the tables (smalltopk.hip)
     int warm_groups = 4;        // option "warm_groups" (1..4): groups per wave of a chunk's first trip that seed the thresholds
     int scan_prio = 0;          // option "scan_prio": 1 / 2 = s_setprio 1 for the younger / older half of a scan block's waves (experiment)
@@ -814,6 +820,13 @@ int query_linear_wide(rii_engine *e, const float *d_queries, int64_t B, int topk
     return RII_OK;
 }
 
+// the one-launch path of smalltopk.hip answers this call (host_query relies on the same predicate)
+static bool takes_small_topk(const rii_engine *e, int64_t B, int topk, int64_t S)
+{
+    return e->QT != 0 && e->small_topk && B > 0 && B < e->fast_min_batch && B <= kMaxBatch &&
+           small_topk_supported(e->M, e->Ks, S ? S : e->N, topk);
+}
+
 int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
                      int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
 {
@@ -833,7 +846,7 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
         // small index, small batch (the reference's README pattern: one query per call, N ~ 10^4, topk = 3): the exact
         // distances of all codes of a query fit LDS -- tables, selection and the tie order in ONE launch (smalltopk.hip)
         const int64_t n_codes = S ? S : e->N;
-        if (e->small_topk && B < e->fast_min_batch && small_topk_supported(e->M, e->Ks, n_codes, topk)) {
+        if (takes_small_topk(e, B, topk, S)) {
             const bool own_tables = e->lut_mode == RII_LUT_EXACT;       // matrix-core tables come from their own kernel
             if (!own_tables) RII_TRY(build_lut(e, d_queries, B, st, false, 1));
             e->lut_valid = false;                                        // s_lut does not hold this batch's tables
@@ -845,7 +858,9 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
             ScopedTimer t(e, "scan", st);
             HIP_TRY(launch_small_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, own_tables ? nullptr : e->s_lut.as<float>(), d_queries,
                                       e->d_codewords.as<float>(), e->Ds, e->arch, B, topk, S ? d_tids : nullptr,
-                                      e->s_keys_a.as<unsigned long long>(), e->s_small_done.as<unsigned int>(), d_out_ids, d_out_dists, st));
+                                      e->s_keys_a.as<unsigned long long>(), e->s_small_done.as<unsigned int>(), d_out_ids, d_out_dists, st,
+                                      e->spin_flag, e->spin_seq));
+            e->spin_used = e->spin_flag != nullptr;
             return RII_OK;
         }
     }
@@ -1369,6 +1384,8 @@ RII_API int rii_get_posting_lists(const rii_engine *e, int64_t *off, int32_t *id
 // copies of the generic path cost more than the kernels at that size.
 namespace {
 constexpr size_t kPinLimit = 1 << 20;
+constexpr size_t kPinFlagBytes = 4096;
+constexpr size_t kSpinMaxInput = 8192;
 
 int ensure_pin(rii_engine *e, size_t bytes)
 {
@@ -1376,7 +1393,10 @@ int ensure_pin(rii_engine *e, size_t bytes)
     if (e->h_pin) HIP_TRY(hipHostFree(e->h_pin));
     e->h_pin = nullptr; e->h_pin_cap = 0;
     const size_t cap = std::max<size_t>(bytes, 64 << 10);
-    HIP_TRY(hipHostMalloc(&e->h_pin, cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&e->h_pin, cap, hipHostMallocMapped | hipHostMallocCoherent));   // (coherent: the kernel-written rows + flag)
+    memset(e->h_pin, 0, cap);
+    e->d_pin = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&e->d_pin, e->h_pin, 0));
     e->h_pin_cap = cap;
     return RII_OK;
 }
@@ -1413,11 +1433,13 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     const size_t q_pad = (q_bytes + 15) & ~(size_t) 15;
     const bool pack_tids = S > 0 && q_pad + t_bytes + out_bytes <= kPinLimit;
     const size_t in_bytes = pack_tids ? q_pad + t_bytes : q_pad;
-    RII_TRY(ensure_pin(e, in_bytes + out_bytes));
+    // the first kPinFlagBytes of the pinned block hold ONLY the per-query sequence flags of host_spin (a fixed place: a flag word
+    // must never have held anything but sequence numbers, or stale data could equal the awaited one)
+    RII_TRY(ensure_pin(e, kPinFlagBytes + in_bytes + out_bytes));
     RII_TRY(e->s_queries.ensure(std::max<size_t>(in_bytes, 16)));
     RII_TRY(e->s_out_pack.ensure(std::max<size_t>(out_bytes, 16)));
     if (!pack_tids) RII_TRY(e->s_tids.ensure(std::max<size_t>(t_bytes, 16)));
-    unsigned char *pin = static_cast<unsigned char *>(e->h_pin);
+    unsigned char *pin = static_cast<unsigned char *>(e->h_pin) + kPinFlagBytes;
     memcpy(pin, queries, q_bytes);
     if (pack_tids) memcpy(pin + q_pad, tids, t_bytes);
     HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, pack_tids ? in_bytes : q_bytes, hipMemcpyHostToDevice, st));
@@ -1428,11 +1450,41 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     int64_t *d_cnt = reinterpret_cast<int64_t *>(dp + ids_bytes);
     int32_t *d_flag = reinterpret_cast<int32_t *>(dp + ids_bytes + c_bytes);
     float *d_d = reinterpret_cast<float *>(dp + ids_bytes + c_bytes + f_bytes);
+    unsigned char *pout = pin + in_bytes;
+    // (inputs above a few KB are copied by a DMA engine instead of a blit kernel; behind such a copy the flag arrives later than the
+    //  stream synchronisation returns -- measured: 3000 target ids 38.6 us with the synchronisation, 41.4 us with the flag)
+    if (!ivf && e->host_spin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes &&
+        takes_small_topk(e, B, topk, S)) {
+        // the kernel writes the rows into the pinned block itself and raises one flag per query behind them; the host spins on the
+        // flags (bounded: after some tens of milliseconds it falls back to the stream synchronisation, which is always correct)
+        unsigned char *dp_host = static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes;
+        volatile unsigned int *flags = reinterpret_cast<volatile unsigned int *>(e->h_pin);
+        const unsigned int seq = ++e->spin_seq ? e->spin_seq : ++e->spin_seq;          // never 0
+        e->spin_flag = reinterpret_cast<unsigned int *>(e->d_pin);
+        e->spin_used = false;
+        const int r = query_linear_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S,
+                                       reinterpret_cast<int64_t *>(dp_host + in_bytes),
+                                       reinterpret_cast<float *>(dp_host + in_bytes + ids_bytes), st);
+        e->spin_flag = nullptr;
+        if (r != RII_OK) return r;
+        bool seen = false;
+        if (e->spin_used) {
+            for (int spins = 0; spins < 400000 && !seen; ++spins) {
+                seen = true;
+                for (int64_t b = 0; b < B; ++b) seen = seen && (flags[b] == seq);
+                if (!seen) __builtin_ia32_pause();
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(st));
+        memcpy(out_ids, pout, ids_bytes);
+        memcpy(out_dists, pout + ids_bytes, d_bytes);
+        return RII_OK;
+    }
     if (ivf)
         RII_TRY(query_ivf_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S, L, d_ids, d_d, d_cnt, st, d_flag));
     else
         RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S, d_ids, d_d, st));
-    unsigned char *pout = pin + in_bytes;
     HIP_TRY(hipMemcpyAsync(pout, dp, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (ivf && e->ivf_has_deferred) {
@@ -1788,6 +1840,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->fc_cov = 0;                  // the formatted lookups are laid out per kernel
     } else if (k == "scan_dual") {
         e->scan_dual = value ? 1 : 0;
+    } else if (k == "host_spin") {
+        e->host_spin = value ? 1 : 0;
     } else if (k == "small_topk") {
         e->small_topk = value ? 1 : 0;
     } else if (k == "warm_groups") {
@@ -1835,6 +1889,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "scan_prio") return e->scan_prio;
     if (k == "warm_groups") return e->warm_groups;
     if (k == "small_topk") return e->small_topk;
+    if (k == "host_spin") return e->host_spin;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;

@@ -240,7 +240,8 @@ int small_topk_slices(int64_t n, int64_t B);
 size_t small_topk_scratch(int64_t n, int64_t B);
 hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, const float *d_queries,
                              const float *d_codewords, int Ds, int arch, int64_t B, int topk, const int64_t *d_remap,
-                             unsigned long long *d_keys, unsigned int *d_done, int64_t *d_out_ids, float *d_out_dists, hipStream_t st);
+                             unsigned long long *d_keys, unsigned int *d_done, int64_t *d_out_ids, float *d_out_dists, hipStream_t st,
+                             unsigned int *host_flag = nullptr, unsigned int seq = 0);   // host_flag: outputs in coherent host memory
 
 // widetab.hip: shapes whose one-query table does not fit LDS (lut_tile_for() == 0): tables stay in global memory
 hipError_t launch_scan_wide(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, const int64_t *d_remap,

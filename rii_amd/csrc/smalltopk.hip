@@ -30,6 +30,8 @@ struct SmallArgs {
     int64_t *out_ids; float *out_dists;
     unsigned long long *gkeys;               // gridDim.x > 1: [b][n] keys of all slices (the last block to finish selects)
     unsigned int *done;                      // [b] blocks of the query that have stored their slice; back to 0 when the launch ends
+    unsigned int *host_flag; unsigned int seq;   // out_ids / out_dists are coherent HOST memory: flag[b] = seq once query b's rows are
+                                                 // written (system-scope release); NULL: ordinary device outputs
 };
 
 // ascending bitonic sort of n (a power of two) 64-bit keys in LDS by all threads of the block
@@ -243,6 +245,15 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
         p.out_ids[b * k + j] = p.remap ? p.remap[idx] : (int64_t) idx;
         p.out_dists[b * k + j] = pq64_dist(e);
     }
+    if (p.host_flag) {
+        // the rows went straight to the caller's pinned block: publish them to the host, which is spinning on the flag instead of
+        // paying a D2H copy and a stream synchronisation (tools/host_latency_probe.hip: 9 us of a 17 us empty call)
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            __hip_atomic_store(&p.host_flag[b], p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 static size_t small_topk_smem(int M, int Ks, int64_t n)
@@ -263,12 +274,13 @@ size_t small_topk_scratch(int64_t n, int64_t B) { return small_topk_slices(n, B)
 
 hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, const float *d_queries,
                              const float *d_codewords, int Ds, int arch, int64_t B, int topk, const int64_t *d_remap,
-                             unsigned long long *d_keys, unsigned int *d_done, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+                             unsigned long long *d_keys, unsigned int *d_done, int64_t *d_out_ids, float *d_out_dists, hipStream_t st,
+                             unsigned int *host_flag, unsigned int seq)
 {
     if (B == 0) return hipSuccess;
     SmallArgs a;
     a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch;
-    a.remap = d_remap; a.topk = topk; a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.gkeys = d_keys; a.done = d_done;
+    a.remap = d_remap; a.topk = topk; a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.gkeys = d_keys; a.done = d_done; a.host_flag = host_flag; a.seq = seq;
     const size_t smem = small_topk_smem(M, Ks, n);
     void (*kern)(SmallArgs) = small_topk_kernel<0>;
     if (M == 16) kern = small_topk_kernel<1>;

@@ -503,7 +503,7 @@ def test_gpu_small_index_topk_one_launch_vs_oracle(case):
     g = RiiGpu(cw, False, simd_arch="avx512")
     o = O.OracleRii(cw, False, simd_arch="avx512")
     g.add_codes(codes, False); o.add_codes(codes, False)
-    assert g.get_option("small_topk") == 1
+    assert g.get_option("small_topk") == 1 and g.get_option("host_spin") == 1
     sub = rng.permutation(N)[:N // 3].astype(np.int64)            # unsorted subset: positions, not ids, break ties
     n_tied = 0
     for topk in [k for k in (1, 2, 3, 10, 100, 1023) if k <= N // 3] + ([N] if N <= 1023 else []):
@@ -512,13 +512,17 @@ def test_gpu_small_index_topk_one_launch_vs_oracle(case):
                 continue
             for B in (1, 5):
                 g.set_option("small_topk", 1)
-                ids, d = g.query_linear_batch(qs[:B], topk, tids)
+                ids, d = g.query_linear_batch(qs[:B], topk, tids)          # rows written to the pinned block by the kernel, flag spin
+                g.set_option("host_spin", 0)
+                ids1, d1 = g.query_linear_batch(qs[:B], topk, tids)        # D2H copy + stream synchronisation
+                g.set_option("host_spin", 1)
                 g.set_option("small_topk", 0)
                 ids0, d0 = g.query_linear_batch(qs[:B], topk, tids)
                 for b in range(B):
                     want = o.query_linear(qs[b], topk, tids)
                     what = "small topk k=%d S=%d B=%d b=%d" % (topk, len(tids), B, b)
                     assert_same_result((ids[b], d[b]), want, what)
+                    assert_same_result((ids1[b], d1[b]), want, what + " (host_spin = 0)")
                     assert_same_result((ids0[b], d0[b]), want, what + " (general path)")
                     n_tied += int(len(np.unique(np.asarray(want[1]))) < topk)
     g.set_option("small_topk", 1)

@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--calls", type=int, default=500)
 ap.add_argument("--topk", type=int, default=3)
 ap.add_argument("--small-topk", type=int, default=1)
+ap.add_argument("--host-spin", type=int, default=1)
 ap.add_argument("--only", default="")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -26,6 +27,7 @@ eng = RiiGpu(cw, False, device=0)
 eng.add_codes(codes, False)
 eng.reconfigure(100, 5)
 eng.set_option("small_topk", a.small_topk)
+eng.set_option("host_spin", a.host_spin)
 E = np.array([], np.int64)
 sub = np.sort(rng.choice(N, 3000, replace=False)).astype(np.int64)
 legs = {"linear top-1": lambda q: eng.query_linear(q, 1, E),
