@@ -995,9 +995,12 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             e->flag_parity ^= 1;
             // common case answered in one launch; queries whose answer could hinge on std::partial_sort's internal
             // order raise flag[b] and are redone by the exact emulation kernels below (which skip the others)
+            if (defer && e->spin_flag) { p.host_flag = e->spin_flag; p.host_seq = e->spin_seq; }
             ScopedTimer t(e, "ivf_fused", st, true);
             HIP_TRY(launch_ivf_fused(p, st));
+            p.host_flag = nullptr;                   // (the deferred fallback re-uses p: nothing after this launch publishes)
             if (defer) {
+                e->spin_used = e->spin_flag != nullptr;
                 e->ivf_deferred = p;
                 e->ivf_has_deferred = true;
                 return RII_OK;
@@ -1479,6 +1482,46 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
         if (!seen) HIP_TRY(hipStreamSynchronize(st));
         memcpy(out_ids, pout, ids_bytes);
         memcpy(out_dists, pout + ids_bytes, d_bytes);
+        return RII_OK;
+    }
+    if (ivf && e->host_spin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes && B < e->fast_min_batch) {
+        // the same for the inverted index: every output field (rows, counts, fallback flags) lives in the pinned block; the fused
+        // kernel raises a query's sequence flag at each of its exits.  A call that takes another path (spin_used stays false) is
+        // simply synchronised -- its kernels wrote the pinned block too.
+        unsigned char *dp_host = static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes + in_bytes;
+        volatile unsigned int *flags = reinterpret_cast<volatile unsigned int *>(e->h_pin);
+        const unsigned int seq = ++e->spin_seq ? e->spin_seq : ++e->spin_seq;
+        e->spin_flag = reinterpret_cast<unsigned int *>(e->d_pin);
+        e->spin_used = false;
+        const int r = query_ivf_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S, L, reinterpret_cast<int64_t *>(dp_host),
+                                    reinterpret_cast<float *>(dp_host + ids_bytes + c_bytes + f_bytes),
+                                    reinterpret_cast<int64_t *>(dp_host + ids_bytes), st,
+                                    reinterpret_cast<int32_t *>(dp_host + ids_bytes + c_bytes));
+        e->spin_flag = nullptr;
+        if (r != RII_OK) return r;
+        bool seen = false;
+        if (e->spin_used) {
+            for (int spins = 0; spins < 400000 && !seen; ++spins) {
+                seen = true;
+                for (int64_t b = 0; b < B; ++b) seen = seen && (flags[b] == seq);
+                if (!seen) __builtin_ia32_pause();
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(st));
+        if (e->ivf_has_deferred) {
+            const int32_t *fl = reinterpret_cast<const int32_t *>(pout + ids_bytes + c_bytes);
+            bool any = false;
+            for (int64_t b = 0; b < B; ++b) any |= (fl[b] != 0);
+            if (any) {
+                RII_TRY(ivf_run_deferred_fallback(e, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            e->ivf_has_deferred = false;
+        }
+        memcpy(out_ids, pout, ids_bytes);
+        memcpy(out_counts, pout + ids_bytes, c_bytes);
+        memcpy(out_dists, pout + ids_bytes + c_bytes + f_bytes, d_bytes);
         return RII_OK;
     }
     if (ivf)

@@ -733,6 +733,16 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     const int nlist = p.nlist;
     const int w = (int) p.w;
     if (bl == 0 && tid == 0 && p.nflag_next) *p.nflag_next = 0;
+    // every exit of the block is uniform: the rows of this query (or its fallback flag) are out -> tell a spinning host (host_spin)
+    auto publish = [&]() {
+        if (p.host_flag) {
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence_system();
+                __hip_atomic_store(&p.host_flag[p.b0 + bl], p.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
 
     if (p.queries) {
         // table built in place (exact fvec_L2sqr order): no global round trip for the common case
@@ -895,6 +905,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
             for (int i = tid; i < MK; i += blockDim.x) dst[i] = lds[i];
         }
+        publish();
         return;
     }
     const int ncand = s_misc[0], nv = s_misc[1];
@@ -955,6 +966,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             p.out_dists[bl] = bestd;
             p.out_counts[bl] = 1;
         }
+        publish();
         return;
     }
     if constexpr (!TOP1 && LSEL) {
@@ -1054,6 +1066,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
                 for (int i = tid; i < MK; i += blockDim.x) dst[i] = lds[i];
             }
+            publish();
             return;
         }
         for (int j = tid; j < p.topk; j += 256) {
@@ -1068,6 +1081,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             p.out_dists[bl * p.topk + j] = __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
         }
         if (tid == 0) p.out_counts[bl] = p.topk;
+        publish();
         return;
     }
     if constexpr (!TOP1 && !LSEL)
@@ -1159,6 +1173,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
                 for (int i = tid; i < MK; i += blockDim.x) dst[i] = lds[i];
             }
+            publish();
             return;
         }
         for (int j = tid; j < p.topk; j += 256) {
@@ -1173,6 +1188,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             p.out_dists[bl * p.topk + j] = __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
         }
         if (tid == 0) p.out_counts[bl] = p.topk;
+        publish();
     }
 }
 

@@ -111,6 +111,9 @@ struct IvfParams {
     int kcap = 0;                    // ivf_fused_kernel, selection in LDS: keys of the final sort (set by launch_ivf_fused)
     int32_t *flag;                // [B] 1 = needs the exact std::partial_sort emulation path (nullptr = all do)
     int force_flag = 0;           // debug/tests: ivf_fused_kernel flags every query (option "ivf_force_exact")
+    // host_spin: the outputs (and `flag`) are coherent HOST memory; ivf_fused_kernel stores host_seq into host_flag[b0 + b] once
+    // query b's rows (or its fallback flag) are written, behind a system-scope release
+    unsigned int *host_flag = nullptr; unsigned int host_seq = 0;
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
 bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk);

@@ -208,6 +208,48 @@ def test_gpu_ivf_empty_and_tail_vs_oracle():
             n_empty += (len(want[0]) == 0)
 
 
+@pytest.mark.parametrize("dup", [0, 1500])
+def test_gpu_ivf_small_calls_flag_wait_vs_oracle(dup):
+    """Small host-pointer inverted-index calls (the README pattern: one query per call): the fused kernel writes rows, counts and
+    fallback flags into the engine's pinned block and raises a sequence flag per query (option host_spin); against the oracle and
+    against the copy + synchronise form, with duplicated codes (exact ties -> the flagged fallback runs behind the wait), target
+    ids, every query forced through the fallback, and the emulation kernels (ivf_fused = 0)."""
+    from rii_amd import RiiGpu
+    arch = "avx512"
+    cw, codes, qs = make_problem(21 + dup, 32, 256, 4, 10000, "sift" if dup else "unit", dup=dup)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    g.add_codes(codes, False); o.add_codes(codes, False)
+    g.reconfigure(100, 3); o.reconfigure(100, 3)
+    assert g.posting_lists == o.posting_lists
+    rng = np.random.default_rng(5)
+    sub = np.sort(rng.choice(10000, 700, replace=False)).astype(np.int64)
+    for force, fused in ((0, 1), (1, 1), (0, 0)):
+        g.set_option("ivf_force_exact", force)
+        g.set_option("ivf_fused", fused)
+        for topk, L in ((1, 100), (3, 100), (10, 400), (50, 60)):
+            for tids in (E, sub):
+                if len(tids) and L > len(tids):
+                    continue
+                for B in (1, 4):
+                    res = {}
+                    for spin in (1, 0):
+                        g.set_option("host_spin", spin)
+                        res[spin] = g.query_ivf_batch(qs[:B], topk, tids, L)
+                    g.set_option("host_spin", 1)
+                    for b in range(B):
+                        want = o.query_ivf(qs[b], topk, tids, L)
+                        for spin in (1, 0):
+                            ids, d, cnt = res[spin]
+                            n = int(cnt[b])
+                            assert_same_result((ids[b, :n], d[b, :n]), want,
+                                               "k=%d L=%d S=%d B=%d b=%d force=%d fused=%d spin=%d" % (topk, L, len(tids), B, b, force, fused, spin))
+    g.set_option("ivf_force_exact", 0); g.set_option("ivf_fused", 1)
+    ids, d = g.query_ivf(qs[0], 3, E, 100)                       # the one-query entry point
+    want = o.query_ivf(qs[0], 3, E, 100)
+    assert_same_result((ids, d), want, "query_ivf")
+
+
 def test_gpu_ivf_empty_return_with_stale_lists():
     """rii.h:324-325 is reachable when codes were appended with update_flag=False after a reconfigure (lists
     cover fewer than L ids): fewer than topk hits in the first w lists, then the walk over the unsorted tail
