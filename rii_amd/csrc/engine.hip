@@ -824,7 +824,7 @@ int query_linear_wide(rii_engine *e, const float *d_queries, int64_t B, int topk
 static bool takes_small_topk(const rii_engine *e, int64_t B, int topk, int64_t S)
 {
     return e->QT != 0 && e->small_topk && B > 0 && B < e->fast_min_batch && B <= kMaxBatch &&
-           small_topk_supported(e->M, e->Ks, S ? S : e->N, topk);
+           small_topk_supported(e->M, e->Ks, e->Ds, S ? S : e->N, topk);
 }
 
 int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
@@ -1445,7 +1445,12 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     unsigned char *pin = static_cast<unsigned char *>(e->h_pin) + kPinFlagBytes;
     memcpy(pin, queries, q_bytes);
     if (pack_tids) memcpy(pin + q_pad, tids, t_bytes);
-    HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, pack_tids ? in_bytes : q_bytes, hipMemcpyHostToDevice, st));
+    const bool spin_linear = !ivf && e->host_spin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes &&
+                             takes_small_topk(e, B, topk, S);
+    // no target ids, exact tables: small_topk_kernel reads the query straight from the pinned block (once per block, through LDS)
+    // -- no H2D copy in front of the launch either
+    const bool q_in_place = spin_linear && S == 0 && e->lut_mode == RII_LUT_EXACT;
+    if (!q_in_place) HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, pack_tids ? in_bytes : q_bytes, hipMemcpyHostToDevice, st));
     if (S && !pack_tids) HIP_TRY(hipMemcpyAsync(e->s_tids.p, tids, t_bytes, hipMemcpyHostToDevice, st));
     const int64_t *d_tids_in = pack_tids ? reinterpret_cast<const int64_t *>(e->s_queries.as<unsigned char>() + q_pad) : e->s_tids.as<int64_t>();
     unsigned char *dp = e->s_out_pack.as<unsigned char>();
@@ -1456,8 +1461,7 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     unsigned char *pout = pin + in_bytes;
     // (inputs above a few KB are copied by a DMA engine instead of a blit kernel; behind such a copy the flag arrives later than the
     //  stream synchronisation returns -- measured: 3000 target ids 38.6 us with the synchronisation, 41.4 us with the flag)
-    if (!ivf && e->host_spin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes &&
-        takes_small_topk(e, B, topk, S)) {
+    if (spin_linear) {
         // the kernel writes the rows into the pinned block itself and raises one flag per query behind them; the host spins on the
         // flags (bounded: after some tens of milliseconds it falls back to the stream synchronisation, which is always correct)
         unsigned char *dp_host = static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes;
@@ -1465,7 +1469,7 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
         const unsigned int seq = ++e->spin_seq ? e->spin_seq : ++e->spin_seq;          // never 0
         e->spin_flag = reinterpret_cast<unsigned int *>(e->d_pin);
         e->spin_used = false;
-        const int r = query_linear_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S,
+        const int r = query_linear_dev(e, q_in_place ? reinterpret_cast<const float *>(dp_host) : e->s_queries.as<float>(), B, topk, d_tids_in, S,
                                        reinterpret_cast<int64_t *>(dp_host + in_bytes),
                                        reinterpret_cast<float *>(dp_host + in_bytes + ids_bytes), st);
         e->spin_flag = nullptr;

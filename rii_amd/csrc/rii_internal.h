@@ -238,7 +238,7 @@ hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, in
 // d_lut == NULL: every block builds its exact table from d_queries and the codebook itself (no table launch).
 // small_topk_slices() > 1: the codes of a query are scored by that many blocks; d_keys = small_topk_scratch() bytes, d_done = B
 // counters that are zero between launches (zeroed once by the caller, put back by the kernel).
-bool small_topk_supported(int M, int Ks, int64_t n, int topk);
+bool small_topk_supported(int M, int Ks, int Ds, int64_t n, int topk);
 int small_topk_slices(int64_t n, int64_t B);
 size_t small_topk_scratch(int64_t n, int64_t B);
 hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, const float *d_queries,

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int MK = p.M * p.Ks, tid = threadIdx.x, lane = tid & 63, n = (int) p.n, k = p.topk;
     float *lds = reinterpret_cast<float *>(smem);
-    pq64_t *s_key = reinterpret_cast<pq64_t *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));     // [n] (distance, index), index order
+    float *s_q = reinterpret_cast<float *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));          // [M * Ds] the query (16-byte aligned)
+    pq64_t *s_key = reinterpret_cast<pq64_t *>(reinterpret_cast<unsigned char *>(s_q) + (((size_t) p.M * p.Ds * 4 + 15) & ~(size_t) 15));   // [n] (distance, index), index order
     unsigned long long *s_buf = s_key + n;                                                           // [kStBuf] keys up to the bound
     unsigned long long *s_out = s_buf + kStBuf;                                                      // [kStRank] rank-sorted
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_out + kStRank);                        // [256]
@@ -97,28 +98,51 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
         }
     }
     if (tid == 0) s_ctl[5] = 0u;
-    if (!p.lut && p.Ds == 4) {
-        // RiiCpp::DTable (src/rii.h:361-373), Ds == 4: straight-line fvec_L2sqr, identical for the three SIMD flavours
-        const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
-        const float4 *q4 = reinterpret_cast<const float4 *>(p.queries + (size_t) b * p.M * 4);
-        const int sh = (p.Ks & (p.Ks - 1)) == 0 ? __ffs(p.Ks) - 1 : -1;
-        for (int i0 = 0; i0 < MK; i0 += 8 * kStThreads) {
-            float4 cv[8], qv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = i0 + u * kStThreads + tid, ic = idx < MK ? idx : MK - 1;
-                cv[u] = cw4[ic];
-                qv[u] = q4[sh >= 0 ? ic >> sh : ic / p.Ks];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = i0 + u * kStThreads + tid;
-                if (idx < MK) lds[idx] = fvec_l2sqr_ds4v(qv[u], cv[u]);
+    if (!p.lut) {
+        // The query goes through LDS: it is read from memory ONCE per block -- it may be the caller's pinned HOST block (host_spin:
+        // no H2D copy in front of this launch; every read of it crosses PCIe).  Its load is requested here, parked in a register
+        // while the first codebook entries are requested too, and only then stored and waited for.
+        const int D = p.M * p.Ds;
+        const float *qg = p.queries + (size_t) b * D;
+        float qreg[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((D & 3) == 0) {
+            if (tid < D / 4) {
+                const float4 v = reinterpret_cast<const float4 *>(qg)[tid];       // D <= 4096 floats: one 16-byte piece per thread
+                qreg[0] = v.x; qreg[1] = v.y; qreg[2] = v.z; qreg[3] = v.w;
             }
         }
-    } else if (!p.lut) {
-        const float *q = p.queries + (size_t) b * p.M * p.Ds;
-        for (int i = tid; i < MK; i += kStThreads) lds[i] = fvec_l2sqr_any(q + (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
+        if (p.Ds == 4) {
+            // RiiCpp::DTable (src/rii.h:361-373), Ds == 4: straight-line fvec_L2sqr, identical for the three SIMD flavours
+            const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
+            const float4 *q4 = reinterpret_cast<const float4 *>(s_q);
+            const int sh = (p.Ks & (p.Ks - 1)) == 0 ? __ffs(p.Ks) - 1 : -1;
+            for (int i0 = 0; i0 < MK; i0 += 8 * kStThreads) {
+                float4 cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = i0 + u * kStThreads + tid, ic = idx < MK ? idx : MK - 1;
+                    cv[u] = cw4[ic];
+                }
+                if (i0 == 0) {
+                    if (tid < D / 4) reinterpret_cast<float4 *>(s_q)[tid] = make_float4(qreg[0], qreg[1], qreg[2], qreg[3]);
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = i0 + u * kStThreads + tid;
+                    if (idx < MK) lds[idx] = fvec_l2sqr_ds4v(q4[sh >= 0 ? idx >> sh : idx / p.Ks], cv[u]);
+                }
+            }
+        } else {
+            if ((D & 3) == 0) {
+                if (tid < D / 4) reinterpret_cast<float4 *>(s_q)[tid] = make_float4(qreg[0], qreg[1], qreg[2], qreg[3]);
+            } else {
+                for (int i = tid; i < D; i += kStThreads) s_q[i] = qg[i];
+            }
+            __syncthreads();
+            for (int i = tid; i < MK; i += kStThreads)
+                lds[i] = fvec_l2sqr_any(s_q + (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
+        }
     } else {
         const float *src = p.lut + (size_t) b * MK;
         if ((MK & 3) == 0) {
@@ -256,13 +280,15 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
     }
 }
 
-static size_t small_topk_smem(int M, int Ks, int64_t n)
+static size_t small_topk_smem(int M, int Ks, int Ds, int64_t n)
 {
-    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) n * 8 + (size_t) (kStBuf + kStRank) * 8 + 256 * 4 + 32;
+    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) n * 8 + (size_t) (kStBuf + kStRank) * 8 + 256 * 4 + 32 +
+           (((size_t) M * Ds * 4 + 15) & ~(size_t) 15);
 }
-bool small_topk_supported(int M, int Ks, int64_t n, int topk)
+bool small_topk_supported(int M, int Ks, int Ds, int64_t n, int topk)
 {
-    return n >= 2 && topk >= 1 && topk <= n && topk + 1 <= kStBuf / 2 && small_topk_smem(M, Ks, n) <= (size_t) 160 * 1024 - 512;
+    return n >= 2 && topk >= 1 && topk <= n && topk + 1 <= kStBuf / 2 && (int64_t) M * Ds <= 4 * kStThreads &&
+           small_topk_smem(M, Ks, Ds, n) <= (size_t) 160 * 1024 - 512;
 }
 int small_topk_slices(int64_t n, int64_t B)
 {
@@ -281,7 +307,7 @@ hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, c
     SmallArgs a;
     a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch;
     a.remap = d_remap; a.topk = topk; a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.gkeys = d_keys; a.done = d_done; a.host_flag = host_flag; a.seq = seq;
-    const size_t smem = small_topk_smem(M, Ks, n);
+    const size_t smem = small_topk_smem(M, Ks, Ds, n);
     void (*kern)(SmallArgs) = small_topk_kernel<0>;
     if (M == 16) kern = small_topk_kernel<1>;
     else if (M == 32) kern = small_topk_kernel<2>;
