@@ -435,9 +435,10 @@ def readme_workload(args, torch, dev, arch):
             cb["queries_compared"] = len(cpu_res)
             o["cpu_baseline"] = cb
         out[name] = o
-    out["note"] = ("latency-bound: one launch (linear: small_topk_kernel) or three (inverted index) + pinned H2D/D2H + one "
-                   "synchronisation, floor 17-20 us on this box (tools/host_latency_probe.hip); no roofline applies (the index is "
-                   "320 KB)")
+    out["note"] = ("latency-bound: linear = ONE launch (small_topk_kernel reads the query from and writes its rows to the engine's "
+                   "pinned block, the host waits on a flag there); inverted index = pinned H2D + three launches, rows and flag "
+                   "likewise; floor of an empty launch + flag on this box 7.5 us (tools/host_latency_probe.hip); no roofline "
+                   "applies (the index is 320 KB)")
     return out
 
 
