@@ -250,6 +250,39 @@ def test_gpu_ivf_small_calls_flag_wait_vs_oracle(dup):
     assert_same_result((ids, d), want, "query_ivf")
 
 
+def test_gpu_flag_wait_soak():
+    """Thousands of one-query calls with changing topk / search kind / target ids through the flag wait (host_spin = 1), each
+    compared with the answer of the copy + synchronise form: a flag that is seen before its rows (or a stale word that equals
+    the awaited sequence number -- which a flag placed behind the rows once did) shows up here."""
+    from rii_amd import RiiGpu
+    cw, codes, qs = make_problem(77, 32, 256, 4, 10000, "unit")
+    rng = np.random.default_rng(77)
+    qs = rng.random((64, 128)).astype(np.float32)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.reconfigure(100, 3)
+    sub = np.sort(rng.choice(10000, 300, replace=False)).astype(np.int64)
+    shapes = [("linear", 1, E), ("linear", 3, E), ("linear", 10, sub), ("linear", 64, E), ("ivf", 1, E), ("ivf", 3, E), ("ivf", 20, sub)]
+    g.set_option("host_spin", 0)
+    want = {}
+    for si, (kind, topk, tids) in enumerate(shapes):
+        for qi in range(len(qs)):
+            want[si, qi] = g.query_linear(qs[qi], topk, tids) if kind == "linear" else g.query_ivf(qs[qi], topk, tids, 200)
+    g.set_option("host_spin", 1)
+    for it in range(6000):
+        si, qi = int(rng.integers(len(shapes))), int(rng.integers(len(qs)))
+        kind, topk, tids = shapes[si]
+        got = g.query_linear(qs[qi], topk, tids) if kind == "linear" else g.query_ivf(qs[qi], topk, tids, 200)
+        assert got == want[si, qi], "call %d: %s topk=%d S=%d q=%d" % (it, kind, topk, len(tids), qi)
+    # small batches as well (one flag word per query)
+    for it in range(300):
+        B = int(rng.integers(2, 9))
+        rows = rng.integers(0, len(qs), B)
+        ids, d = g.query_linear_batch(qs[rows], 3, None)
+        for j, qi in enumerate(rows):
+            assert (ids[j].tolist(), d[j].tolist()) == want[1, int(qi)], "batch call %d row %d" % (it, j)
+
+
 def test_gpu_ivf_empty_return_with_stale_lists():
     """rii.h:324-325 is reachable when codes were appended with update_flag=False after a reconfigure (lists
     cover fewer than L ids): fewer than topk hits in the first w lists, then the walk over the unsorted tail
