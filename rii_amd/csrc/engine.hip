@@ -179,6 +179,8 @@ struct rii_engine : ScratchSet {
     int64_t fc_cov = 0;
     int scan_order = 1;         // option "scan_order"
     int scan_mx = 1;            // option "scan_mx": 1 = rotated shapes scan with fscan_mx_kernel (its own lookup order), 0 = fscan_kernel
+    int slice_topk = 1;         // option "slice_topk": host-pointer calls of up to 8 queries on an index too large for the one-block
+                                // kernel take ONE launch (slice_topk_kernel: slices on all CUs, last block merges, ties -> general path)
     int host_spin = 1;          // option "host_spin": small host-pointer calls answered by the one-launch kernel get their rows written
                                 // straight into the pinned block and wait on a flag there instead of a D2H copy + stream synchronisation
     unsigned int *spin_flag = nullptr;   // (set by host_query around the call: device address of the flags in the pinned block)
@@ -820,6 +822,16 @@ int query_linear_wide(rii_engine *e, const float *d_queries, int64_t B, int topk
     return RII_OK;
 }
 
+// per-query arrival counters of the multi-block one-launch kernels: zeroed once, the kernels put the zeros back
+static int ensure_small_done(rii_engine *e, hipStream_t st)
+{
+    if (e->s_small_done.cap < (size_t) kMaxBatch * sizeof(unsigned int)) {
+        RII_TRY(e->s_small_done.ensure((size_t) kMaxBatch * sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(e->s_small_done.p, 0, (size_t) kMaxBatch * sizeof(unsigned int), st));
+    }
+    return RII_OK;
+}
+
 // the one-launch path of smalltopk.hip answers this call (host_query relies on the same predicate)
 static bool takes_small_topk(const rii_engine *e, int64_t B, int topk, int64_t S)
 {
@@ -851,10 +863,7 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
             if (!own_tables) RII_TRY(build_lut(e, d_queries, B, st, false, 1));
             e->lut_valid = false;                                        // s_lut does not hold this batch's tables
             RII_TRY(e->s_keys_a.ensure(std::max<size_t>(small_topk_scratch(n_codes, B), 16)));
-            if (e->s_small_done.cap < (size_t) kMaxBatch * sizeof(unsigned int)) {
-                RII_TRY(e->s_small_done.ensure((size_t) kMaxBatch * sizeof(unsigned int)));
-                HIP_TRY(hipMemsetAsync(e->s_small_done.p, 0, (size_t) kMaxBatch * sizeof(unsigned int), st));   // once: the kernel leaves zeros
-            }
+            RII_TRY(ensure_small_done(e, st));
             ScopedTimer t(e, "scan", st);
             HIP_TRY(launch_small_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, own_tables ? nullptr : e->s_lut.as<float>(), d_queries,
                                       e->d_codewords.as<float>(), e->Ds, e->arch, B, topk, S ? d_tids : nullptr,
@@ -1449,7 +1458,11 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
                              takes_small_topk(e, B, topk, S);
     // no target ids, exact tables: small_topk_kernel reads the query straight from the pinned block (once per block, through LDS)
     // -- no H2D copy in front of the launch either
-    const bool q_in_place = spin_linear && S == 0 && e->lut_mode == RII_LUT_EXACT;
+    // a few queries on an index too large for that kernel: slice_topk_kernel (one launch; exact ties come back as a flag and the
+    // call is redone on the general path)
+    const bool slice_linear = !ivf && !spin_linear && e->host_spin && e->slice_topk && e->QT != 0 && e->lut_mode == RII_LUT_EXACT &&
+                              in_bytes <= kSpinMaxInput && slice_topk_supported(e->M, e->Ks, e->Ds, S ? S : e->N, B, topk);
+    const bool q_in_place = (spin_linear || slice_linear) && S == 0 && e->lut_mode == RII_LUT_EXACT;
     if (!q_in_place) HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, pack_tids ? in_bytes : q_bytes, hipMemcpyHostToDevice, st));
     if (S && !pack_tids) HIP_TRY(hipMemcpyAsync(e->s_tids.p, tids, t_bytes, hipMemcpyHostToDevice, st));
     const int64_t *d_tids_in = pack_tids ? reinterpret_cast<const int64_t *>(e->s_queries.as<unsigned char>() + q_pad) : e->s_tids.as<int64_t>();
@@ -1461,6 +1474,46 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     unsigned char *pout = pin + in_bytes;
     // (inputs above a few KB are copied by a DMA engine instead of a blit kernel; behind such a copy the flag arrives later than the
     //  stream synchronisation returns -- measured: 3000 target ids 38.6 us with the synchronisation, 41.4 us with the flag)
+    if (slice_linear) {
+        const int64_t n_codes = S ? S : e->N;
+        unsigned char *dp_host = static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes;
+        volatile unsigned int *flags = reinterpret_cast<volatile unsigned int *>(e->h_pin);
+        volatile int32_t *ties = reinterpret_cast<volatile int32_t *>(static_cast<unsigned char *>(e->h_pin) + kPinFlagBytes / 2);
+        const unsigned int seq = ++e->spin_seq ? e->spin_seq : ++e->spin_seq;
+        RII_TRY(e->s_keys_b.ensure(std::max<size_t>(slice_topk_scratch(n_codes, B, topk), 16)));
+        RII_TRY(ensure_small_done(e, st));
+        {
+            ScopedTimer t(e, "scan", st);
+            HIP_TRY(launch_slice_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks,
+                                      q_in_place ? reinterpret_cast<const float *>(dp_host) : e->s_queries.as<float>(),
+                                      e->d_codewords.as<float>(), e->Ds, e->arch, B, topk, S ? d_tids_in : nullptr,
+                                      e->s_keys_b.as<unsigned long long>(), e->s_small_done.as<unsigned int>(),
+                                      reinterpret_cast<int64_t *>(dp_host + in_bytes), reinterpret_cast<float *>(dp_host + in_bytes + ids_bytes),
+                                      reinterpret_cast<int32_t *>(static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes / 2), st,
+                                      reinterpret_cast<unsigned int *>(e->d_pin), seq));
+        }
+        bool seen = false;
+        for (int spins = 0; spins < 400000 && !seen; ++spins) {
+            seen = true;
+            for (int64_t b = 0; b < B; ++b) seen = seen && (flags[b] == seq);
+            if (!seen) __builtin_ia32_pause();
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (!seen) HIP_TRY(hipStreamSynchronize(st));
+        bool any_tie = false;
+        for (int64_t b = 0; b < B; ++b) any_tie |= (ties[b] != 0);
+        if (any_tie) {
+            // two of the k + 1 smallest distances of some query are bit-equal: std::partial_sort's order is decided by the general
+            // path (tieorder.hip) -- the whole (small) call again
+            if (q_in_place) HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, q_bytes, hipMemcpyHostToDevice, st));
+            RII_TRY(query_linear_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S, d_ids, d_d, st));
+            HIP_TRY(hipMemcpyAsync(pout, dp, out_bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        memcpy(out_ids, pout, ids_bytes);
+        memcpy(out_dists, pout + ids_bytes, d_bytes);
+        return RII_OK;
+    }
     if (spin_linear) {
         // the kernel writes the rows into the pinned block itself and raises one flag per query behind them; the host spins on the
         // flags (bounded: after some tens of milliseconds it falls back to the stream synchronisation, which is always correct)
@@ -1887,6 +1940,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->fc_cov = 0;                  // the formatted lookups are laid out per kernel
     } else if (k == "scan_dual") {
         e->scan_dual = value ? 1 : 0;
+    } else if (k == "slice_topk") {
+        e->slice_topk = value ? 1 : 0;
     } else if (k == "host_spin") {
         e->host_spin = value ? 1 : 0;
     } else if (k == "small_topk") {
@@ -1937,6 +1992,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "warm_groups") return e->warm_groups;
     if (k == "small_topk") return e->small_topk;
     if (k == "host_spin") return e->host_spin;
+    if (k == "slice_topk") return e->slice_topk;
     if (k == "fast_min_batch") return e->fast_min_batch;
     if (k == "cand_total" || k == "cand_max") {       // debug: candidates emitted by the last filter pass (synchronises)
         if (e->last_fs_B == 0 || !e->s_cand_cnt.p) return 0;

@@ -246,6 +246,15 @@ hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, c
                              unsigned long long *d_keys, unsigned int *d_done, int64_t *d_out_ids, float *d_out_dists, hipStream_t st,
                              unsigned int *host_flag = nullptr, unsigned int seq = 0);   // host_flag: outputs in coherent host memory
 
+// smalltopk.hip: a few queries per HOST call on a large index, one launch (slices of the codes on all CUs, last block merges);
+// d_out_tie[b] = 1: two of the k+1 smallest distances tie -- the caller reruns the call on the general path.  d_cand =
+// slice_topk_scratch() bytes, d_done = B counters that are zero between launches.
+bool slice_topk_supported(int M, int Ks, int Ds, int64_t n, int64_t B, int topk);
+size_t slice_topk_scratch(int64_t n, int64_t B, int topk);
+hipError_t launch_slice_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_queries, const float *d_codewords, int Ds, int arch,
+                             int64_t B, int topk, const int64_t *d_remap, unsigned long long *d_cand, unsigned int *d_done,
+                             int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_tie, hipStream_t st, unsigned int *host_flag, unsigned int seq);
+
 // widetab.hip: shapes whose one-query table does not fit LDS (lut_tile_for() == 0): tables stay in global memory
 hipError_t launch_scan_wide(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, const int64_t *d_remap,
                             int b0, int bc, unsigned long long *d_keys, hipStream_t st);

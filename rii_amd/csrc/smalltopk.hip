@@ -64,6 +64,53 @@ __device__ __forceinline__ float st_adist(const float *lds, const uint4 (&w)[NV]
     return d;
 }
 
+// The exact table of ONE query (RiiCpp::DTable, src/rii.h:361-373) built by the block into LDS (no barrier after the last store: the
+// caller's next barrier covers it).  The query goes through LDS: it is read from memory ONCE per block -- it may be the caller's
+// pinned HOST block (host_spin: no H2D copy in front of the launch; every read of it crosses PCIe).  Its load is requested first,
+// parked in a register while the first codebook entries are requested too, and only then stored and waited for.
+__device__ __forceinline__ void st_build_table(const float *qg, const float *codewords, int M, int Ks, int Ds, int arch, float *lds, float *s_q)
+{
+    const int tid = threadIdx.x, MK = M * Ks, D = M * Ds;
+    float qreg[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((D & 3) == 0) {
+        if (tid < D / 4) {
+            const float4 v = reinterpret_cast<const float4 *>(qg)[tid];       // D <= 4096 floats: one 16-byte piece per thread
+            qreg[0] = v.x; qreg[1] = v.y; qreg[2] = v.z; qreg[3] = v.w;
+        }
+    }
+    if (Ds == 4) {
+        // Ds == 4: straight-line fvec_L2sqr, identical for the three SIMD flavours
+        const float4 *cw4 = reinterpret_cast<const float4 *>(codewords);
+        const float4 *q4 = reinterpret_cast<const float4 *>(s_q);
+        const int sh = (Ks & (Ks - 1)) == 0 ? __ffs(Ks) - 1 : -1;
+        for (int i0 = 0; i0 < MK; i0 += 8 * kStThreads) {
+            float4 cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * kStThreads + tid, ic = idx < MK ? idx : MK - 1;
+                cv[u] = cw4[ic];
+            }
+            if (i0 == 0) {
+                if (tid < D / 4) reinterpret_cast<float4 *>(s_q)[tid] = make_float4(qreg[0], qreg[1], qreg[2], qreg[3]);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * kStThreads + tid;
+                if (idx < MK) lds[idx] = fvec_l2sqr_ds4v(q4[sh >= 0 ? idx >> sh : idx / Ks], cv[u]);
+            }
+        }
+    } else {
+        if ((D & 3) == 0) {
+            if (tid < D / 4) reinterpret_cast<float4 *>(s_q)[tid] = make_float4(qreg[0], qreg[1], qreg[2], qreg[3]);
+        } else {
+            for (int i = tid; i < D; i += kStThreads) s_q[i] = qg[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < MK; i += kStThreads) lds[i] = fvec_l2sqr_any(s_q + (i / Ks) * Ds, codewords + (size_t) i * Ds, Ds, arch);
+    }
+}
+
 // NV > 0: M == 16 * NV, code rows loaded as NV 16-byte words.  NV == 0: any M.
 // One block of 1024 threads per (slice, query).  Everything here is a chain of dependent memory round trips (~1 us each at one block
 // per CU), so every phase issues all its loads before it uses any: the code rows of a thread's first codes are requested BEFORE the
@@ -99,50 +146,7 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
     }
     if (tid == 0) s_ctl[5] = 0u;
     if (!p.lut) {
-        // The query goes through LDS: it is read from memory ONCE per block -- it may be the caller's pinned HOST block (host_spin:
-        // no H2D copy in front of this launch; every read of it crosses PCIe).  Its load is requested here, parked in a register
-        // while the first codebook entries are requested too, and only then stored and waited for.
-        const int D = p.M * p.Ds;
-        const float *qg = p.queries + (size_t) b * D;
-        float qreg[4] = {0.f, 0.f, 0.f, 0.f};
-        if ((D & 3) == 0) {
-            if (tid < D / 4) {
-                const float4 v = reinterpret_cast<const float4 *>(qg)[tid];       // D <= 4096 floats: one 16-byte piece per thread
-                qreg[0] = v.x; qreg[1] = v.y; qreg[2] = v.z; qreg[3] = v.w;
-            }
-        }
-        if (p.Ds == 4) {
-            // RiiCpp::DTable (src/rii.h:361-373), Ds == 4: straight-line fvec_L2sqr, identical for the three SIMD flavours
-            const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
-            const float4 *q4 = reinterpret_cast<const float4 *>(s_q);
-            const int sh = (p.Ks & (p.Ks - 1)) == 0 ? __ffs(p.Ks) - 1 : -1;
-            for (int i0 = 0; i0 < MK; i0 += 8 * kStThreads) {
-                float4 cv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = i0 + u * kStThreads + tid, ic = idx < MK ? idx : MK - 1;
-                    cv[u] = cw4[ic];
-                }
-                if (i0 == 0) {
-                    if (tid < D / 4) reinterpret_cast<float4 *>(s_q)[tid] = make_float4(qreg[0], qreg[1], qreg[2], qreg[3]);
-                    __syncthreads();
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = i0 + u * kStThreads + tid;
-                    if (idx < MK) lds[idx] = fvec_l2sqr_ds4v(q4[sh >= 0 ? idx >> sh : idx / p.Ks], cv[u]);
-                }
-            }
-        } else {
-            if ((D & 3) == 0) {
-                if (tid < D / 4) reinterpret_cast<float4 *>(s_q)[tid] = make_float4(qreg[0], qreg[1], qreg[2], qreg[3]);
-            } else {
-                for (int i = tid; i < D; i += kStThreads) s_q[i] = qg[i];
-            }
-            __syncthreads();
-            for (int i = tid; i < MK; i += kStThreads)
-                lds[i] = fvec_l2sqr_any(s_q + (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
-        }
+        st_build_table(p.queries + (size_t) b * p.M * p.Ds, p.codewords, p.M, p.Ks, p.Ds, p.arch, lds, s_q);
     } else {
         const float *src = p.lut + (size_t) b * MK;
         if ((MK & 3) == 0) {
@@ -316,6 +320,238 @@ hipError_t launch_small_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, c
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned) small_topk_slices(n, B), (unsigned) B), dim3(kStThreads), smem, st, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// ONE query per call on a LARGE index (round 3): the reference is used one query per call (rii/rii.py: Rii.query), and at N = 10^6
+// the general top-k path spends eight launches on a single query (110 us for topk = 3; 43 us for topk = 1).  Host-pointer calls
+// with a few queries (B <= 8) take ONE launch instead: grid (G slices, B queries), every block builds the query's exact table
+// (st_build_table), scores its slice of the codes in passes of `pass_cap` codes -- keys (orderable distance << 32 | index) in LDS,
+// the k+1 smallest under (distance, index) carried from pass to pass -- and writes its k+1 smallest keys to a global scratch; the
+// LAST block to arrive at the per-query counter merges the G x (k+1) keys the same way and writes the rows.  If two of the k+1
+// smallest distances of a query are bit-equal (the one case where std::partial_sort's answer is not the (distance, index) order),
+// the kernel says so in out_tie[b] and the HOST reruns the call on the general path -- which is why only host-pointer calls (whose
+// caller waits for the result anyway) come here.
+// =====================================================================================================================
+struct SliceArgs {
+    const uint8_t *codes; int64_t n; int M, Ks;
+    const float *queries, *codewords; int Ds, arch;
+    const int64_t *remap;                    // subset search: index i stands for the code remap[i], or NULL
+    int topk, k1max, pass_cap;               // k1max = topk + 1 (row pitch of cand)
+    unsigned long long *cand;                // [B][G][k1max] the slices' smallest keys (padded with ~0)
+    unsigned int *done;                      // [B] arrivals (low 16 bits) + "too many tied keys" marks (<< 16); zero between launches
+    int64_t *out_ids; float *out_dists; int32_t *out_tie;
+    unsigned int *host_flag; unsigned int seq;
+};
+
+// the kk smallest of keys[0, tot) in ascending (distance, index) order; *many: more than kStBuf keys lie under the bound (masses of
+// bit-equal distances) -- the result is then only kk keys under the bound, not the smallest.  All threads call it.
+__device__ __forceinline__ const unsigned long long *st_smallest(const pq64_t *keys, int tot, int kk, unsigned long long *s_buf,
+                                                                 unsigned long long *s_out, unsigned int *s_hist, unsigned int *s_ctl, bool *many)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    __syncthreads();
+    const uint32_t T = block_kth_bound([&](int i) { return (uint32_t) (keys[i] >> 32); }, tot, (uint32_t) kk, (uint32_t) kStBuf, s_hist, s_ctl);
+    if (tid == 0) s_ctl[5] = 0u;
+    __syncthreads();
+    for (int i0 = 0; i0 < tot; i0 += kStThreads) {
+        const int i = i0 + tid;
+        const pq64_t e = i < tot ? keys[i] : ~0ull;
+        const bool keep = i < tot && (uint32_t) (e >> 32) <= T;
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            unsigned int at0 = 0u;
+            if (lane == 0) at0 = atomicAdd(&s_ctl[5], (unsigned int) __popcll(bal));
+            at0 = (unsigned int) __shfl((int) at0, 0);
+            const unsigned int at = at0 + (unsigned int) __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && at < (unsigned int) kStBuf) s_buf[at] = e;
+        }
+    }
+    __syncthreads();
+    const unsigned int nkeep = s_ctl[5];
+    *many = nkeep > (unsigned int) kStBuf;
+    if (*many) return s_buf;
+    if (nkeep <= (unsigned int) kStRank) {
+        if (tid < (int) nkeep) {
+            const unsigned long long mine = s_buf[tid];
+            unsigned int rank = 0u;
+            for (unsigned int j = 0; j < nkeep; ++j) rank += s_buf[j] < mine ? 1u : 0u;
+            s_out[rank] = mine;
+        }
+        __syncthreads();
+        return s_out;
+    }
+    int nsort = 512;
+    while (nsort < (int) nkeep) nsort <<= 1;
+    for (int i = tid; i < nsort; i += kStThreads)
+        if ((unsigned int) i >= nkeep) s_buf[i] = ~0ull;
+    st_bitonic(s_buf, tid, nsort);
+    return s_buf;
+}
+
+template <int NV>
+__global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int MK = p.M * p.Ks, tid = threadIdx.x, lane = tid & 63, k = p.topk;
+    const int cap_keys = p.pass_cap + p.k1max;
+    float *lds = reinterpret_cast<float *>(smem);
+    float *s_q = reinterpret_cast<float *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));
+    pq64_t *s_key = reinterpret_cast<pq64_t *>(reinterpret_cast<unsigned char *>(s_q) + (((size_t) p.M * p.Ds * 4 + 15) & ~(size_t) 15));   // [cap_keys]
+    unsigned long long *s_buf = s_key + cap_keys;                                                    // [kStBuf]
+    unsigned long long *s_out = s_buf + kStBuf;                                                      // [kStRank]
+    unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_out + kStRank);                        // [256]
+    unsigned int *s_ctl = s_hist + 256;                                                              // [8]
+    const int64_t b = blockIdx.y;
+    const int G = (int) gridDim.x, g = (int) blockIdx.x;
+    const int64_t n = p.n;
+    const int k1 = (int) ((int64_t) k + 1 < n ? (int64_t) k + 1 : n);
+    const int64_t per = (n + G - 1) / G;
+    const int64_t s_lo = (int64_t) g * per < n ? (int64_t) g * per : n, s_hi = s_lo + per < n ? s_lo + per : n;
+    st_build_table(p.queries + (size_t) b * p.M * p.Ds, p.codewords, p.M, p.Ks, p.Ds, p.arch, lds, s_q);
+    __syncthreads();
+    int carried = 0;
+    bool many_any = false;
+    for (int64_t lo = s_lo; lo < s_hi; lo += p.pass_cap) {
+        const int cnt = (int) (s_hi - lo < (int64_t) p.pass_cap ? s_hi - lo : (int64_t) p.pass_cap);
+        pq64_t *dst = s_key + carried;                 // the carried keys stay in front
+        if constexpr (NV > 0) {
+            for (int j = tid; j < cnt; j += 2 * kStThreads) {                 // two codes per trip: both rows in flight before the first lookup
+                const int j2 = j + kStThreads < cnt ? j + kStThreads : j;
+                const int64_t i1 = lo + j, i2 = lo + j2;
+                const int64_t r1 = p.remap ? p.remap[i1] : i1, r2 = p.remap ? p.remap[i2] : i2;
+                const uint4 *row1 = reinterpret_cast<const uint4 *>(p.codes + (size_t) r1 * (NV * 16));
+                const uint4 *row2 = reinterpret_cast<const uint4 *>(p.codes + (size_t) r2 * (NV * 16));
+                uint4 w1[NV], w2[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) { w1[v] = row1[v]; w2[v] = row2[v]; }
+                const pq64_t e1 = pq64_make(st_adist<NV>(lds, w1, p.Ks), (uint32_t) i1);              // RiiCpp::ADist, m order
+                const pq64_t e2 = pq64_make(st_adist<NV>(lds, w2, p.Ks), (uint32_t) i2);
+                dst[j] = e1;
+                dst[j2] = e2;
+            }
+        } else {
+            for (int j = tid; j < cnt; j += kStThreads) {
+                const int64_t i = lo + j;
+                const uint8_t *code = p.codes + (size_t) (p.remap ? p.remap[i] : i) * p.M;
+                dst[j] = pq64_make(exact_adist(lds, code, p.M, p.Ks), (uint32_t) i);
+            }
+        }
+        const int tot = carried + cnt, kk = k1 < tot ? k1 : tot;
+        bool many;
+        const unsigned long long *res = st_smallest(s_key, tot, kk, s_buf, s_out, s_hist, s_ctl, &many);   // (barrier first)
+        many_any = many_any || many;
+        __syncthreads();
+        for (int j = tid; j < kk; j += kStThreads) s_key[j] = res[j];
+        carried = kk;
+        __syncthreads();
+    }
+    {
+        unsigned long long *out = p.cand + ((size_t) b * G + g) * p.k1max;
+        for (int j = tid; j < k1; j += kStThreads) out[j] = j < carried ? s_key[j] : ~0ull;
+    }
+    // ---- the last block to arrive merges (release / acquire at device scope around the counter, as in small_topk_kernel) ----
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        s_ctl[6] = atomicAdd(&p.done[b], 1u + (many_any ? 0x10000u : 0u));
+        __threadfence();
+    }
+    __syncthreads();
+    const unsigned int arrived = s_ctl[6];
+    if ((arrived & 0xffffu) != (unsigned int) (G - 1)) return;
+    if (tid == 0) { p.done[b] = 0u; s_ctl[5] = 0u; }
+    __syncthreads();
+    const bool many_before = (arrived >> 16) != 0u || many_any;
+    const unsigned long long *src = p.cand + (size_t) b * G * p.k1max;
+    const int total = G * k1;                          // (host: G * k1max <= cap_keys)
+    for (int i0 = 0; i0 < total; i0 += 8 * kStThreads) {
+        pq64_t e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kStThreads + tid, ic = i < total ? i : total - 1;
+            e[u] = __hip_atomic_load(src + (size_t) (ic / k1) * p.k1max + (ic % k1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past this XCD's L2
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kStThreads + tid;
+            const bool keep = i < total && e[u] != ~0ull;
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                unsigned int at0 = 0u;
+                if (lane == 0) at0 = atomicAdd(&s_ctl[5], (unsigned int) __popcll(bal));
+                at0 = (unsigned int) __shfl((int) at0, 0);
+                if (keep) s_key[at0 + (unsigned int) __popcll(bal & ((1ull << lane) - 1ull))] = e[u];
+            }
+        }
+    }
+    __syncthreads();
+    const int tot = (int) s_ctl[5], kk = k1 < tot ? k1 : tot;       // tot >= min(k + 1, n)
+    bool many;
+    const unsigned long long *res = st_smallest(s_key, tot, kk, s_buf, s_out, s_hist, s_ctl, &many);
+    int tie = (many || many_before) ? 1 : 0;
+    if (!many)
+        for (int j = tid; j + 1 < kk; j += kStThreads)
+            if ((res[j] >> 32) == (res[j + 1] >> 32)) tie = 1;
+    tie = __syncthreads_or(tie);
+    for (int j = tid; j < k; j += kStThreads) {
+        const pq64_t e = res[j < kk ? j : kk - 1];
+        const uint32_t idx = pq64_id(e);
+        p.out_ids[b * k + j] = p.remap ? p.remap[idx] : (int64_t) idx;
+        p.out_dists[b * k + j] = pq64_dist(e);
+    }
+    if (tid == 0) p.out_tie[b] = tie;                  // 1: the host reruns the call on the general path (std::partial_sort's order)
+    if (p.host_flag) {
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            __hip_atomic_store(&p.host_flag[b], p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+constexpr int kSlicePass = 4096;             // codes scored per pass of a block
+constexpr int kSliceMaxTopk = 128;
+constexpr int64_t kSliceMaxPerBlock = 32768; // codes per block beyond which the general path is the better deal
+
+static size_t slice_topk_smem(int M, int Ks, int Ds, int k1max)
+{
+    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (((size_t) M * Ds * 4 + 15) & ~(size_t) 15) + (size_t) (kSlicePass + k1max) * 8 +
+           (size_t) (kStBuf + kStRank) * 8 + 256 * 4 + 32;
+}
+int slice_topk_slices(int64_t n, int64_t B, int topk)
+{
+    const int64_t by_b = 256 / std::max<int64_t>(B, 1), by_k = (kSlicePass + topk + 1) / (topk + 1), by_n = (n + kStThreads - 1) / kStThreads;
+    return (int) std::max<int64_t>(1, std::min<int64_t>(std::min(by_b, by_k), by_n));
+}
+bool slice_topk_supported(int M, int Ks, int Ds, int64_t n, int64_t B, int topk)
+{
+    if (n < 2 || n >= ((int64_t) 1 << 32) || topk < 1 || topk > kSliceMaxTopk || topk > n || B < 1 || B > 8) return false;
+    if ((int64_t) M * Ds > 4 * kStThreads || slice_topk_smem(M, Ks, Ds, topk + 1) > (size_t) 160 * 1024 - 512) return false;
+    const int G = slice_topk_slices(n, B, topk);
+    return (n + G - 1) / G <= kSliceMaxPerBlock;
+}
+size_t slice_topk_scratch(int64_t n, int64_t B, int topk) { return (size_t) B * slice_topk_slices(n, B, topk) * (topk + 1) * 8; }
+
+hipError_t launch_slice_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_queries, const float *d_codewords, int Ds, int arch,
+                             int64_t B, int topk, const int64_t *d_remap, unsigned long long *d_cand, unsigned int *d_done,
+                             int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_tie, hipStream_t st, unsigned int *host_flag, unsigned int seq)
+{
+    if (B == 0) return hipSuccess;
+    SliceArgs a;
+    a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch;
+    a.remap = d_remap; a.topk = topk; a.k1max = topk + 1; a.pass_cap = kSlicePass; a.cand = d_cand; a.done = d_done;
+    a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_tie = d_out_tie; a.host_flag = host_flag; a.seq = seq;
+    const size_t smem = slice_topk_smem(M, Ks, Ds, topk + 1);
+    void (*kern)(SliceArgs) = slice_topk_kernel<0>;
+    if (M == 16) kern = slice_topk_kernel<1>;
+    else if (M == 32) kern = slice_topk_kernel<2>;
+    else if (M == 48) kern = slice_topk_kernel<3>;
+    else if (M == 64) kern = slice_topk_kernel<4>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned) slice_topk_slices(n, B, topk), (unsigned) B), dim3(kStThreads), smem, st, a);
     return hipGetLastError();
 }
 

@@ -250,6 +250,46 @@ def test_gpu_ivf_small_calls_flag_wait_vs_oracle(dup):
     assert_same_result((ids, d), want, "query_ivf")
 
 
+@pytest.mark.parametrize("case", [(32, 256, 4, 200000, "unit", 0), (32, 256, 4, 60000, "sift", 20000), (16, 256, 6, 70000, "unit", 0),
+                                  (8, 16, 2, 40000, "round", 0), (64, 256, 2, 30000, "unit", 3000)])
+def test_gpu_few_queries_large_index_one_launch_vs_oracle(case):
+    """One to eight queries per host call on an index too large for the one-block kernel: slice_topk_kernel (slices of the codes on
+    all CUs, the last block merges) against the oracle and against the general path (option slice_topk = 0); exactly tied distances
+    (duplicated codes, integer-valued tables) come back as a flag and are redone on the general path -- same answers required."""
+    from rii_amd import RiiGpu
+    M, Ks, Ds, N, scale, dup = case
+    if scale == "round":
+        rng = np.random.default_rng(N)
+        cw = np.round(rng.random((M, Ks, Ds)) * 3.0).astype(np.float32)
+        qs = np.round(rng.random((16, M * Ds)) * 3.0).astype(np.float32)
+        codes = rng.integers(0, Ks, size=(N, M), dtype=np.uint8)
+    else:
+        cw, codes, qs = make_problem(N + M, M, Ks, Ds, N, scale, dup=dup)
+    rng = np.random.default_rng(N + 2)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False); o.add_codes(codes, False)
+    assert g.get_option("slice_topk") == 1
+    sub = rng.permutation(N)[:N // 2].astype(np.int64)            # unsorted: positions, not ids, break ties
+    n_tied = 0
+    for topk in (1, 3, 10, 128):
+        for tids in (E, sub[:900], sub):                          # (900 ids: inputs small enough for the flag wait; N / 2: they are not)
+            for B in (1, 3, 8):
+                g.set_option("slice_topk", 1)
+                ids, d = g.query_linear_batch(qs[:B], topk, tids)
+                g.set_option("slice_topk", 0)
+                ids0, d0 = g.query_linear_batch(qs[:B], topk, tids)
+                for b in range(B):
+                    want = o.query_linear(qs[b], topk, tids)
+                    what = "few queries k=%d S=%d B=%d b=%d" % (topk, len(tids), B, b)
+                    assert_same_result((ids[b], d[b]), want, what)
+                    assert_same_result((ids0[b], d0[b]), want, what + " (general path)")
+                    n_tied += int(len(np.unique(np.asarray(want[1]))) < topk)
+    g.set_option("slice_topk", 1)
+    if dup or scale == "round":
+        assert n_tied > 0, "the case was meant to produce exactly tied distances inside the top-k"
+
+
 def test_gpu_flag_wait_soak():
     """Thousands of one-query calls with changing topk / search kind / target ids through the flag wait (host_spin = 1), each
     compared with the answer of the copy + synchronise form: a flag that is seen before its rows (or a stale word that equals
