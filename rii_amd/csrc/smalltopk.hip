@@ -409,6 +409,24 @@ __global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
     const int k1 = (int) ((int64_t) k + 1 < n ? (int64_t) k + 1 : n);
     const int64_t per = (n + G - 1) / G;
     const int64_t s_lo = (int64_t) g * per < n ? (int64_t) g * per : n, s_hi = s_lo + per < n ? s_lo + per : n;
+    // CPT codes per thread and trip, all their rows in flight before the first lookup; the rows of the very first trip are
+    // requested BEFORE the table is built (they do not depend on it): every phase of a block is an exposed memory round trip
+    constexpr int CPT = NV == 0 ? 1 : NV <= 2 ? 4 : 2;
+    uint4 rows[CPT * NV + 1];
+    auto load_rows = [&](int64_t lo, int j0, int cnt) {
+        if constexpr (NV > 0) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const int j = j0 + tid + c * kStThreads;
+                const int64_t i = lo + (j < cnt ? j : 0);
+                const int64_t r = p.remap ? p.remap[i] : i;
+                const uint4 *row = reinterpret_cast<const uint4 *>(p.codes + (size_t) r * (NV * 16));
+#pragma unroll
+                for (int v = 0; v < NV; ++v) rows[c * NV + v] = row[v];
+            }
+        }
+    };
+    if (s_lo < s_hi) load_rows(s_lo, 0, (int) (s_hi - s_lo < (int64_t) p.pass_cap ? s_hi - s_lo : (int64_t) p.pass_cap));
     st_build_table(p.queries + (size_t) b * p.M * p.Ds, p.codewords, p.M, p.Ks, p.Ds, p.arch, lds, s_q);
     __syncthreads();
     int carried = 0;
@@ -417,19 +435,16 @@ __global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
         const int cnt = (int) (s_hi - lo < (int64_t) p.pass_cap ? s_hi - lo : (int64_t) p.pass_cap);
         pq64_t *dst = s_key + carried;                 // the carried keys stay in front
         if constexpr (NV > 0) {
-            for (int j = tid; j < cnt; j += 2 * kStThreads) {                 // two codes per trip: both rows in flight before the first lookup
-                const int j2 = j + kStThreads < cnt ? j + kStThreads : j;
-                const int64_t i1 = lo + j, i2 = lo + j2;
-                const int64_t r1 = p.remap ? p.remap[i1] : i1, r2 = p.remap ? p.remap[i2] : i2;
-                const uint4 *row1 = reinterpret_cast<const uint4 *>(p.codes + (size_t) r1 * (NV * 16));
-                const uint4 *row2 = reinterpret_cast<const uint4 *>(p.codes + (size_t) r2 * (NV * 16));
-                uint4 w1[NV], w2[NV];
+            for (int j0 = 0; j0 < cnt; j0 += CPT * kStThreads) {
+                if (lo != s_lo || j0 != 0) load_rows(lo, j0, cnt);
 #pragma unroll
-                for (int v = 0; v < NV; ++v) { w1[v] = row1[v]; w2[v] = row2[v]; }
-                const pq64_t e1 = pq64_make(st_adist<NV>(lds, w1, p.Ks), (uint32_t) i1);              // RiiCpp::ADist, m order
-                const pq64_t e2 = pq64_make(st_adist<NV>(lds, w2, p.Ks), (uint32_t) i2);
-                dst[j] = e1;
-                dst[j2] = e2;
+                for (int c = 0; c < CPT; ++c) {
+                    const int j = j0 + tid + c * kStThreads;
+                    uint4 w[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) w[v] = rows[c * NV + v];
+                    if (j < cnt) dst[j] = pq64_make(st_adist<NV>(lds, w, p.Ks), (uint32_t) (lo + j));   // RiiCpp::ADist, m order
+                }
             }
         } else {
             for (int j = tid; j < cnt; j += kStThreads) {
