@@ -214,6 +214,17 @@ class Rii(object):
         return (self.nlist > 0) if flag == "auto" else flag
 
 
+class _FlooredLine(np.poly1d):
+    """thre_|S| = max(a L + b, floor): an np.poly1d (what the reference's estimator returns) that never falls below `floor`."""
+
+    def __init__(self, coeff, floor=0.0):
+        super().__init__(coeff)
+        self.__dict__["floor"] = floor
+
+    def __call__(self, val):
+        return np.maximum(super().__call__(val), self.__dict__.get("floor", 0.0))
+
+
 class CrossoverModel(object):
     """Learns, per candidate budget L, the subset size |S|* at which the inverted index starts to beat the linear scan,
     by timing both on the engine itself, and fits |S|* = f(L) with a line.  batched=False: one query per call (the decision
@@ -294,7 +305,9 @@ class CrossoverModel(object):
         # slope is timing noise -- fall back to the mean crossover (constant in L)
         if len(Ls) > 1 and (not np.all(np.isfinite(coeff)) or coeff[0] < 0):
             coeff = [0, float(np.mean(cuts))]
-        model = np.poly1d(coeff)
+        # the line is a fit through noisy points and may dip below every crossover that was actually measured at the small-L end
+        # (even below zero): never answer less than the smallest measured one
+        model = _FlooredLine(coeff, floor=float(min(cuts)))
         if idx.verbose:
             print("crossover |S|* per L:", dict(zip(Ls, cuts)), "->", model)
         return model
