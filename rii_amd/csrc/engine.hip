@@ -1405,10 +1405,17 @@ int ensure_pin(rii_engine *e, size_t bytes)
     if (e->h_pin) HIP_TRY(hipHostFree(e->h_pin));
     e->h_pin = nullptr; e->h_pin_cap = 0;
     const size_t cap = std::max<size_t>(bytes, 64 << 10);
-    HIP_TRY(hipHostMalloc(&e->h_pin, cap, hipHostMallocMapped | hipHostMallocCoherent));   // (coherent: the kernel-written rows + flag)
-    memset(e->h_pin, 0, cap);
     e->d_pin = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&e->d_pin, e->h_pin, 0));
+    if (hipHostMalloc(&e->h_pin, cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||      // (coherent: the kernel-written
+        hipHostGetDevicePointer(&e->d_pin, e->h_pin, 0) != hipSuccess || !e->d_pin) {                    //  rows + flags of host_spin)
+        // no coherent mapped host memory on this system: plain pinned staging, every call copies and synchronises
+        (void) hipGetLastError();
+        if (e->h_pin) (void) hipHostFree(e->h_pin);
+        e->h_pin = nullptr; e->d_pin = nullptr;
+        e->host_spin = 0;
+        HIP_TRY(hipHostMalloc(&e->h_pin, cap, hipHostMallocDefault));
+    }
+    memset(e->h_pin, 0, cap);
     e->h_pin_cap = cap;
     return RII_OK;
 }
@@ -1454,13 +1461,13 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     unsigned char *pin = static_cast<unsigned char *>(e->h_pin) + kPinFlagBytes;
     memcpy(pin, queries, q_bytes);
     if (pack_tids) memcpy(pin + q_pad, tids, t_bytes);
-    const bool spin_linear = !ivf && e->host_spin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes &&
+    const bool spin_linear = !ivf && e->host_spin && e->d_pin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes &&
                              takes_small_topk(e, B, topk, S);
     // no target ids, exact tables: small_topk_kernel reads the query straight from the pinned block (once per block, through LDS)
     // -- no H2D copy in front of the launch either
     // a few queries on an index too large for that kernel: slice_topk_kernel (one launch; exact ties come back as a flag and the
     // call is redone on the general path)
-    const bool slice_linear = !ivf && !spin_linear && e->host_spin && e->slice_topk && e->QT != 0 && e->lut_mode == RII_LUT_EXACT &&
+    const bool slice_linear = !ivf && !spin_linear && e->host_spin && e->d_pin && e->slice_topk && e->QT != 0 && e->lut_mode == RII_LUT_EXACT &&
                               in_bytes <= kSpinMaxInput && slice_topk_supported(e->M, e->Ks, e->Ds, S ? S : e->N, B, topk);
     const bool q_in_place = (spin_linear || slice_linear) && S == 0 && e->lut_mode == RII_LUT_EXACT;
     if (!q_in_place) HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, pack_tids ? in_bytes : q_bytes, hipMemcpyHostToDevice, st));
@@ -1541,7 +1548,7 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
         memcpy(out_dists, pout + ids_bytes, d_bytes);
         return RII_OK;
     }
-    if (ivf && e->host_spin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes && B < e->fast_min_batch) {
+    if (ivf && e->host_spin && e->d_pin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes && B < e->fast_min_batch) {
         // the same for the inverted index: every output field (rows, counts, fallback flags) lives in the pinned block; the fused
         // kernel raises a query's sequence flag at each of its exits.  A call that takes another path (spin_used stays false) is
         // simply synchronised -- its kernels wrote the pinned block too.
