@@ -390,6 +390,43 @@ __device__ __forceinline__ const unsigned long long *st_smallest(const pq64_t *k
     return s_buf;
 }
 
+// The kk (<= 16; used up to 6) smallest of the block's keys -- four per thread in registers, ~0 = none -- in ascending (distance, index) order into
+// s_res[0, kk), without a histogram and with two barriers: every wave extracts its own kk smallest with wave-wide DPP minima
+// (rii_device.h: wave_min_u64; keys are distinct, so "the smallest key greater than the last one" walks them in order), wave 0 then
+// extracts the kk smallest of the 16 x kk picks the same way.  s_w: 16 x 16 keys of LDS.  All threads call it.
+__device__ __forceinline__ void st_wave_smallest(const unsigned long long (&v)[4], int kk, unsigned long long *s_w, unsigned long long *s_res)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long last = 0ull;
+    for (int r = 0; r < kk; ++r) {
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((r == 0 || v[u] > last) && v[u] < best) best = v[u];
+        last = wave_min_u64(best);                      // ~0 once the wave's keys are used up
+        if (lane == 0) s_w[wave * 16 + r] = last;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = lane + 64 * u;                // i = wave * kk + r
+            c[u] = i < (kStThreads / 64) * kk ? s_w[(i / kk) * 16 + (i % kk)] : ~0ull;
+        }
+        unsigned long long prev = 0ull;
+        for (int r = 0; r < kk; ++r) {
+            unsigned long long best = ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((r == 0 || c[u] > prev) && c[u] < best) best = c[u];
+            prev = wave_min_u64(best);
+            if (lane == 0) s_res[r] = prev;
+        }
+    }
+    __syncthreads();
+}
+
 template <int NV>
 __global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
 {
@@ -403,6 +440,8 @@ __global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
     unsigned long long *s_out = s_buf + kStBuf;                                                      // [kStRank]
     unsigned int *s_hist = reinterpret_cast<unsigned int *>(s_out + kStRank);                        // [256]
     unsigned int *s_ctl = s_hist + 256;                                                              // [8]
+    unsigned long long *s_w = s_buf;                                                                 // [16][16] (wave path: s_buf is free)
+    unsigned long long *s_carry = s_out;                                                             // [16]
     const int64_t b = blockIdx.y;
     const int G = (int) gridDim.x, g = (int) blockIdx.x;
     const int64_t n = p.n;
@@ -431,35 +470,71 @@ __global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
     __syncthreads();
     int carried = 0;
     bool many_any = false;
+    const bool wave_path = k1 <= 6;                    // (topk <= 5; measured at N = 1M: -3.4 us at topk = 1, -2 us at 3, +4 us at 10)
     for (int64_t lo = s_lo; lo < s_hi; lo += p.pass_cap) {
         const int cnt = (int) (s_hi - lo < (int64_t) p.pass_cap ? s_hi - lo : (int64_t) p.pass_cap);
-        pq64_t *dst = s_key + carried;                 // the carried keys stay in front
+        // the pass's keys: four per thread (pass_cap = 4 x 1024), ~0 past the end
+        unsigned long long val[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         if constexpr (NV > 0) {
-            for (int j0 = 0; j0 < cnt; j0 += CPT * kStThreads) {
-                if (lo != s_lo || j0 != 0) load_rows(lo, j0, cnt);
+#pragma unroll
+            for (int t0 = 0; t0 < 4; t0 += CPT) {
+                if (lo != s_lo || t0 != 0) load_rows(lo, t0 * kStThreads, cnt);
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) {
-                    const int j = j0 + tid + c * kStThreads;
+                    const int j = (t0 + c) * kStThreads + tid;
                     uint4 w[NV];
 #pragma unroll
                     for (int v = 0; v < NV; ++v) w[v] = rows[c * NV + v];
-                    if (j < cnt) dst[j] = pq64_make(st_adist<NV>(lds, w, p.Ks), (uint32_t) (lo + j));   // RiiCpp::ADist, m order
+                    if (j < cnt) val[t0 + c] = pq64_make(st_adist<NV>(lds, w, p.Ks), (uint32_t) (lo + j));   // RiiCpp::ADist, m order
                 }
             }
         } else {
-            for (int j = tid; j < cnt; j += kStThreads) {
-                const int64_t i = lo + j;
-                const uint8_t *code = p.codes + (size_t) (p.remap ? p.remap[i] : i) * p.M;
-                dst[j] = pq64_make(exact_adist(lds, code, p.M, p.Ks), (uint32_t) i);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = c * kStThreads + tid;
+                if (j < cnt) {
+                    const int64_t i = lo + j;
+                    const uint8_t *code = p.codes + (size_t) (p.remap ? p.remap[i] : i) * p.M;
+                    val[c] = pq64_make(exact_adist(lds, code, p.M, p.Ks), (uint32_t) i);
+                }
             }
         }
         const int tot = carried + cnt, kk = k1 < tot ? k1 : tot;
+        if (wave_path) {
+            // the pass's own smallest by wave-level selection (no histogram, two barriers), then merged with the carried ones
+            st_wave_smallest(val, kk < cnt ? kk : cnt, s_w, s_buf + 512);                   // -> s_buf[512 ..)
+            const int kn = kk < cnt ? kk : cnt;
+            // merge of two sorted runs (carried, new), kk <= 16 outputs: one thread per output position by rank counting
+            if (tid < carried + kn) {
+                const bool from_old = tid < carried;
+                const unsigned long long mine = from_old ? s_carry[tid] : s_buf[512 + tid - carried];
+                int rank = 0;
+                for (int j = 0; j < carried; ++j) rank += s_carry[j] < mine ? 1 : 0;
+                for (int j = 0; j < kn; ++j) rank += s_buf[512 + j] < mine ? 1 : 0;
+                if (rank < kk) s_buf[1024 + rank] = mine;
+            }
+            __syncthreads();
+            if (tid < kk) s_carry[tid] = s_buf[1024 + tid];
+            carried = kk;
+            __syncthreads();
+            continue;
+        }
+        pq64_t *dst = s_key + carried;                 // histogram path: the carried keys stay in front of the pass's keys
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = c * kStThreads + tid;
+            if (j < cnt) dst[j] = val[c];
+        }
         bool many;
         const unsigned long long *res = st_smallest(s_key, tot, kk, s_buf, s_out, s_hist, s_ctl, &many);   // (barrier first)
         many_any = many_any || many;
         __syncthreads();
         for (int j = tid; j < kk; j += kStThreads) s_key[j] = res[j];
         carried = kk;
+        __syncthreads();
+    }
+    if (wave_path) {                                   // where the tail of the kernel expects the carried keys
+        if (tid < carried) s_key[tid] = s_carry[tid];
         __syncthreads();
     }
     {
@@ -503,8 +578,17 @@ __global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
     }
     __syncthreads();
     const int tot = (int) s_ctl[5], kk = k1 < tot ? k1 : tot;       // tot >= min(k + 1, n)
-    bool many;
-    const unsigned long long *res = st_smallest(s_key, tot, kk, s_buf, s_out, s_hist, s_ctl, &many);
+    bool many = false;
+    const unsigned long long *res;
+    if (wave_path) {
+        unsigned long long val[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) val[u] = u * kStThreads + tid < tot ? s_key[u * kStThreads + tid] : ~0ull;    // tot <= G k1 <= 4096
+        st_wave_smallest(val, kk, s_w, s_buf + 512);
+        res = s_buf + 512;
+    } else {
+        res = st_smallest(s_key, tot, kk, s_buf, s_out, s_hist, s_ctl, &many);
+    }
     int tie = (many || many_before) ? 1 : 0;
     if (!many)
         for (int j = tid; j + 1 < kk; j += kStThreads)
@@ -537,7 +621,7 @@ static size_t slice_topk_smem(int M, int Ks, int Ds, int k1max)
 }
 int slice_topk_slices(int64_t n, int64_t B, int topk)
 {
-    const int64_t by_b = 256 / std::max<int64_t>(B, 1), by_k = (kSlicePass + topk + 1) / (topk + 1), by_n = (n + kStThreads - 1) / kStThreads;
+    const int64_t by_b = 256 / std::max<int64_t>(B, 1), by_k = kSlicePass / (topk + 1), by_n = (n + kStThreads - 1) / kStThreads;
     return (int) std::max<int64_t>(1, std::min<int64_t>(std::min(by_b, by_k), by_n));
 }
 bool slice_topk_supported(int M, int Ks, int Ds, int64_t n, int64_t B, int topk)

@@ -272,7 +272,7 @@ def test_gpu_few_queries_large_index_one_launch_vs_oracle(case):
     assert g.get_option("slice_topk") == 1
     sub = rng.permutation(N)[:N // 2].astype(np.int64)            # unsorted: positions, not ids, break ties
     n_tied = 0
-    for topk in (1, 3, 10, 128):
+    for topk in (1, 3, 5, 10, 128):                               # (topk <= 5: wave-level selection; above: histogram bound)
         for tids in (E, sub[:900], sub):                          # (900 ids: inputs small enough for the flag wait; N / 2: they are not)
             for B in (1, 3, 8):
                 g.set_option("slice_topk", 1)
