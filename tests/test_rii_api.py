@@ -283,6 +283,20 @@ def test_crossover_model_is_sane_and_picks_the_faster_side():
                 name, S, thr, picked * 1e6, other * 1e6)
 
 
+def test_crossover_line_never_answers_below_the_smallest_measured_crossover():
+    """CPU: a least-squares line through noisy crossovers can dip below every measured one (even below zero) at the small-L end;
+    the model's answer is floored there, stays an np.poly1d (what the reference's estimator returns) and survives pickling."""
+    import pickle
+    from rii_amd.api import _FlooredLine
+    f = _FlooredLine(np.polyfit([100, 200, 400, 800, 1600], [128, 20000, 80000, 190000, 400000], 1), floor=128.0)
+    assert isinstance(f, np.poly1d)
+    vals = [float(f(L)) for L in (100, 200, 400, 800, 1600)]
+    assert vals[0] == 128.0 and all(b >= a for a, b in zip(vals, vals[1:])) and vals[-1] > 300000
+    assert np.array_equal(f(np.array([1, 100])), np.array([128.0, 128.0]))
+    g = pickle.loads(pickle.dumps(f))
+    assert float(g(100)) == 128.0 and float(g(1600)) == vals[-1]
+
+
 def test_crossover_model_fit_on_a_synthetic_engine():
     """CPU: the model's search and fit against an engine whose costs are known in closed form (linear = a |S|, inverted index =
     c + b L): the crossover (c + b L) / a must be recovered, it rises with L, and the batched / single models are independent."""
