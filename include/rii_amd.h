@@ -105,6 +105,18 @@ int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk
                       int64_t S, int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts,
                       void *stream);
 
+/* Queries resident in HBM, results delivered to the HOST (NEW): the batched form of what the reference's caller observes --
+ * the rows are host-visible when the call returns (src/main.cpp:17-27 return Python lists) -- and what SURVEY 8d's metric times
+ * ("one batched call incl. table build, scan, top-k, device->host of results").  d_queries / d_tids are device pointers, out_* HOST
+ * pointers (any memory).  The kernels write the rows straight into the engine's pinned, coherent host block; where the last kernel
+ * of the step raises sequence flags behind them (linear top-1 of the M = 16 / 32, Ks = 256 shapes: the re-rank is the tail of the
+ * scan launch, one flag per tile) the call returns as soon as the host has seen the flags -- no D2H copy, no stream
+ * synchronisation -- otherwise after one hipStreamSynchronize.  Synchronous; `stream` as for the *_dev calls. */
+int rii_query_linear_dev_to_host(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
+                                 int64_t *out_ids, float *out_dists, void *stream);
+int rii_query_ivf_dev_to_host(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
+                              int64_t L, int64_t *out_ids, float *out_dists, int64_t *out_counts, void *stream);
+
 /* Database-sharded inverted index (NEW, not in the reference: it has no multi-device code).  Rank `rank` of G holds
  * a contiguous id range of the database; coarse centres are replicated (rii_set_coarse_centers), posting lists are local.
  * The reference's "candidates in list order, stop at exactly L" rule (src/rii.h:283-321) is global and sequential, so

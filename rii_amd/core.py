@@ -126,6 +126,8 @@ def _lib():
         "rii_query_ivf": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
         "rii_query_linear_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
         "rii_query_ivf_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+        "rii_query_linear_dev_to_host": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+        "rii_query_ivf_dev_to_host": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
         "rii_ivf_list_lengths_dev": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
         "rii_query_ivf_shard_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int,
                                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -339,6 +341,16 @@ class RiiGpu(object):
     def query_ivf_dev(self, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts, stream=0):
         _check(_lib().rii_query_ivf_dev(self._h, d_queries, B, int(topk), d_tids or None, S, int(L), d_out_ids,
                                         d_out_dists, d_out_counts, stream or None))
+
+    def query_linear_dev_to_host(self, d_queries, B, topk, d_tids, S, out_ids, out_dists, stream=0):
+        """Device-resident queries (raw pointer) -> rows in the HOST arrays out_ids [B, topk] int64 / out_dists [B, topk] float32 when
+        the call returns (rii_query_linear_dev_to_host: rows written by the kernels into the engine's pinned block, flag wait)."""
+        _check(_lib().rii_query_linear_dev_to_host(self._h, d_queries, int(B), int(topk), d_tids or None, int(S), out_ids.ctypes.data,
+                                                   out_dists.ctypes.data, stream or None))
+
+    def query_ivf_dev_to_host(self, d_queries, B, topk, d_tids, S, L, out_ids, out_dists, out_counts, stream=0):
+        _check(_lib().rii_query_ivf_dev_to_host(self._h, d_queries, int(B), int(topk), d_tids or None, int(S), int(L), out_ids.ctypes.data,
+                                                out_dists.ctypes.data, out_counts.ctypes.data, stream or None))
 
     # ---- database-sharded inverted index (device pointers; protocol: include/rii_amd.h, rii_amd/dist.py) ----
     def linear_tie_emit_dev(self, d_queries, nf, topk, d_tids, S, d_bound, id_offset, cap, d_out_ids, d_out_dists, d_out_count,

@@ -16,6 +16,7 @@
 #include <numeric>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define RII_API extern "C" __attribute__((visibility("default")))
@@ -98,7 +99,7 @@ struct ScratchSet {
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
         s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
-        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident, s_big, s_small_done;
+        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident, s_big, s_small_done, s_tile_done;
     bool have_ident = false;    // s_ident = [count | 0 .. 63]: work list of rii_linear_tie_emit_dev (every query of the call is "flagged")
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
@@ -126,7 +127,7 @@ struct ScratchSet {
                           &s_keys_b, &s_assign, &s_coarse_d, &s_coarse_i, &s_cum, &s_ncand, &s_nvis, &s_cand_i, &s_cand_d,
                           &s_bitmap, &s_fids, &s_flen, &s_hist, &s_cnt, &s_sample, &s_qlut, &s_slack, &s_cand, &s_cand_cnt,
                           &s_flag, &s_segmin, &s_thr16, &s_gthr, &s_qc, &s_flag_list, &s_tie_list, &s_tie_hid, &s_tie_hd,
-                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident, &s_big, &s_small_done};
+                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident, &s_big, &s_small_done, &s_tile_done};
         for (DevBuf *b : bufs) b->release();
         if (sort_temp) (void) hipFree(sort_temp);
         sort_temp = nullptr; sort_temp_bytes = 0;
@@ -186,10 +187,20 @@ struct rii_engine : ScratchSet {
     unsigned int *spin_flag = nullptr;   // (set by host_query around the call: device address of the flags in the pinned block)
     unsigned int spin_seq = 0;
     bool spin_used = false;
+    int64_t spin_nflags = 0;    // flag words the kernel that took the spin path raises (queries, or tiles of the fused re-rank)
+    // option "host_zero_copy" (round 4): host-pointer linear batches hand the kernels the queries in the pinned block itself (the table
+    // kernel and the re-rank read them over PCIe) and get their rows written straight into it: no H2D copy in front of the launches,
+    // no D2H copy behind them.  1 (default): batches of at most 128 KiB of queries (measured at N = 1M, M = 32: B = 128 0.1055 ->
+    // 0.0925 ms per call, B = 1024 0.372 vs 0.379: the 512 KiB go faster through the copy engine); 2: always; 0: never
+    int host_zero_copy = 1;
+    // option "fused_rerank" (round 4): top-1 of the M = 16 / 32, Ks = 256 filter re-ranked by the LAST chunk-block of every tile inside
+    // the scan launch (fs_tail_rerank) instead of a second kernel.  Measured (tools/r4_measure.py, same box, N = 1M, M = 32): B = 1024
+    // 0.3335 vs 0.3333 ms per step, B = 128 0.0833 vs 0.0798 -- the tail's chain of dependent round trips (arrival, counts, records,
+    // codes, two batches of codeword gathers) is as long as the separate kernel's, which runs on B blocks instead of B / 16, and a
+    // queued launch costs nothing -- so the default is 0.  1 buys ONE launch per batch with one host flag per tile behind the rows
+    // (rii_query_linear_dev_to_host: B = 128 0.0901 vs 0.0938 ms per synchronous call).
+    int fused_rerank = 0;
     int small_topk = 1;         // option "small_topk": a small batch over a small index in one launch after the tables (smalltopk.hip)
-    int warm_groups = 4;        // option "warm_groups" (1..4): groups per wave of a chunk's first trip that seed the thresholds
-    int scan_prio = 0;          // option "scan_prio": 1 / 2 = s_setprio 1 for the younger / older half of a scan block's waves (experiment)
-    int adopt_rr = 0;           // option "adopt_rr": 1 = the waves of a scan block take turns adopting the shared thresholds (measured: no gain at B = 1024, 4 % slower at B = 128: tools/opt_ab.py)
     int scan_dual = 1;          // option "scan_dual": M = 16 keeps two 16-query tiles per scan block (fscan_mx_dual_kernel)
     int64_t scan_cov = 0;       // codes [0, scan_cov) are final (whole windows)
     int64_t scan_N = -1;        // N the order was last completed for
@@ -551,6 +562,18 @@ int gather_plain(rii_engine *e, const int64_t *d_tids, int64_t S, hipStream_t st
     return RII_OK;
 }
 
+// arrival counters of the fused re-rank (one per scan tile): zeroed once, the last block of a tile puts the zero back
+constexpr size_t kPinFlagWords = 1024;        // sequence flags at the head of a lane's pinned block (host_spin)
+int ensure_tile_done(rii_engine *e, hipStream_t st)
+{
+    const size_t bytes = 1024 * sizeof(unsigned int);            // >= kMaxBatch / 16 tiles
+    if (e->s_tile_done.cap < bytes) {
+        RII_TRY(e->s_tile_done.ensure(bytes));
+        HIP_TRY(hipMemsetAsync(e->s_tile_done.p, 0, bytes, st));
+    }
+    return RII_OK;
+}
+
 // the scan for B queries whose tables are in s_lut over the whole database (S == 0) or the S target ids d_remap (scored
 // in the order given: position s stands for the code d_remap[s], and ids are translated through d_remap at the end)
 int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_remap, int64_t S,
@@ -653,13 +676,30 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 RII_TRY(e->s_gthr.ensure((size_t) B * sizeof(uint32_t)));
                 if (!e->qlut_ready)
                     HIP_TRY(hipMemsetAsync(e->s_gthr.p, 0xff, (size_t) B * sizeof(uint32_t), st));   // > any 16-bit threshold
+                // no fp32 table was written (fused tables): the last chunk-block of every tile re-ranks the tile's queries straight from
+                // the codebook inside the scan launch (round 4) -- one launch less per batch, rows possibly straight to the host
+                const bool tail_rr = !e->lut_valid && e->fused_rerank && !d_perm && fscan_tail_supported(e->M, e->Ks, e->Ds, e->scan_mx);
+                FsTail tl;
+                if (tail_rr) {
+                    RII_TRY(ensure_tile_done(e, st));
+                    tl.queries = d_queries; tl.codewords = e->d_codewords.as<float>(); tl.codes = d_rr; tl.remap = d_remap;
+                    tl.indirect = indirect; tl.Ds = e->Ds; tl.topk = topk; tl.out_ids = d_out_ids; tl.out_dists = d_out_dists;
+                    tl.tile_done = e->s_tile_done.as<unsigned int>();
+                    const int64_t nfl = fscan_tail_flags(e->M, e->Ks, e->scan_mx, e->scan_dual, B);
+                    if (e->spin_flag && nfl * sizeof(unsigned int) <= kPinFlagWords * sizeof(unsigned int)) {
+                        tl.host_flag = e->spin_flag; tl.seq = e->spin_seq;
+                        e->spin_used = true; e->spin_nflags = nfl;
+                    }
+                }
                 {
                     ScopedTimer t(e, "scan", st, true);
                     HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(),
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
-                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9) | ((e->warm_groups - 1) << 11), e->qlut_levels));
+                                         e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual, e->qlut_levels,
+                                         tail_rr ? &tl : nullptr));
                 }
+                if (tail_rr) return RII_OK;
                 ScopedTimer t(e, "rerank", st);
                 if (!e->lut_valid) {     // no fp32 table was written: distances of the candidates straight from the codebook
                     HIP_TRY(launch_rerank_top1_direct(d_rr, n_codes, e->M, e->Ds, d_queries, e->d_codewords.as<float>(),
@@ -682,7 +722,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, nullptr, nullptr, 0, 1, e->s_segmin.as<uint16_t>(), nullptr, nullptr, stride,
-                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9) | ((e->warm_groups - 1) << 11), e->qlut_levels));
+                                     e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual, e->qlut_levels));
             }
             {
                 ScopedTimer t(e, "kth", st);
@@ -693,7 +733,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 ScopedTimer t(e, "scan", st, true);
                 HIP_TRY(launch_fscan(d_scan, n_codes, e->M, e->Ks, e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), (int) B,
                                      chunks, len, e->s_cand.as<unsigned long long>(), e->s_cand_cnt.as<unsigned int>(), cap,
-                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual | (e->adopt_rr << 8) | (e->scan_prio << 9) | ((e->warm_groups - 1) << 11), e->qlut_levels));
+                                     2, nullptr, e->s_thr16.as<uint32_t>(), nullptr, 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual, e->qlut_levels));
             }
             RII_TRY(tie_list_reset(e, B, st));
             {
@@ -870,6 +910,7 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
                                       e->s_keys_a.as<unsigned long long>(), e->s_small_done.as<unsigned int>(), d_out_ids, d_out_dists, st,
                                       e->spin_flag, e->spin_seq));
             e->spin_used = e->spin_flag != nullptr;
+            e->spin_nflags = B;
             return RII_OK;
         }
     }
@@ -1010,6 +1051,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             p.host_flag = nullptr;                   // (the deferred fallback re-uses p: nothing after this launch publishes)
             if (defer) {
                 e->spin_used = e->spin_flag != nullptr;
+                e->spin_nflags = p.B;
                 e->ivf_deferred = p;
                 e->ivf_has_deferred = true;
                 return RII_OK;
@@ -1395,9 +1437,36 @@ RII_API int rii_get_posting_lists(const rii_engine *e, int64_t *off, int32_t *id
 // staging buffer: queries in with a single async H2D, [ids | dists | counts] back with a single D2H -- the pageable
 // copies of the generic path cost more than the kernels at that size.
 namespace {
-constexpr size_t kPinLimit = 1 << 20;
-constexpr size_t kPinFlagBytes = 4096;
+constexpr size_t kPinLimit = 8 << 20;
+// head of a lane's pinned block: [0, 4096) the kPinFlagWords sequence flags of host_spin -- words that never hold anything but
+// sequence numbers -- and [4096, 8192) the tie words of slice_topk_kernel (their own page: ADVICE r3); data follows
+constexpr size_t kPinTieOffset = kPinFlagWords * sizeof(unsigned int);
+constexpr size_t kPinFlagBytes = 2 * kPinTieOffset;
 constexpr size_t kSpinMaxInput = 8192;
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+// bounded wait for the n sequence flags a kernel raises behind its rows in the pinned block; false: not seen (the caller
+// synchronises the stream, which is always correct)
+bool spin_wait(const volatile unsigned int *flags, int64_t n, unsigned int seq)
+{
+    bool seen = false;
+    for (int spins = 0; spins < 400000 && !seen; ++spins) {
+        seen = true;
+        for (int64_t b = 0; b < n; ++b) seen = seen && (flags[b] == seq);
+        if (!seen) cpu_relax();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return seen;
+}
 
 int ensure_pin(rii_engine *e, size_t bytes)
 {
@@ -1461,7 +1530,7 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     unsigned char *pin = static_cast<unsigned char *>(e->h_pin) + kPinFlagBytes;
     memcpy(pin, queries, q_bytes);
     if (pack_tids) memcpy(pin + q_pad, tids, t_bytes);
-    const bool spin_linear = !ivf && e->host_spin && e->d_pin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes &&
+    const bool spin_linear = !ivf && e->host_spin && e->d_pin && in_bytes <= kSpinMaxInput && (size_t) B <= kPinFlagWords &&
                              takes_small_topk(e, B, topk, S);
     // no target ids, exact tables: small_topk_kernel reads the query straight from the pinned block (once per block, through LDS)
     // -- no H2D copy in front of the launch either
@@ -1469,7 +1538,11 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     // call is redone on the general path)
     const bool slice_linear = !ivf && !spin_linear && e->host_spin && e->d_pin && e->slice_topk && e->QT != 0 && e->lut_mode == RII_LUT_EXACT &&
                               in_bytes <= kSpinMaxInput && slice_topk_supported(e->M, e->Ks, e->Ds, S ? S : e->N, B, topk);
-    const bool q_in_place = (spin_linear || slice_linear) && S == 0 && e->lut_mode == RII_LUT_EXACT;
+    // a batch on the general path: rows written straight into the pinned block (see below); host_zero_copy: queries read from it too
+    const bool zc = !ivf && !spin_linear && !slice_linear && e->host_spin && e->d_pin && B <= kMaxBatch && S == 0 && e->lut_mode == RII_LUT_EXACT &&
+                    e->QT != 0 && (e->host_zero_copy == 2 || (e->host_zero_copy == 1 && q_bytes <= (128u << 10)));
+    const bool batch_pin = zc;
+    const bool q_in_place = ((spin_linear || slice_linear) && S == 0 && e->lut_mode == RII_LUT_EXACT) || zc;
     if (!q_in_place) HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, pack_tids ? in_bytes : q_bytes, hipMemcpyHostToDevice, st));
     if (S && !pack_tids) HIP_TRY(hipMemcpyAsync(e->s_tids.p, tids, t_bytes, hipMemcpyHostToDevice, st));
     const int64_t *d_tids_in = pack_tids ? reinterpret_cast<const int64_t *>(e->s_queries.as<unsigned char>() + q_pad) : e->s_tids.as<int64_t>();
@@ -1485,7 +1558,7 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
         const int64_t n_codes = S ? S : e->N;
         unsigned char *dp_host = static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes;
         volatile unsigned int *flags = reinterpret_cast<volatile unsigned int *>(e->h_pin);
-        volatile int32_t *ties = reinterpret_cast<volatile int32_t *>(static_cast<unsigned char *>(e->h_pin) + kPinFlagBytes / 2);
+        volatile int32_t *ties = reinterpret_cast<volatile int32_t *>(static_cast<unsigned char *>(e->h_pin) + kPinTieOffset);
         const unsigned int seq = ++e->spin_seq ? e->spin_seq : ++e->spin_seq;
         RII_TRY(e->s_keys_b.ensure(std::max<size_t>(slice_topk_scratch(n_codes, B, topk), 16)));
         RII_TRY(ensure_small_done(e, st));
@@ -1496,16 +1569,10 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
                                       e->d_codewords.as<float>(), e->Ds, e->arch, B, topk, S ? d_tids_in : nullptr,
                                       e->s_keys_b.as<unsigned long long>(), e->s_small_done.as<unsigned int>(),
                                       reinterpret_cast<int64_t *>(dp_host + in_bytes), reinterpret_cast<float *>(dp_host + in_bytes + ids_bytes),
-                                      reinterpret_cast<int32_t *>(static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes / 2), st,
+                                      reinterpret_cast<int32_t *>(static_cast<unsigned char *>(e->d_pin) + kPinTieOffset), st,
                                       reinterpret_cast<unsigned int *>(e->d_pin), seq));
         }
-        bool seen = false;
-        for (int spins = 0; spins < 400000 && !seen; ++spins) {
-            seen = true;
-            for (int64_t b = 0; b < B; ++b) seen = seen && (flags[b] == seq);
-            if (!seen) __builtin_ia32_pause();
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const bool seen = spin_wait(flags, B, seq);
         if (!seen) HIP_TRY(hipStreamSynchronize(st));
         bool any_tie = false;
         for (int64_t b = 0; b < B; ++b) any_tie |= (ties[b] != 0);
@@ -1534,21 +1601,13 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
                                        reinterpret_cast<float *>(dp_host + in_bytes + ids_bytes), st);
         e->spin_flag = nullptr;
         if (r != RII_OK) return r;
-        bool seen = false;
-        if (e->spin_used) {
-            for (int spins = 0; spins < 400000 && !seen; ++spins) {
-                seen = true;
-                for (int64_t b = 0; b < B; ++b) seen = seen && (flags[b] == seq);
-                if (!seen) __builtin_ia32_pause();
-            }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        }
+        const bool seen = e->spin_used && spin_wait(flags, e->spin_nflags, seq);
         if (!seen) HIP_TRY(hipStreamSynchronize(st));
         memcpy(out_ids, pout, ids_bytes);
         memcpy(out_dists, pout + ids_bytes, d_bytes);
         return RII_OK;
     }
-    if (ivf && e->host_spin && e->d_pin && in_bytes <= kSpinMaxInput && (size_t) B * sizeof(unsigned int) <= kPinFlagBytes && B < e->fast_min_batch) {
+    if (ivf && e->host_spin && e->d_pin && in_bytes <= kSpinMaxInput && (size_t) B <= kPinFlagWords && B < e->fast_min_batch) {
         // the same for the inverted index: every output field (rows, counts, fallback flags) lives in the pinned block; the fused
         // kernel raises a query's sequence flag at each of its exits.  A call that takes another path (spin_used stays false) is
         // simply synchronised -- its kernels wrote the pinned block too.
@@ -1563,15 +1622,7 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
                                     reinterpret_cast<int32_t *>(dp_host + ids_bytes + c_bytes));
         e->spin_flag = nullptr;
         if (r != RII_OK) return r;
-        bool seen = false;
-        if (e->spin_used) {
-            for (int spins = 0; spins < 400000 && !seen; ++spins) {
-                seen = true;
-                for (int64_t b = 0; b < B; ++b) seen = seen && (flags[b] == seq);
-                if (!seen) __builtin_ia32_pause();
-            }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        }
+        const bool seen = e->spin_used && spin_wait(flags, e->spin_nflags, seq);
         if (!seen) HIP_TRY(hipStreamSynchronize(st));
         if (e->ivf_has_deferred) {
             const int32_t *fl = reinterpret_cast<const int32_t *>(pout + ids_bytes + c_bytes);
@@ -1586,6 +1637,25 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
         memcpy(out_ids, pout, ids_bytes);
         memcpy(out_counts, pout + ids_bytes, c_bytes);
         memcpy(out_dists, pout + ids_bytes + c_bytes + f_bytes, d_bytes);
+        return RII_OK;
+    }
+    if (batch_pin) {
+        // a batch (round 4, host_zero_copy): the kernels read the queries from the pinned block and write the rows straight into it --
+        // no H2D copy, no D2H copy; with fused_rerank the last block of every tile raises a flag behind its rows (no stream
+        // synchronisation either)
+        unsigned char *dp_host = static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes;
+        volatile unsigned int *flags = reinterpret_cast<volatile unsigned int *>(e->h_pin);
+        const unsigned int seq = ++e->spin_seq ? e->spin_seq : ++e->spin_seq;
+        e->spin_flag = reinterpret_cast<unsigned int *>(e->d_pin);
+        e->spin_used = false;
+        const int r = query_linear_dev(e, reinterpret_cast<const float *>(dp_host), B, topk, d_tids_in, S,
+                                       reinterpret_cast<int64_t *>(dp_host + in_bytes), reinterpret_cast<float *>(dp_host + in_bytes + ids_bytes), st);
+        e->spin_flag = nullptr;
+        if (r != RII_OK) return r;
+        const bool seen = e->spin_used && spin_wait(flags, e->spin_nflags, seq);
+        if (!seen) HIP_TRY(hipStreamSynchronize(st));
+        memcpy(out_ids, pout, ids_bytes);
+        memcpy(out_dists, pout + ids_bytes, d_bytes);
         return RII_OK;
     }
     if (ivf)
@@ -1678,6 +1748,101 @@ RII_API int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, 
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     RII_TRY(begin_on(e, st));
     const int r = query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts, st);
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
+}
+
+// Queries resident in HBM, rows delivered to the HOST: what SURVEY 8d's metric times ("one batched call incl. table build, scan,
+// top-k, device->host of results").  The kernels write the rows straight into the lane's pinned, coherent block; where the last
+// kernel of the step raises sequence flags behind them (the fused re-rank of the linear scan: one flag per tile) the call
+// returns as soon as the host has seen the flags -- no D2H copy, no stream synchronisation -- otherwise after one
+// hipStreamSynchronize.  Synchronous: the rows are in out_* when the call returns (src/main.cpp:17-27: results are
+// Python-visible when the call returns).
+namespace {
+int dev_to_host(rii_engine *e, bool ivf, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S, int64_t L,
+                int64_t *out_ids, float *out_dists, int64_t *out_counts, hipStream_t st)
+{
+    const size_t ids_bytes = (size_t) B * topk * sizeof(int64_t), d_bytes = (size_t) B * topk * sizeof(float);
+    const size_t c_bytes = ivf ? (size_t) B * sizeof(int64_t) : 0;
+    const size_t out_bytes = ids_bytes + c_bytes + d_bytes;
+    if (out_bytes > ((size_t) 64 << 20) || B > kMaxBatch) {         // huge results: device buffers, D2H copies, one synchronisation
+        RII_TRY(e->s_out_ids.ensure(std::max<size_t>(ids_bytes, 16)));
+        RII_TRY(e->s_out_dists.ensure(std::max<size_t>(d_bytes, 16)));
+        RII_TRY(e->s_out_counts.ensure(std::max<size_t>(c_bytes, 16)));
+        if (ivf) RII_TRY(query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, e->s_out_ids.as<int64_t>(), e->s_out_dists.as<float>(), e->s_out_counts.as<int64_t>(), st));
+        else RII_TRY(query_linear_dev(e, d_queries, B, topk, d_tids, S, e->s_out_ids.as<int64_t>(), e->s_out_dists.as<float>(), st));
+        HIP_TRY(hipMemcpyAsync(out_ids, e->s_out_ids.p, ids_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_dists, e->s_out_dists.p, d_bytes, hipMemcpyDeviceToHost, st));
+        if (ivf) HIP_TRY(hipMemcpyAsync(out_counts, e->s_out_counts.p, c_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return RII_OK;
+    }
+    RII_TRY(ensure_pin(e, kPinFlagBytes + out_bytes));
+    unsigned char *hp = static_cast<unsigned char *>(e->h_pin) + kPinFlagBytes;
+    if (!e->d_pin) {                                                 // no mapped host memory on this system: copy + synchronise
+        RII_TRY(e->s_out_pack.ensure(std::max<size_t>(out_bytes, 16)));
+        unsigned char *dp = e->s_out_pack.as<unsigned char>();
+        if (ivf) RII_TRY(query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, reinterpret_cast<int64_t *>(dp), reinterpret_cast<float *>(dp + ids_bytes + c_bytes),
+                                       reinterpret_cast<int64_t *>(dp + ids_bytes), st));
+        else RII_TRY(query_linear_dev(e, d_queries, B, topk, d_tids, S, reinterpret_cast<int64_t *>(dp), reinterpret_cast<float *>(dp + ids_bytes), st));
+        HIP_TRY(hipMemcpyAsync(hp, dp, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        unsigned char *dp = static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes;
+        volatile unsigned int *flags = reinterpret_cast<volatile unsigned int *>(e->h_pin);
+        const unsigned int seq = ++e->spin_seq ? e->spin_seq : ++e->spin_seq;
+        e->spin_used = false;
+        int r;
+        if (ivf) {
+            r = query_ivf_dev(e, d_queries, B, topk, d_tids, S, L, reinterpret_cast<int64_t *>(dp), reinterpret_cast<float *>(dp + ids_bytes + c_bytes),
+                              reinterpret_cast<int64_t *>(dp + ids_bytes), st);
+        } else {
+            e->spin_flag = e->host_spin ? reinterpret_cast<unsigned int *>(e->d_pin) : nullptr;
+            r = query_linear_dev(e, d_queries, B, topk, d_tids, S, reinterpret_cast<int64_t *>(dp), reinterpret_cast<float *>(dp + ids_bytes), st);
+            e->spin_flag = nullptr;
+        }
+        if (r != RII_OK) return r;
+        const bool seen = e->spin_used && spin_wait(flags, e->spin_nflags, seq);
+        if (!seen) HIP_TRY(hipStreamSynchronize(st));
+    }
+    memcpy(out_ids, hp, ids_bytes);
+    if (ivf) memcpy(out_counts, hp + ids_bytes, c_bytes);
+    memcpy(out_dists, hp + ids_bytes + c_bytes, d_bytes);
+    return RII_OK;
+}
+}  // namespace
+
+RII_API int rii_query_linear_dev_to_host(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
+                                         int64_t *out_ids, float *out_dists, void *stream)
+{
+    if (!e || (B > 0 && (!d_queries || !out_ids || !out_dists)) || (S > 0 && !d_tids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(check_query_args(e, B, topk, S));
+    if (B == 0) return RII_OK;
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    RII_TRY(begin_on(e, st));
+    const int r = dev_to_host(e, false, d_queries, B, topk, d_tids, S, 0, out_ids, out_dists, nullptr, st);
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
+}
+
+RII_API int rii_query_ivf_dev_to_host(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
+                                      int64_t L, int64_t *out_ids, float *out_dists, int64_t *out_counts, void *stream)
+{
+    if (!e || (B > 0 && (!d_queries || !out_ids || !out_dists || !out_counts)) || (S > 0 && !d_tids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(check_query_args(e, B, topk, S));
+    RII_TRY(check_ivf_args(e, topk, L));
+    if (B == 0) return RII_OK;
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    RII_TRY(begin_on(e, st));
+    const int r = dev_to_host(e, true, d_queries, B, topk, d_tids, S, L, out_ids, out_dists, out_counts, st);
     const std::string msg = g_err;
     const int r2 = end_on(e, st);
     if (r != RII_OK) { g_err = msg; return r; }
@@ -1953,13 +2118,11 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->host_spin = value ? 1 : 0;
     } else if (k == "small_topk") {
         e->small_topk = value ? 1 : 0;
-    } else if (k == "warm_groups") {
-        if (value < 1 || value > 4) return set_err(RII_ERR_INVALID, "warm_groups must be 1..4");
-        e->warm_groups = (int) value;
-    } else if (k == "scan_prio") {
-        e->scan_prio = (int) (value & 3);
-    } else if (k == "adopt_rr") {
-        e->adopt_rr = value ? 1 : 0;
+    } else if (k == "host_zero_copy") {
+        if (value < 0 || value > 2) return set_err(RII_ERR_INVALID, "host_zero_copy must be 0 (never), 1 (auto) or 2 (always)");
+        e->host_zero_copy = (int) value;
+    } else if (k == "fused_rerank") {
+        e->fused_rerank = value ? 1 : 0;
     } else if (k == "lanes") {
         if (value != 1 && value != 2) return set_err(RII_ERR_INVALID, "lanes must be 1 or 2");
         HIP_TRY(hipSetDevice(e->device));
@@ -1994,10 +2157,9 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "lanes") return e->lanes;
     if (k == "scan_mx") return e->scan_mx;
     if (k == "scan_dual") return e->scan_dual;
-    if (k == "adopt_rr") return e->adopt_rr;
-    if (k == "scan_prio") return e->scan_prio;
-    if (k == "warm_groups") return e->warm_groups;
     if (k == "small_topk") return e->small_topk;
+    if (k == "fused_rerank") return e->fused_rerank;
+    if (k == "host_zero_copy") return e->host_zero_copy;
     if (k == "host_spin") return e->host_spin;
     if (k == "slice_topk") return e->slice_topk;
     if (k == "fast_min_batch") return e->fast_min_batch;

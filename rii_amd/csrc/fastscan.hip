@@ -706,7 +706,12 @@ template <bool MAX> __device__ __forceinline__ float fs_wave_extremum_l63(float 
     return v;
 }
 
-template <typename Vec, int MW, int LEVELS>          // float4: Ds = 4, float2: Ds = 2; MW = subspaces per wave (M = 16 MW)
+// NQ = 4: grid (tile, quarter), a block builds the quarter's four queries and stores whole dwords.  NQ = 1 (round 4, small batches):
+// grid (tile, query of the tile) -- a quarter of the instructions per wave (the kernel is issue-bound inside a CU: 1011 vector
+// instructions x 16 waves), four times the blocks: at B = 128 the tables take 128 CUs instead of 32.  The block owns ONE byte of
+// every dword of its quarter table (byte stores; the other three bytes come from the blocks of the quarter's other queries).
+// Identical bytes either way.
+template <typename Vec, int MW, int LEVELS, int NQ>  // float4: Ds = 4, float2: Ds = 2; MW = subspaces per wave (M = 16 MW)
 __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restrict__ queries, int64_t B,
                                                           const float *__restrict__ codewords, float *__restrict__ lut,
                                                           uint32_t *__restrict__ qlut4, int32_t *__restrict__ slack,
@@ -715,10 +720,11 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
     constexpr int M = 16 * MW;
     constexpr int Ds = (int) (sizeof(Vec) / sizeof(float));
     constexpr int MK = M * 256;
-    __shared__ float s_lo[4][M], s_hi[4][M];
-    __shared__ float s_inv[4];
+    __shared__ float s_lo[NQ][M], s_hi[NQ][M];
+    __shared__ float s_inv[NQ];
     const int64_t tile = blockIdx.x;
-    const int quarter = blockIdx.y;
+    const int quarter = NQ == 4 ? (int) blockIdx.y : (int) (blockIdx.y >> 2);
+    const int j0 = NQ == 4 ? 0 : (int) (blockIdx.y & 3);          // first query of the quarter this block builds
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int m0 = wave * MW;
@@ -728,10 +734,10 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
     for (int s_ = 0; s_ < MW; ++s_)
 #pragma unroll
         for (int e = 0; e < 4; ++e) cv[s_][e] = cw4[(m0 + s_) * 256 + lane + 64 * e];
-    float t[4][MW][4], lo[4][MW], hi[4][MW];
+    float t[NQ][MW][4], lo[NQ][MW], hi[NQ][MW];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int64_t b = tile * 16 + quarter * 4 + jj;
+    for (int jj = 0; jj < NQ; ++jj) {
+        const int64_t b = tile * 16 + quarter * 4 + j0 + jj;
         const Vec *q4 = reinterpret_cast<const Vec *>(queries + (b < B ? b : 0) * (int64_t) (M * Ds));
 #pragma unroll
         for (int s_ = 0; s_ < MW; ++s_) {
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
         }
     }
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int jj = 0; jj < NQ; ++jj)
 #pragma unroll
         for (int s_ = 0; s_ < MW; ++s_) {
             const float l = fs_wave_extremum_l63<false>(lo[jj][s_]), h = fs_wave_extremum_l63<true>(hi[jj][s_]);
@@ -755,12 +761,12 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
         }
     __syncthreads();
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)                      // every lane needs its subspaces' minima for the levels
+    for (int jj = 0; jj < NQ; ++jj)                      // every lane needs its subspaces' minima for the levels
 #pragma unroll
         for (int s_ = 0; s_ < MW; ++s_) lo[jj][s_] = s_lo[jj][m0 + s_];
     double my_dmax = 0.0;
     float my_delta = 0.f;
-    if (threadIdx.x < 4 * 32) {          // 32 lanes per query: the range over the M subspaces -> step and reciprocal
+    if (threadIdx.x < NQ * 32) {         // 32 lanes per query: the range over the M subspaces -> step and reciprocal
         const int j = threadIdx.x >> 5, l32 = threadIdx.x & 31;
         float range = 0.f;
         for (int m = l32; m < M; m += 32) {
@@ -775,9 +781,9 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
         if (l32 == 0) s_inv[j] = 1.0f / my_delta;
     }
     __syncthreads();
-    if (threadIdx.x < 4 * 32) {          // the per-query state of the filter stage, OFF the critical path of the other waves (double math)
+    if (threadIdx.x < NQ * 32) {         // the per-query state of the filter stage, OFF the critical path of the other waves (double math)
         const int j = threadIdx.x >> 5, l32 = threadIdx.x & 31;
-        const int64_t b = tile * 16 + quarter * 4 + j;
+        const int64_t b = tile * 16 + quarter * 4 + j0 + j;
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) my_dmax += __shfl_xor(my_dmax, off);
         if (l32 == 0 && b < B) {         // (see qlut_tile_quant_kernel for the slack)
@@ -796,8 +802,8 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
         for (int e = 0; e < 4; ++e) {
             uint32_t w = 0u;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int64_t b = tile * 16 + quarter * 4 + jj;
+            for (int jj = 0; jj < NQ; ++jj) {
+                const int64_t b = tile * 16 + quarter * 4 + j0 + jj;
                 uint32_t c = 0u;
                 if (b < B) {
                     // x >= 1/2 always (t >= lo), so floor = the truncating conversion (which saturates and sends NaN to 0), then one
@@ -809,12 +815,13 @@ __global__ __launch_bounds__(1024) void qlut_fused_kernel(const float *__restric
                 if (LEVELS > 127) c ^= 0x80u;            // stored as the signed byte (level - 128); dead queries: -128, never judged
                 w |= c << (8 * jj);
             }
-            dst[(m0 + s_) * 256 + lane + 64 * e] = w;
+            if constexpr (NQ == 4) dst[(m0 + s_) * 256 + lane + 64 * e] = w;
+            else reinterpret_cast<uint8_t *>(dst)[(size_t) ((m0 + s_) * 256 + lane + 64 * e) * 4 + j0] = (uint8_t) w;
         }
     if (lut) {                            // the exact table, plain [b][M*Ks]: only for the callers that read it (top-k, tie order)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int64_t b = tile * 16 + quarter * 4 + jj;
+        for (int jj = 0; jj < NQ; ++jj) {
+            const int64_t b = tile * 16 + quarter * 4 + j0 + jj;
             if (b < B)
 #pragma unroll
                 for (int s_ = 0; s_ < MW; ++s_)
@@ -830,8 +837,11 @@ hipError_t launch_qlut_fused(const float *d_queries, int64_t B, const float *d_c
                              uint32_t *d_qlut4, int32_t *d_slack, unsigned int *d_cand_cnt, uint32_t *d_gthr, int levels, hipStream_t st)
 {
     if (B == 0) return hipSuccess;
-    const dim3 grid((unsigned) ((B + 15) / 16), 4), block(1024);
-#define RII_QF(VEC, MW, LV) hipLaunchKernelGGL((qlut_fused_kernel<VEC, MW, LV>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr)
+    // small batches: one query per block (four times the blocks, a quarter of the instructions per wave)
+    const bool one = B <= 256;
+    const dim3 grid((unsigned) ((B + 15) / 16), one ? 16 : 4), block(1024);
+#define RII_QF(VEC, MW, LV) do { if (one) hipLaunchKernelGGL((qlut_fused_kernel<VEC, MW, LV, 1>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr); \
+                                 else hipLaunchKernelGGL((qlut_fused_kernel<VEC, MW, LV, 4>), grid, block, 0, st, d_queries, B, d_codewords, d_lut_or_null, d_qlut4, d_slack, d_cand_cnt, d_gthr); } while (0)
     if (levels != 63 && levels != 127 && levels != 255) return hipErrorInvalidValue;
 #define RII_QF3(VEC, MW) { if (levels == 255) RII_QF(VEC, MW, 255); else if (levels == 127) RII_QF(VEC, MW, 127); else RII_QF(VEC, MW, 63); }
     if (M == 32 && Ds == 4) RII_QF3(float4, 2)
@@ -917,11 +927,18 @@ struct FsArgs {
     int sample_stride;             // MODE 1: visit every sample_stride-th 1024-code slab of the chunk only (>= 1)
     int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
     int dual = 0;                  // M = 16: two 16-query tiles per block (fscan_mx_dual_kernel)
-    int warm_groups = 4;           // fscan_mx_*: groups per wave of the chunk's first trip whose minima become the first thresholds
-    int prio = 0;                  // fscan_mx_kernel: 1 = s_setprio 1 for the younger half of the block's waves, 2 = for the older half
-    int adopt_rr = 0;              // fscan_mx_*: 1 = the waves take turns adopting the other chunks' thresholds (0: wave 0 every trip)
     int bias = 0;                  // fscan_mx_*: initial value of the accumulators (128 M for tables of signed bytes = 255 levels, else 0)
+    FsTail tail;                   // fscan_mx_* MODE 0, TAIL instances: the last chunk-block of a tile re-ranks the tile's queries (round 4)
 };
+
+// TAIL instances of fscan_mx_*: the staged candidate records leave the CU write-through (agent-scope store = `sc1`) so that the
+// fused re-rank -- another block of the SAME launch, possibly behind another XCD's L2 -- can read them with `sc1` loads.  (Records
+// that missed the LDS staging area are stored plainly from the hot loop's rare branch -- an agent-scope store there costs the
+// loop its register allocation -- and a block that had any is released with one L2 write-back before it arrives: fs_tail_arrive.)
+__device__ __forceinline__ void fs_cand_store(unsigned long long *dst, unsigned long long rec)
+{
+    __hip_atomic_store(dst, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // MODE 0: top-1, thresholds adapt to the block's running minimum.  MODE 1 / 2: the two passes of top-k (k > 1):
 // pass 1 records, per lane, the minimum a() over the codes that lane saw (a partition of the codes into G segments);
@@ -1821,12 +1838,186 @@ template <int PENDING> __device__ __forceinline__ v4i_t fs_mx_group8(v2i_t (&r)[
     return acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the top-1 re-rank as the TAIL of the scan (fs_tail_rerank), run by the last chunk-block of a tile.
+//
+// Every chunk-block of a tile appends its candidates to the tile's global candidate lists.  With TAIL the records are stored
+// write-through (agent-scope stores: `sc1`), the block drains its stores (s_waitcnt vmcnt(0)) and THEN counts itself on the
+// tile's arrival counter with a device-scope atomic; the block that finds chunks - 1 earlier arrivals is the last one and reads
+// all records back with agent-scope (`sc1`) loads -- the write-through / `sc1`-load pairing needs no L2 write-back and no
+// cache invalidate (MI355X guide, "inter-workgroup visibility": valid form {sc1 payload -> vmcnt(0) -> flag, sc1 loads}).  It
+// then does exactly what rerank_top1_direct_kernel does for one query, for the <= 32 queries of the tile at once:
+//   pass A  all records of the tile, flat over (query, record): the minimum quantised sum per query; records parked in LDS
+//   pass B  records within the proven slack of that minimum are compacted into one survivor list (LDS)
+//   pass C  one thread per survivor: exact distance from the codebook in the reference's m order (16 codeword loads in flight),
+//           (orderable distance << 32 | position) minimum per query by LDS atomics
+// and writes the tile's rows.  A query whose candidate buffer overflowed is scanned exhaustively by the whole block with its
+// exact table in LDS (rare: thousands of duplicated nearest codes).  LDS: the byte tables are dead by then.
+// One launch less per batch, no second kernel's start-up latency (8 us at B = 1024), and the rows can go straight to the host.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kFsTailRec = 8192, kFsTailSurv = 4096;
+constexpr size_t kFsTailLds = 32768 + 1024 + (size_t) kFsTailRec * 8 + (size_t) kFsTailSurv * 8;
+// P: pointer to the kernel's own FsArgs in the kernarg segment (constant address space), laundered by the caller so that the
+// tail's fields are fetched (s_load) here, behind the hot loop, instead of living in SGPRs through it
+typedef const __attribute__((address_space(4))) FsArgs *fs_kernarg_t;
+template <typename Vec>
+__device__ __forceinline__ void fs_tail_score(fs_kernarg_t pa, const Vec *s_q, unsigned long long *s_best, int q, uint32_t n)
+{
+    const FsArgs &p = *(const FsArgs *) pa;
+    const Vec *cw = reinterpret_cast<const Vec *>(p.tail.codewords);
+    const int M = p.M;
+    const uint2 *code = reinterpret_cast<const uint2 *>(p.tail.codes + (size_t) (p.tail.indirect ? (int64_t) p.tail.remap[n] : (int64_t) n) * M);
+    const Vec *sq = s_q + q * M;
+    float dist = 0.f;
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        const uint2 wa = code[m0 >> 3];
+        const uint2 wb = (m0 + 8 < M) ? code[(m0 >> 3) + 1] : make_uint2(0u, 0u);
+        const uint32_t wd[4] = {wa.x, wa.y, wb.x, wb.y};
+        Vec cv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t ks = (wd[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            cv[j] = cw[(m0 + j < M ? m0 + j : 0) * 256 + ks];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (m0 + j < M) dist = __fadd_rn(dist, fvec_l2sqr_vec(sq[m0 + j], cv[j]));
+    }
+    atomicMin(&s_best[q], ((unsigned long long) f32_orderable(__float_as_uint(dist)) << 32) | n);
+}
+template <typename Vec, int NQ>
+__device__ __forceinline__ void fs_tail_rerank(fs_kernarg_t pa, int qbase, unsigned char *smem, int tid)
+{
+    const FsArgs &p = *(const FsArgs *) pa;
+    constexpr int Ds = (int) (sizeof(Vec) / sizeof(float));
+    const int M = p.M;
+    Vec *s_q = reinterpret_cast<Vec *>(smem);                                                    // [NQ][M]: <= 32 KiB
+    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(smem + 32768);           // [32]
+    uint32_t *s_pre = reinterpret_cast<uint32_t *>(smem + 32768 + 256);                           // [33] prefix of the usable record counts
+    uint32_t *s_raw = s_pre + 40;                                                                 // [32] counts as the scan left them
+    uint32_t *s_amin = s_raw + 32;                                                                // [32]
+    uint32_t *s_ctl = s_amin + 32;                                                                // [0] survivors
+    unsigned long long *s_rec = reinterpret_cast<unsigned long long *>(smem + 32768 + 1024);     // [kFsTailRec]
+    unsigned long long *s_surv = s_rec + kFsTailRec;                                              // [kFsTailSurv] (query << 32 | position)
+    const int nlive = (p.B - qbase) < NQ ? (p.B - qbase) : NQ;
+    {
+        const Vec *src = reinterpret_cast<const Vec *>(p.tail.queries + (int64_t) qbase * (M * Ds));
+        for (int i = tid; i < nlive * M; i += kFsThreads) s_q[i] = src[i];
+    }
+    if (tid < 64) {                       // wave 0: counts -> exclusive prefix (lanes 0 .. 31)
+        uint32_t raw = 0u;
+        if (tid < nlive) raw = __hip_atomic_load(&p.cand_count[qbase + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t use = raw <= (uint32_t) p.cap ? raw : 0u;      // an overflowed list is not used at all
+        uint32_t inc = use;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if ((tid & 63) >= off) inc += o;
+        }
+        if (tid < 32) { s_raw[tid] = raw; s_pre[tid + 1] = inc; s_best[tid] = ~0ull; s_amin[tid] = 0xffffffffu; }
+        if (tid == 0) { s_pre[0] = 0u; s_ctl[0] = 0u; }
+    }
+    __syncthreads();
+    const uint32_t T = s_pre[NQ < 32 ? NQ : 32];
+    auto owner = [&](uint32_t f) {        // query of flat record f: the last q with s_pre[q] <= f
+        int q = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+            if (q + step < NQ && s_pre[q + step] <= f) q += step;
+        return q;
+    };
+    auto fetch = [&](int q, uint32_t f) {
+        return __hip_atomic_load(&p.cand[(size_t) (qbase + q) * p.cap + (f - s_pre[q])], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (uint32_t f = tid; f < T; f += kFsThreads) {
+        const int q = owner(f);
+        const unsigned long long rec = fetch(q, f);
+        if (f < (uint32_t) kFsTailRec) s_rec[f] = rec;
+        atomicMin(&s_amin[q], (uint32_t) (rec >> 32));
+    }
+    __syncthreads();
+    for (uint32_t f = tid; f < T; f += kFsThreads) {
+        const int q = owner(f);
+        const unsigned long long rec = f < (uint32_t) kFsTailRec ? s_rec[f] : fetch(q, f);
+        if ((uint32_t) (rec >> 32) > s_amin[q] + (uint32_t) p.slack[qbase + q]) continue;
+        const uint32_t pos = atomicAdd(&s_ctl[0], 1u);
+        if (pos < (uint32_t) kFsTailSurv) s_surv[pos] = ((unsigned long long) q << 32) | (rec & 0xffffffffull);
+        else fs_tail_score<Vec>(pa, s_q, s_best, q, (uint32_t) (rec & 0xffffffffull));       // (list full: scored on the spot)
+    }
+    __syncthreads();
+    {
+        const uint32_t ns = s_ctl[0] < (uint32_t) kFsTailSurv ? s_ctl[0] : (uint32_t) kFsTailSurv;
+        for (uint32_t i = tid; i < ns; i += kFsThreads) {
+            const unsigned long long e = s_surv[i];
+            fs_tail_score<Vec>(pa, s_q, s_best, (int) (e >> 32), (uint32_t) (e & 0xffffffffull));
+        }
+    }
+    // candidate buffer overflowed: exact table of the query in LDS (over the parked records: dead), every code scanned
+    for (int q = 0; q < nlive; ++q) {
+        if (s_raw[q] <= (uint32_t) p.cap) continue;              // (block-uniform)
+        __syncthreads();
+        float *s_tab = reinterpret_cast<float *>(s_rec);
+        const Vec *cw = reinterpret_cast<const Vec *>(p.tail.codewords);
+        for (int i = tid; i < M * 256; i += kFsThreads) s_tab[i] = fvec_l2sqr_vec(s_q[q * M + (i >> 8)], cw[i]);
+        __syncthreads();
+        unsigned long long best = ~0ull;
+        for (int64_t n = tid; n < p.n_codes; n += kFsThreads) {
+            const float d = exact_adist(s_tab, p.tail.codes + (size_t) (p.tail.indirect ? (int64_t) p.tail.remap[n] : (int64_t) n) * M, M, 256);
+            const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | (uint32_t) n;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        if ((tid & 63) == 0 && best != ~0ull) atomicMin(&s_best[q], best);
+    }
+    __syncthreads();
+    if (tid < nlive) {
+        const unsigned long long k = s_best[tid];
+        const uint32_t idx = (uint32_t) (k & 0xffffffffu);
+        const int64_t b = qbase + tid;
+        p.tail.out_ids[b * p.tail.topk] = (k == ~0ull) ? -1 : (p.tail.remap ? p.tail.remap[idx] : (int64_t) idx);
+        p.tail.out_dists[b * p.tail.topk] = (k == ~0ull) ? INFINITY : __uint_as_float(f32_unorderable((uint32_t) (k >> 32)));
+    }
+    if (p.tail.host_flag) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the rows (coherent host memory) have left the CU ahead of the flag
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            __hip_atomic_store(&p.tail.host_flag[blockIdx.y], p.tail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// arrival of a chunk-block at its tile's counter; true for the last one (which also puts the zero back for the next launch).
+// s_word: one LDS word for the broadcast.
+// spilled: some record of this block went to global memory with a plain store (LDS staging area full): one L2 write-back first.
+__device__ __forceinline__ bool fs_tail_arrive(fs_kernarg_t pa, uint32_t *s_word, int tid, bool spilled)
+{
+    const FsArgs &p = *(const FsArgs *) pa;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's candidate stores have left the CU
+    __syncthreads();
+    if (tid == 0) {
+        if (spilled) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the wait behind buffer_wbl2: MI355X guide)
+        }
+        const unsigned int prev = __hip_atomic_fetch_add(&p.tail.tile_done[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) __hip_atomic_store(&p.tail.tile_done[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_word = prev;
+    }
+    __syncthreads();
+    return *s_word == gridDim.x - 1;
+}
+
 constexpr int kFsMxSeg = 256;        // MODE 1 segments per chunk and query: (wave, column) pairs
 
 // grid = (chunks, ceil(B / 16)), 1024 threads.  Thresholds: 16 words in LDS, candidate <=> a < thr (thr = bound + slack + 1).
-template <int T, int MODE, int QR = 16>
+template <int T, int MODE, int QR = 16, bool TAIL = false>
 __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
 {
+    static_assert(!TAIL || (MODE == 0 && QR == 16), "the fused re-rank is the top-1 pass of the 16-byte-row shapes");
     static_assert((QR == 16 && (T == 4 || T == 8)) || (QR == 8 && T == 16), "M = 16 / 32 with 16-byte rows, M = 64 with 8-byte rows");
     constexpr int M = 4 * T;
     typedef typename FsMxW<T>::V W;
@@ -1951,11 +2142,10 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     };
     auto load_thr = [&]() { return *reinterpret_cast<const v4i_t *>(s_thr + 4 * gq); };
     // adopt thresholds published by the blocks scanning the other chunks for the same queries (stale = a few more candidates)
-    // `turn`: the wave that does it this time.  The global load stalls the wave that issues it for an L2 round trip (its lookups
-    // in flight are drained by the wait); taking turns spreads that over the 16 waves instead of making wave 0 the block's straggler.
-    auto adopt = [&](bool first, int turn = 0) {
+    // (wave 0 does it; taking turns over the 16 waves was measured in round 3: no gain at B = 1024, 4 % slower at B = 128)
+    auto adopt = [&](bool first) {
         const int q = tid & 63;
-        if (MODE == 0 && (tid >> 6) == (turn & 15) && q < QR) {
+        if (MODE == 0 && tid < 64 && q < QR) {
             const int b = tile * QR + q;
             if (b < p.B) {
                 const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1993,7 +2183,8 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     if constexpr (MODE == 0) {
         if (full > 0) {
             const v4i_t none = {0, 0, 0, 0};
-            for (int j = 0; j < p.warm_groups; ++j) slow_group(wave * 4 + j, true, none);      // (1 .. 4 of the first trip's groups)
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) slow_group(wave * 4 + j, true, none);      // (the wave's four groups of the first trip; fewer: more candidates, DESIGN 3.1 v)
         } else {
             tail(true);
         }
@@ -2009,8 +2200,6 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
     const int step = (MODE == 1) ? p.sample_stride : 1;
     const int ntrip = (MODE == 1) ? (full + step - 1) / step : full;
     auto trip_of = [&](int k) { return (MODE == 0) ? (k + 1 < full ? k + 1 : 0) : k * step; };
-    if (p.prio == 1 && wave >= 8) __builtin_amdgcn_s_setprio(1);        // (experiment: MI355X guide, "static priority for the younger half")
-    if (p.prio == 2 && wave < 8) __builtin_amdgcn_s_setprio(1);
     if (ntrip > 0) {
         // a zero accumulator kept in registers: the matrix instruction accumulates in place, and built from a literal the
         // compiler clears it with six moves per group instead of two
@@ -2068,7 +2257,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx, zero4);
                 fs_mx_load<S>(q[1], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
-                adopt(false, p.adopt_rr ? k + 1 : 0);
+                adopt(false);
             }
             fs_mx_wait<0>(ra);            // the rows and lookups fetched past the last trip are never used, but must have landed
             fs_mx_wait<0>(rb);
@@ -2121,7 +2310,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                 acc = fs_mx_group8<12>(r, q[0], C, spa, spidx, zero4);          // group 3; refills = next trip's group 0
                 fs_mx_load<0>(q[0], pnn);
                 if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
-                adopt(false, p.adopt_rr ? k + 1 : 0);
+                adopt(false);
             }
             fs_mx_wait8<0>(r[0], r[1], r[2], r[3]);       // everything fetched past the last trip has landed
             fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
@@ -2141,7 +2330,21 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
             const int b = tile * QR + q;
             const unsigned int c = min(s_lcnt[q], (unsigned int) p.lcap), base = s_lcnt[QR + q];
             for (unsigned int i = tid & 63; i < c; i += 64)
-                if (base + i < (unsigned int) p.cap) p.cand[(size_t) b * p.cap + base + i] = s_lcand[(size_t) q * p.lcap + i];
+                if (base + i < (unsigned int) p.cap) {
+                    if constexpr (TAIL) fs_cand_store(&p.cand[(size_t) b * p.cap + base + i], s_lcand[(size_t) q * p.lcap + i]);     // write-through: read by the tile's last block
+                    else p.cand[(size_t) b * p.cap + base + i] = s_lcand[(size_t) q * p.lcap + i];
+                }
+        }
+    }
+    if constexpr (TAIL) {
+        // the last chunk-block of the tile re-ranks the tile's 16 queries (fs_tail_rerank); everybody else is done
+        fs_kernarg_t pa = (fs_kernarg_t) __builtin_amdgcn_kernarg_segment_ptr();     // FsArgs is the only parameter
+        asm volatile("" : "+s"(pa));
+        bool spilled = false;
+        for (int q = 0; q < 16; ++q) spilled |= s_lcnt[q] > (uint32_t) pa->lcap;
+        if (fs_tail_arrive(pa, s_lcnt, tid, spilled)) {
+            if (pa->tail.Ds == 4) fs_tail_rerank<float4, 16>(pa, tile * 16, smem, tid);
+            else fs_tail_rerank<float2, 16>(pa, tile * 16, smem, tid);
         }
     }
     if constexpr (MODE == 1) {
@@ -2202,9 +2405,10 @@ __device__ __forceinline__ void fs_mx_reduce_refill_dual(v4i_t (&r)[8], uint32_t
 }
 
 // grid = (chunks, ceil(B / 32)), 1024 threads
-template <int MODE>
+template <int MODE, bool TAIL = false>
 __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
 {
+    static_assert(!TAIL || MODE == 0, "the fused re-rank is the top-1 pass");
     constexpr int M = 16, NQ = 32;
     constexpr size_t tile_bytes = (size_t) M * 256 * 16;               // 64 KiB: one tile's rotated byte rows
     constexpr size_t lut_bytes = 2 * tile_bytes;
@@ -2325,9 +2529,9 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             if (col == 0 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[q], fs_thr_of((uint32_t) v, s_slk[q]));
         }
     };
-    auto adopt = [&](bool first, int turn = 0) {                       // (the waves take turns: see fscan_mx_kernel)
+    auto adopt = [&](bool first) {
         const int q = tid & 63;
-        if (MODE == 0 && (tid >> 6) == (turn & 15) && q < NQ) {
+        if (MODE == 0 && tid < 64 && q < NQ) {
             const int b = qbase + q;
             if (b < p.B) {
                 const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2369,7 +2573,8 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
     };
     if constexpr (MODE == 0) {
         if (full > 0) {
-            for (int j = 0; j < p.warm_groups; ++j) slow_group(wave * 4 + j, true);
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) slow_group(wave * 4 + j, true);
         } else {
             tail(true);
         }
@@ -2433,7 +2638,7 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             fs_mx_reduce_refill_dual(rb, q[1], C, spa, spidx, zero4, accA, accB);
             fs_mx_load<S>(q[1], pnn);
             if (MODE == 1) { take_min(keepA, accA); take_min(keepB, accB); } else { judge(accA, thrA, n + 48, 0); judge(accB, thrB, n + 48, 16); }
-            adopt(false, p.adopt_rr ? k + 1 : 0);
+            adopt(false);
         }
         fs_mx_wait<0>(ra);
         fs_mx_wait<0>(rb);
@@ -2453,7 +2658,20 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             const int b = qbase + q;
             const unsigned int c = min(s_lcnt[q], (unsigned int) p.lcap), base = s_lcnt[NQ + q];
             for (unsigned int i = tid & 63; i < c; i += 64)
-                if (base + i < (unsigned int) p.cap) p.cand[(size_t) b * p.cap + base + i] = s_lcand[(size_t) q * p.lcap + i];
+                if (base + i < (unsigned int) p.cap) {
+                    if constexpr (TAIL) fs_cand_store(&p.cand[(size_t) b * p.cap + base + i], s_lcand[(size_t) q * p.lcap + i]);     // write-through: read by the tile's last block
+                    else p.cand[(size_t) b * p.cap + base + i] = s_lcand[(size_t) q * p.lcap + i];
+                }
+        }
+    }
+    if constexpr (TAIL) {
+        fs_kernarg_t pa = (fs_kernarg_t) __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pa));
+        bool spilled = false;
+        for (int q = 0; q < NQ; ++q) spilled |= s_lcnt[q] > (uint32_t) pa->lcap;
+        if (fs_tail_arrive(pa, s_lcnt, tid, spilled)) {        // the last chunk-block of the tile pair re-ranks its 32 queries
+            if (pa->tail.Ds == 4) fs_tail_rerank<float4, 32>(pa, qbase, smem, tid);
+            else fs_tail_rerank<float2, 32>(pa, qbase, smem, tid);
         }
     }
     if constexpr (MODE == 1) {
@@ -2468,26 +2686,28 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
     }
 }
 
-template <int MODE> static hipError_t launch_fscan_mx_dual_t(const FsArgs &a, int chunks, hipStream_t st)
+template <int MODE, bool TAIL = false> static hipError_t launch_fscan_mx_dual_t(const FsArgs &a, int chunks, hipStream_t st)
 {
     const size_t tab = (size_t) 2 * 16 * 256 * 16 + 32 * 4 + 32 * 8 + 32 * 4;
     FsArgs b = a;
     b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) 32 * 8));
-    const size_t smem = tab + (size_t) 32 * 8 * b.lcap;
-    auto kern = fscan_mx_dual_kernel<MODE>;
+    size_t smem = tab + (size_t) 32 * 8 * b.lcap;
+    if (TAIL) smem = std::max(smem, kFsTailLds);
+    auto kern = fscan_mx_dual_kernel<MODE, TAIL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     launch_timed(kern, dim3(chunks, (a.B + 31) / 32), dim3(kFsThreads), smem, st, b);
     return hipGetLastError();
 }
 
-template <int T, int MODE, int QR = 16> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
+template <int T, int MODE, int QR = 16, bool TAIL = false> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
     const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8 + 64;
     FsArgs b = a;
     b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) QR * 8));
-    const size_t smem = tab + (size_t) QR * 8 * b.lcap;
-    auto kern = fscan_mx_kernel<T, MODE, QR>;
+    size_t smem = tab + (size_t) QR * 8 * b.lcap;
+    if (TAIL) smem = std::max(smem, kFsTailLds);
+    auto kern = fscan_mx_kernel<T, MODE, QR, TAIL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     launch_timed(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
@@ -2499,6 +2719,14 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
     const int qr = fastscan_rows(a.M, a.Ks);
     const int tiles = (a.B + qr - 1) / qr;
     if (rot && mx) {
+        if constexpr (MODE == 0) {
+            if (a.tail.queries) {             // top-1 with the re-rank folded into the scan's tail
+                if (a.M == 16 && a.dual) return launch_fscan_mx_dual_t<0, true>(a, chunks, st);
+                if (a.M == 16) return launch_fscan_mx_t<4, 0, 16, true>(a, chunks, tiles, st);
+                if (a.M == 32) return launch_fscan_mx_t<8, 0, 16, true>(a, chunks, tiles, st);
+                return hipErrorInvalidValue;
+            }
+        }
         if (a.M == 16 && a.dual) return launch_fscan_mx_dual_t<MODE>(a, chunks, st);
         if (a.M == 16) return launch_fscan_mx_t<4, MODE>(a, chunks, tiles, st);
         if (a.M == 32) return launch_fscan_mx_t<8, MODE>(a, chunks, tiles, st);
@@ -2523,7 +2751,7 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter, int dual, int levels)
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter, int dual, int levels, const FsTail *tail)
 {
     // d_codes: formatted lookups (launch_fcodes_format, same `mx`) for fs_rot_supported shapes, the plain codes otherwise
     if (B == 0 || n_codes == 0) return hipSuccess;
@@ -2532,9 +2760,10 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     a.quarter = quarter;
     a.dual = ((dual & 1) && mx && M == 16 && rot) ? 1 : 0;
     a.bias = levels > 127 ? 128 * M : 0;
-    a.adopt_rr = (dual >> 8) & 1;               // (bit 8 of `dual`: engine option adopt_rr)
-    a.prio = (dual >> 9) & 3;                   // (bits 9-10: engine option scan_prio)
-    a.warm_groups = ((dual >> 11) & 3) + 1;     // (bits 11-12: engine option warm_groups - 1)
+    if (tail && tail->queries) {
+        if (mode != 0 || !fscan_tail_supported(M, Ks, tail->Ds, mx)) return hipErrorInvalidValue;
+        a.tail = *tail;
+    }
     a.gthr = d_gthr;
     a.sample_stride = sample_stride < 1 ? 1 : sample_stride;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.qlut = d_qlut; a.slack = d_slack; a.B = B;
@@ -2545,6 +2774,15 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     return launch_fscan_mode<0>(a, chunks, rot, mx != 0, st);
 }
 
+bool fscan_tail_supported(int M, int Ks, int Ds, int mx)
+{
+    return mx && Ks == 256 && (M == 16 || M == 32) && (Ds == 4 || Ds == 2) && fs_rot_supported(M, Ks, mx);
+}
+int fscan_tail_flags(int M, int Ks, int mx, int dual, int64_t B)
+{
+    const int qpb = fscan_queries_per_block(M, Ks, mx, dual);
+    return (int) ((B + qpb - 1) / qpb);
+}
 int fscan_queries_per_block(int M, int Ks, int mx, int dual)
 {
     return (dual && mx && M == 16 && fs_rot_supported(M, Ks, mx)) ? 32 : fastscan_rows(M, Ks);

@@ -736,6 +736,9 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     // every exit of the block is uniform: the rows of this query (or its fallback flag) are out -> tell a spinning host (host_spin)
     auto publish = [&]() {
         if (p.host_flag) {
+            // every thread's row stores have left the CU before the barrier (coherent host memory is uncached on the device: a drained
+            // store is on its way to the host ahead of the flag; the workgroup-scope barrier alone does not wait for vmcnt: ADVICE r3)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
                 __threadfence_system();

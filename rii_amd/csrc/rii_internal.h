@@ -156,10 +156,29 @@ hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
                                   int arch, float *d_lut, uint8_t *d_qc, uint8_t *d_qlut, int32_t *d_slack,
                                   unsigned int *d_cand_cnt, uint32_t *d_gthr, int mx, hipStream_t st);
+// round 4: the top-1 re-rank folded into the filter scan's tail (fscan_mx_kernel / fscan_mx_dual_kernel, M = 16 / 32, Ks = 256,
+// Ds = 4 / 2: the shapes of rerank_top1_direct_kernel).  The chunk-blocks of a tile publish their candidates write-through and
+// count themselves on tile_done[blockIdx.y]; the LAST one re-ranks the tile's queries from the codebook and writes the rows --
+// into device memory, or straight into coherent host memory with host_flag[blockIdx.y] = seq raised behind them.
+struct FsTail {
+    const float *queries = nullptr;       // non-null: enabled
+    const float *codewords = nullptr;
+    const uint8_t *codes = nullptr;       // what a candidate's position indexes: the plain codes (id order)
+    const int64_t *remap = nullptr;       // subset search: position -> id (also the code index when `indirect`)
+    int indirect = 0, Ds = 4, topk = 1;
+    int64_t *out_ids = nullptr;
+    float *out_dists = nullptr;
+    unsigned int *tile_done = nullptr;    // [grid.y] arrival counters: zero between launches (the last block puts the zero back)
+    unsigned int *host_flag = nullptr;    // [grid.y] (coherent host memory) or NULL
+    unsigned int seq = 0;
+};
+bool fscan_tail_supported(int M, int Ks, int Ds, int mx);
+int fscan_tail_flags(int M, int Ks, int mx, int dual, int64_t B);       // number of tile_done counters / host flags a launch uses
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter = 0, int dual = 0, int levels = 63);
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter = 0, int dual = 0, int levels = 63,
+                        const FsTail *tail = nullptr);
 // queries per block of the filter scan: 32 when the M = 16 shape runs two tiles per block (option scan_dual), else fastscan_rows()
 int fscan_queries_per_block(int M, int Ks, int mx, int dual);
 int fastscan_max_sum(int M, int levels = 0);      // largest quantised sum: M x levels (0 = the default 63)

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(kStThreads) void small_topk_kernel(SmallArgs p)
     if (p.host_flag) {
         // the rows went straight to the caller's pinned block: publish them to the host, which is spinning on the flag instead of
         // paying a D2H copy and a stream synchronisation (tools/host_latency_probe.hip: 9 us of a 17 us empty call)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every thread's row stores have left the CU before the barrier
         __syncthreads();
         if (tid == 0) {
             __threadfence_system();
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
     }
     if (tid == 0) p.out_tie[b] = tie;                  // 1: the host reruns the call on the general path (std::partial_sort's order)
     if (p.host_flag) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every thread's row stores have left the CU before the barrier
         __syncthreads();
         if (tid == 0) {
             __threadfence_system();

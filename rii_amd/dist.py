@@ -336,7 +336,27 @@ class DbShardedIndex(object):
             mi = torch.empty((B, rows), dtype=torch.int64, device=dev)
             md = torch.empty((B, rows), dtype=torch.float32, device=dev)
             self.last_tie_overflow = self._zero_flags(B, dev)
-            if topk == 1:
+            if G * rows > 8192 or G > 64:
+                # beyond the merge kernel's LDS sort (rii_merge_topk_ex_dev: G * k <= 8192 keys, G <= 64 offsets): the per-rank id
+                # offsets are added to the finite rows here and torch merges under (dist, id), as the host path does
+                gi, gd = [], []
+                for r in range(G):
+                    di = _field(g, r, nid, B * rows, torch.float32).reshape(B, rows)
+                    ii = _field(g, r, 0, B * rows, torch.int64).reshape(B, rows)
+                    gi.append(torch.where(torch.isfinite(di), ii + int(self.all_starts()[r]), ii))
+                    gd.append(di)
+                mi, md = merge_topk(torch.cat(gi, dim=1), torch.cat(gd, dim=1), rows)
+                if topk == 1:
+                    self.last_tie_flags = self._zero_flags(B, dev)
+                    out = (mi, md)
+                else:
+                    tie = ((md[:, :topk] == md[:, 1:rows]) & torch.isfinite(md[:, 1:rows])).any(dim=1)
+                    out_i, out_d = mi[:, :topk].contiguous(), md[:, :topk].contiguous()
+                    self.last_tie_flags = tie
+                    if bool(tie.any().item()) and hasattr(self.engine, "linear_tie_emit_dev"):
+                        self._replay_linear_ties_device(q, torch.nonzero(tie).flatten(), topk, rows, t, tl, g, out_i, out_d, dev, sh)
+                    out = (out_i, out_d)
+            elif topk == 1:
                 core.merge_topk_ex_dev(g.data_ptr(), G, B, rows, rows, self.all_starts(), mi.data_ptr(), md.data_ptr(), stream=sh)
                 self.last_tie_flags = self._zero_flags(B, dev)
                 out = (mi, md)
@@ -350,13 +370,12 @@ class DbShardedIndex(object):
                 if int(anyf.item()) and hasattr(self.engine, "linear_tie_emit_dev"):     # the batch's one host read
                     self._replay_linear_ties_device(q, torch.nonzero(tie).flatten(), topk, rows, t, tl, g, out_i, out_d, dev, sh)
                 out = (out_i, out_d)
+        _handoff(self.last_tie_flags, self.last_tie_overflow)       # (allocated on the side stream, read by the caller's)
         return _handoff(*out)
 
     def _zero_flags(self, B, dev):
-        z = getattr(self, "_zflags", None)
-        if z is None or z.numel() != B or z.device != dev:
-            z = self._zflags = torch.zeros(B, dtype=torch.bool, device=dev)
-        return z
+        """A fresh all-false flag tensor (callers may keep or mutate `last_tie_flags` / `last_tie_overflow`: ADVICE r3)."""
+        return torch.zeros(B, dtype=torch.bool, device=dev)
 
     def _tie_bound(self, gd, fsel, topk):
         """bound of this rank = the smallest k-th distance any EARLIER shard reported (an earlier shard's codes come first in the

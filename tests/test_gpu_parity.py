@@ -835,11 +835,6 @@ def test_matrix_core_scan_equals_vector_scan(M, Ds):
         g.set_option("fused_tables", 1)
         g.set_option("scan_dual", 1)
         g.set_option("table_levels", 127)
-        g.set_option("adopt_rr", 1)                  # experimental schedule knobs: never the results
-        g.set_option("scan_prio", 1)
-        out.append(g.query_linear_batch(qs, topk, tids))
-        g.set_option("adopt_rr", 0)
-        g.set_option("scan_prio", 0)
         a = out[0]
         for o_ in out[1:]:
             assert np.array_equal(a[0], o_[0]) and np.array_equal(a[1], o_[1]), (topk, g.N)

@@ -1,0 +1,184 @@
+"""Round 4, GPU: the top-1 re-rank folded into the scan launch (fs_tail_rerank), the one-query-per-block table kernel of small
+batches, and the device-queries -> host-rows entry points (rii_query_*_dev_to_host).  Everything is compared bit for bit with
+the path it replaces and with the CPU oracle; the host-delivery paths are hammered with changing batches so that a stale row
+or a flag raised early would show."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import make_problem, assert_same_result
+
+pytestmark = pytest.mark.gpu
+E = np.array([], np.int64)
+
+
+def _engine(M, Ds, N, seed, dup=0):
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(seed)
+    cw = rng.random((M, 256, Ds)).astype(np.float32)
+    codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
+    if dup:
+        codes[rng.integers(0, N, dup)] = codes[rng.integers(0, N, dup)]
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    return g, cw, codes, rng
+
+
+@pytest.mark.parametrize("M,Ds", [(32, 4), (16, 4), (32, 2), (16, 2)])
+def test_fused_rerank_equals_the_separate_kernel_and_the_oracle(M, Ds):
+    """option fused_rerank = 1 (default): the last chunk-block of every scan tile re-ranks the tile's queries inside the scan
+    launch; = 0: rerank_top1_direct_kernel.  Same ids and distances for every batch size (one-query-per-block tables up to 256
+    queries, ragged last tiles, an odd number of tiles for the two-tile M = 16 kernel), duplicated codes (exact ties: the
+    smallest id wins), target ids, one and many chunks per tile."""
+    g, cw, codes, rng = _engine(M, Ds, 90000 + 7, 500 + M + Ds, dup=3000)
+    qs = rng.random((600, M * Ds)).astype(np.float32)
+    tids = np.sort(rng.choice(g.N, 30000, replace=False)).astype(np.int64)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    for B in (33, 100, 128, 257, 600):
+        for t in (None, tids):
+            for dual in (1, 0):
+                for chunks in (0, 1):
+                    g.set_option("scan_dual", dual)
+                    g.set_option("scan_chunks", chunks)
+                    g.set_option("fused_rerank", 1)
+                    a = g.query_linear_batch(qs[:B], 1, t)
+                    g.set_option("fused_rerank", 0)
+                    b = g.query_linear_batch(qs[:B], 1, t)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (B, dual, chunks)
+            for bq in (0, B // 2, B - 1):
+                assert_same_result((a[0][bq], a[1][bq]), o.query_linear(qs[bq], 1, E if t is None else t), "fused re-rank B=%d" % B)
+    g.set_option("scan_chunks", 0)
+    g.set_option("scan_dual", 1)
+    g.set_option("fused_rerank", 1)
+
+
+def test_fused_rerank_overflowed_candidate_buffers():
+    """cand_cap forced tiny: the fused tail scans the overflowed queries exhaustively (exact table in LDS), the others from their
+    candidate lists -- still exact."""
+    g, cw, codes, rng = _engine(32, 4, 40000, 77, dup=0)
+    codes2 = codes.copy()
+    codes2[5000:9000] = codes2[4999]             # thousands of duplicates of one code: every query near it overflows
+    from rii_amd import RiiGpu
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes2, False)
+    qs = rng.random((80, 128)).astype(np.float32)
+    g.set_option("scan_mode", 0)
+    want = g.query_linear_batch(qs, 1, None)
+    g.set_option("scan_mode", 1)
+    for cap in (4, 64):
+        g.set_option("cand_cap", cap)
+        for fr in (1, 0):
+            g.set_option("fused_rerank", fr)
+            got = g.query_linear_batch(qs, 1, None)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (cap, fr)
+
+
+def test_small_batch_tables_equal_the_four_query_blocks():
+    """B <= 256 builds the byte tables with one query per block (qlut_fused_kernel<.., 1>): the scan over them gives the same
+    candidates' answers as over the four-query blocks' tables -- checked through the results of batches on both sides of the
+    switch that share their first rows."""
+    g, cw, codes, rng = _engine(32, 4, 120000, 31)
+    qs = rng.random((300, 128)).astype(np.float32)
+    big = g.query_linear_batch(qs, 1, None)                 # 300 queries: four-query blocks
+    for B in (40, 129, 256):
+        small = g.query_linear_batch(qs[:B], 1, None)       # one query per block
+        assert np.array_equal(small[0], big[0][:B]) and np.array_equal(small[1], big[1][:B]), B
+    for lv in (63, 255):
+        g.set_option("table_levels", lv)
+        small = g.query_linear_batch(qs[:100], 1, None)
+        assert np.array_equal(small[0], big[0][:100]) and np.array_equal(small[1], big[1][:100]), lv
+
+
+@pytest.mark.parametrize("M,Ds", [(32, 4), (16, 6), (8, 16)])
+def test_dev_to_host_rows_equal_the_device_call(M, Ds):
+    """rii_query_linear_dev_to_host / rii_query_ivf_dev_to_host: queries in HBM, rows in the caller's host arrays when the call
+    returns.  Top-1 of the fused shapes takes the flag path (rows written by the scan's tail, one flag per tile), everything else
+    one synchronisation: all must equal the plain device call.  Batches change from call to call (a stale row would show)."""
+    import torch
+    g, cw, codes, rng = _engine(M, Ds, 50000, 900 + M)
+    g.reconfigure(64, 3)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(dev)
+    D = M * Ds
+    for it in range(12):
+        g.set_option("fused_rerank", (it // 2) & 1)         # rows by the scan's tail + one flag per tile / by the re-rank kernel + a synchronisation
+        B = int(rng.integers(1, 400))
+        topk = [1, 1, 1, 3, 20][it % 5]
+        qs = rng.random((B, D)).astype(np.float32)
+        q = torch.from_numpy(qs).to(dev)
+        want = g.query_linear_batch(qs, topk, None)
+        ids = np.full((B, topk), -7, np.int64)
+        d = np.full((B, topk), -7, np.float32)
+        g.query_linear_dev_to_host(q.data_ptr(), B, topk, 0, 0, ids, d, st.cuda_stream if it % 2 else 0)
+        assert np.array_equal(ids, want[0]) and np.array_equal(d.view(np.uint32), want[1].view(np.uint32)), (it, B, topk)
+        if it % 3 == 0:
+            t = np.sort(rng.choice(g.N, 5000, replace=False)).astype(np.int64)
+            td = torch.from_numpy(t).to(dev)
+            want = g.query_linear_batch(qs, topk, t)
+            g.query_linear_dev_to_host(q.data_ptr(), B, topk, td.data_ptr(), t.size, ids, d, 0)
+            assert np.array_equal(ids, want[0]) and np.array_equal(d.view(np.uint32), want[1].view(np.uint32)), (it, B, topk, "tids")
+            L = 900
+            wi, wd, wc = g.query_ivf_batch(qs, topk, None, L)
+            cnt = np.full(B, -7, np.int64)
+            g.query_ivf_dev_to_host(q.data_ptr(), B, topk, 0, 0, L, ids, d, cnt, 0)
+            assert np.array_equal(cnt, wc)
+            for b in range(B):
+                n = int(cnt[b])
+                assert np.array_equal(ids[b, :n], wi[b, :n]) and np.array_equal(d[b, :n], wd[b, :n])
+
+
+def test_dev_to_host_flag_path_under_load_every_word():
+    """The flag path again, the way the guide asks for hand-offs to be tested: many back-to-back calls with DIFFERENT answers,
+    uneven load (batch sizes from one tile to many), every returned word compared.  Also through the host-pointer batch call
+    with and without host_zero_copy (queries read by the kernels from the pinned block)."""
+    import torch
+    g, cw, codes, rng = _engine(32, 4, 200000, 4242, dup=500)
+    dev = torch.device("cuda:0")
+    pool = rng.random((4096, 128)).astype(np.float32)
+    qd = torch.from_numpy(pool).to(dev)
+    g.set_option("fused_rerank", 0)
+    ref_i, ref_d = g.query_linear_batch(pool, 1, None)
+    g.set_option("fused_rerank", 1)
+    for it in range(60):
+        B = int(rng.choice([33, 48, 64, 130, 512, 1024]))
+        s = int(rng.integers(0, 4096 - B))
+        ids = np.empty((B, 1), np.int64)
+        d = np.empty((B, 1), np.float32)
+        g.query_linear_dev_to_host(qd.data_ptr() + s * 128 * 4, B, 1, 0, 0, ids, d, 0)
+        assert np.array_equal(ids, ref_i[s:s + B]) and np.array_equal(d, ref_d[s:s + B]), (it, B, s)
+    for zc in (0, 2):
+        g.set_option("host_zero_copy", zc)
+        for it in range(20):
+            B = int(rng.choice([40, 100, 700, 1024, 2000]))
+            s = int(rng.integers(0, 4096 - B))
+            got = g.query_linear_batch(pool[s:s + B], 1, None)
+            assert np.array_equal(got[0], ref_i[s:s + B]) and np.array_equal(got[1], ref_d[s:s + B]), (zc, it, B, s)
+    g.set_option("host_zero_copy", 1)
+    g.set_option("host_spin", 0)                      # the copy + synchronise form of the same calls
+    got = g.query_linear_batch(pool[:300], 1, None)
+    assert np.array_equal(got[0], ref_i[:300]) and np.array_equal(got[1], ref_d[:300])
+
+
+def test_db_sharded_device_path_beyond_the_merge_kernel_limits():
+    """DbShardedIndex on device tensors: G * (topk + 1) rows above the merge kernel's 8192-key LDS sort fall back to the torch merge
+    (the device path used to raise there) -- same rows as the single engine.  (Exactly tied distances among more than
+    1024 rows cannot be replayed across shards -- include/rii_amd.h: topk <= 1024 -- so the big case uses queries without ties.)"""
+    import torch
+    from rii_amd.dist import DbShardedIndex
+    g, cw, codes, rng = _engine(8, 4, 12000, 5)
+    idx = DbShardedIndex(g, 0, g.N)
+    big = 9000
+    qs = []
+    while len(qs) < 3:
+        q = rng.random((1, 32)).astype(np.float32)
+        d = g.query_linear_batch(q, big + 1, None)[1][0]
+        if not np.any(d[1:] == d[:-1]):
+            qs.append(q[0])
+    qs = np.stack(qs)
+    Q = torch.from_numpy(qs).cuda()
+    for topk in (1, 50, big):
+        ids, d = idx.query_linear_batch(Q, topk)
+        want = g.query_linear_batch(qs, topk, None)
+        assert np.array_equal(ids.cpu().numpy(), want[0]) and np.array_equal(d.cpu().numpy(), want[1]), topk
+        assert idx.last_tie_flags.shape[0] == 3
