@@ -68,7 +68,9 @@ def parse():
     ap.add_argument("--no-others", action="store_true",
                     help="skip the `others` object (the other BASELINE configs measured in the same process)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurements")
-    ap.add_argument("--deep-shard", type=int, default=16_000_000, help="codes of the `others.deep_shard` measurement")
+    ap.add_argument("--deep-shard", type=int, default=64_000_000,
+                    help="codes of the `others.deep_shard` measurement (default 64 M codes = 1 GB: four times the 256 MB Infinity Cache, so "
+                         "the code stream really comes from HBM; 125000000 = the per-GPU shard of Deep1B over 8 GPUs)")
     ap.add_argument("--preheat", type=float, default=0.15,
                     help="seconds of untimed steps before the W warm-up steps (clock ramp; 0 under rocprofv3 counter passes)")
     ap.add_argument("--latency", action="store_true",
@@ -652,15 +654,30 @@ def main():
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
 
-    def run(qt):
+    def run(qt, oi=None, od=None, oc=None):
+        oi, od, oc = oi if oi is not None else out_ids, od if od is not None else out_d, oc if oc is not None else out_cnt
         if ivf:
-            eng.query_ivf_dev(qt.data_ptr(), qt.shape[0], topk, d_tids, S, L, out_ids.data_ptr(), out_d.data_ptr(),
-                              out_cnt.data_ptr(), stream)
+            eng.query_ivf_dev(qt.data_ptr(), qt.shape[0], topk, d_tids, S, L, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), stream)
         else:
-            eng.query_linear_dev(qt.data_ptr(), qt.shape[0], topk, d_tids, S, out_ids.data_ptr(), out_d.data_ptr(), stream)
+            eng.query_linear_dev(qt.data_ptr(), qt.shape[0], topk, d_tids, S, oi.data_ptr(), od.data_ptr(), stream)
+
+    # `value` (round 4): SURVEY 8d's metric counts the device->host of the results, so the step that is timed hands the engine HOST
+    # rows -- two pinned buffers in rotation; the last kernel of the step (re-rank / inverted-index kernel) writes its rows straight
+    # into them over PCIe, no D2H copy is enqueued -- and the closing barrier of the timed region is what makes the last steps' rows
+    # visible.  Queries stay resident in HBM.  `device_resident` below is the same loop with the rows left in HBM, `sync_call` one
+    # rii_query_*_dev_to_host call per step (rows in the caller's arrays when each call returns).
+    host_rows = [(torch.empty((B, topk), dtype=torch.int64).pin_memory(), torch.empty((B, topk), dtype=torch.float32).pin_memory(),
+                  torch.empty((B,), dtype=torch.int64).pin_memory()) for _ in range(2)]
+    it_h = [0]
 
     def step():
-        run(my_q)       # query sharding: every rank owns the results of its own queries, no exchange
+        # query sharding: every rank owns the results of its own queries, no exchange
+        oi, od, oc = host_rows[it_h[0] & 1]
+        it_h[0] += 1
+        run(my_q, oi, od, oc)
+
+    def step_dev():
+        run(my_q)
 
     gathered = [None]
 
@@ -689,18 +706,35 @@ def main():
     cold = timed_loop(step, args.steps, barrier)
     # ... then the steady state: pre-heat, W warm-up steps, K timed steps (this is `value`)
     elapsed, dom, extra = measure(eng, step, args.steps, args.warmup, barrier, torch.cuda.synchronize)
-    res_ids = out_ids.cpu().numpy().copy()
-    res_cnt = out_cnt.cpu().numpy().copy() if ivf else None
+    last = host_rows[(it_h[0] - 1) & 1]
+    res_ids = last[0].numpy().copy()                 # (host memory: the rows the timed steps delivered)
+    res_cnt = last[2].numpy().copy() if ivf else None
+    rows_both_buffers_equal = bool(np.array_equal(host_rows[0][0].numpy(), host_rows[1][0].numpy()))
     # the same K steps with no timing event at all (twice): what the events attached to the dominant kernel's dispatches cost,
     # and how stable a K-step sample is
     plain = [timed_loop(step, args.steps, barrier) for _ in range(2)]
+    # ... with the rows left in HBM (round 3's `value`), and one synchronous device-queries -> host-rows call per step
+    dev_res = timed_loop(step_dev, args.steps, barrier)
+    assert np.array_equal(out_ids.cpu().numpy(), res_ids), "host-delivered rows differ from the device-resident ones"
+    h_i, h_d, h_c = np.empty((B, topk), np.int64), np.empty((B, topk), np.float32), np.empty(B, np.int64)
+
+    def step_sync():
+        if ivf:
+            eng.query_ivf_dev_to_host(my_q.data_ptr(), B, topk, d_tids, S, L, h_i, h_d, h_c, stream)
+        else:
+            eng.query_linear_dev_to_host(my_q.data_ptr(), B, topk, d_tids, S, h_i, h_d, stream)
+
+    for _ in range(max(args.warmup, 1)):
+        step_sync()
+    sync_call = timed_loop(step_sync, args.steps, barrier)
+    assert np.array_equal(h_i, res_ids)
     elapsed_g = None
     if use_dist:
         preheat_count(step_gather, torch.cuda.synchronize, 100)
         for _ in range(args.warmup):
             step_gather()
         elapsed_g = timed_loop(step_gather, args.steps, barrier)
-        elapsed, elapsed_g, plain[0], plain[1], cold = max_over_ranks(elapsed, elapsed_g, plain[0], plain[1], cold)
+        elapsed, elapsed_g, plain[0], plain[1], cold, dev_res, sync_call = max_over_ranks(elapsed, elapsed_g, plain[0], plain[1], cold, dev_res, sync_call)
         allq = gathered[0][0]                        # the gathered batch really is every rank's rows, in rank order
         assert allq.shape[0] == B * world and torch.equal(allq[rank * B:(rank + 1) * B].to(out_ids.device), out_ids)
 
@@ -716,12 +750,13 @@ def main():
         try:
             qidx = rd.QueryShardedIndex(eng)
             res_q = [None]
+            out_q = None if host_coll else (torch.empty((B, topk), dtype=torch.int64, device=dev), torch.empty((B, topk), dtype=torch.float32, device=dev))
 
             def step_strong_q():
                 if ivf:
                     res_q[0] = qidx.query_ivf_batch(Qs, topk, tids_np, L)
                 else:
-                    res_q[0] = qidx.query_linear_batch(Qs, topk, tids_np)
+                    res_q[0] = qidx.query_linear_batch(Qs, topk, tids_np, out=out_q)
 
             preheat_count(step_strong_q, torch.cuda.synchronize, 100)
             for _ in range(max(args.warmup, 1)):
@@ -734,8 +769,9 @@ def main():
                                        "global_batch": B, "rows_per_rank": [rd.shard_range(B, r, world)[1] - rd.shard_range(B, r, world)[0]
                                                                               for r in range(world)],
                                        "results_match_single_engine": ok_q,
-                                       "what": "index replicated, rank r answers its slice of the global batch, ONE all-gather of the "
-                                               "packed result rows inside the timed region (QueryShardedIndex)"}
+                                       "what": "index replicated, rank r answers its slice of the global batch, ONE all-gather of the packed result rows "
+                                               "inside the timed region -- engine kernels, ncclAllGather and the unpack kernel enqueued by ONE "
+                                               "C-ABI call (rii_query_linear_qsharded_dev; QueryShardedIndex is its thin caller)"}
         except Exception as ex:                              # noqa: BLE001
             strong["query_sharded"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if not ivf and S == 0:
@@ -748,9 +784,10 @@ def main():
                 didx = rd.DbShardedIndex(eng_s, s0, s1)
                 didx.all_starts()
                 res_d = [None]
+                out_dd = None if host_coll else (torch.empty((B, topk), dtype=torch.int64, device=dev), torch.empty((B, topk), dtype=torch.float32, device=dev))
 
                 def step_strong_d():
-                    res_d[0] = didx.query_linear_batch(Qs, topk)
+                    res_d[0] = didx.query_linear_batch(Qs, topk, out=out_dd)
 
                 preheat_count(step_strong_d, torch.cuda.synchronize, 100)
                 for _ in range(max(args.warmup, 1)):
@@ -759,9 +796,9 @@ def main():
                 ok_d = bool(torch.equal(torch.as_tensor(res_d[0][0]).to(dev), out_ids) and torch.equal(torch.as_tensor(res_d[0][1]).to(dev), out_d))
                 strong["db_sharded"] = {"value": B * args.steps / e_d, "unit": "queries/s", "ms_per_step": e_d / args.steps * 1e3,
                                         "global_batch": B, "codes_per_rank": s1 - s0, "results_match_single_engine": ok_d,
-                                        "what": "codes split into contiguous id ranges, every rank answers the whole batch on its shard, "
-                                                "ONE all-gather + device (dist, id) merge inside the timed region (DbShardedIndex: "
-                                                "rii_merge_topk_ex_dev, no host synchronisation for top-1)"}
+                                        "what": "codes split into contiguous id ranges, every rank answers the whole batch on its shard, ONE all-gather "
+                                                "+ device (dist, id) merge inside the timed region, all enqueued by ONE C-ABI call "
+                                                "(rii_query_linear_dbsharded_dev; no host synchronisation for top-1)"}
                 del didx, eng_s
             except Exception as ex:                          # noqa: BLE001
                 strong["db_sharded"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
@@ -890,6 +927,17 @@ def main():
                        "lut_mode": args.lut_mode, "simd_order": arch,
                        "scan_mode": "8-bit filter + exact fp32 re-rank" if args.scan_mode else "exact fp32 scan"},
             "recall_at_1": recall,
+            "results": {"delivery": "host: the last kernel of every timed step writes its rows (ids int64, dists f32%s) straight into pinned host "
+                                    "memory (two buffers in rotation, %d B per step over PCIe; no D2H copy, no per-step synchronisation); queries "
+                                    "resident in HBM" % (", counts int64" if ivf else "", B * topk * 12 + (8 * B if ivf else 0)),
+                        "rows_checked": "host rows == device-resident rows == reference rows (cpu_baseline.ids_match_gpu); both host "
+                                        "buffers hold the batch's rows: %s" % rows_both_buffers_equal,
+                        "device_resident": {"ms_per_step": dev_res / args.steps * 1e3, "value": B * world * args.steps / dev_res,
+                                            "unit": "queries/s", "what": "the same K steps with the rows left in HBM (round 3's `value`)"},
+                        "sync_call": {"ms_per_step": sync_call / args.steps * 1e3, "value": B * world * args.steps / sync_call, "unit": "queries/s",
+                                      "what": "one rii_query_%s_dev_to_host call per step: queries in HBM, rows in the caller's host arrays when "
+                                              "EACH call returns (one host wait per step: nothing of step i+1 is enqueued before step i "
+                                              "has landed)" % ("ivf" if ivf else "linear")}},
             "roofline": roof,
             "preheat": {"seconds": PREHEAT_S, "what": "untimed steps before the W warm-up steps: the shader clock ramps over the first ~30 ms "
                                                         "of sustained load (profiles/r03_clock_ramp.json); `value` is the steady state",

@@ -180,6 +180,55 @@ int rii_merge_topk_ex_dev(const void *d_gathered, int G, int64_t B, int k, int k
                           int64_t *d_out_keys, float *d_out_dists, int64_t *d_out_payload, int tie_cols, int32_t *d_out_tie,
                           int32_t *d_out_any, void *stream);
 
+/* ---- Multi-GPU behind the C ABI (NEW, round 4; not in the reference: it has no multi-device code) ----
+ * One rii_comm per process and GPU = one RCCL communicator (over xGMI inside a node).  RCCL is bound at run time (dlopen of the
+ * copy already in the process -- PyTorch-ROCm ships one -- else the system's librccl.so.1); without it rii_comm_init fails with
+ * RII_ERR_HIP.  Rank 0 (or anyone) calls rii_comm_unique_id and hands the RII_COMM_ID_BYTES bytes to every rank by whatever means
+ * the host program has (MPI, a file, torch.distributed); every rank then calls rii_comm_init (collective).  The sharded calls below
+ * enqueue  engine kernels -> ONE ncclAllGather of pre-sized records -> unpack / merge kernel  on `stream` (NULL = the engine's);
+ * the calls that use one communicator must be issued in the same order on every rank, one stream at a time. */
+#define RII_COMM_ID_BYTES 128
+typedef struct rii_comm rii_comm;
+int rii_comm_unique_id(void *id_out /* RII_COMM_ID_BYTES */);
+int rii_comm_init(const void *id, int rank, int nranks, int device, rii_comm **out);
+void rii_comm_destroy(rii_comm *c);
+int rii_comm_rank(const rii_comm *c);
+int rii_comm_size(const rii_comm *c);
+
+/* Query sharding (index replicated on every GPU): every rank passes the SAME d_queries [B, D]; rank r answers rows
+ * [r * (B / G) + min(r, B % G), ...) -- slices differ by at most one row -- and one all-gather of the packed rows gives every rank
+ * all B rows: row b is exactly what rii_query_linear_dev / rii_query_ivf_dev return for query b (RiiCpp::QueryLinear, src/rii.h:195-242;
+ * RiiCpp::QueryIvf, src/rii.h:244-326: its "stop at exactly L candidates in list order" rule is per query, so the inverted index is
+ * sharded over queries).  Asynchronous on the stream. */
+int rii_query_linear_qsharded_dev(rii_engine *e, rii_comm *c, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                                  int64_t S, int64_t *d_out_ids, float *d_out_dists, void *stream);
+int rii_query_ivf_qsharded_dev(rii_engine *e, rii_comm *c, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                               int64_t S, int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, void *stream);
+
+/* The same for callers that run the collective themselves: rank r's record is [nmax * k] int64 ids, [nmax] int64 counts (only with
+ * `counts`: the inverted index), [nmax * k] f32 distances, padded to rii_qshard_record_bytes() -- nmax = ceil(B / G) rows, of which the
+ * rank fills its rii_qshard_begin(B, G, r + 1) - rii_qshard_begin(B, G, r) -- and rii_qshard_unpack_dev lays the G gathered records
+ * out as the [B, k] outputs.  Stateless. */
+int64_t rii_qshard_begin(int64_t B, int G, int rank);
+int64_t rii_qshard_record_bytes(int64_t B, int G, int k, int counts);
+int rii_qshard_unpack_dev(const void *d_gathered, int64_t B, int G, int k, int counts, int64_t *d_out_ids, float *d_out_dists,
+                          int64_t *d_out_counts, void *stream);
+
+/* Database sharding, linear search (Deep1B: 16 GB of codes -> 2 GB per GPU): rank r's engine holds the codes with global ids
+ * [id_offset, id_offset + N_local) -- contiguous id ranges in rank order.  Every rank answers the WHOLE batch on its shard (k + 1
+ * rows per query; one row for top-1), ONE all-gather, and every rank merges the G records under (distance, global id): the answer of
+ * RiiCpp::QueryLinear (src/rii.h:195-242) on the concatenated database, GLOBAL ids, identical on every rank.  Where two of the merged
+ * k + 1 best distances are bit-equal the reference's order is std::partial_sort's (src/rii.h:234-235) over all distances in index
+ * order: those queries (d_out_tie [B] int32, or NULL) are replayed exactly with rii_linear_tie_emit_dev / _replay_dev's kernels and
+ * one more all-gather (tie_cap rows per flagged query and rank, 0 = 12288; a longer list keeps the (distance, id) answer and is
+ * marked in d_out_overflow [B] int32, or NULL).  top-1 is asynchronous on the stream; top-k synchronises once per batch (the host
+ * reads one word: is any query flagged?).  d_tids_local: this rank's share of the target ids as LOCAL ids, S_local of them; S_global =
+ * size of the whole target set, 0 = none (a rank may own none of the targets: S_local == 0, S_global != 0).
+ * G <= 64; topk > 1: G * (topk + 1) <= 8192 and topk <= 1024 for the replay. */
+int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset, const float *d_queries, int64_t B, int topk,
+                                   const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t *d_out_ids,
+                                   float *d_out_dists, int32_t *d_out_tie, int32_t *d_out_overflow, int tie_cap, void *stream);
+
 /* Distance-table build alone (RiiCpp::DTable, src/rii.h:361-373) for B queries -> out[B,M,Ks] (host). */
 int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out);
 /* Coarse assignment alone (PQKMeans::predict_one over codes, src/rii.h:350-354): assign[n] in [0,nlist). */

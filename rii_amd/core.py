@@ -138,6 +138,17 @@ def _lib():
         "rii_merge_record_bytes": (c_i64, [c_i64, c_int, c_int]),
         "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
         "rii_merge_topk_ex_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, i64p, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+        "rii_comm_unique_id": (c_int, [c_vp]),
+        "rii_comm_init": (c_int, [c_vp, c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
+        "rii_comm_destroy": (None, [c_vp]),
+        "rii_comm_rank": (c_int, [c_vp]),
+        "rii_comm_size": (c_int, [c_vp]),
+        "rii_query_linear_qsharded_dev": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+        "rii_query_ivf_qsharded_dev": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+        "rii_query_linear_dbsharded_dev": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+        "rii_qshard_begin": (c_i64, [c_i64, c_int, c_int]),
+        "rii_qshard_record_bytes": (c_i64, [c_i64, c_int, c_int, c_int]),
+        "rii_qshard_unpack_dev": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
         "rii_dtable": (c_int, [c_vp, f32p, c_i64, f32p]),
         "rii_assign": (c_int, [c_vp, u8p, c_i64, i32p]),
         "rii_fscan_lane_subspace": (c_int, [c_int, c_int, c_int]),
@@ -192,6 +203,48 @@ def linear_tie_record_bytes(nf, cap):
 def linear_tie_replay_dev(d_gathered, G, nf, cap, topk, d_out_ids, d_out_dists, stream=0):
     """Replay of std::partial_sort over the all-gathered candidate lists of database-sharded linear search (include/rii_amd.h)."""
     _check(_lib().rii_linear_tie_replay_dev(d_gathered, int(G), int(nf), int(cap), int(topk), d_out_ids, d_out_dists, stream))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """RII_COMM_ID_BYTES opaque bytes from rii_comm_unique_id: created by one rank, handed to all (any transport)."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(_lib().rii_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm(object):
+    """One RCCL communicator behind the C ABI (rii_comm_init: collective over `nranks` processes, one GPU each) and the sharded
+    query entry points that use it: engine kernels -> ONE ncclAllGather -> unpack / merge kernel, all enqueued by the library."""
+
+    def __init__(self, comm_id, rank, nranks, device):
+        self._h = ctypes.c_void_p()
+        _check(_lib().rii_comm_init(ctypes.c_char_p(comm_id), int(rank), int(nranks), int(device), ctypes.byref(self._h)))
+        self.rank, self.size = int(rank), int(nranks)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib().rii_comm_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def query_linear_qsharded_dev(self, engine, d_queries, B, topk, d_tids, S, d_out_ids, d_out_dists, stream=0):
+        _check(_lib().rii_query_linear_qsharded_dev(engine._h, self._h, d_queries, int(B), int(topk), d_tids or None, int(S), d_out_ids,
+                                                    d_out_dists, stream or None))
+
+    def query_ivf_qsharded_dev(self, engine, d_queries, B, topk, d_tids, S, L, d_out_ids, d_out_dists, d_out_counts, stream=0):
+        _check(_lib().rii_query_ivf_qsharded_dev(engine._h, self._h, d_queries, int(B), int(topk), d_tids or None, int(S), int(L),
+                                                 d_out_ids, d_out_dists, d_out_counts, stream or None))
+
+    def query_linear_dbsharded_dev(self, engine, id_offset, d_queries, B, topk, d_tids_local, S_local, S_global, d_out_ids, d_out_dists,
+                                   d_out_tie=0, d_out_overflow=0, tie_cap=0, stream=0):
+        _check(_lib().rii_query_linear_dbsharded_dev(engine._h, self._h, int(id_offset), d_queries, int(B), int(topk), d_tids_local or None,
+                                                     int(S_local), int(S_global), d_out_ids, d_out_dists, d_out_tie or None,
+                                                     d_out_overflow or None, int(tie_cap), stream or None))
 
 
 def fscan_lane_subspace(M, lane, t):

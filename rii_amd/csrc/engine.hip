@@ -1945,6 +1945,48 @@ RII_API int rii_ivf_shard_replay_dev(const void *d_gathered, int G, int64_t nf, 
 }
 
 // Database-sharded linear search, exact ties (not in the reference; kernels and argument: tieorder.hip).
+namespace {
+// the body of rii_linear_tie_emit_dev: the caller holds e->mu and has begun on `st`
+int linear_tie_emit_locked(rii_engine *e, const float *d_queries, int64_t nf, int topk, const int64_t *d_tids, int64_t S,
+                           const float *d_bound, int64_t id_offset, int cap, int64_t *d_out_ids, float *d_out_dists,
+                           int32_t *d_out_count, hipStream_t st)
+{
+    const int64_t n = S ? S : e->N;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_out_count, 0, (size_t) nf * sizeof(int32_t), st));
+        return RII_OK;
+    }
+    const int64_t D = (int64_t) e->M * e->Ds;
+    // Cost: the emit scans the whole shard once per group of flagged queries with ~9 bytes of scratch per code and query, so
+    // the group size is what fits 1 GiB of scratch (64 queries up to 1.8 M codes, ONE query per launch at a 125 M-code shard:
+    // a tie-heavy batch on a Deep1B-sized shard costs nf full-shard passes -- exactness first; docs: DESIGN.md section 6).
+    const int64_t fq_max = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t) 1 << 30) / (n * 9 + 1)));
+    // work list of a group = [count | 0, 1, 2, ...]: the indices are uploaded once per engine, the count is a 4-byte memset in
+    // stream order (no host synchronisation inside the loop)
+    if (!e->have_ident) {
+        int32_t ident[65];
+        ident[0] = 0;
+        for (int i = 0; i < 64; ++i) ident[i + 1] = i;
+        RII_TRY(e->s_ident.ensure(sizeof(ident)));
+        HIP_TRY(hipMemcpyAsync(e->s_ident.p, ident, sizeof(ident), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        e->have_ident = true;
+    }
+    for (int64_t f0 = 0; f0 < nf; f0 += fq_max) {
+        const int cur = (int) std::min<int64_t>(fq_max, nf - f0);
+        RII_TRY(build_lut(e, d_queries + f0 * D, cur, st, false, 0));
+        RII_TRY(e->s_tie_chunk.ensure(linear_tie_chunked_scratch(n, cur)));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) e->s_ident.p, cur, 1, st));
+        ScopedTimer t(e, "tie", st);
+        HIP_TRY(launch_linear_tie_emit(e->d_codes.as<uint8_t>(), n, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, 0,
+                                       e->s_ident.as<int32_t>() + 1, e->s_ident.as<int>(), S ? d_tids : nullptr, topk, cur,
+                                       e->s_tie_chunk.p, S ? 1 : 0, d_bound ? d_bound + f0 : nullptr, id_offset, cap,
+                                       d_out_ids + f0 * cap, d_out_dists + f0 * cap, d_out_count + f0, st));
+    }
+    return RII_OK;
+}
+}  // namespace
+
 RII_API int rii_linear_tie_emit_dev(rii_engine *e, const float *d_queries, int64_t nf, int topk, const int64_t *d_tids, int64_t S,
                                     const float *d_bound, int64_t id_offset, int cap, int64_t *d_out_ids, float *d_out_dists,
                                     int32_t *d_out_count, void *stream)
@@ -1959,42 +2001,7 @@ RII_API int rii_linear_tie_emit_dev(rii_engine *e, const float *d_queries, int64
     if (nf == 0) return RII_OK;
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     RII_TRY(begin_on(e, st));
-    const int64_t n = S ? S : e->N;
-    int r = RII_OK;
-    if (n == 0) {
-        if (hipMemsetAsync(d_out_count, 0, (size_t) nf * sizeof(int32_t), st) != hipSuccess) r = set_err(RII_ERR_HIP, "memset failed");
-    } else {
-        const int64_t D = (int64_t) e->M * e->Ds;
-        // Cost: the emit scans the whole shard once per group of flagged queries with ~9 bytes of scratch per code and query, so
-        // the group size is what fits 1 GiB of scratch (64 queries up to 1.8 M codes, ONE query per launch at a 125 M-code shard:
-        // a tie-heavy batch on a Deep1B-sized shard costs nf full-shard passes -- exactness first; docs: DESIGN.md section 6).
-        const int64_t fq_max = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t) 1 << 30) / (n * 9 + 1)));
-        // work list of a group = [count | 0, 1, 2, ...]: the indices are uploaded once per engine, the count is a 4-byte memset in
-        // stream order (no host synchronisation inside the loop)
-        if (!e->have_ident) {
-            int32_t ident[65];
-            ident[0] = 0;
-            for (int i = 0; i < 64; ++i) ident[i + 1] = i;
-            if ((r = e->s_ident.ensure(sizeof(ident))) == RII_OK &&
-                (hipMemcpyAsync(e->s_ident.p, ident, sizeof(ident), hipMemcpyHostToDevice, st) != hipSuccess ||
-                 hipStreamSynchronize(st) != hipSuccess))
-                r = set_err(RII_ERR_HIP, "copy failed");
-            e->have_ident = (r == RII_OK);
-        }
-        for (int64_t f0 = 0; f0 < nf && r == RII_OK; f0 += fq_max) {
-            const int cur = (int) std::min<int64_t>(fq_max, nf - f0);
-            r = build_lut(e, d_queries + f0 * D, cur, st, false, 0);
-            if (r != RII_OK) break;
-            if ((r = e->s_tie_chunk.ensure(linear_tie_chunked_scratch(n, cur))) != RII_OK) break;
-            if (hipMemsetD32Async((hipDeviceptr_t) e->s_ident.p, cur, 1, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
-            ScopedTimer t(e, "tie", st);
-            if (launch_linear_tie_emit(e->d_codes.as<uint8_t>(), n, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, 0,
-                                       e->s_ident.as<int32_t>() + 1, e->s_ident.as<int>(), S ? d_tids : nullptr, topk, cur,
-                                       e->s_tie_chunk.p, S ? 1 : 0, d_bound ? d_bound + f0 : nullptr, id_offset, cap,
-                                       d_out_ids + f0 * cap, d_out_dists + f0 * cap, d_out_count + f0, st) != hipSuccess)
-                r = set_err(RII_ERR_HIP, "tie emission launch failed");
-        }
-    }
+    const int r = linear_tie_emit_locked(e, d_queries, nf, topk, d_tids, S, d_bound, id_offset, cap, d_out_ids, d_out_dists, d_out_count, st);
     const std::string msg = g_err;
     const int r2 = end_on(e, st);
     if (r != RII_OK) { g_err = msg; return r; }
@@ -2034,9 +2041,265 @@ RII_API int rii_merge_topk_ex_dev(const void *d_gathered, int G, int64_t B, int 
         return set_err(RII_ERR_INVALID, "bad arguments");
     if ((int64_t) G * k > merge_topk_max_keys())
         return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d keys per query exceeds %d", G, k, merge_topk_max_keys());
+    if (k == 1 && k_out == 1 && !payload && !d_out_tie && G <= 64) {        // one row per rank: one thread per query (comm.hip)
+        HIP_TRY(launch_merge_top1(d_gathered, G, B, id_offsets, d_out_keys, d_out_dists, (hipStream_t) stream));
+        return RII_OK;
+    }
     HIP_TRY(launch_merge_topk(d_gathered, G, B, k, k_out, payload, d_out_keys, d_out_dists, d_out_payload, (hipStream_t) stream,
                               id_offsets, tie_cols, d_out_tie, d_out_any));
     return RII_OK;
+}
+
+// Query sharding, for callers that run the collective themselves: the record of a rank and the unpack of the G gathered records
+// (what rii_query_*_qsharded_dev do internally).  Stateless.
+RII_API int64_t rii_qshard_begin(int64_t B, int G, int rank) { return (G < 1 || rank < 0 || rank > G || B < 0) ? -1 : qshard_begin(B, G, rank); }
+RII_API int64_t rii_qshard_record_bytes(int64_t B, int G, int k, int counts) { return (G < 1 || B < 0 || k < 1) ? -1 : (int64_t) qshard_record_bytes(B, G, k, counts); }
+RII_API int rii_qshard_unpack_dev(const void *d_gathered, int64_t B, int G, int k, int counts, int64_t *d_out_ids, float *d_out_dists,
+                                  int64_t *d_out_counts, void *stream)
+{
+    if (!d_gathered || B < 0 || G < 1 || k < 1 || (B > 0 && (!d_out_ids || !d_out_dists)) || (counts && B > 0 && !d_out_counts))
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(launch_qshard_unpack(d_gathered, B, G, k, counts, d_out_ids, d_out_dists, d_out_counts, (hipStream_t) stream));
+    return RII_OK;
+}
+
+// =====================================================================================================
+// Multi-GPU behind the C ABI (round 4; protocol and kernels: comm.hip, merge.hip, tieorder.hip).  One rii_comm per process and
+// GPU = one RCCL communicator; the sharded entry points enqueue  engine kernels -> ONE ncclAllGather of pre-sized records ->
+// unpack / merge kernel  on the caller's stream.  Not in the reference (it has no multi-device code): the parity
+// target is the single-index answer (src/rii.h:195-242, :244-326) on the concatenated database / the whole batch.
+// =====================================================================================================
+struct rii_comm {
+    void *nccl = nullptr;
+    int rank = 0, G = 1, device = 0;
+    DevBuf rec, gathered, tmp_i, tmp_d, mi, md, tie, anyf, fsel, qf, bound, rec2, gg, r_i, r_d, starts_dev;
+    std::vector<int64_t> starts;          // first global id of every rank's shard (database sharding), all-gathered once per id_offset
+    int64_t my_start = -1;
+    std::mutex mu;
+};
+
+RII_API int rii_comm_unique_id(void *id_out)
+{
+    if (!id_out) return set_err(RII_ERR_INVALID, "id_out is NULL");
+    if (const char *err = comm_unique_id(id_out)) return set_err(RII_ERR_HIP, "RCCL: %s", err);
+    return RII_OK;
+}
+
+RII_API int rii_comm_init(const void *id, int rank, int nranks, int device, rii_comm **out)
+{
+    if (!out) return set_err(RII_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) return set_err(RII_ERR_INVALID, "bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(RII_ERR_HIP, "no HIP device available");
+    if (device < 0 || device >= ndev) return set_err(RII_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    rii_comm *c = new rii_comm();
+    c->rank = rank; c->G = nranks; c->device = device;
+    if (const char *err = comm_create(id, rank, nranks, &c->nccl)) {
+        delete c;
+        return set_err(RII_ERR_HIP, "RCCL communicator: %s", err);
+    }
+    *out = c;
+    return RII_OK;
+}
+
+RII_API void rii_comm_destroy(rii_comm *c)
+{
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    (void) hipDeviceSynchronize();
+    comm_destroy(c->nccl);
+    DevBuf *bufs[] = {&c->rec, &c->gathered, &c->tmp_i, &c->tmp_d, &c->mi, &c->md, &c->tie, &c->anyf, &c->fsel, &c->qf, &c->bound,
+                      &c->rec2, &c->gg, &c->r_i, &c->r_d, &c->starts_dev};
+    for (DevBuf *b : bufs) b->release();
+    delete c;
+}
+RII_API int rii_comm_rank(const rii_comm *c) { return c ? c->rank : -1; }
+RII_API int rii_comm_size(const rii_comm *c) { return c ? c->G : 0; }
+
+namespace {
+int comm_gather(rii_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st)
+{
+    if (const char *err = comm_all_gather(c->nccl, d_send, d_recv, bytes, st)) return set_err(RII_ERR_HIP, "ncclAllGather: %s", err);
+    return RII_OK;
+}
+// shared tail of the query-sharded calls: this rank's rows are in c->rec
+int qshard_exchange(rii_comm *c, int64_t B, int topk, int counts, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st)
+{
+    const size_t rec_bytes = qshard_record_bytes(B, c->G, topk, counts);
+    RII_TRY(comm_gather(c, c->rec.p, c->gathered.p, rec_bytes, st));
+    HIP_TRY(launch_qshard_unpack(c->gathered.p, B, c->G, topk, counts, d_out_ids, d_out_dists, d_out_counts, st));
+    return RII_OK;
+}
+}  // namespace
+
+// Query sharding: the index is replicated, rank r answers rows [qshard_begin(r), qshard_begin(r + 1)) of the batch -- every rank
+// passes the SAME d_queries [B, D] -- and ONE all-gather of the packed rows gives every rank all B rows.
+RII_API int rii_query_linear_qsharded_dev(rii_engine *e, rii_comm *c, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                                          int64_t S, int64_t *d_out_ids, float *d_out_dists, void *stream)
+{
+    if (!e || !c || (B > 0 && (!d_queries || !d_out_ids || !d_out_dists)) || (S > 0 && !d_tids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> gc(c->mu);
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(check_query_args(e, B, topk, S));
+    if (B == 0) return RII_OK;
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    const int64_t s0 = qshard_begin(B, c->G, c->rank), n = qshard_begin(B, c->G, c->rank + 1) - s0, nmax = (B + c->G - 1) / c->G;
+    const size_t rec_bytes = qshard_record_bytes(B, c->G, topk, 0);
+    RII_TRY(c->rec.ensure(rec_bytes));
+    RII_TRY(c->gathered.ensure(rec_bytes * (size_t) c->G));
+    RII_TRY(begin_on(e, st));
+    int r = RII_OK;
+    if (n > 0)
+        r = query_linear_dev(e, d_queries + s0 * (int64_t) (e->M * e->Ds), n, topk, d_tids, S, c->rec.as<int64_t>(),
+                             reinterpret_cast<float *>(c->rec.as<unsigned char>() + (size_t) nmax * topk * 8), st);
+    if (r == RII_OK) r = qshard_exchange(c, B, topk, 0, d_out_ids, d_out_dists, nullptr, st);
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
+}
+
+RII_API int rii_query_ivf_qsharded_dev(rii_engine *e, rii_comm *c, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                                       int64_t S, int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, void *stream)
+{
+    if (!e || !c || (B > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts)) || (S > 0 && !d_tids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> gc(c->mu);
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(check_query_args(e, B, topk, S));
+    RII_TRY(check_ivf_args(e, topk, L));
+    if (B == 0) return RII_OK;
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    const int64_t s0 = qshard_begin(B, c->G, c->rank), n = qshard_begin(B, c->G, c->rank + 1) - s0, nmax = (B + c->G - 1) / c->G;
+    const size_t rec_bytes = qshard_record_bytes(B, c->G, topk, 1);
+    RII_TRY(c->rec.ensure(rec_bytes));
+    RII_TRY(c->gathered.ensure(rec_bytes * (size_t) c->G));
+    RII_TRY(begin_on(e, st));
+    int r = RII_OK;
+    unsigned char *rp = c->rec.as<unsigned char>();
+    if (n > 0)
+        r = query_ivf_dev(e, d_queries + s0 * (int64_t) (e->M * e->Ds), n, topk, d_tids, S, L, reinterpret_cast<int64_t *>(rp),
+                          reinterpret_cast<float *>(rp + (size_t) nmax * topk * 8 + (size_t) nmax * 8),
+                          reinterpret_cast<int64_t *>(rp + (size_t) nmax * topk * 8), st);
+    if (r == RII_OK) r = qshard_exchange(c, B, topk, 1, d_out_ids, d_out_dists, d_out_counts, st);
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
+}
+
+// Database sharding, linear search: rank r's engine holds the codes with global ids [id_offset, id_offset + N_local) (contiguous id
+// ranges in rank order); every rank answers the WHOLE batch on its shard (k + 1 rows per query; one row for top-1: a heap of one
+// keeps the first minimum in index order = the smallest id), ONE all-gather, and every rank merges the G records under (distance,
+// global id).  Where two of the merged k + 1 best distances are bit-equal the reference's order is std::partial_sort's over ALL
+// distances in index order: those queries (d_out_tie, identical on every rank) are replayed exactly -- every rank emits, in index
+// order, the codes that can touch the heap (tie_cap rows per query and rank), the lists are all-gathered in rank order and one
+// wave per query replays the library's heap (tieorder.hip).  Top-1 is asynchronous on the stream; top-k reads ONE word per batch
+// on the host (is any query flagged?) and is synchronous only in that.  d_tids_local: this rank's share of the target ids as
+// LOCAL ids (S_global = size of the whole target set, 0 = none; a rank may own none: S_local == 0).
+RII_API int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset, const float *d_queries, int64_t B, int topk,
+                                           const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t *d_out_ids,
+                                           float *d_out_dists, int32_t *d_out_tie, int32_t *d_out_overflow, int tie_cap, void *stream)
+{
+    if (!e || !c || B < 0 || topk < 1 || S_local < 0 || S_global < 0 || (S_local > 0 && !d_tids_local) || S_local > S_global + (S_global == 0 ? S_local : 0) ||
+        (B > 0 && (!d_queries || !d_out_ids || !d_out_dists)) || id_offset < 0)
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    if (S_global == 0 && S_local != 0) return set_err(RII_ERR_INVALID, "S_local=%lld target ids but S_global=0", (long long) S_local);
+    std::lock_guard<std::mutex> gc(c->mu);
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    if (S_local > e->N) return set_err(RII_ERR_INVALID, "S_local=%lld must satisfy S <= N", (long long) S_local);
+    if (c->G > 64) return set_err(RII_ERR_UNSUPPORTED, "database sharding over %d ranks: at most 64", c->G);
+    if (B == 0) return RII_OK;
+    const int G = c->G;
+    const int rows = topk == 1 ? 1 : topk + 1;
+    if (topk > 1 && (int64_t) G * rows > merge_topk_max_keys())
+        return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d rows per query exceeds %d keys", G, rows, merge_topk_max_keys());
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    const int64_t n_local = S_global ? S_local : e->N;
+    const int k_local = (int) std::min<int64_t>(rows, n_local);
+    const size_t rec_bytes = merge_record_bytes(B, rows, 0);
+    RII_TRY(c->rec.ensure(rec_bytes));
+    RII_TRY(c->gathered.ensure(rec_bytes * (size_t) G));
+    int64_t *rec_i = c->rec.as<int64_t>();
+    float *rec_d = reinterpret_cast<float *>(c->rec.as<unsigned char>() + (size_t) B * rows * 8);
+    RII_TRY(begin_on(e, st));
+    int r = RII_OK;
+    do {
+        // the shards' first ids, all-gathered once (and again if this rank is handed another offset)
+        if (c->my_start != id_offset || (int) c->starts.size() != G) {
+            if ((r = c->starts_dev.ensure((size_t) (G + 1) * sizeof(int64_t))) != RII_OK) break;
+            int64_t *sd = c->starts_dev.as<int64_t>();
+            if (hipMemcpyAsync(sd + G, &id_offset, sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+            if ((r = comm_gather(c, sd + G, sd, sizeof(int64_t), st)) != RII_OK) break;
+            c->starts.assign((size_t) G, 0);
+            if (hipMemcpyAsync(c->starts.data(), sd, (size_t) G * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+            c->my_start = id_offset;
+        }
+        if (k_local == rows) {                 // the engine writes its LOCAL ids and distances straight into the record
+            if ((r = query_linear_dev(e, d_queries, B, rows, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, rec_i, rec_d, st)) != RII_OK) break;
+        } else {                               // fewer local codes / targets than rows: padding rows (key 2^62, distance +inf)
+            if (launch_fill_pad(rec_i, rec_d, B * rows, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "fill failed"); break; }
+            if (k_local > 0) {
+                if ((r = c->tmp_i.ensure((size_t) B * k_local * 8)) != RII_OK || (r = c->tmp_d.ensure((size_t) B * k_local * 4)) != RII_OK) break;
+                if ((r = query_linear_dev(e, d_queries, B, k_local, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, c->tmp_i.as<int64_t>(),
+                                          c->tmp_d.as<float>(), st)) != RII_OK) break;
+                if (launch_copy_cols(c->tmp_i.as<int64_t>(), c->tmp_d.as<float>(), B, k_local, rows, k_local, rec_i, rec_d, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+            }
+        }
+        if ((r = comm_gather(c, c->rec.p, c->gathered.p, rec_bytes, st)) != RII_OK) break;
+        if (d_out_overflow && hipMemsetAsync(d_out_overflow, 0, (size_t) B * sizeof(int32_t), st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
+        if (topk == 1) {
+            if (d_out_tie && hipMemsetAsync(d_out_tie, 0, (size_t) B * sizeof(int32_t), st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
+            if (launch_merge_top1(c->gathered.p, G, B, c->starts.data(), d_out_ids, d_out_dists, st) != hipSuccess) r = set_err(RII_ERR_HIP, "merge failed");
+            break;
+        }
+        if ((r = c->mi.ensure((size_t) B * rows * 8)) != RII_OK || (r = c->md.ensure((size_t) B * rows * 4)) != RII_OK ||
+            (r = c->tie.ensure((size_t) B * 4)) != RII_OK || (r = c->anyf.ensure(16)) != RII_OK) break;
+        int32_t *d_tie = d_out_tie ? d_out_tie : c->tie.as<int32_t>();
+        if (hipMemsetAsync(c->anyf.p, 0, 4, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
+        if (launch_merge_topk(c->gathered.p, G, B, rows, rows, 0, c->mi.as<int64_t>(), c->md.as<float>(), nullptr, st, c->starts.data(), rows,
+                              d_tie, c->anyf.as<int32_t>()) != hipSuccess ||
+            launch_copy_cols(c->mi.as<int64_t>(), c->md.as<float>(), B, rows, topk, topk, d_out_ids, d_out_dists, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "merge failed"); break; }
+        int32_t h_any = 0;                     // the batch's one host read
+        if (hipMemcpyAsync(&h_any, c->anyf.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        if (!h_any) break;
+        // ---- exact ties across the shards: replay (identical decisions on every rank: the flags come from identical merges) ----
+        if (e->QT == 0 || !linear_tie_chunked_supported(e->M, e->Ks, topk)) { r = set_err(RII_ERR_UNSUPPORTED, "tie replay across shards: topk=%d / M*Ks=%d not supported", topk, e->M * e->Ks); break; }
+        std::vector<int32_t> h_tie((size_t) B), h_sel;
+        if (hipMemcpy(h_tie.data(), d_tie, (size_t) B * 4, hipMemcpyDeviceToHost) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        for (int64_t b = 0; b < B; ++b) if (h_tie[(size_t) b]) h_sel.push_back((int32_t) b);
+        const int nf = (int) h_sel.size();
+        const int cap = tie_cap > 0 ? tie_cap : 12288;
+        if ((int64_t) G * cap >= ((int64_t) 1 << 32)) { r = set_err(RII_ERR_INVALID, "tie_cap too large"); break; }
+        const int D = e->M * e->Ds;
+        const size_t rec2 = linear_tie_record_bytes(nf, cap);
+        if ((r = c->fsel.ensure((size_t) nf * 4)) != RII_OK || (r = c->qf.ensure((size_t) nf * D * 4)) != RII_OK || (r = c->bound.ensure((size_t) nf * 4)) != RII_OK ||
+            (r = c->rec2.ensure(rec2)) != RII_OK || (r = c->gg.ensure(rec2 * (size_t) G)) != RII_OK || (r = c->r_i.ensure((size_t) nf * topk * 8)) != RII_OK ||
+            (r = c->r_d.ensure((size_t) nf * topk * 4)) != RII_OK) break;
+        if (hipMemcpyAsync(c->fsel.p, h_sel.data(), (size_t) nf * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        if (launch_tie_prepare(c->gathered.p, c->rank, B, rows, topk, c->fsel.as<int32_t>(), nf, d_queries, D, c->qf.as<float>(), c->bound.as<float>(), st) != hipSuccess) { r = set_err(RII_ERR_HIP, "launch failed"); break; }
+        unsigned char *r2p = c->rec2.as<unsigned char>();
+        const size_t cnt_bytes = ((size_t) nf * 4 + 7) / 8 * 8;
+        if (hipMemsetAsync(r2p, 0, rec2, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
+        // a rank whose share of the target ids is EMPTY contributes nothing (S = 0 would mean "no target set" to the engine)
+        if (!(S_global != 0 && S_local == 0))
+            if ((r = linear_tie_emit_locked(e, c->qf.as<float>(), nf, topk, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, c->bound.as<float>(), id_offset, cap,
+                                            reinterpret_cast<int64_t *>(r2p + cnt_bytes), reinterpret_cast<float *>(r2p + cnt_bytes + (size_t) nf * cap * 8),
+                                            reinterpret_cast<int32_t *>(r2p), st)) != RII_OK) break;
+        if ((r = comm_gather(c, r2p, c->gg.p, rec2, st)) != RII_OK) break;
+        if (launch_linear_shard_replay(c->gg.p, G, nf, cap, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), st) != hipSuccess ||
+            launch_tie_scatter(c->gg.p, G, nf, cap, topk, c->fsel.as<int32_t>(), c->r_i.as<int64_t>(), c->r_d.as<float>(), d_out_ids, d_out_dists, d_out_overflow, st) != hipSuccess)
+            r = set_err(RII_ERR_HIP, "replay launch failed");
+    } while (0);
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
 }
 
 RII_API int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out)

@@ -295,4 +295,24 @@ hipError_t launch_linear_tie_emit(const uint8_t *d_codes, int64_t n, int M, int 
 size_t linear_tie_record_bytes(int64_t nf, int cap);
 hipError_t launch_linear_shard_replay(const void *d_gathered, int G, int64_t nf, int cap, int topk, int64_t *d_out_ids,
                                       float *d_out_dists, hipStream_t st);
+// comm.hip (round 4): the exchange step behind the C ABI -- RCCL bound at run time (dlopen), the packed-record all-gather, and the
+// kernels around it.  The const char* results are error messages (NULL = success).
+const char *rccl_load_error();
+const char *comm_unique_id(void *out128);
+const char *comm_create(const void *id128, int rank, int G, void **out_comm);
+void comm_destroy(void *comm);
+const char *comm_all_gather(void *comm, const void *d_send, void *d_recv, size_t bytes, hipStream_t st);
+int64_t qshard_begin(int64_t B, int G, int r);                                 // first row of rank r's slice of a batch of B
+size_t qshard_record_bytes(int64_t B, int G, int k, int counts);
+hipError_t launch_qshard_unpack(const void *d_gathered, int64_t B, int G, int k, int counts, int64_t *d_out_ids, float *d_out_dists,
+                                int64_t *d_out_counts, hipStream_t st);
+hipError_t launch_merge_top1(const void *d_gathered, int G, int64_t B, const int64_t *id_offsets, int64_t *d_out_ids, float *d_out_dists,
+                             hipStream_t st);
+hipError_t launch_tie_prepare(const void *d_gathered, int rank, int64_t B, int rows, int topk, const int32_t *d_fsel, int nf,
+                              const float *d_queries, int D, float *d_qf, float *d_bound, hipStream_t st);
+hipError_t launch_tie_scatter(const void *d_gg, int G, int nf, int cap, int topk, const int32_t *d_fsel, const int64_t *d_r_ids,
+                              const float *d_r_d, int64_t *d_out_ids, float *d_out_dists, int32_t *d_overflow, hipStream_t st);
+hipError_t launch_copy_cols(const int64_t *d_in_i, const float *d_in_d, int64_t B, int in_stride, int out_stride, int ncols, int64_t *d_out_i,
+                            float *d_out_d, hipStream_t st);
+hipError_t launch_fill_pad(int64_t *d_ids, float *d_d, int64_t n, hipStream_t st);
 }  // namespace riiamd

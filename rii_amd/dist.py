@@ -223,6 +223,43 @@ def _is_device_engine(engine):
     return torch.cuda.is_available()
 
 
+_COMMS = {}
+
+
+def _use_c_comm():
+    """The exchange runs behind the C ABI (rii_comm_*: RCCL bound by librii_amd.so itself, engine kernels -> ncclAllGather -> unpack /
+    merge enqueued by ONE library call) whenever the records live in HBM: under the "nccl" backend, or with no process group at all
+    (a single engine: a one-rank communicator).  Under "gloo" (the CPU tests, and two ranks sharing one GPU) the collectives run on
+    host tensors through torch.distributed as before."""
+    if not torch.cuda.is_available():
+        return False
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_backend() == "nccl"
+    return True
+
+
+def get_comm(group=None):
+    """The process's rii_comm for `group` (default: the whole world; none initialised: one rank), created on first use -- rank 0 of
+    the group draws the id (rii_comm_unique_id) and torch.distributed carries its 128 bytes to the others."""
+    from . import core
+    dev = torch.cuda.current_device()
+    if dist.is_available() and dist.is_initialized():
+        rank, w = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, w = 0, 1
+    key = (id(group) if group is not None else 0, dev, rank, w)
+    c = _COMMS.get(key)
+    if c is None:
+        if w > 1 or (dist.is_available() and dist.is_initialized()):
+            box = [core.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            cid = box[0]
+        else:
+            cid = core.comm_unique_id()
+        c = _COMMS[key] = core.Comm(cid, rank, w, dev)
+    return c
+
+
 class DbShardedIndex(object):
     """Database-sharded linear search.  `engine` is this rank's local engine holding codes [start, stop) of the global
     database; it must offer query_linear_batch(Q, topk, target_ids) (and query_linear_dev for the device-resident path:
@@ -255,8 +292,9 @@ class DbShardedIndex(object):
                 self._all_starts = [self.start]
         return self._all_starts
 
-    def query_linear_batch(self, Q, topk, target_ids=None):
-        """Top-k over the whole sharded database, in the reference's order.  Every rank contributes its k + 1 best rows (k = 1:
+    def query_linear_batch(self, Q, topk, target_ids=None, out=None):
+        """Top-k over the whole sharded database, in the reference's order.  (`out`: optional preallocated (ids [B, topk] int64, dists
+        [B, topk] float32) device tensors for the device path.)  Every rank contributes its k + 1 best rows (k = 1:
         its best row -- a heap of one keeps the first minimum in index order = the smallest id, so top-1 never needs a replay);
         the merge under (dist, id) is the reference's answer unless two of the merged k + 1 best distances are bit-equal -- then
         the order (and, at the cut, the membership) is what std::partial_sort makes of ALL distances in index order, and those
@@ -271,7 +309,7 @@ class DbShardedIndex(object):
         tl, k_local = self._local_targets(target_ids, rows)
         B = Q.shape[0]
         if _is_device_engine(self.engine):
-            return self._query_linear_device(Q, B, topk, rows, tl, k_local)
+            return self._query_linear_device(Q, B, topk, rows, tl, k_local, 0 if tl is None else len(target_ids), out)
         big = np.iinfo(np.int64).max // 2
         ids = torch.full((B, rows), big, dtype=torch.int64)
         d = torch.full((B, rows), float("inf"), dtype=torch.float32)
@@ -302,7 +340,43 @@ class DbShardedIndex(object):
                                             g.to(cdev), out_i, out_d, cdev, None)
         return out_i, out_d
 
-    def _query_linear_device(self, Q, B, topk, rows, tl, k_local):
+    def _query_linear_device(self, Q, B, topk, rows, tl, k_local, S_global=0, out=None):
+        """Device engines: ONE library call -- engine kernels -> record -> ncclAllGather -> merge kernel (+ the exact-tie replay) are
+        enqueued by rii_query_linear_dbsharded_dev (round 4).  Shapes beyond the merge kernel's limits (G x (k + 1) > 8192 rows, more
+        than 64 ranks) and host collectives ("gloo") keep the torch path below."""
+        rank, G = world()
+        if _use_c_comm() and G <= 64 and (topk == 1 or G * rows <= 8192):
+            dev = torch.device("cuda", torch.cuda.current_device())
+            comm = get_comm(self.group)
+            with _engine_stream() as sh:
+                q = _as_tensor(Q, torch.float32, dev)
+                t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).to(dev)
+                if out is None:
+                    out = (torch.empty((B, topk), dtype=torch.int64, device=dev), torch.empty((B, topk), dtype=torch.float32, device=dev))
+                if topk == 1:
+                    comm.query_linear_dbsharded_dev(self.engine, self.start, q.data_ptr(), B, topk, 0 if t is None else t.data_ptr(),
+                                                    0 if t is None else t.numel(), S_global, out[0].data_ptr(), out[1].data_ptr(), stream=sh)
+                    self.last_tie_flags = self._zero_flags(B, dev)
+                    self.last_tie_overflow = self._zero_flags(B, dev)
+                else:
+                    tie = torch.empty(B, dtype=torch.int32, device=dev)
+                    ovf = torch.empty(B, dtype=torch.int32, device=dev)
+                    comm.query_linear_dbsharded_dev(self.engine, self.start, q.data_ptr(), B, topk, 0 if t is None else t.data_ptr(),
+                                                    0 if t is None else t.numel(), S_global, out[0].data_ptr(), out[1].data_ptr(),
+                                                    tie.data_ptr(), ovf.data_ptr(), self.TIE_CAP, sh)
+                    self.last_tie_flags = tie.bool()
+                    self.last_tie_overflow = ovf.bool()
+                    nbad = int(ovf.sum().item())
+                    if nbad:
+                        import warnings
+                        warnings.warn("rii_amd.dist: %d tied quer%s produced more than TIE_CAP=%d replay candidates on some shard; exactly "
+                                      "tied distances of those rows are ordered by id, not in std::partial_sort's order (see "
+                                      "last_tie_overflow)" % (nbad, "y" if nbad == 1 else "ies", self.TIE_CAP))
+            _handoff(self.last_tie_flags, self.last_tie_overflow)
+            return _handoff(*out)
+        return self._query_linear_device_torch(Q, B, topk, rows, tl, k_local)
+
+    def _query_linear_device_torch(self, Q, B, topk, rows, tl, k_local):
         from . import core
         dev = _comm_device()
         if dev.type != "cuda":
@@ -602,9 +676,22 @@ class QueryShardedIndex(object):
         rows = [shard_range(B, r, w)[1] - shard_range(B, r, w)[0] for r in range(w)]
         return shard_range(B, rank, w), rows
 
-    def query_linear_batch(self, Q, topk, target_ids=None):
+    def query_linear_batch(self, Q, topk, target_ids=None, out=None):
         (s, e), rows = self._slices(Q.shape[0])
         n = e - s
+        if _is_device_engine(self.engine) and _use_c_comm():
+            # ONE library call (round 4): this rank's slice through the engine -> ncclAllGather of the packed rows -> unpack kernel
+            dev = torch.device("cuda", torch.cuda.current_device())
+            comm = get_comm(self.group)
+            B = Q.shape[0]
+            with _engine_stream() as sh:
+                q = _as_tensor(Q, torch.float32, dev)
+                t = None if target_ids is None or len(target_ids) == 0 else _as_tensor(target_ids, torch.int64, dev)
+                if out is None:
+                    out = (torch.empty((B, topk), dtype=torch.int64, device=dev), torch.empty((B, topk), dtype=torch.float32, device=dev))
+                comm.query_linear_qsharded_dev(self.engine, q.data_ptr(), B, topk, 0 if t is None else t.data_ptr(),
+                                               0 if t is None else t.numel(), out[0].data_ptr(), out[1].data_ptr(), sh)
+            return _handoff(*out)
         if _is_device_engine(self.engine):
             dev = _comm_device()
             q = _as_tensor(Q, torch.float32, dev)[s:e].contiguous()
@@ -644,6 +731,19 @@ class QueryShardedIndex(object):
         Returns (ids [B,topk], dists [B,topk], counts [B]) on every rank."""
         (s, e), rows = self._slices(Q.shape[0])
         n = e - s
+        if _is_device_engine(self.engine) and _use_c_comm():
+            dev = torch.device("cuda", torch.cuda.current_device())
+            comm = get_comm(self.group)
+            B = Q.shape[0]
+            with _engine_stream() as sh:
+                q = _as_tensor(Q, torch.float32, dev)
+                t = None if target_ids is None or len(target_ids) == 0 else _as_tensor(target_ids, torch.int64, dev)
+                ids = torch.empty((B, topk), dtype=torch.int64, device=dev)
+                d = torch.empty((B, topk), dtype=torch.float32, device=dev)
+                cnt = torch.empty((B,), dtype=torch.int64, device=dev)
+                comm.query_ivf_qsharded_dev(self.engine, q.data_ptr(), B, topk, 0 if t is None else t.data_ptr(),
+                                            0 if t is None else t.numel(), L, ids.data_ptr(), d.data_ptr(), cnt.data_ptr(), sh)
+            return _handoff(ids, d, cnt)
         if _is_device_engine(self.engine):
             dev = _comm_device()
             q = _as_tensor(Q, torch.float32, dev)[s:e].contiguous()

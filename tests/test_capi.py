@@ -113,6 +113,22 @@ def test_plain_c_client_on_gpu(tmp_path):
     assert out.returncode == 0 and "C ABI smoke OK" in out.stdout, (out.stdout, out.stderr)
 
 
+@pytest.mark.gpu
+def test_plain_c_client_shards_without_python(tmp_path):
+    """tests/c_abi/c_abi_sharded.c: a gcc-compiled C99 program creates an RCCL communicator through the library (world size 1) and
+    runs the query-sharded, database-sharded and device-queries -> host-rows entry points; every row equals the single-engine call."""
+    import subprocess
+    from rii_amd import core
+    so = core.build_library()
+    exe = str(tmp_path / "c_abi_sharded")
+    subprocess.check_call(["gcc", "-O1", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "c_abi_sharded.c"), "-o", exe,
+                           "-L", os.path.dirname(so), "-lrii_amd", "-Wl,-rpath," + os.path.dirname(so),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "C ABI sharded OK" in out.stdout, (out.stdout, out.stderr)
+
+
 def test_main_module_shim_exposes_riicpp():
     """`rii_amd.main.RiiCpp` is what `import main` resolves to after the one-line swap of INTEGRATION.md §2: it must carry
     every member the reference's `rii/rii.py` touches on `main.RiiCpp` (src/main.cpp:12-54)."""

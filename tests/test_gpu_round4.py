@@ -182,3 +182,65 @@ def test_db_sharded_device_path_beyond_the_merge_kernel_limits():
         want = g.query_linear_batch(qs, topk, None)
         assert np.array_equal(ids.cpu().numpy(), want[0]) and np.array_equal(d.cpu().numpy(), want[1]), topk
         assert idx.last_tie_flags.shape[0] == 3
+
+
+def test_query_shard_unpack_and_top1_merge_kernels_for_many_ranks():
+    """The exchange kernels of comm.hip for G > 1 (the one-GPU box only ever runs G = 1 through RCCL): records of G fake ranks built
+    with numpy -> rii_qshard_unpack_dev gives the rows in batch order for even and ragged splits, with and without counts;
+    rii_merge_topk_ex_dev with one row per rank (merge_top1_kernel) equals the general sort kernel, ties across ranks broken by the
+    GLOBAL id, padding rows ignored."""
+    import ctypes
+    import torch
+    from rii_amd import core
+    L = core._lib()
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    for B, G, k, counts in ((1024, 8, 1, 0), (1000, 8, 3, 1), (5, 8, 2, 1), (129, 4, 10, 0), (7, 1, 4, 1)):
+        rec = int(L.rii_qshard_record_bytes(B, G, k, counts))
+        nmax = (B + G - 1) // G
+        want_i = rng.integers(0, 1 << 40, size=(B, k)).astype(np.int64)
+        want_d = rng.random((B, k)).astype(np.float32)
+        want_c = rng.integers(0, k + 1, size=B).astype(np.int64)
+        buf = np.zeros((G, rec), np.uint8)
+        for r in range(G):
+            s, e = int(L.rii_qshard_begin(B, G, r)), int(L.rii_qshard_begin(B, G, r + 1))
+            n = e - s
+            buf[r, :n * k * 8] = want_i[s:e].reshape(-1).view(np.uint8)
+            off = nmax * k * 8
+            if counts:
+                buf[r, off:off + n * 8] = want_c[s:e].view(np.uint8)
+                off += nmax * 8
+            buf[r, off:off + n * k * 4] = want_d[s:e].reshape(-1).view(np.uint8)
+        g = torch.from_numpy(buf).to(dev)
+        oi = torch.empty((B, k), dtype=torch.int64, device=dev)
+        od = torch.empty((B, k), dtype=torch.float32, device=dev)
+        oc = torch.empty((B,), dtype=torch.int64, device=dev)
+        core._check(L.rii_qshard_unpack_dev(g.data_ptr(), B, G, k, counts, oi.data_ptr(), od.data_ptr(), oc.data_ptr() if counts else None, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(oi.cpu().numpy(), want_i) and np.array_equal(od.cpu().numpy(), want_d), (B, G, k)
+        if counts:
+            assert np.array_equal(oc.cpu().numpy(), want_c)
+    for B, G in ((300, 8), (17, 64), (5, 2)):
+        rec = core.merge_record_bytes(B, 1)
+        buf = np.zeros((G, rec), np.uint8)
+        ids = rng.integers(0, 1000, size=(G, B)).astype(np.int64)
+        d = rng.integers(0, 4, size=(G, B)).astype(np.float32)            # many exact ties across the ranks
+        pad = rng.random((G, B)) < 0.2
+        ids[pad] = np.iinfo(np.int64).max // 2
+        d[pad] = np.inf
+        for r in range(G):
+            buf[r, :B * 8] = ids[r].view(np.uint8)
+            buf[r, B * 8:B * 12] = d[r].view(np.uint8)
+        offs = [1000 * r for r in range(G)]
+        g = torch.from_numpy(buf).to(dev)
+        a_i = torch.empty((B, 1), dtype=torch.int64, device=dev); a_d = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        b_i = torch.empty((B, 1), dtype=torch.int64, device=dev); b_d = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        tie = torch.zeros(B, dtype=torch.int32, device=dev)
+        core.merge_topk_ex_dev(g.data_ptr(), G, B, 1, 1, offs, a_i.data_ptr(), a_d.data_ptr())                      # merge_top1_kernel
+        core.merge_topk_ex_dev(g.data_ptr(), G, B, 1, 1, offs, b_i.data_ptr(), b_d.data_ptr(), tie_cols=1, d_out_tie=tie.data_ptr())   # the sort kernel
+        torch.cuda.synchronize()
+        assert torch.equal(a_i, b_i) and torch.equal(a_d, b_d), (B, G)
+        gid = np.where(pad, ids, ids + np.array(offs)[:, None])
+        for b in range(B):
+            j = min(range(G), key=lambda r: (d[r, b], gid[r, b]))
+            assert int(a_i[b, 0]) == int(gid[j, b]) and float(a_d[b, 0]) == float(d[j, b])
