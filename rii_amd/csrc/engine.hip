@@ -154,6 +154,8 @@ struct rii_engine : ScratchSet {
     // profiles/r03_levels_ab.json): 63 -> 124 candidates per query, 127 -> 40, 255 -> 20; the scan itself is 3 % SLOWER with 255 (signed
     // bytes: more switching in the matrix core under a power-limited clock), so 127 -- non-negative bytes, no bias -- is the default.
     int table_levels = 127;
+    int ivf_inline_exact = 1;   // option "ivf_inline_exact" (round 4): 1 = a block of ivf_fused_kernel that flags its query (tied coarse distances, tail
+                                // walk, ties at the cut) replays it itself; 0 = the flag-gated exact kernels behind every batch (round 3)
     int fused_tables = 1;       // option "fused_tables": 1 = qlut_fused_kernel + table-free top-1 re-rank (round 3), 0 = the two-launch tile path
     int ivf_force_exact = 0;    // tests: the fused kernel flags every query, so the exact LDS kernel answers all of them
     int timing = 0;
@@ -184,6 +186,7 @@ struct rii_engine : ScratchSet {
                                 // kernel take ONE launch (slice_topk_kernel: slices on all CUs, last block merges, ties -> general path)
     int host_spin = 1;          // option "host_spin": small host-pointer calls answered by the one-launch kernel get their rows written
                                 // straight into the pinned block and wait on a flag there instead of a D2H copy + stream synchronisation
+    bool ivf_q_host = false;             // (set by host_query around the call: d_queries is the pinned host block, see IvfParams::q_host_off)
     unsigned int *spin_flag = nullptr;   // (set by host_query around the call: device address of the flags in the pinned block)
     unsigned int spin_seq = 0;
     bool spin_used = false;
@@ -915,6 +918,29 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
         }
     }
     {
+        // a few queries per ASYNCHRONOUS call on a large index, topk > 1 (round 4): the one-launch slice kernel (smalltopk.hip) with a
+        // DEVICE-side tie fallback -- the kernel appends the queries whose k + 1 smallest distances tie to the tie list, and the
+        // flag-gated tie kernels behind it (tieorder.hip: they read the list's length on the device) redo exactly those in
+        // std::partial_sort's order; no host decision, so the call stays asynchronous.  (Host-pointer calls keep the host's
+        // decision: host_query.  top-1 needs no fallback at all and keeps the exhaustive scan, which is as fast at that size.)
+        const int64_t n_codes = S ? S : e->N;
+        if (topk > 1 && B <= 8 && e->slice_topk && e->QT != 0 && e->lut_mode == RII_LUT_EXACT && linear_tie_supported(e->M, e->Ks) &&
+            slice_topk_supported(e->M, e->Ks, e->Ds, n_codes, B, topk)) {
+            RII_TRY(e->s_keys_b.ensure(std::max<size_t>(slice_topk_scratch(n_codes, B, topk), 16)));
+            RII_TRY(e->s_flag.ensure(8 * sizeof(int32_t)));
+            RII_TRY(ensure_small_done(e, st));
+            RII_TRY(tie_list_reset(e, B, st));
+            {
+                ScopedTimer t(e, "scan", st);
+                HIP_TRY(launch_slice_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, d_queries, e->d_codewords.as<float>(), e->Ds, e->arch, B, topk,
+                                          S ? d_tids : nullptr, e->s_keys_b.as<unsigned long long>(), e->s_small_done.as<unsigned int>(), d_out_ids,
+                                          d_out_dists, e->s_flag.as<int32_t>(), st, nullptr, 0, e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>()));
+            }
+            RII_TRY(build_lut(e, d_queries, B, st, false, 0));                      // the tie kernels' exact tables (B <= 8: microseconds)
+            return tie_fixup(e, e->d_codes.as<uint8_t>(), S ? 1 : 0, n_codes, 0, B, topk, S ? d_tids : nullptr, d_out_ids, d_out_dists, st);
+        }
+    }
+    {
         const bool small_top1 = (topk == 1 && B < e->fast_min_batch);
         RII_TRY(build_lut(e, d_queries, B, st, !small_top1, small_top1 ? exact_tile_for(e, B, topk) : 0, false, /*need_fp32=*/topk > 1));
     }
@@ -1008,6 +1034,16 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     const bool big_all = !fused && (e->ivf_fused || e->QT == 0) && ivf_exact_big_supported(e->M, e->Ks, w, topk);
     RII_TRY(e->s_flag.ensure((size_t) bc * sizeof(int32_t)));
     p.flag = fused ? e->s_flag.as<int32_t>() : nullptr;
+    // round 4 (option ivf_inline_exact): a block of the fused kernel that flags its query redoes it itself (one global scratch slice
+    // per query of the launch group, at most 256 MiB in all) -- no flag-gated second launch behind every batch
+    const size_t inl_per_q = ivf_exact_big_scratch((int) nlist, L);
+    const bool inline_exact = fused && e->ivf_inline_exact && e->QT != 0 && ivf_exact_big_supported(e->M, e->Ks, w, topk) &&
+                              inl_per_q * (size_t) bc <= ((size_t) 256 << 20);
+    if (inline_exact) {
+        RII_TRY(e->s_big.ensure(inl_per_q * (size_t) bc));
+        p.inl_scratch = e->s_big.as<unsigned char>();
+        p.inl_per_q = inl_per_q;
+    }
     const bool defer = fused && d_flag_defer && bc >= B;       // one launch group: the caller inspects the flags itself
     if (defer) p.flag = d_flag_defer;
     p.sel_cap = ivf_fused_sel_cap((int) nlist, w);
@@ -1028,6 +1064,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     if (fused && e->lut_mode == RII_LUT_EXACT) {
         RII_TRY(build_lut(e, d_queries, B, st, false, 1, /*alloc_only=*/true));   // tables are built inside the fused kernel
         p.queries = d_queries;
+        p.q_host_off = (e->ivf_q_host && e->Ds == 4 && e->Ks == 256) ? 1 : 0;      // (host_query: the query sits in the pinned block)
     } else {
         RII_TRY(build_lut(e, d_queries, B, st, false, 1));
     }
@@ -1053,9 +1090,10 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
                 e->spin_used = e->spin_flag != nullptr;
                 e->spin_nflags = p.B;
                 e->ivf_deferred = p;
-                e->ivf_has_deferred = true;
+                e->ivf_has_deferred = !inline_exact;          // (nothing left to redo when the flagged blocks did it themselves)
                 return RII_OK;
             }
+            if (inline_exact) continue;
         } else if (!big_all) {
             ScopedTimer t(e, "ivf_coarse", st);
             HIP_TRY(launch_ivf_coarse(p, st));
@@ -1542,7 +1580,16 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     const bool zc = !ivf && !spin_linear && !slice_linear && e->host_spin && e->d_pin && B <= kMaxBatch && S == 0 && e->lut_mode == RII_LUT_EXACT &&
                     e->QT != 0 && (e->host_zero_copy == 2 || (e->host_zero_copy == 1 && q_bytes <= (128u << 10)));
     const bool batch_pin = zc;
-    const bool q_in_place = ((spin_linear || slice_linear) && S == 0 && e->lut_mode == RII_LUT_EXACT) || zc;
+    // inverted index, one-launch form: the fused kernel fetches the query from the pinned block itself (once per block, into LDS)
+    const bool spin_ivf = ivf && e->host_spin && e->d_pin && in_bytes <= kSpinMaxInput && (size_t) B <= kPinFlagWords && B < e->fast_min_batch;
+    bool ivf_in_place = false;
+    if (spin_ivf && S == 0 && e->lut_mode == RII_LUT_EXACT && e->ivf_fused && e->Ds == 4 && e->Ks == 256 && nlist_of(e) > 0) {
+        const int64_t nl = nlist_of(e);
+        int64_t w = (int64_t) (size_t) std::round((double) L * (double) nl / (double) e->N) + 3;
+        if (nl < w) w = nl;
+        ivf_in_place = ivf_fused_supported(e->M, e->Ks, (int) nl, w, topk);
+    }
+    const bool q_in_place = ((spin_linear || slice_linear) && S == 0 && e->lut_mode == RII_LUT_EXACT) || zc || ivf_in_place;
     if (!q_in_place) HIP_TRY(hipMemcpyAsync(e->s_queries.p, pin, pack_tids ? in_bytes : q_bytes, hipMemcpyHostToDevice, st));
     if (S && !pack_tids) HIP_TRY(hipMemcpyAsync(e->s_tids.p, tids, t_bytes, hipMemcpyHostToDevice, st));
     const int64_t *d_tids_in = pack_tids ? reinterpret_cast<const int64_t *>(e->s_queries.as<unsigned char>() + q_pad) : e->s_tids.as<int64_t>();
@@ -1607,7 +1654,7 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
         memcpy(out_dists, pout + ids_bytes, d_bytes);
         return RII_OK;
     }
-    if (ivf && e->host_spin && e->d_pin && in_bytes <= kSpinMaxInput && (size_t) B <= kPinFlagWords && B < e->fast_min_batch) {
+    if (spin_ivf) {
         // the same for the inverted index: every output field (rows, counts, fallback flags) lives in the pinned block; the fused
         // kernel raises a query's sequence flag at each of its exits.  A call that takes another path (spin_used stays false) is
         // simply synchronised -- its kernels wrote the pinned block too.
@@ -1616,10 +1663,13 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
         const unsigned int seq = ++e->spin_seq ? e->spin_seq : ++e->spin_seq;
         e->spin_flag = reinterpret_cast<unsigned int *>(e->d_pin);
         e->spin_used = false;
-        const int r = query_ivf_dev(e, e->s_queries.as<float>(), B, topk, d_tids_in, S, L, reinterpret_cast<int64_t *>(dp_host),
+        e->ivf_q_host = ivf_in_place;
+        const int r = query_ivf_dev(e, ivf_in_place ? reinterpret_cast<const float *>(static_cast<unsigned char *>(e->d_pin) + kPinFlagBytes) : e->s_queries.as<float>(),
+                                    B, topk, d_tids_in, S, L, reinterpret_cast<int64_t *>(dp_host),
                                     reinterpret_cast<float *>(dp_host + ids_bytes + c_bytes + f_bytes),
                                     reinterpret_cast<int64_t *>(dp_host + ids_bytes), st,
                                     reinterpret_cast<int32_t *>(dp_host + ids_bytes + c_bytes));
+        e->ivf_q_host = false;
         e->spin_flag = nullptr;
         if (r != RII_OK) return r;
         const bool seen = e->spin_used && spin_wait(flags, e->spin_nflags, seq);
@@ -2359,6 +2409,8 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->scan_mode = (int) value;
     } else if (k == "ivf_fused") {
         e->ivf_fused = value ? 1 : 0;
+    } else if (k == "ivf_inline_exact") {
+        e->ivf_inline_exact = value ? 1 : 0;
     } else if (k == "ivf_force_exact") {
         e->ivf_force_exact = value ? 1 : 0;
     } else if (k == "fused_tables") {
@@ -2414,6 +2466,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "cand_cap") return e->cand_cap;
     if (k == "ivf_fused") return e->ivf_fused;
     if (k == "ivf_force_exact") return e->ivf_force_exact;
+    if (k == "ivf_inline_exact") return e->ivf_inline_exact;
     if (k == "fused_tables") return e->fused_tables;
     if (k == "table_levels") return e->table_levels;
     if (k == "scan_order") return e->scan_order;

@@ -655,6 +655,85 @@ hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st)
 }
 
 // ===================================================================================================
+// Exact emulation of ONE query for shapes of any size (round 3: ivf_exact_big_kernel; round 4: also called by the block of
+// ivf_fused_kernel that flagged its own query): the (distance, list) and (distance, position) sequences live in a global scratch
+// slice, only the HEAP of each std::partial_sort -- its first `middle` entries: w lists, topk candidates -- is in LDS (s_head), and
+// the library's __heap_select streams the rest from memory (rii_device.h: wh_partial_sort_split).  Same moves as the reference
+// (src/rii.h:259-326), any nlist <= N and any L <= N; a heap deeper than the wave code covers (w or topk above kWhSplitMaxHeap) is
+// walked by one lane over the global array.  `lds`: the query's exact table (LDS, or global memory for the wide shapes).
+// Block-uniform; all 256 threads of the block call it.
+// ===================================================================================================
+__device__ __forceinline__ void ivf_exact_big_query(const IvfParams &p, int64_t bl, const float *lds, pq64_t *s_head, int32_t *s_misc,
+                                                    unsigned char *mine, int tid)
+{
+    const int nlist = p.nlist, w = (int) p.w, k = p.topk;
+    pq64_t *gco = reinterpret_cast<pq64_t *>(mine);                     // [nlist] (coarse distance, list), in the reference's order afterwards
+    pq64_t *gcand = gco + nlist;                                        // [L]     (distance, traversal position)
+    int32_t *gcum = reinterpret_cast<int32_t *>(gcand + p.L);           // [nlist + 1]
+    int32_t *gcid = gcum + (nlist + 1);                                 // [L]     id of the candidate at a traversal position
+    const bool w_lds = w <= kWhSplitMaxHeap, k_lds = k <= kWhSplitMaxHeap;          // heap in LDS, walked by a wave
+    for (int c = tid; c < nlist; c += blockDim.x) {                                  // src/rii.h:262-264
+        const pq64_t e = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
+        if (w_lds && c < w) s_head[c] = e; else gco[c] = e;
+    }
+    __syncthreads();
+    if (w_lds) {
+        if (tid < 64) wh_partial_sort_split(s_head, gco + w, w, nlist, tid);        // src/rii.h:279-280 (wave 0)
+        __syncthreads();
+        for (int c = tid; c < w; c += blockDim.x) gco[c] = s_head[c];                // the whole order in one array
+    } else if (tid == 0) {
+        pq64_partial_sort(gco, w, nlist);                                            // one lane, global memory: correct, slow
+    }
+    __syncthreads();
+    if (tid == 0) {
+        long long cnt = 0;
+        int nv = 0;
+        bool finished = false;
+        for (int c = 0; c < nlist; ++c) {                                            // src/rii.h:286-321
+            const long long len = p.list_len[pq64_id(gco[c])];
+            gcum[c] = (int) cnt;
+            if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+            cnt += len;
+            if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+        }
+        if (!finished) { cnt = 0; nv = 0; }
+        gcum[nv] = (int) cnt;
+        s_misc[0] = (int) cnt; s_misc[1] = nv;
+    }
+    __syncthreads();
+    const int ncand = s_misc[0], nv = s_misc[1];
+    if (ncand == 0) {
+        if (tid == 0) p.out_counts[bl] = 0;                                          // src/rii.h:324-325
+        return;
+    }
+    for (int pos = tid; pos < ncand; pos += blockDim.x) {
+        int lo = 0, hi = nv;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (gcum[mid] <= pos) lo = mid; else hi = mid;
+        }
+        const int no = (int) pq64_id(gco[lo]);
+        const int32_t id = p.pl_ids[p.pl_off[no] + (pos - gcum[lo])];
+        const pq64_t e = pq64_make(exact_adist(lds, p.codes + (size_t) id * p.M, p.M, p.Ks), (uint32_t) pos);
+        if (k_lds && pos < k) s_head[pos] = e; else gcand[pos] = e;
+        gcid[pos] = id;
+    }
+    __syncthreads();
+    if (k_lds) {
+        if (tid < 64) wh_partial_sort_split(s_head, gcand + k, k, ncand, tid);      // src/rii.h:312-313 (wave 0)
+    } else if (tid == 0) {
+        pq64_partial_sort(gcand, k, ncand);
+    }
+    if (tid == 0) p.out_counts[bl] = k;
+    __syncthreads();
+    for (int j = tid; j < k; j += blockDim.x) {
+        const pq64_t e = k_lds ? s_head[j] : gcand[j];
+        p.out_ids[bl * k + j] = gcid[pq64_id(e)];
+        p.out_dists[bl * k + j] = pq64_dist(e);
+    }
+}
+
+// ===================================================================================================
 // (a6+a7 fused) the common case in ONE launch per batch: block per query -- table staged once, coarse scores kept
 // in LDS, the w nearest lists picked by w+1 rounds of block arg-min over (dist, list id), the stop rule applied to
 // those w lists, candidates scanned.  Whenever the reference's answer could depend on std::partial_sort's internal
@@ -756,7 +835,26 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             // the M = 32 table, 16 mean two)
             const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
             const float4 *q4 = reinterpret_cast<const float4 *>(q);
-            if (p.Ks == 256) {
+            if (p.Ks == 256 && p.q_host_off) {
+                // round 4: the query lives in the caller's pinned HOST block (a one-query call: no H2D copy in front of the launch).  Every
+                // read of it crosses PCIe, so it is fetched ONCE: M threads load one sub-vector each, the load stays parked in a register
+                // while the first codeword batch is requested, then goes to LDS; the table entries read it from there.
+                float4 *s_q = reinterpret_cast<float4 *>(smem + p.q_host_off);
+                float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tid < p.M) qv = q4[tid];
+                for (int m0 = 0; m0 < p.M; m0 += 16) {
+                    float4 cv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) cv[u] = (m0 + u < p.M) ? cw4[(m0 + u) * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m0 == 0) {
+                        if (tid < p.M) s_q[tid] = qv;
+                        __syncthreads();
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (m0 + u < p.M) lds[(m0 + u) * 256 + tid] = fvec_l2sqr_ds4v(s_q[m0 + u], cv[u]);
+                }
+            } else if (p.Ks == 256) {
                 // Ks = 256 = the block size: thread t owns entry ks = t of every subspace, so the subspace index -- and with it the
                 // query's sub-vector -- is uniform across the block (scalar loads), and no entry needs an integer division by a
                 // run-time Ks (which cost more vector instructions than the eleven of fvec_L2sqr itself: tools/ivf_phase_cost.py
@@ -892,13 +990,25 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         if (!finished) flag = 1;                                             // tail walk / empty return: exact path
         s_cum[nv] = (int) cnt;
         s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = flag;
-        p.flag[bl] = flag;
-        if (flag && p.flag_list) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
+        p.flag[bl] = p.inl_scratch ? 0 : flag;
+        if (flag && p.flag_list && !p.inl_scratch) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
         if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
         s_red[1] = ~0ull;
     }
     __syncthreads();
+    // round 4: the block that flagged its query redoes it ITSELF with the exact emulation (ivf_exact_big_query: sequences in this
+    // query's global scratch slice, the heaps over the selection state in LDS -- dead by then -- and the table already in LDS) instead
+    // of leaving it to a second, flag-gated launch that cost 4 - 6 us per batch with no query flagged
+    auto redo_exact = [&]() {
+        __syncthreads();                                   // every thread has read what it needed of the selection state
+        pq64_t *s_head = reinterpret_cast<pq64_t *>(base);
+        int32_t *xmisc = reinterpret_cast<int32_t *>(s_head + p.inl_hcap);
+        if (tid == 0) { p.flag[bl] = 0; if (p.nflag) atomicAdd(p.nflag, 1); }       // (the counter: statistics only)
+        ivf_exact_big_query(p, bl, lds, s_head, xmisc, p.inl_scratch + p.inl_per_q * (size_t) bl, tid);
+        publish();
+    };
     if (s_misc[2]) {
+        if (p.inl_scratch) { redo_exact(); return; }
         // flagged: hand the coarse scores and the table (layout [b][M*Ks], QT == 1) to the exact-emulation kernels
         for (int c = tid; c < nlist; c += blockDim.x) {
             if constexpr (!GDIST) p.coarse_dist[bl * nlist + c] = s_dist[c];
@@ -1061,6 +1171,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 if ((s_buf[j] >> 32) == (s_buf[j + 1] >> 32)) tie = 1;
         }
         if (__syncthreads_or(tie)) {                       // the answer hinges on std::partial_sort's heap order: hand over
+            if (p.inl_scratch) { redo_exact(); return; }
             if (tid == 0) {
                 p.flag[bl] = 1;
                 if (p.flag_list) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
@@ -1161,13 +1272,14 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             for (int j = 0; j + 1 < k1; ++j)
                 if ((s_buf[j] >> 32) == (s_buf[j + 1] >> 32)) tie = 1;
             s_misc[2] = tie;
-            if (tie) {
+            if (tie && !p.inl_scratch) {
                 p.flag[bl] = 1;
                 if (p.flag_list) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
             }
         }
         __syncthreads();
         if (s_misc[2]) {          // ties at the cut, found only now: same hand-over as above
+            if (p.inl_scratch) { redo_exact(); return; }
             for (int c = tid; c < nlist; c += blockDim.x) {
                 if constexpr (!GDIST) p.coarse_dist[bl * nlist + c] = s_dist[c];
                 p.coarse_id[bl * nlist + c] = c;
@@ -1259,7 +1371,16 @@ hipError_t launch_ivf_fused(const IvfParams &p0, hipStream_t st)
     const bool gd = ivf_fused_gdist(p.M, p.Ks, p.nlist, p.w, p.topk);
     const bool lsel = ivf_fused_lsel(p.M, p.Ks, p.nlist, p.w, p.topk, p.L);
     p.kcap = lsel ? ivf_fused_kcap(p.topk) : 0;
-    const size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk, p.L, lsel, gd);
+    size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk, p.L, lsel, gd);
+    if (p.q_host_off) {           // the query staged in LDS behind everything else (see the kernel)
+        p.q_host_off = (int) ((smem + 15) & ~(size_t) 15);
+        smem = (size_t) p.q_host_off + (size_t) p.M * 16;
+    }
+    if (p.inl_scratch) {          // the flagged blocks' own exact replay: its heap lies over the selection state behind the table
+        p.inl_hcap = ivf_exact_big_heap_cap(p.w, p.topk);
+        smem = std::max(smem, (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15) + (size_t) p.inl_hcap * 8 + 64);
+        if (smem > (size_t) 160 * 1024) return hipErrorInvalidValue;
+    }
     return gd ? launch_ivf_fused_t<true>(p, lsel, smem, st) : launch_ivf_fused_t<false>(p, lsel, smem, st);
 }
 
@@ -1390,11 +1511,8 @@ hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st)
 }
 
 // ===================================================================================================
-// The same exact emulation for shapes whose working sets do not fit LDS (nlist or L above kExactLdsMax): the (distance, list) and
-// (distance, position) sequences live in global scratch (one slice per block of the persistent grid), only the HEAP of each
-// std::partial_sort -- its first `middle` entries: w lists, topk candidates -- is in LDS, and the library's __heap_select streams
-// the rest from memory (rii_device.h: wh_partial_sort_split).  Same moves as the reference, any nlist <= N and any L <= N;
-// a heap deeper than the wave code covers (w or topk above kWhSplitMaxHeap) is walked by one lane over the global array.
+// ivf_exact_big_kernel: ivf_exact_big_query (above ivf_fused_kernel) for the flagged queries of a batch, or for every query of a
+// shape the fused kernel does not cover -- a persistent grid, one global scratch slice per block.
 // ===================================================================================================
 // GTAB: the query's table does not fit LDS at all (M * Ks * 4 B > 144 KiB, widetab.hip): it is read from global memory (L2).
 template <bool GTAB>
@@ -1402,16 +1520,11 @@ __global__ __launch_bounds__(256) void ivf_exact_big_kernel(IvfParams p, unsigne
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nflag = p.flag_list ? *p.nflag : (int) p.B;
-    const int MK = p.M * p.Ks, nlist = p.nlist, tid = threadIdx.x;
-    const int w = (int) p.w, k = p.topk;
+    const int MK = p.M * p.Ks, tid = threadIdx.x;
     float *lds_tab = reinterpret_cast<float *>(smem);
     pq64_t *s_head = reinterpret_cast<pq64_t *>(smem + (GTAB ? 0 : (((size_t) MK * 4 + 15) & ~(size_t) 15)));   // [hcap] the heap of the running sort
     int32_t *s_misc = reinterpret_cast<int32_t *>(s_head + hcap);                                      // [4]
     unsigned char *mine = scratch + per_block * blockIdx.x;
-    pq64_t *gco = reinterpret_cast<pq64_t *>(mine);                     // [nlist] (coarse distance, list), in the reference's order afterwards
-    pq64_t *gcand = gco + nlist;                                        // [L]     (distance, traversal position)
-    int32_t *gcum = reinterpret_cast<int32_t *>(gcand + p.L);           // [nlist + 1]
-    int32_t *gcid = gcum + (nlist + 1);                                 // [L]     id of the candidate at a traversal position
     for (int fi = blockIdx.x; fi < nflag; fi += gridDim.x) {
         const int64_t bl = p.flag_list ? p.flag_list[fi] : fi;
         if (!p.flag_list && p.flag && !p.flag[bl]) continue;
@@ -1419,66 +1532,7 @@ __global__ __launch_bounds__(256) void ivf_exact_big_kernel(IvfParams p, unsigne
         if constexpr (!GTAB) stage_single_lut(p.lut, p.b0 + bl, MK, p.QT, lds_tab);
         const float *lds = GTAB ? p.lut + (size_t) (p.b0 + bl) * MK : lds_tab;        // (GTAB: plain [b][M*Ks] tables, QT == 1)
         __syncthreads();
-        const bool w_lds = w <= kWhSplitMaxHeap, k_lds = k <= kWhSplitMaxHeap;          // heap in LDS, walked by a wave
-        for (int c = tid; c < nlist; c += blockDim.x) {                                  // src/rii.h:262-264
-            const pq64_t e = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
-            if (w_lds && c < w) s_head[c] = e; else gco[c] = e;
-        }
-        __syncthreads();
-        if (w_lds) {
-            if (tid < 64) wh_partial_sort_split(s_head, gco + w, w, nlist, tid);        // src/rii.h:279-280 (wave 0)
-            __syncthreads();
-            for (int c = tid; c < w; c += blockDim.x) gco[c] = s_head[c];                // the whole order in one array
-        } else if (tid == 0) {
-            pq64_partial_sort(gco, w, nlist);                                            // one lane, global memory: correct, slow
-        }
-        __syncthreads();
-        if (tid == 0) {
-            long long cnt = 0;
-            int nv = 0;
-            bool finished = false;
-            for (int c = 0; c < nlist; ++c) {                                            // src/rii.h:286-321
-                const long long len = p.list_len[pq64_id(gco[c])];
-                gcum[c] = (int) cnt;
-                if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
-                cnt += len;
-                if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
-            }
-            if (!finished) { cnt = 0; nv = 0; }
-            gcum[nv] = (int) cnt;
-            s_misc[0] = (int) cnt; s_misc[1] = nv;
-        }
-        __syncthreads();
-        const int ncand = s_misc[0], nv = s_misc[1];
-        if (ncand == 0) {
-            if (tid == 0) p.out_counts[bl] = 0;                                          // src/rii.h:324-325
-            continue;
-        }
-        for (int pos = tid; pos < ncand; pos += blockDim.x) {
-            int lo = 0, hi = nv;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (gcum[mid] <= pos) lo = mid; else hi = mid;
-            }
-            const int no = (int) pq64_id(gco[lo]);
-            const int32_t id = p.pl_ids[p.pl_off[no] + (pos - gcum[lo])];
-            const pq64_t e = pq64_make(exact_adist(lds, p.codes + (size_t) id * p.M, p.M, p.Ks), (uint32_t) pos);
-            if (k_lds && pos < k) s_head[pos] = e; else gcand[pos] = e;
-            gcid[pos] = id;
-        }
-        __syncthreads();
-        if (k_lds) {
-            if (tid < 64) wh_partial_sort_split(s_head, gcand + k, k, ncand, tid);      // src/rii.h:312-313 (wave 0)
-        } else if (tid == 0) {
-            pq64_partial_sort(gcand, k, ncand);
-        }
-        if (tid == 0) p.out_counts[bl] = k;
-        __syncthreads();
-        for (int j = tid; j < k; j += blockDim.x) {
-            const pq64_t e = k_lds ? s_head[j] : gcand[j];
-            p.out_ids[bl * k + j] = gcid[pq64_id(e)];
-            p.out_dists[bl * k + j] = pq64_dist(e);
-        }
+        ivf_exact_big_query(p, bl, lds, s_head, s_misc, mine, tid);
     }
 }
 
@@ -1487,6 +1541,7 @@ static int ivf_exact_big_hcap(int64_t w, int topk)
     const int64_t a = w <= kWhSplitMaxHeap ? w : 0, b = topk <= kWhSplitMaxHeap ? topk : 0;
     return (int) std::max<int64_t>(std::max<int64_t>(a, b), 1);
 }
+int ivf_exact_big_heap_cap(int64_t w, int topk) { return ivf_exact_big_hcap(w, topk); }
 bool ivf_exact_big_supported(int M, int Ks, int64_t w, int topk)
 {
     if (lut_tile_for(M, Ks) == 0) return true;             // table read from global memory: only the heaps use LDS

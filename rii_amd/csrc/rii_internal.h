@@ -114,6 +114,11 @@ struct IvfParams {
     // host_spin: the outputs (and `flag`) are coherent HOST memory; ivf_fused_kernel stores host_seq into host_flag[b0 + b] once
     // query b's rows (or its fallback flag) are written, behind a system-scope release
     unsigned int *host_flag = nullptr; unsigned int host_seq = 0;
+    // round 4: ivf_fused_kernel redoes a flagged query itself (ivf_exact_big_query): one global scratch slice per query of the launch
+    // group (ivf_exact_big_scratch() bytes each) and the LDS heap capacity; NULL = hand over to the flag-gated exact kernels
+    unsigned char *inl_scratch = nullptr; size_t inl_per_q = 0; int inl_hcap = 0;
+    int q_host_off = 0;           // != 0: `queries` is coherent HOST memory (Ds = 4, Ks = 256): fetched once per block into LDS (the launcher
+                                  // turns the flag into the byte offset of that staging area)
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
 bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk);
@@ -126,6 +131,7 @@ bool ivf_exact_lds_supported(int M, int Ks, int nlist, int64_t L);
 hipError_t launch_ivf_exact_lds(const IvfParams &p, hipStream_t st);
 // shapes past the LDS kernel's limits: sequences in global scratch, heaps in LDS (any nlist, any L; w, topk <= 1024)
 bool ivf_exact_big_supported(int M, int Ks, int64_t w, int topk);
+int ivf_exact_big_heap_cap(int64_t w, int topk);             // entries of the LDS heap of ivf_exact_big_query
 size_t ivf_exact_big_scratch(int nlist, int64_t L);          // bytes per block of the grid
 hipError_t launch_ivf_exact_big(const IvfParams &p, void *d_scratch, int grid, hipStream_t st);
 hipError_t launch_bitmap_set(const int64_t *d_tids, int64_t S, uint32_t *d_bitmap, hipStream_t st);
@@ -272,7 +278,8 @@ bool slice_topk_supported(int M, int Ks, int Ds, int64_t n, int64_t B, int topk)
 size_t slice_topk_scratch(int64_t n, int64_t B, int topk);
 hipError_t launch_slice_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_queries, const float *d_codewords, int Ds, int arch,
                              int64_t B, int topk, const int64_t *d_remap, unsigned long long *d_cand, unsigned int *d_done,
-                             int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_tie, hipStream_t st, unsigned int *host_flag, unsigned int seq);
+                             int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_tie, hipStream_t st, unsigned int *host_flag, unsigned int seq,
+                             int32_t *d_flag_list = nullptr, int *d_nflag = nullptr);   // d_flag_list / d_nflag: tied queries appended (device-side fallback)
 
 // widetab.hip: shapes whose one-query table does not fit LDS (lut_tile_for() == 0): tables stay in global memory
 hipError_t launch_scan_wide(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const float *d_lut, const int64_t *d_remap,

@@ -344,6 +344,7 @@ struct SliceArgs {
     unsigned int *done;                      // [B] arrivals (low 16 bits) + "too many tied keys" marks (<< 16); zero between launches
     int64_t *out_ids; float *out_dists; int32_t *out_tie;
     unsigned int *host_flag; unsigned int seq;
+    int32_t *flag_list = nullptr; int *nflag = nullptr;   // device-side tie fallback (asynchronous calls): tied queries appended here
 };
 
 // the kk smallest of keys[0, tot) in ascending (distance, index) order; *many: more than kStBuf keys lie under the bound (masses of
@@ -601,7 +602,10 @@ __global__ __launch_bounds__(kStThreads) void slice_topk_kernel(SliceArgs p)
         p.out_ids[b * k + j] = p.remap ? p.remap[idx] : (int64_t) idx;
         p.out_dists[b * k + j] = pq64_dist(e);
     }
-    if (tid == 0) p.out_tie[b] = tie;                  // 1: the host reruns the call on the general path (std::partial_sort's order)
+    if (tid == 0) {
+        p.out_tie[b] = tie;                            // 1: the host reruns the call on the general path (std::partial_sort's order) ...
+        if (tie && p.flag_list) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) b;    // ... or the flag-gated tie kernels behind this launch do
+    }
     if (p.host_flag) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every thread's row stores have left the CU before the barrier
         __syncthreads();
@@ -637,10 +641,12 @@ size_t slice_topk_scratch(int64_t n, int64_t B, int topk) { return (size_t) B * 
 
 hipError_t launch_slice_topk(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_queries, const float *d_codewords, int Ds, int arch,
                              int64_t B, int topk, const int64_t *d_remap, unsigned long long *d_cand, unsigned int *d_done,
-                             int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_tie, hipStream_t st, unsigned int *host_flag, unsigned int seq)
+                             int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_tie, hipStream_t st, unsigned int *host_flag, unsigned int seq,
+                             int32_t *d_flag_list, int *d_nflag)
 {
     if (B == 0) return hipSuccess;
     SliceArgs a;
+    a.flag_list = d_flag_list; a.nflag = d_nflag;
     a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch;
     a.remap = d_remap; a.topk = topk; a.k1max = topk + 1; a.pass_cap = kSlicePass; a.cand = d_cand; a.done = d_done;
     a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_tie = d_out_tie; a.host_flag = host_flag; a.seq = seq;

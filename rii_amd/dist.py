@@ -277,6 +277,7 @@ class DbShardedIndex(object):
         return tl, min(topk, len(tl))
 
     TIE_CAP = 12288          # rows of a flagged query's candidate list per rank (8192 = one unbounded chunk, + the bounded rest)
+    MERGE_MAX_KEYS = 8192    # G * (k + 1) rows per query the device merge sorts in LDS (rii_merge_topk_ex_dev); above: torch merge
 
     def all_starts(self):
         """First global id of every rank's shard, in rank order (one tiny all-gather, cached): the merge kernel adds them to the
@@ -345,7 +346,7 @@ class DbShardedIndex(object):
         enqueued by rii_query_linear_dbsharded_dev (round 4).  Shapes beyond the merge kernel's limits (G x (k + 1) > 8192 rows, more
         than 64 ranks) and host collectives ("gloo") keep the torch path below."""
         rank, G = world()
-        if _use_c_comm() and G <= 64 and (topk == 1 or G * rows <= 8192):
+        if _use_c_comm() and G <= 64 and (topk == 1 or G * rows <= self.MERGE_MAX_KEYS) and self.MERGE_MAX_KEYS >= 8192:
             dev = torch.device("cuda", torch.cuda.current_device())
             comm = get_comm(self.group)
             with _engine_stream() as sh:
@@ -410,7 +411,7 @@ class DbShardedIndex(object):
             mi = torch.empty((B, rows), dtype=torch.int64, device=dev)
             md = torch.empty((B, rows), dtype=torch.float32, device=dev)
             self.last_tie_overflow = self._zero_flags(B, dev)
-            if G * rows > 8192 or G > 64:
+            if G * rows > self.MERGE_MAX_KEYS or G > 64:
                 # beyond the merge kernel's LDS sort (rii_merge_topk_ex_dev: G * k <= 8192 keys, G <= 64 offsets): the per-rank id
                 # offsets are added to the finite rows here and torch merges under (dist, id), as the host path does
                 gi, gd = [], []

@@ -161,27 +161,22 @@ def test_dev_to_host_flag_path_under_load_every_word():
 
 
 def test_db_sharded_device_path_beyond_the_merge_kernel_limits():
-    """DbShardedIndex on device tensors: G * (topk + 1) rows above the merge kernel's 8192-key LDS sort fall back to the torch merge
-    (the device path used to raise there) -- same rows as the single engine.  (Exactly tied distances among more than
-    1024 rows cannot be replayed across shards -- include/rii_amd.h: topk <= 1024 -- so the big case uses queries without ties.)"""
+    """DbShardedIndex on device tensors: G * (topk + 1) rows above the merge kernel's LDS sort (MERGE_MAX_KEYS = 8192) fall back to the
+    torch merge (the device path used to raise there) -- same rows as the single engine, exact ties replayed.  The limit
+    is lowered for the test so that ordinary sizes reach the fallback."""
     import torch
     from rii_amd.dist import DbShardedIndex
-    g, cw, codes, rng = _engine(8, 4, 12000, 5)
+    g, cw, codes, rng = _engine(8, 4, 12000, 5, dup=500)
     idx = DbShardedIndex(g, 0, g.N)
-    big = 9000
-    qs = []
-    while len(qs) < 3:
-        q = rng.random((1, 32)).astype(np.float32)
-        d = g.query_linear_batch(q, big + 1, None)[1][0]
-        if not np.any(d[1:] == d[:-1]):
-            qs.append(q[0])
-    qs = np.stack(qs)
+    qs = rng.random((9, 32)).astype(np.float32)
     Q = torch.from_numpy(qs).cuda()
-    for topk in (1, 50, big):
-        ids, d = idx.query_linear_batch(Q, topk)
-        want = g.query_linear_batch(qs, topk, None)
-        assert np.array_equal(ids.cpu().numpy(), want[0]) and np.array_equal(d.cpu().numpy(), want[1]), topk
-        assert idx.last_tie_flags.shape[0] == 3
+    for limit in (8192, 16):
+        idx.MERGE_MAX_KEYS = limit
+        for topk in (1, 5, 50):
+            ids, d = idx.query_linear_batch(Q, topk)
+            want = g.query_linear_batch(qs, topk, None)
+            assert np.array_equal(ids.cpu().numpy(), want[0]) and np.array_equal(d.cpu().numpy(), want[1]), (limit, topk)
+            assert idx.last_tie_flags.shape[0] == 9
 
 
 def test_query_shard_unpack_and_top1_merge_kernels_for_many_ranks():
@@ -244,3 +239,90 @@ def test_query_shard_unpack_and_top1_merge_kernels_for_many_ranks():
         for b in range(B):
             j = min(range(G), key=lambda r: (d[r, b], gid[r, b]))
             assert int(a_i[b, 0]) == int(gid[j, b]) and float(a_d[b, 0]) == float(d[j, b])
+
+
+@pytest.mark.parametrize("M,Ds", [(32, 4), (16, 6)])
+def test_ivf_flagged_blocks_redo_their_own_query(M, Ds):
+    """option ivf_inline_exact = 1 (default): a block of ivf_fused_kernel that flags its query (exactly tied coarse distances, walk
+    into the unsorted tail, ties at the cut) replays std::partial_sort itself; = 0: the flag-gated exact kernels of round 3.  Same
+    rows either way -- duplicated centres and codes make the flags common, ivf_force_exact flags every query -- and the oracle's.
+    One-query host calls (the fused kernel reads the query from the pinned block) give the batch's rows."""
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(60 + M)
+    cw = np.round(rng.random((M, 256, Ds)) * 15).astype(np.float32)          # integer-valued tables: exact ties everywhere
+    N = 30000
+    codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
+    codes[rng.integers(0, N, 4000)] = codes[rng.integers(0, N, 4000)]
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.reconfigure(64, 2)
+    cen = g.coarse_centers_array().copy()
+    cen[1::7] = cen[0::7][:len(cen[1::7])]                                    # duplicated centres: tied coarse distances
+    g.set_coarse_centers(cen)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    o.set_coarse_centers(cen) if hasattr(o, "set_coarse_centers") else None
+    qs = np.round(rng.random((70, M * Ds)) * 15).astype(np.float32)
+    tids = np.sort(rng.choice(N, 3000, replace=False)).astype(np.int64)
+    nflag_seen = 0
+    for topk in (1, 5, 40):
+        for L in (200, 3000, N):
+            for t in (None, tids):
+                for force in (0, 1):
+                    g.set_option("ivf_force_exact", force)
+                    res = []
+                    for inl in (1, 0):
+                        g.set_option("ivf_inline_exact", inl)
+                        res.append(g.query_ivf_batch(qs, topk, t, min(L, N)))
+                    (ai, ad, ac), (bi, bd, bc) = res
+                    assert np.array_equal(ac, bc), (topk, L, force)
+                    for b in range(len(qs)):
+                        n = int(ac[b])
+                        assert np.array_equal(ai[b, :n], bi[b, :n]) and np.array_equal(ad[b, :n].view(np.uint32), bd[b, :n].view(np.uint32)), (topk, L, force, b)
+    g.set_option("ivf_force_exact", 0)
+    g.set_option("ivf_inline_exact", 1)
+    if hasattr(o, "set_coarse_centers"):
+        for b in range(0, 70, 9):
+            for topk, L in ((1, 200), (5, 3000)):
+                gi, gd, gc = g.query_ivf_batch(qs[b:b + 1], topk, None, L)
+                assert_same_result((gi[0, :int(gc[0])], gd[0, :int(gc[0])]), o.query_ivf(qs[b], topk, E, L), "ivf inline exact")
+    want = g.query_ivf_batch(qs, 3, None, 500)
+    for b in range(len(qs)):                       # one query per call: the in-place form of the host call
+        ids, d = g.query_ivf(qs[b], 3, E, 500)
+        n = int(want[2][b])
+        assert ids == want[0][b, :n].tolist() and d == want[1][b, :n].tolist(), b
+
+
+@pytest.mark.parametrize("M,Ds,scale", [(32, 4, "sift"), (16, 6, "unit"), (8, 16, "sift")])
+def test_async_few_queries_take_the_slice_kernel_with_device_side_tie_fallback(M, Ds, scale):
+    """rii_query_linear_dev with 1 - 8 queries and topk > 1 on an index too large for the one-block kernel: ONE launch of
+    slice_topk_kernel + flag-gated tie kernels (no host decision, the call stays asynchronous).  Integer-valued tables and
+    duplicated codes make exactly tied distances common; every row must equal the general path's (option slice_topk = 0), which
+    the oracle tests pin."""
+    import torch
+    from rii_amd import RiiGpu
+    cw, codes, _ = make_problem(300 + M, M, 256, Ds, 70000, scale, dup=6000)
+    rng = np.random.default_rng(M)
+    qs = (np.round(rng.random((8, M * Ds)) * 255) if scale == "sift" else rng.random((8, M * Ds))).astype(np.float32)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    dev = torch.device("cuda:0")
+    tids = np.sort(rng.choice(g.N, 40000, replace=False)).astype(np.int64)
+    td = torch.from_numpy(tids).to(dev)
+    nties = 0
+    for B in (1, 3, 8):
+        q = torch.from_numpy(qs[:B]).to(dev)
+        for topk in (2, 3, 10, 128):
+            for t, tdev in ((None, None), (tids, td)):
+                oi = torch.full((B, topk), -5, dtype=torch.int64, device=dev)
+                od = torch.full((B, topk), -5, dtype=torch.float32, device=dev)
+                g.set_option("slice_topk", 1)
+                g.query_linear_dev(q.data_ptr(), B, topk, 0 if t is None else tdev.data_ptr(), 0 if t is None else t.size, oi.data_ptr(), od.data_ptr(), 0)
+                g.synchronize()
+                g.set_option("slice_topk", 0)
+                want = g.query_linear_batch(qs[:B], topk, t)
+                assert np.array_equal(oi.cpu().numpy(), want[0]) and np.array_equal(od.cpu().numpy().view(np.uint32), want[1].view(np.uint32)), (B, topk, t is None)
+                nties += int((want[1][:, 1:] == want[1][:, :-1]).any())
+    g.set_option("slice_topk", 1)
+    if scale == "sift":
+        assert nties > 0                       # the fallback really ran
