@@ -398,6 +398,49 @@ def sift_workload(name, eng, args, torch, dev, stream, q_dev, cw, codes, barrier
     return obj
 
 
+def sharded_world1_workload(eng, args, torch, dev, stream, t_q, B, topk, barrier, out_ids):
+    """BASELINE's metric is quoted at 1 / 2 / 4 / 8 GPUs: what the multi-GPU step costs on top of the kernels is visible on ONE GPU too --
+    the sharded C-ABI entry points (rii_query_linear_qsharded_dev / _dbsharded_dev: engine kernels -> ncclAllGather -> unpack / merge,
+    all enqueued by one library call) over a ONE-rank RCCL communicator, at the global batch and at 128 queries (the per-GPU share of
+    the 1024-query batch on 8 GPUs).  Same index (world size 1: the shard IS the database), same queries, rows checked."""
+    from rii_amd import dist as rd
+    comm = rd.get_comm()
+    N = eng.N
+    out = {"what": "one-rank RCCL communicator behind the C ABI; per step: ONE rii_query_linear_{q,db}sharded_dev call on the bench stream, "
+                   "device-resident queries and rows; `plain` = rii_query_linear_dev on the same box, same loop",
+           "rccl_ranks": comm.size}
+    for b in (B, 128):
+        if b > t_q.shape[0]:
+            continue
+        q = t_q[:b].contiguous()
+        oi = torch.empty((b, topk), dtype=torch.int64, device=dev)
+        od = torch.empty((b, topk), dtype=torch.float32, device=dev)
+        ri = torch.empty((b, topk), dtype=torch.int64, device=dev)
+        rdd = torch.empty((b, topk), dtype=torch.float32, device=dev)
+
+        def plain():
+            eng.query_linear_dev(q.data_ptr(), b, topk, 0, 0, ri.data_ptr(), rdd.data_ptr(), stream)
+
+        def qsh():
+            comm.query_linear_qsharded_dev(eng, q.data_ptr(), b, topk, 0, 0, oi.data_ptr(), od.data_ptr(), stream)
+
+        def dbsh():
+            comm.query_linear_dbsharded_dev(eng, 0, q.data_ptr(), b, topk, 0, 0, 0, oi.data_ptr(), od.data_ptr(), stream=stream)
+
+        res = {}
+        K = max(args.steps, 50)
+        for name, fn in (("plain", plain), ("query_sharded", qsh), ("db_sharded", dbsh)):
+            preheat(fn, torch.cuda.synchronize, 0.05)
+            ms = min(timed_loop(fn, K, barrier) for _ in range(2)) / K * 1e3
+            res[name] = {"ms_per_step": ms, "value": b / ms * 1e3, "unit": "queries/s"}
+            if name != "plain":
+                res[name]["rows_match_plain"] = bool(torch.equal(oi, ri) and torch.equal(od, rdd))
+        res["query_sharded"]["added_us"] = (res["query_sharded"]["ms_per_step"] - res["plain"]["ms_per_step"]) * 1e3
+        res["db_sharded"]["added_us"] = (res["db_sharded"]["ms_per_step"] - res["plain"]["ms_per_step"]) * 1e3
+        out["batch_%d" % b] = res
+    return out
+
+
 def readme_workload(args, torch, dev, arch):
     """configs[0]: the README example (N=10k, D=128, M=32, Ks=256, uniform random vectors; nlist = sqrt(N) = 100, topk = 3),
     ONE query per call through the host-pointer C ABI with a synchronisation per call -- the reference's own usage pattern --
@@ -985,6 +1028,7 @@ def main():
             for name in ("subset", "ivf", "subset_ivf"):            # (reconfigure happens once, before the two ivf legs)
                 others[name] = guarded(sift_workload, name, eng, args, torch, dev, stream, my_q, cw, codes, barrier, arch, N, M, Ks,
                                        D // M, B, topk)
+            others["sharded_world1"] = guarded(sharded_world1_workload, eng, args, torch, dev, stream, t_q, B, topk, barrier, out_ids)
             others["readme_n10k"] = guarded(readme_workload, args, torch, dev, arch)
             if args.deep_shard > 0:
                 others["deep_shard"] = guarded(deep_shard_workload, args, torch, dev, arch, barrier)

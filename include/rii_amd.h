@@ -242,13 +242,37 @@ int rii_assign(rii_engine *e, const uint8_t *codes, int64_t n, int32_t *assign);
  * its M subspaces exactly once). */
 int rii_fscan_lane_subspace(int M, int lane, int t);
 
-/* Options: "lut_mode" (RII_LUT_*), "scan_mode" (1 = 8-bit filter + exact re-rank for top-1 [default], 0 = exact scan
- * only; results are identical), "ivf_fused" (1 = one fused launch for the common inverted-index case with per-query
- * exact fallback [default], 0 = always the std::partial_sort emulation kernels; results are identical),
- * "fast_min_batch" (top-1 batches smaller than this use the exact scan; default 33), "scan_order" (1 = the filter
- * scans an LDS-friendly permutation of the codes [default], 0 = id order; results are identical), "cand_cap",
- * "scan_chunks" (0 = auto), "timing" (0/1/2), "lanes" (2 [default] or 1, see below), "scan_mx" (1 = the M = 16 / 32 / 64, Ks = 256
- * filter scan sums its table bytes on the matrix cores [default], 0 = on the vector ALU; results are identical).
+/* Options (rii_set_option / rii_get_option; every one of them except "lut_mode" leaves the results bit-identical -- they select
+ * among implementations that the parity tests compare with each other; defaults in brackets; measurements: INTEGRATION.md section 5):
+ *   "lut_mode"         RII_LUT_EXACT [default] / RII_LUT_MFMA
+ *   "scan_mode"        1 = 8-bit filter + exact re-rank [default], 0 = exhaustive fp32 scan only
+ *   "scan_mx"          1 = the M = 16 / 32 / 64, Ks = 256 filter sums its table bytes on the matrix cores (fscan_mx_kernel) [default],
+ *                      0 = on the vector ALU (fscan_kernel)
+ *   "scan_dual"        M = 16: 1 = two 16-query tiles per scan block (fscan_mx_dual_kernel) [default], 0 = one
+ *   "scan_order"       1 = the shapes without the rotated table layout scan an LDS-friendly permutation of the codes [default], 0 = id order
+ *   "scan_chunks"      chunks of the code array per query tile (grid.x of the scan kernels); 0 = automatic [default]
+ *   "fast_min_batch"   top-1 batches smaller than this take the exhaustive scan / the one-launch kernels [33]
+ *   "cand_cap"         candidate slots per query of the filter stage (tests force small values to reach the overflow path) [automatic]
+ *   "fused_tables"     1 = byte tables of M = 16 / 32, Ks = 256, Ds = 4 / 2 from ONE launch (qlut_fused_kernel), top-1 re-ranked from the
+ *                      codebook [default]; 0 = the two-launch tile path
+ *   "table_levels"     quantisation levels of those tables: 63, 127 [default] or 255
+ *   "fused_rerank"     1 = the top-1 re-rank runs as the tail of the scan launch (one launch per batch, one host flag per tile for
+ *                      rii_query_linear_dev_to_host); 0 = rerank_top1_direct_kernel [default: measured equal or faster]
+ *   "small_topk"       1 = a small batch over a small index (<= ~13 800 codes at M = 32) in ONE launch (small_topk_kernel) [default]
+ *   "slice_topk"       1 = 1 - 8 queries on a larger index in ONE launch (slice_topk_kernel; exact ties redone by the general path:
+ *                      decided by the host for host-pointer calls, by flag-gated tie kernels for asynchronous calls) [default]
+ *   "host_spin"        1 = small host-pointer calls get their rows written into the engine's pinned block and wait on sequence flags
+ *                      there instead of a D2H copy + stream synchronisation [default]
+ *   "host_zero_copy"   host-pointer linear batches read their queries from / write their rows to the pinned block: 1 = up to 128 KiB
+ *                      of queries [default], 2 = always, 0 = never
+ *   "ivf_fused"        1 = one fused launch per batch for the inverted index with per-query exact fallback [default], 0 = the
+ *                      std::partial_sort emulation kernels for every query
+ *   "ivf_inline_exact" 1 = a block of the fused kernel that flags its own query replays it itself [default], 0 = flag-gated exact
+ *                      kernels behind every batch
+ *   "ivf_force_exact"  tests / measurement: 1 = every query of the fused path is flagged [0]
+ *   "lanes"            scratch-buffer sets: 2 [default] or 1 (see Threading below)
+ *   "timing"           0 [default] / 1 (HIP events around every kernel) / 2 (only around the dominant kernel of a step): rii_timing_read
+ * Read-only (rii_get_option): "lut_tile", "n_cu", "cand_total", "cand_max" (debug counters of the last filter pass; synchronise).
  *
  * Threading: every entry point locks the engine, concurrent callers are serialised.  The *_dev calls return after
  * enqueueing.  The engine keeps two sets of scratch buffers ("lanes"): a caller that issues successive batches alternately

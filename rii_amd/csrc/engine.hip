@@ -1577,7 +1577,11 @@ int host_query(rii_engine *e, bool ivf, const float *queries, int64_t B, int top
     const bool slice_linear = !ivf && !spin_linear && e->host_spin && e->d_pin && e->slice_topk && e->QT != 0 && e->lut_mode == RII_LUT_EXACT &&
                               in_bytes <= kSpinMaxInput && slice_topk_supported(e->M, e->Ks, e->Ds, S ? S : e->N, B, topk);
     // a batch on the general path: rows written straight into the pinned block (see below); host_zero_copy: queries read from it too
-    const bool zc = !ivf && !spin_linear && !slice_linear && e->host_spin && e->d_pin && B <= kMaxBatch && S == 0 && e->lut_mode == RII_LUT_EXACT &&
+    // (only where every kernel of the path reads a query O(1) times: the fused table kernel + the codebook re-rank; the per-entry table
+    //  kernels of the other shapes and of the small exhaustive batches would fetch it over PCIe thousands of times)
+    const bool zc_path = e->scan_mode == 1 && e->fused_tables && qlut_fused_supported(e->M, e->Ks, e->Ds, e->scan_mx) && topk <= rerank_topk_max_k() &&
+                         !(topk == 1 && B < e->fast_min_batch);
+    const bool zc = !ivf && !spin_linear && !slice_linear && zc_path && e->host_spin && e->d_pin && B <= kMaxBatch && S == 0 && e->lut_mode == RII_LUT_EXACT &&
                     e->QT != 0 && (e->host_zero_copy == 2 || (e->host_zero_copy == 1 && q_bytes <= (128u << 10)));
     const bool batch_pin = zc;
     // inverted index, one-launch form: the fused kernel fetches the query from the pinned block itself (once per block, into LDS)

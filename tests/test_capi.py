@@ -129,6 +129,19 @@ def test_plain_c_client_shards_without_python(tmp_path):
     assert out.returncode == 0 and "C ABI sharded OK" in out.stdout, (out.stdout, out.stderr)
 
 
+def test_header_documents_every_engine_option():
+    """the public header had drifted behind rii_set_option.  Every key the engine accepts (and every read-only key of
+    rii_get_option) must be named in include/rii_amd.h, and the header must not name options the engine no longer has."""
+    eng = open(os.path.join(ROOT, "rii_amd", "csrc", "engine.hip")).read()
+    a, b = eng.index("RII_API int rii_set_option"), eng.index("RII_API int rii_timing_read")
+    keys = set(re.findall(r'k == "([a-z_0-9]+)"', eng[a:b]))
+    hdr = open(os.path.join(ROOT, "include", "rii_amd.h")).read()
+    doc = hdr[hdr.index("/* Options (rii_set_option"):hdr.index("int rii_set_option")]
+    named = set(re.findall(r'"([a-z_0-9]+)"', doc))
+    assert keys - named == set(), "options missing from the header: %s" % sorted(keys - named)
+    assert named - keys == set(), "the header names options the engine does not have: %s" % sorted(named - keys)
+
+
 def test_main_module_shim_exposes_riicpp():
     """`rii_amd.main.RiiCpp` is what `import main` resolves to after the one-line swap of INTEGRATION.md §2: it must carry
     every member the reference's `rii/rii.py` touches on `main.RiiCpp` (src/main.cpp:12-54)."""

@@ -206,3 +206,38 @@ def test_large_index_beyond_2_pow_24_codes():
     assert np.array_equal(i5, j5) and np.array_equal(d5.view(np.uint32), e5.view(np.uint32))
     assert (i1[:8, 0] == plant).all()
     assert (i1 >= (1 << 24)).any()
+
+
+def test_deep_shard_64m_codes_filter_equals_exhaustive_and_shards_compose():
+    """BASELINE configs[4] per-GPU shape at a size that is a true HBM stream (64 M codes x M = 16 = 1 GB, four times the Infinity
+    Cache; the 125 M-code shard of Deep1B over 8 GPUs is the same code path, twice as long): size-independent properties of the
+    default path -- (1) filter + re-rank (fscan_mx_dual_kernel) == exhaustive fp32 scan on every row, (2) idempotence, (3) the
+    minimum over the whole shard == the minimum of the minima of two half-shard target ranges (what the database-sharded merge
+    relies on), (4) a few-query call (exact scan path) agrees with the batch's rows.  Random bytes as codes (throughput shape)."""
+    from rii_amd import RiiGpu
+    n, m, ds = 64_000_000, 16, 6
+    rng = np.random.default_rng(77)
+    cw = rng.random((m, 256, ds)).astype(np.float32)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    step = 16_000_000
+    for s in range(0, n, step):
+        g.add_codes(rng.integers(0, 256, size=(step, m), dtype=np.uint8), False)
+    assert g.N == n
+    Q = rng.random((64, m * ds)).astype(np.float32)
+    i1, d1 = g.query_linear_batch(Q, 1, None)
+    again = g.query_linear_batch(Q, 1, None)
+    assert np.array_equal(again[0], i1) and np.array_equal(again[1], d1)
+    g.set_option("scan_mode", 0)
+    i0, d0 = g.query_linear_batch(Q, 1, None)
+    g.set_option("scan_mode", 1)
+    assert np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
+    few = g.query_linear_batch(Q[:3], 1, None)
+    assert np.array_equal(few[0], i1[:3]) and np.array_equal(few[1], d1[:3])
+    half = 4_000_000                                   # two adjacent target ranges around the winners of the first queries
+    lo = int(max(0, min(int(i1[0, 0]), n - 2 * half)))
+    ta, tb = np.arange(lo, lo + half, dtype=np.int64), np.arange(lo + half, lo + 2 * half, dtype=np.int64)
+    (ia, da), (ib, db) = g.query_linear_batch(Q[:8], 1, ta), g.query_linear_batch(Q[:8], 1, tb)
+    both = g.query_linear_batch(Q[:8], 1, np.concatenate([ta, tb]))
+    pick = np.where((da < db) | ((da == db) & (ia < ib)), ia, ib)
+    assert np.array_equal(pick, both[0]) and np.array_equal(np.minimum(da, db), both[1])
+    assert int(both[0][0, 0]) == int(i1[0, 0])         # (the range was chosen around query 0's winner)
