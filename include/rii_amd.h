@@ -229,6 +229,18 @@ int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset
                                    const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t *d_out_ids,
                                    float *d_out_dists, int32_t *d_out_tie, int32_t *d_out_overflow, int tie_cap, void *stream);
 
+/* Database sharding, inverted index: the protocol described above rii_ivf_list_lengths_dev, driven by the library -- the per-rank list
+ * lengths all-gathered (nlist int32 per rank), the reference's global walk (src/rii.h:283-321) replayed on them by every rank, ONE
+ * all-gather of the ranks' k + 1 best (position, global id, distance) rows merged under (distance, position), and the queries whose
+ * k + 1 best distances tie exactly (d_out_tie [B] int32, or NULL) redone with every owned candidate gathered (rows = L) and
+ * std::partial_sort (src/rii.h:312-313) replayed on the rebuilt sequence.  Coarse centres replicated (rii_set_coarse_centers on every
+ * rank), posting lists over this rank's codes [id_offset, id_offset + N_local); N_global = codes of the whole database.  Outputs: GLOBAL
+ * ids, distances, counts (topk, or 0 where the reference returns ({}, {})), identical on every rank.  top-1 is asynchronous on the
+ * stream; top-k synchronises once per batch.  L <= 8192, G * (topk + 1) <= 8192. */
+int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset, int64_t N_global, const float *d_queries, int64_t B,
+                                int topk, const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t L,
+                                int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, int32_t *d_out_tie, void *stream);
+
 /* Distance-table build alone (RiiCpp::DTable, src/rii.h:361-373) for B queries -> out[B,M,Ks] (host). */
 int rii_dtable(rii_engine *e, const float *queries, int64_t B, float *out);
 /* Coarse assignment alone (PQKMeans::predict_one over codes, src/rii.h:350-354): assign[n] in [0,nlist). */

@@ -146,6 +146,7 @@ def _lib():
         "rii_query_linear_qsharded_dev": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
         "rii_query_ivf_qsharded_dev": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
         "rii_query_linear_dbsharded_dev": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+        "rii_query_ivf_dbsharded_dev": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "rii_qshard_begin": (c_i64, [c_i64, c_int, c_int]),
         "rii_qshard_record_bytes": (c_i64, [c_i64, c_int, c_int, c_int]),
         "rii_qshard_unpack_dev": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -245,6 +246,16 @@ class Comm(object):
         _check(_lib().rii_query_linear_dbsharded_dev(engine._h, self._h, int(id_offset), d_queries, int(B), int(topk), d_tids_local or None,
                                                      int(S_local), int(S_global), d_out_ids, d_out_dists, d_out_tie or None,
                                                      d_out_overflow or None, int(tie_cap), stream or None))
+
+
+def _comm_query_ivf_dbsharded_dev(self, engine, id_offset, N_global, d_queries, B, topk, d_tids_local, S_local, S_global, L, d_out_ids,
+                                  d_out_dists, d_out_counts, d_out_tie=0, stream=0):
+    _check(_lib().rii_query_ivf_dbsharded_dev(engine._h, self._h, int(id_offset), int(N_global), d_queries, int(B), int(topk),
+                                              d_tids_local or None, int(S_local), int(S_global), int(L), d_out_ids, d_out_dists,
+                                              d_out_counts, d_out_tie or None, stream or None))
+
+
+Comm.query_ivf_dbsharded_dev = _comm_query_ivf_dbsharded_dev
 
 
 def fscan_lane_subspace(M, lane, t):

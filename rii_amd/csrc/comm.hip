@@ -278,4 +278,87 @@ hipError_t launch_fill_pad(int64_t *d_ids, float *d_d, int64_t n, hipStream_t st
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// database-sharded inverted index (protocol: ivfshard.hip, include/rii_amd.h): this rank's rows -> the merge record with payload
+// ([n] int64 traversal positions, [n] int64 GLOBAL ids, [n] f32 distances; rows the rank does not have: position INT32_MAX, id -1,
+// distance +inf), and the finishing touches on the merged rows.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ivf_pack_kernel(const int64_t *__restrict__ ids, const int32_t *__restrict__ pos, const float *__restrict__ d,
+                                                       int64_t n, int64_t id_offset, int64_t *__restrict__ rec_pos, int64_t *__restrict__ rec_id,
+                                                       float *__restrict__ rec_d)
+{
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t id = ids[i];
+        rec_pos[i] = (int64_t) pos[i];
+        rec_id[i] = id >= 0 ? id + id_offset : id;
+        rec_d[i] = d[i];
+    }
+}
+hipError_t launch_ivf_pack(const int64_t *d_ids, const int32_t *d_pos, const float *d_d, int64_t n, int64_t id_offset, void *d_rec, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    unsigned char *r = static_cast<unsigned char *>(d_rec);
+    const int grid = (int) std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(ivf_pack_kernel, dim3(grid), dim3(256), 0, st, d_ids, d_pos, d_d, n, id_offset, reinterpret_cast<int64_t *>(r),
+                       reinterpret_cast<int64_t *>(r + (size_t) n * 8), reinterpret_cast<float *>(r + (size_t) n * 16));
+    return hipGetLastError();
+}
+// merged rows [B, k1] (payload ids, distances) -> outputs [B, topk]: a query the reference answers with ({}, {}) (count 0) gets
+// ids -1 / distances +inf; its tie flag is cleared (nothing to replay), as it is for top-1
+__global__ __launch_bounds__(256) void ivf_finish_kernel(const int64_t *__restrict__ mi, const float *__restrict__ md, const int64_t *__restrict__ cnt,
+                                                         int64_t B, int k1, int topk, int64_t *__restrict__ out_ids, float *__restrict__ out_d,
+                                                         int64_t *__restrict__ out_cnt, int32_t *__restrict__ tie, int32_t *__restrict__ any)
+{
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < B * topk; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t b = i / topk, j = i - b * topk;
+        const bool found = cnt[b] > 0;
+        out_ids[i] = found ? mi[b * k1 + j] : (int64_t) -1;
+        out_d[i] = found ? md[b * k1 + j] : INFINITY;
+        if (j == 0) {
+            out_cnt[b] = cnt[b];
+            const int t = (found && topk > 1) ? tie[b] : 0;
+            tie[b] = t;
+            if (t) atomicOr(any, 1);
+        }
+    }
+}
+hipError_t launch_ivf_finish(const int64_t *d_mi, const float *d_md, const int64_t *d_cnt, int64_t B, int k1, int topk, int64_t *d_out_ids,
+                             float *d_out_d, int64_t *d_out_cnt, int32_t *d_tie, int32_t *d_any, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    const int grid = (int) std::min<int64_t>((B * topk + 255) / 256, 2048);
+    hipLaunchKernelGGL(ivf_finish_kernel, dim3(grid), dim3(256), 0, st, d_mi, d_md, d_cnt, B, k1, topk, d_out_ids, d_out_d, d_out_cnt, d_tie, d_any);
+    return hipGetLastError();
+}
+// rows fsel[f] of src [.][D] -> dst [nf][D] (the flagged queries' vectors); rows r [nf][k] -> rows fsel[f] of out [.][k]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ fsel, int D, float *__restrict__ dst)
+{
+    const int f = blockIdx.x;
+    const int64_t b = fsel[f];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) dst[(size_t) f * D + i] = src[(size_t) b * D + i];
+}
+hipError_t launch_gather_rows(const float *d_src, const int32_t *d_fsel, int nf, int D, float *d_dst, hipStream_t st)
+{
+    if (nf == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned) nf), dim3(256), 0, st, d_src, d_fsel, D, d_dst);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const int32_t *__restrict__ fsel, int k, const int64_t *__restrict__ r_i,
+                                                           const float *__restrict__ r_d, int64_t *__restrict__ out_i, float *__restrict__ out_d)
+{
+    const int f = blockIdx.x;
+    const int64_t b = fsel[f];
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        out_i[b * k + j] = r_i[(size_t) f * k + j];
+        out_d[b * k + j] = r_d[(size_t) f * k + j];
+    }
+}
+hipError_t launch_scatter_rows(const int32_t *d_fsel, int nf, int k, const int64_t *d_r_i, const float *d_r_d, int64_t *d_out_i, float *d_out_d,
+                               hipStream_t st)
+{
+    if (nf == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned) nf), dim3(256), 0, st, d_fsel, k, d_r_i, d_r_d, d_out_i, d_out_d);
+    return hipGetLastError();
+}
+
 }  // namespace riiamd

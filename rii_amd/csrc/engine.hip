@@ -1929,19 +1929,24 @@ RII_API int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64
     return r2;
 }
 
-RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
-                                    int64_t S, int64_t S_global, int64_t L, int64_t N_global, const int32_t *d_glen, int G,
-                                    int rank, int rows, int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos,
-                                    int32_t *d_out_nloc, int64_t *d_out_counts, void *stream)
+namespace {
+// the bodies of rii_ivf_list_lengths_dev / rii_query_ivf_shard_dev: the caller holds e->mu and has begun on `st`
+int ivf_list_lengths_locked(rii_engine *e, const int64_t *d_tids, int64_t S, int64_t S_global, int32_t *d_out_len, hipStream_t st)
 {
-    if (rows <= 0) rows = topk + 1;
-    if (rows > ivf_shard_max_L()) return set_err(RII_ERR_INVALID, "rows=%d: at most %d output rows per query", rows, ivf_shard_max_L());
-    if (!e || B < 0 || (B > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_pos || !d_out_nloc || !d_out_counts)) ||
-        !d_glen || G < 1 || rank < 0 || rank >= G || (S > 0 && !d_tids) || S < 0)
-        return set_err(RII_ERR_INVALID, "bad arguments");
-    std::lock_guard<std::mutex> guard(e->mu);
-    HIP_TRY(hipSetDevice(e->device));
     const int64_t nlist = nlist_of(e);
+    RII_TRY(sync_lists(e));
+    const int32_t *src = e->d_list_len.as<int32_t>();
+    if (S_global) {      // a target set exists: this rank's share of it may be empty (then every list is empty here)
+        RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
+        src = e->s_flen.as<int32_t>();
+    }
+    HIP_TRY(hipMemcpyAsync(d_out_len, src, (size_t) nlist * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return RII_OK;
+}
+int ivf_shard_check(const rii_engine *e, int64_t B, int topk, int64_t S_global, int64_t L, int64_t N_global, int rows, int64_t *w_out)
+{
+    const int64_t nlist = nlist_of(e);
+    if (rows > ivf_shard_max_L()) return set_err(RII_ERR_INVALID, "rows=%d: at most %d output rows per query", rows, ivf_shard_max_L());
     if (nlist == 0) return set_err(RII_ERR_STATE, "no posting lists: call reconfigure() / set_coarse_centers() first");
     if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
     // the reference's preconditions, on the GLOBAL sizes (src/rii.h:252-253,271)
@@ -1956,33 +1961,58 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
     if (!ivf_shard_supported(e->M, e->Ks, (int) nlist, L, w))
         return set_err(RII_ERR_UNSUPPORTED, "sharded inverted index: L=%lld must be <= %d (the candidate keys of a query are sorted in LDS)",
                        (long long) L, ivf_shard_max_L());
-    if (B == 0) return RII_OK;
-    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
-    RII_TRY(begin_on(e, st));
-    int r = sync_lists(e);          // (end_on runs on every path below)
+    *w_out = w;
+    return RII_OK;
+}
+int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S, int64_t S_global, int64_t L,
+                     int64_t w, const int32_t *d_glen, int G, int rank, int rows, int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos,
+                     int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st)
+{
+    const int64_t nlist = nlist_of(e);
+    RII_TRY(sync_lists(e));
     const int32_t *pl_ids = e->d_pl_ids.as<int32_t>();
     const int32_t *list_len = e->d_list_len.as<int32_t>();
-    if (r == RII_OK && S_global != 0) {   // this rank's share of the target ids (possibly none: every list is then empty here)
-        r = filter_lists_by_targets(e, d_tids, S, st);
+    if (S_global != 0) {   // this rank's share of the target ids (possibly none: every list is then empty here)
+        RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
         pl_ids = e->s_fids.as<int32_t>();
         list_len = e->s_flen.as<int32_t>();
     }
     // nlist past the LDS limit: coarse order + cumulative counts of a query in global scratch, <= 256 MiB per launch
     const size_t per_q = ivf_shard_scratch_per_query((int) nlist);
     const int64_t step = per_q ? std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, ((int64_t) 256 << 20) / (int64_t) per_q)) : kMaxBatch;
-    if (r == RII_OK && per_q) r = e->s_big.ensure(per_q * (size_t) std::min<int64_t>(step, B));
-    for (int64_t b0 = 0; b0 < B && r == RII_OK; b0 += step) {
+    if (per_q) RII_TRY(e->s_big.ensure(per_q * (size_t) std::min<int64_t>(step, B)));
+    for (int64_t b0 = 0; b0 < B; b0 += step) {
         const int64_t cur = std::min<int64_t>(step, B - b0);
         const int64_t D = (int64_t) e->M * e->Ds;
-        r = build_lut(e, d_queries + b0 * D, cur, st, false, 1);
-        if (r != RII_OK) break;
+        RII_TRY(build_lut(e, d_queries + b0 * D, cur, st, false, 1));
         ScopedTimer t(e, "ivf_shard", st);
-        if (launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
-                             e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
-                             d_out_ids + b0 * rows, d_out_dists + b0 * rows, d_out_pos + b0 * rows,
-                             d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st) != hipSuccess)
-            r = set_err(RII_ERR_HIP, "ivf_shard_kernel launch failed");
+        HIP_TRY(launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
+                                 e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
+                                 d_out_ids + b0 * rows, d_out_dists + b0 * rows, d_out_pos + b0 * rows,
+                                 d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st));
     }
+    return RII_OK;
+}
+}  // namespace
+
+RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
+                                    int64_t S, int64_t S_global, int64_t L, int64_t N_global, const int32_t *d_glen, int G,
+                                    int rank, int rows, int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos,
+                                    int32_t *d_out_nloc, int64_t *d_out_counts, void *stream)
+{
+    if (rows <= 0) rows = topk + 1;
+    if (!e || B < 0 || (B > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_pos || !d_out_nloc || !d_out_counts)) ||
+        !d_glen || G < 1 || rank < 0 || rank >= G || (S > 0 && !d_tids) || S < 0)
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    int64_t w = 0;
+    RII_TRY(ivf_shard_check(e, B, topk, S_global, L, N_global, rows, &w));
+    if (B == 0) return RII_OK;
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    RII_TRY(begin_on(e, st));
+    const int r = ivf_shard_locked(e, d_queries, B, topk, d_tids, S, S_global, L, w, d_glen, G, rank, rows, d_out_ids, d_out_dists, d_out_pos,
+                                   d_out_nloc, d_out_counts, st);
     const std::string msg = g_err;
     const int r2 = end_on(e, st);
     if (r != RII_OK) { g_err = msg; return r; }
@@ -2348,6 +2378,99 @@ RII_API int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t i
         if ((r = comm_gather(c, r2p, c->gg.p, rec2, st)) != RII_OK) break;
         if (launch_linear_shard_replay(c->gg.p, G, nf, cap, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), st) != hipSuccess ||
             launch_tie_scatter(c->gg.p, G, nf, cap, topk, c->fsel.as<int32_t>(), c->r_i.as<int64_t>(), c->r_d.as<float>(), d_out_ids, d_out_dists, d_out_overflow, st) != hipSuccess)
+            r = set_err(RII_ERR_HIP, "replay launch failed");
+    } while (0);
+    const std::string msg = g_err;
+    const int r2 = end_on(e, st);
+    if (r != RII_OK) { g_err = msg; return r; }
+    return r2;
+}
+
+// Database sharding, inverted index: the protocol of ivfshard.hip driven from C (round 4; rii_amd/dist.py used to).  Coarse centres
+// replicated (rii_set_coarse_centers), posting lists over this rank's codes.  (1) the per-rank list lengths after the batch's target-id
+// filter are all-gathered (nlist int32 per rank); (2) every rank replays the reference's global walk on them and scores the candidates
+// it owns (k + 1 rows per query); (3) ONE all-gather of (position, global id, distance) rows, merged under (distance, position);
+// (4) queries whose k + 1 best distances tie exactly (d_out_tie) are redone with ALL candidates gathered (rows = L) and
+// std::partial_sort replayed on the rebuilt sequence.  top-1 is asynchronous; top-k reads one word per batch on the host.
+RII_API int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset, int64_t N_global, const float *d_queries, int64_t B,
+                                        int topk, const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t L,
+                                        int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, int32_t *d_out_tie, void *stream)
+{
+    if (!e || !c || B < 0 || S_local < 0 || S_global < 0 || (S_local > 0 && !d_tids_local) || id_offset < 0 || N_global < 1 ||
+        (B > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts)) || (S_global == 0 && S_local != 0))
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> gc(c->mu);
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    const int G = c->G;
+    const int k1 = topk + 1;
+    int64_t w = 0;
+    RII_TRY(ivf_shard_check(e, B, topk, S_global, L, N_global, k1, &w));
+    if ((int64_t) G * k1 > merge_topk_max_keys())
+        return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d rows per query exceeds %d keys", G, k1, merge_topk_max_keys());
+    if (B == 0) return RII_OK;
+    hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    const int64_t nlist = nlist_of(e);
+    const int D = e->M * e->Ds;
+    RII_TRY(begin_on(e, st));
+    int r = RII_OK;
+    do {
+        // (1) list lengths of every rank
+        if ((r = c->starts_dev.ensure((size_t) (G + 1) * (size_t) nlist * sizeof(int32_t) + 64)) != RII_OK) break;
+        int32_t *glen = c->starts_dev.as<int32_t>(), *mylen = glen + (size_t) G * nlist;
+        c->my_start = -1;                      // (the buffer is shared with the shard-offset cache of the linear call)
+        if ((r = ivf_list_lengths_locked(e, d_tids_local, S_local, S_global, mylen, st)) != RII_OK) break;
+        if ((r = comm_gather(c, mylen, glen, (size_t) nlist * sizeof(int32_t), st)) != RII_OK) break;
+        // (2) this rank's k + 1 best candidates per query
+        const size_t n1 = (size_t) B * k1;
+        if ((r = c->tmp_i.ensure(n1 * 8)) != RII_OK || (r = c->tmp_d.ensure(n1 * 4)) != RII_OK || (r = c->qf.ensure(n1 * 4 + (size_t) B * 4)) != RII_OK ||
+            (r = c->bound.ensure((size_t) B * 8)) != RII_OK) break;
+        int32_t *pos = c->qf.as<int32_t>(), *nloc = pos + n1;
+        int64_t *cnt = c->bound.as<int64_t>();
+        if ((r = ivf_shard_locked(e, d_queries, B, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, k1, c->tmp_i.as<int64_t>(),
+                                  c->tmp_d.as<float>(), pos, nloc, cnt, st)) != RII_OK) break;
+        // (3) one all-gather + merge under (distance, position), the global ids as payload
+        const size_t rec_bytes = merge_record_bytes(B, k1, 1);
+        if ((r = c->rec.ensure(rec_bytes)) != RII_OK || (r = c->gathered.ensure(rec_bytes * (size_t) G)) != RII_OK ||
+            (r = c->mi.ensure(n1 * 8)) != RII_OK || (r = c->md.ensure(n1 * 4)) != RII_OK || (r = c->r_i.ensure(n1 * 8)) != RII_OK ||
+            (r = c->tie.ensure((size_t) B * 4)) != RII_OK || (r = c->anyf.ensure(16)) != RII_OK) break;
+        int32_t *d_tie = d_out_tie ? d_out_tie : c->tie.as<int32_t>();
+        if (launch_ivf_pack(c->tmp_i.as<int64_t>(), pos, c->tmp_d.as<float>(), (int64_t) n1, id_offset, c->rec.p, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "pack failed"); break; }
+        if ((r = comm_gather(c, c->rec.p, c->gathered.p, rec_bytes, st)) != RII_OK) break;
+        if (hipMemsetAsync(c->anyf.p, 0, 8, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
+        // (keys = positions -> r_i, payload = ids -> mi; the merge's own OR of the flags goes to the second word: the finishing kernel
+        //  recomputes it over the queries that were found)
+        if (launch_merge_topk(c->gathered.p, G, B, k1, k1, 1, c->r_i.as<int64_t>(), c->md.as<float>(), c->mi.as<int64_t>(), st, nullptr, k1, d_tie,
+                              c->anyf.as<int32_t>() + 1) != hipSuccess ||
+            launch_ivf_finish(c->mi.as<int64_t>(), c->md.as<float>(), cnt, B, k1, topk, d_out_ids, d_out_dists, d_out_counts, d_tie, c->anyf.as<int32_t>(), st) != hipSuccess) {
+            r = set_err(RII_ERR_HIP, "merge failed");
+            break;
+        }
+        if (topk == 1) break;
+        int32_t h_any = 0;                     // the batch's one host read
+        if (hipMemcpyAsync(&h_any, c->anyf.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        if (!h_any) break;
+        // (4) exact ties among the k + 1 best: every rank sends ALL the candidates it owns for those queries, the sequence is rebuilt by
+        //     position and std::partial_sort (src/rii.h:312-313) replayed on it -- identically on every rank
+        std::vector<int32_t> h_tie((size_t) B), h_sel;
+        if (hipMemcpy(h_tie.data(), d_tie, (size_t) B * 4, hipMemcpyDeviceToHost) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        for (int64_t b = 0; b < B; ++b) if (h_tie[(size_t) b]) h_sel.push_back((int32_t) b);
+        const int nf = (int) h_sel.size(), rows = (int) L;
+        if (rows > ivf_shard_max_L()) { r = set_err(RII_ERR_UNSUPPORTED, "tie replay of the sharded inverted index: L=%lld must be <= %d", (long long) L, ivf_shard_max_L()); break; }
+        const size_t nr = (size_t) nf * rows, rec2 = merge_record_bytes(nf, rows, 1);
+        if ((r = c->fsel.ensure((size_t) nf * 4)) != RII_OK || (r = c->rec2.ensure(rec2 + (size_t) nf * D * 4 + 64)) != RII_OK || (r = c->gg.ensure(rec2 * (size_t) G)) != RII_OK ||
+            (r = c->tmp_i.ensure(nr * 8)) != RII_OK || (r = c->tmp_d.ensure(nr * 4)) != RII_OK || (r = c->qf.ensure(nr * 4 + (size_t) nf * 4)) != RII_OK ||
+            (r = c->bound.ensure((size_t) nf * 8)) != RII_OK || (r = c->r_i.ensure((size_t) nf * topk * 8)) != RII_OK || (r = c->r_d.ensure((size_t) nf * topk * 4)) != RII_OK) break;
+        float *qsel = reinterpret_cast<float *>(c->rec2.as<unsigned char>() + ((rec2 + 63) & ~(size_t) 63));
+        if (hipMemcpyAsync(c->fsel.p, h_sel.data(), (size_t) nf * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        if (launch_gather_rows(d_queries, c->fsel.as<int32_t>(), nf, D, qsel, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "launch failed"); break; }
+        int32_t *fpos = c->qf.as<int32_t>(), *fnloc = fpos + nr;
+        if ((r = ivf_shard_locked(e, qsel, nf, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, rows, c->tmp_i.as<int64_t>(), c->tmp_d.as<float>(),
+                                  fpos, fnloc, c->bound.as<int64_t>(), st)) != RII_OK) break;
+        if (launch_ivf_pack(c->tmp_i.as<int64_t>(), fpos, c->tmp_d.as<float>(), (int64_t) nr, id_offset, c->rec2.p, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "pack failed"); break; }
+        if ((r = comm_gather(c, c->rec2.p, c->gg.p, rec2, st)) != RII_OK) break;
+        if (launch_shard_replay(c->gg.p, G, nf, rows, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), st) != hipSuccess ||
+            launch_scatter_rows(c->fsel.as<int32_t>(), nf, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), d_out_ids, d_out_dists, st) != hipSuccess)
             r = set_err(RII_ERR_HIP, "replay launch failed");
     } while (0);
     const std::string msg = g_err;

@@ -322,4 +322,10 @@ hipError_t launch_tie_scatter(const void *d_gg, int G, int nf, int cap, int topk
 hipError_t launch_copy_cols(const int64_t *d_in_i, const float *d_in_d, int64_t B, int in_stride, int out_stride, int ncols, int64_t *d_out_i,
                             float *d_out_d, hipStream_t st);
 hipError_t launch_fill_pad(int64_t *d_ids, float *d_d, int64_t n, hipStream_t st);
+hipError_t launch_ivf_pack(const int64_t *d_ids, const int32_t *d_pos, const float *d_d, int64_t n, int64_t id_offset, void *d_rec, hipStream_t st);
+hipError_t launch_ivf_finish(const int64_t *d_mi, const float *d_md, const int64_t *d_cnt, int64_t B, int k1, int topk, int64_t *d_out_ids,
+                             float *d_out_d, int64_t *d_out_cnt, int32_t *d_tie, int32_t *d_any, hipStream_t st);
+hipError_t launch_gather_rows(const float *d_src, const int32_t *d_fsel, int nf, int D, float *d_dst, hipStream_t st);
+hipError_t launch_scatter_rows(const int32_t *d_fsel, int nf, int k, const int64_t *d_r_i, const float *d_r_d, int64_t *d_out_i, float *d_out_d,
+                               hipStream_t st);
 }  // namespace riiamd

@@ -559,6 +559,23 @@ class DbShardedIndex(object):
         S_global = 0 if target_ids is None else len(target_ids)
         N_global = self.total_codes()
         dev = _comm_device()
+        if _is_device_engine(self.engine) and _use_c_comm() and w * k1 <= self.MERGE_MAX_KEYS and self.MERGE_MAX_KEYS >= 8192:
+            # ONE library call (round 4): list lengths -> all-gather -> the shard's walk -> all-gather -> merge (+ the exact-tie replay)
+            dev = torch.device("cuda", torch.cuda.current_device())
+            comm = get_comm(self.group)
+            with _engine_stream() as sh:
+                t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).to(dev)
+                q = _as_tensor(Q, torch.float32, dev)
+                ids = torch.empty((B, topk), dtype=torch.int64, device=dev)
+                d = torch.empty((B, topk), dtype=torch.float32, device=dev)
+                cnt = torch.empty((B,), dtype=torch.int64, device=dev)
+                tie = torch.empty((B,), dtype=torch.int32, device=dev)
+                comm.query_ivf_dbsharded_dev(self.engine, self.start, N_global, q.data_ptr(), B, topk, 0 if t is None else t.data_ptr(),
+                                             0 if t is None else t.numel(), S_global, L, ids.data_ptr(), d.data_ptr(), cnt.data_ptr(),
+                                             tie.data_ptr(), sh)
+                self.last_tie_flags = tie.bool()
+            _handoff(self.last_tie_flags)
+            return _handoff(ids, d, cnt)
         if _is_device_engine(self.engine):
             with _engine_stream() as sh:
                 t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).to(dev)

@@ -91,6 +91,17 @@ int main(void)
             if (got_c[b] != want_c[b]) { fprintf(stderr, "ivf count differs at %d\n", b); return 6; }
             if (!same_rows(got_i + b * topk, got_d + b * topk, want_i + b * topk, want_d + b * topk, (int) want_c[b], "qsharded ivf")) return 6;
         }
+        /* inverted index, database-sharded (one shard = the whole database at world size 1: list lengths all-gathered, the global
+         * walk replayed, rows merged by (distance, position), exact ties replayed from all candidates) */
+        CHECK(rii_query_ivf_dbsharded_dev(e, c, 0, N, dq, B, topk, NULL, 0, 0, 2000, d_ids, d_d, d_cnt, d_tie, NULL));
+        CHECK(rii_synchronize(e));
+        HCHECK(hipMemcpy(got_i, d_ids, sizeof(int64_t) * B * topk, hipMemcpyDeviceToHost));
+        HCHECK(hipMemcpy(got_d, d_d, sizeof(float) * B * topk, hipMemcpyDeviceToHost));
+        HCHECK(hipMemcpy(got_c, d_cnt, sizeof(int64_t) * B, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) {
+            if (got_c[b] != want_c[b]) { fprintf(stderr, "dbsharded ivf count differs at %d\n", b); return 7; }
+            if (!same_rows(got_i + b * topk, got_d + b * topk, want_i + b * topk, want_d + b * topk, (int) want_c[b], "dbsharded ivf")) return 7;
+        }
     }
     rii_comm_destroy(c);
     rii_destroy(e);
