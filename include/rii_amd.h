@@ -260,6 +260,8 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *   "scan_mode"        1 = 8-bit filter + exact re-rank [default], 0 = exhaustive fp32 scan only
  *   "scan_mx"          1 = the M = 16 / 32 / 64, Ks = 256 filter sums its table bytes on the matrix cores (fscan_mx_kernel) [default],
  *                      0 = on the vector ALU (fscan_kernel)
+ *   "scan_pipe"        the top-1 scan of M = 16 (one tile per block) / 32 with unsigned table bytes judges a group's sums one group late,
+ *                      behind the next group's matrix instructions: 1 = for batches of at most 128 queries [default], 2 = always, 0 = never
  *   "scan_dual"        M = 16: 1 = two 16-query tiles per scan block (fscan_mx_dual_kernel) [default], 0 = one
  *   "scan_order"       1 = the shapes without the rotated table layout scan an LDS-friendly permutation of the codes [default], 0 = id order
  *   "scan_chunks"      chunks of the code array per query tile (grid.x of the scan kernels); 0 = automatic [default]

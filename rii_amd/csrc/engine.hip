@@ -204,6 +204,13 @@ struct rii_engine : ScratchSet {
     // (rii_query_linear_dev_to_host: B = 128 0.0901 vs 0.0938 ms per synchronous call).
     int fused_rerank = 0;
     int small_topk = 1;         // option "small_topk": a small batch over a small index in one launch after the tables (smalltopk.hip)
+    // option "scan_pipe" (round 4): top-1 of M = 16 (one tile per block) / 32 with unsigned table bytes judges a group's sums one group late,
+    // behind the next group's matrix instructions (fscan_mx_kernel<.., PIPE>: no `s_nop 7` between the last v_smfmac of a group and its
+    // compares).  Same-box A/B (tools/opt_ab.py scan_pipe 0 1, profiles/r04_scan_pipe_ab.json): scan kernel B = 64 0.0551 -> 0.0540 ms, B = 128
+    // 0.0602 -> 0.0576, B = 256 0.0916 -> 0.0914, B = 512 +0.3 %, B = 1024 0.3214 -> 0.3228 (+0.4 %), B = 4096 +0.5 %: with many tiles the other
+    // waves of the SIMD already fill the matrix pipe's latency and the longer-lived accumulators cost a little.  1 = batches of at most 128
+    // queries [default], 2 = always, 0 = never
+    int scan_pipe = 1;
     int scan_dual = 1;          // option "scan_dual": M = 16 keeps two 16-query tiles per scan block (fscan_mx_dual_kernel)
     int64_t scan_cov = 0;       // codes [0, scan_cov) are final (whole windows)
     int64_t scan_N = -1;        // N the order was last completed for
@@ -700,7 +707,7 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                                          (int) B, chunks, len, e->s_cand.as<unsigned long long>(),
                                          e->s_cand_cnt.as<unsigned int>(), cap, 0, nullptr, nullptr,
                                          e->s_gthr.as<uint32_t>(), 1, e->scan_mx, st, e->qlut_quarter ? 1 : 0, e->scan_dual, e->qlut_levels,
-                                         tail_rr ? &tl : nullptr));
+                                         tail_rr ? &tl : nullptr, e->scan_pipe == 2 || (e->scan_pipe == 1 && B <= 128)));
                 }
                 if (tail_rr) return RII_OK;
                 ScopedTimer t(e, "rerank", st);
@@ -2552,6 +2559,9 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         RII_TRY(begin_exclusive(e));
         e->scan_mx = value ? 1 : 0;
         e->fc_cov = 0;                  // the formatted lookups are laid out per kernel
+    } else if (k == "scan_pipe") {
+        if (value < 0 || value > 2) return set_err(RII_ERR_INVALID, "scan_pipe must be 0 (never), 1 (batches <= 128) or 2 (always)");
+        e->scan_pipe = (int) value;
     } else if (k == "scan_dual") {
         e->scan_dual = value ? 1 : 0;
     } else if (k == "slice_topk") {
@@ -2600,6 +2610,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "lanes") return e->lanes;
     if (k == "scan_mx") return e->scan_mx;
     if (k == "scan_dual") return e->scan_dual;
+    if (k == "scan_pipe") return e->scan_pipe;
     if (k == "small_topk") return e->small_topk;
     if (k == "fused_rerank") return e->fused_rerank;
     if (k == "host_zero_copy") return e->host_zero_copy;

@@ -17,6 +17,7 @@
 #include "rii_device.h"
 #include <float.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace riiamd {
 
@@ -928,6 +929,7 @@ struct FsArgs {
     int quarter = 0;               // fscan_mx_kernel: qlut holds quarter tables [tile][quarter][m][ks] u32 (qlut_fused_kernel)
     int dual = 0;                  // M = 16: two 16-query tiles per block (fscan_mx_dual_kernel)
     int bias = 0;                  // fscan_mx_*: initial value of the accumulators (128 M for tables of signed bytes = 255 levels, else 0)
+    int pipe = 1;                  // fscan_mx_kernel MODE 0, unsigned table bytes: 1 = judge one group late (PIPE instances; engine option scan_pipe)
     FsTail tail;                   // fscan_mx_* MODE 0, TAIL instances: the last chunk-block of a tile re-ranks the tile's queries (round 4)
 };
 
@@ -2014,10 +2016,11 @@ __device__ __forceinline__ bool fs_tail_arrive(fs_kernarg_t pa, uint32_t *s_word
 constexpr int kFsMxSeg = 256;        // MODE 1 segments per chunk and query: (wave, column) pairs
 
 // grid = (chunks, ceil(B / 16)), 1024 threads.  Thresholds: 16 words in LDS, candidate <=> a < thr (thr = bound + slack + 1).
-template <int T, int MODE, int QR = 16, bool TAIL = false>
+template <int T, int MODE, int QR = 16, bool TAIL = false, bool PIPE = false>
 __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
 {
     static_assert(!TAIL || (MODE == 0 && QR == 16), "the fused re-rank is the top-1 pass of the 16-byte-row shapes");
+    static_assert(!PIPE || (MODE == 0 && QR == 16), "the one-group-late judge is the top-1 pass of the 16-byte-row shapes (unsigned table bytes)");
     static_assert((QR == 16 && (T == 4 || T == 8)) || (QR == 8 && T == 16), "M = 16 / 32 with 16-byte rows, M = 64 with 8-byte rows");
     constexpr int M = 4 * T;
     typedef typename FsMxW<T>::V W;
@@ -2228,36 +2231,85 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
             const uint32_t thr_addr = (uint32_t) (lut_bytes + 16 * gq);       // s_thr + 4 * gq as an LDS address (dynamic LDS starts at 0)
             v4i_t thr;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(thr) : "v"(thr_addr));     // (not a compiler-visible load: it would be waited for inside the loop)
-            for (int k = 0; k < ntrip; ++k) {
-                const int it = trip_of(k);
-                const W *pn = trip_ptr(k + 1), *pnn = trip_ptr(k + 2);
-                const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;     // positions fit 32 bits (the records hold 32)
-                v4i_t acc;
-                constexpr int S = 64 * (int) sizeof(W);                // bytes between the lookups of consecutive groups
-                fs_mx_vmwait<3>(q[2]);
-                fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
-                acc = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx, zero4);   // ... refilled with group 2's rows
-                fs_mx_load<2 * S>(q[2], pn);
-                if (MODE == 1) take_min(acc); else judge(acc, thr, n);
-                fs_mx_vmwait<3>(q[3]);
-                fs_mx_wait<T>(rb);                                    // group 1
-                acc = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx, zero4);
-                fs_mx_load<3 * S>(q[3], pn);
-                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
-                // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
-                // of old and new words is a valid set of thresholds (each word is an upper bound at all times)
-                if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thr) : "v"(thr_addr));
-                fs_mx_vmwait<3>(q[0]);
-                fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
-                acc = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx, zero4);   // next trip's group 0
-                fs_mx_load<0>(q[0], pnn);
-                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
-                fs_mx_vmwait<3>(q[1]);
-                fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
-                acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx, zero4);
-                fs_mx_load<S>(q[1], pnn);
-                if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
-                adopt(false);
+            // Round 4: the sums of a group are judged ONE GROUP LATER, behind the matrix instructions of the next group -- a vector
+            // compare right behind the last v_smfmac of its own group waits out the matrix pipe's result latency (the compiler pads it
+            // with `s_nop 7`: ~11 idle issue cycles per group and wave, 6 % of a wave's time per group).  Two accumulator sets alternate;
+            // the registers come from the zero accumulator, which is a literal when the table bytes are unsigned (bias == 0: 63 / 127
+            // levels); signed tables (255 levels: bias = 128 M) keep the in-order judge.  Any threshold read later than before is still
+            // an upper bound, so the candidates stay a superset of what the proof needs.
+            if constexpr (PIPE) {
+                auto hot = [&](auto zlit) {
+                    constexpr bool ZLIT = decltype(zlit)::value;
+                    v4i_t zero_l = {0, 0, 0, 0};
+                    const v4i_t &zz = ZLIT ? zero_l : zero4;
+                    v4i_t accp = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};      // (nothing pending: never below a threshold)
+                    uint32_t np = 0u;
+                    for (int k = 0; k < ntrip; ++k) {
+                        const int it = trip_of(k);
+                        const W *pn = trip_ptr(k + 1), *pnn = trip_ptr(k + 2);
+                        const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;     // positions fit 32 bits (the records hold 32)
+                        constexpr int S = 64 * (int) sizeof(W);                // bytes between the lookups of consecutive groups
+                        auto settle = [&](const v4i_t &a, uint32_t nn) { if (MODE == 1) take_min(a); else judge(a, thr, nn); };
+                        fs_mx_vmwait<3>(q[2]);
+                        fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
+                        const v4i_t acc0 = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx, zz);   // ... refilled with group 2's rows
+                        fs_mx_load<2 * S>(q[2], pn);
+                        if constexpr (ZLIT) settle(accp, np); else settle(acc0, n);
+                        fs_mx_vmwait<3>(q[3]);
+                        fs_mx_wait<T>(rb);                                    // group 1
+                        const v4i_t acc1 = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx, zz);
+                        fs_mx_load<3 * S>(q[3], pn);
+                        if constexpr (ZLIT) settle(acc0, n); else settle(acc1, n + 16);
+                        // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
+                        // of old and new words is a valid set of thresholds (each word is an upper bound at all times)
+                        if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thr) : "v"(thr_addr));
+                        fs_mx_vmwait<3>(q[0]);
+                        fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
+                        const v4i_t acc2 = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx, zz);   // next trip's group 0
+                        fs_mx_load<0>(q[0], pnn);
+                        if constexpr (ZLIT) settle(acc1, n + 16); else settle(acc2, n + 32);
+                        fs_mx_vmwait<3>(q[1]);
+                        fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
+                        const v4i_t acc3 = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx, zz);
+                        fs_mx_load<S>(q[1], pnn);
+                        if constexpr (ZLIT) { settle(acc2, n + 32); accp = acc3; np = n + 48; } else settle(acc3, n + 48);
+                        adopt(false);
+                    }
+                    if constexpr (ZLIT) { if (MODE == 1) take_min(accp); else judge(accp, thr, np); }
+                };
+                hot(std::true_type{});
+            } else {
+                for (int k = 0; k < ntrip; ++k) {
+                    const int it = trip_of(k);
+                    const W *pn = trip_ptr(k + 1), *pnn = trip_ptr(k + 2);
+                    const uint32_t n = (uint32_t) c_begin + (uint32_t) it * kFsThreads + wave * 64 + col;     // positions fit 32 bits (the records hold 32)
+                    v4i_t acc;
+                    constexpr int S = 64 * (int) sizeof(W);                // bytes between the lookups of consecutive groups
+                    fs_mx_vmwait<3>(q[2]);
+                    fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
+                    acc = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx, zero4);   // ... refilled with group 2's rows
+                    fs_mx_load<2 * S>(q[2], pn);
+                    if (MODE == 1) take_min(acc); else judge(acc, thr, n);
+                    fs_mx_vmwait<3>(q[3]);
+                    fs_mx_wait<T>(rb);                                    // group 1
+                    acc = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx, zero4);
+                    fs_mx_load<3 * S>(q[3], pn);
+                    if (MODE == 1) take_min(acc); else judge(acc, thr, n + 16);
+                    // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
+                    // of old and new words is a valid set of thresholds (each word is an upper bound at all times)
+                    if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thr) : "v"(thr_addr));
+                    fs_mx_vmwait<3>(q[0]);
+                    fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
+                    acc = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx, zero4);   // next trip's group 0
+                    fs_mx_load<0>(q[0], pnn);
+                    if (MODE == 1) take_min(acc); else judge(acc, thr, n + 32);
+                    fs_mx_vmwait<3>(q[1]);
+                    fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
+                    acc = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx, zero4);
+                    fs_mx_load<S>(q[1], pnn);
+                    if (MODE == 1) take_min(acc); else judge(acc, thr, n + 48);
+                    adopt(false);
+                }
             }
             fs_mx_wait<0>(ra);            // the rows and lookups fetched past the last trip are never used, but must have landed
             fs_mx_wait<0>(rb);
@@ -2700,14 +2752,14 @@ template <int MODE, bool TAIL = false> static hipError_t launch_fscan_mx_dual_t(
     return hipGetLastError();
 }
 
-template <int T, int MODE, int QR = 16, bool TAIL = false> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
+template <int T, int MODE, int QR = 16, bool TAIL = false, bool PIPE = false> static hipError_t launch_fscan_mx_t(const FsArgs &a, int chunks, int tiles, hipStream_t st)
 {
     const size_t tab = (size_t) a.M * a.Ks * QR + 64 + (size_t) QR * 8 + 64;
     FsArgs b = a;
     b.lcap = (MODE != 0) ? 0 : (int) std::min<size_t>(128, (kFsLdsBytes - tab) / ((size_t) QR * 8));
     size_t smem = tab + (size_t) QR * 8 * b.lcap;
     if (TAIL) smem = std::max(smem, kFsTailLds);
-    auto kern = fscan_mx_kernel<T, MODE, QR, TAIL>;
+    auto kern = fscan_mx_kernel<T, MODE, QR, TAIL, PIPE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     launch_timed(kern, dim3(chunks, tiles), dim3(kFsThreads), smem, st, b);
@@ -2725,6 +2777,12 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
                 if (a.M == 16) return launch_fscan_mx_t<4, 0, 16, true>(a, chunks, tiles, st);
                 if (a.M == 32) return launch_fscan_mx_t<8, 0, 16, true>(a, chunks, tiles, st);
                 return hipErrorInvalidValue;
+            }
+            // unsigned table bytes (63 / 127 levels): the sums of a group are judged one group late, behind the next group's matrix
+            // instructions (PIPE); signed bytes (255 levels: accumulators start at 128 M) keep the in-order judge
+            if (a.bias == 0 && a.pipe) {
+                if (a.M == 16 && !a.dual) return launch_fscan_mx_t<4, 0, 16, false, true>(a, chunks, tiles, st);
+                if (a.M == 32) return launch_fscan_mx_t<8, 0, 16, false, true>(a, chunks, tiles, st);
             }
         }
         if (a.M == 16 && a.dual) return launch_fscan_mx_dual_t<MODE>(a, chunks, st);
@@ -2751,7 +2809,7 @@ template <int MODE> static hipError_t launch_fscan_mode(const FsArgs &a, int chu
 hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, const uint8_t *d_qlut,
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
-                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter, int dual, int levels, const FsTail *tail)
+                        uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter, int dual, int levels, const FsTail *tail, int pipe)
 {
     // d_codes: formatted lookups (launch_fcodes_format, same `mx`) for fs_rot_supported shapes, the plain codes otherwise
     if (B == 0 || n_codes == 0) return hipSuccess;
@@ -2760,6 +2818,7 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
     a.quarter = quarter;
     a.dual = ((dual & 1) && mx && M == 16 && rot) ? 1 : 0;
     a.bias = levels > 127 ? 128 * M : 0;
+    a.pipe = pipe;
     if (tail && tail->queries) {
         if (mode != 0 || !fscan_tail_supported(M, Ks, tail->Ds, mx)) return hipErrorInvalidValue;
         a.tail = *tail;

@@ -184,7 +184,7 @@ hipError_t launch_fscan(const uint8_t *d_codes, int64_t n_codes, int M, int Ks, 
                         const int32_t *d_slack, int B, int chunks, int64_t chunk_len, unsigned long long *d_cand,
                         unsigned int *d_cand_count, int cap, int mode, uint16_t *d_segmin, const uint32_t *d_thr16,
                         uint32_t *d_gthr, int sample_stride, int mx, hipStream_t st, int quarter = 0, int dual = 0, int levels = 63,
-                        const FsTail *tail = nullptr);
+                        const FsTail *tail = nullptr, int pipe = 1);
 // queries per block of the filter scan: 32 when the M = 16 shape runs two tiles per block (option scan_dual), else fastscan_rows()
 int fscan_queries_per_block(int M, int Ks, int mx, int dual);
 int fastscan_max_sum(int M, int levels = 0);      // largest quantised sum: M x levels (0 = the default 63)

@@ -835,6 +835,15 @@ def test_matrix_core_scan_equals_vector_scan(M, Ds):
         g.set_option("fused_tables", 1)
         g.set_option("scan_dual", 1)
         g.set_option("table_levels", 127)
+        g.set_option("scan_pipe", 0)                 # round 4: the in-order judge against the one-group-late judge (default) ...
+        out.append(g.query_linear_batch(qs, topk, tids))
+        g.set_option("scan_dual", 0)                 # ... also for M = 16 with one tile per block
+        out.append(g.query_linear_batch(qs, topk, tids))
+        g.set_option("scan_pipe", 2)
+        out.append(g.query_linear_batch(qs, topk, tids))
+        g.set_option("scan_dual", 1)
+        out.append(g.query_linear_batch(qs, topk, tids))
+        g.set_option("scan_pipe", 1)
         a = out[0]
         for o_ in out[1:]:
             assert np.array_equal(a[0], o_[0]) and np.array_equal(a[1], o_[1]), (topk, g.N)
