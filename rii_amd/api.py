@@ -167,13 +167,13 @@ class Rii(object):
         return np.array(ids, np.int64), np.array(dists)
 
     def query_batch(self, Q, topk=1, L=None, target_ids=None, sort_target_ids=True, method="auto"):
-        """B queries in one call (Q float32 [B, D]); row b equals `query(Q[b], ...)`.
+        """B queries in one call (Q float32 [B, D]).  Row b equals `query(Q[b], ..., method=m)` for the ONE method m the whole batch
+        resolves to: with method="linear" / "ivf" that is the method asked for; with method="auto" the batch picks it from the BATCHED
+        crossover model (`threshold_batch`, fitted by `reconfigure` / `add_configure` -- never here: a query call does not time
+        anything or mutate the index; an index unpickled from a state without it falls back to `threshold`), which can differ from what
+        a single `query` call would pick for the same arguments -- and since the inverted index is approximate, so can the rows.
         Returns (ids int64 [B, topk], dists float32 [B, topk], counts int64 [B]) with counts[b] in {topk, 0}."""
         _require(Q.ndim == 2 and Q.dtype == np.float32, "Q must be float32 (B, D)")
-        if method == "auto" and getattr(self, "threshold_batch", None) is None and self.threshold is not None and \
-                hasattr(self.impl_cpp, "query_linear_batch"):
-            probes = self.fine_quantizer.decode(self.codes[:min(256, self.N)])
-            self.threshold_batch = CrossoverModel(self, probes, batched=True).fit()
         plan = _SearchPlan(self, topk, L, target_ids, sort_target_ids, method, batched=True)
         Qv = self._rotated(Q)
         if plan.method == "linear":
