@@ -281,8 +281,6 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *                      of queries [default], 2 = always, 0 = never
  *   "ivf_fused"        1 = one fused launch per batch for the inverted index with per-query exact fallback [default], 0 = the
  *                      std::partial_sort emulation kernels for every query
- *   "ivf_wide_block"   1 = top-1, Ds = 4, Ks = 256 inverted-index queries run 512 threads per query at <= 64 registers (8 waves per SIMD), 0 = 256
- *                      threads [see INTEGRATION.md for the measured default]
  *   "ivf_inline_exact" 1 = a block of the fused kernel that flags its own query replays it itself [default], 0 = flag-gated exact
  *                      kernels behind every batch
  *   "ivf_force_exact"  tests / measurement: 1 = every query of the fused path is flagged [0]

@@ -154,8 +154,6 @@ struct rii_engine : ScratchSet {
     // profiles/r03_levels_ab.json): 63 -> 124 candidates per query, 127 -> 40, 255 -> 20; the scan itself is 3 % SLOWER with 255 (signed
     // bytes: more switching in the matrix core under a power-limited clock), so 127 -- non-negative bytes, no bias -- is the default.
     int table_levels = 127;
-    int ivf_wide_block = 0;     // option "ivf_wide_block" (round 4): top-1, Ds = 4, Ks = 256 inverted-index batches run 512 threads per query at <= 64 registers
-                                // (ivf_top1_w512_kernel: 8 waves per SIMD instead of 4)
     int ivf_inline_exact = 1;   // option "ivf_inline_exact" (round 4): 1 = a block of ivf_fused_kernel that flags its query (tied coarse distances, tail
                                 // walk, ties at the cut) replays it itself; 0 = the flag-gated exact kernels behind every batch (round 3)
     int fused_tables = 1;       // option "fused_tables": 1 = qlut_fused_kernel + table-free top-1 re-rank (round 3), 0 = the two-launch tile path
@@ -1056,7 +1054,6 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     const bool defer = fused && d_flag_defer && bc >= B;       // one launch group: the caller inspects the flags itself
     if (defer) p.flag = d_flag_defer;
     p.sel_cap = ivf_fused_sel_cap((int) nlist, w);
-    p.w512 = e->ivf_wide_block;
     p.force_flag = e->ivf_force_exact;
     p.flag_list = nullptr; p.nflag = nullptr;
     if (fused) {
@@ -2546,8 +2543,6 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->scan_mode = (int) value;
     } else if (k == "ivf_fused") {
         e->ivf_fused = value ? 1 : 0;
-    } else if (k == "ivf_wide_block") {
-        e->ivf_wide_block = value ? 1 : 0;
     } else if (k == "ivf_inline_exact") {
         e->ivf_inline_exact = value ? 1 : 0;
     } else if (k == "ivf_force_exact") {
@@ -2609,7 +2604,6 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_fused") return e->ivf_fused;
     if (k == "ivf_force_exact") return e->ivf_force_exact;
     if (k == "ivf_inline_exact") return e->ivf_inline_exact;
-    if (k == "ivf_wide_block") return e->ivf_wide_block;
     if (k == "fused_tables") return e->fused_tables;
     if (k == "table_levels") return e->table_levels;
     if (k == "scan_order") return e->scan_order;

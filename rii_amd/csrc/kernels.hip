@@ -1307,230 +1307,6 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     }
 }
 
-// ===================================================================================================
-// Round 4: the common inverted-index case -- top-1, Ds = 4, Ks = 256, M = 16 / 32 / 48 / 64, nlist <= 4096, w <= 32 -- with 512 threads
-// per query and at most 64 registers per thread.  ivf_fused_kernel is a chain of dependent phases per block and needs 101 - 109
-// registers, i.e. 4 waves per SIMD: with four 256-thread blocks on a CU (38 KiB of LDS each) the vector ALU is busy 39 % of the time and
-// the waves are parked in s_waitcnt 46 % (profiles/r04_ivf_pmc.json).  Here a block has eight waves and a thread half the entries,
-// lists and candidates; load batches are 8 deep instead of 16 (32 registers) so that four blocks = 32 waves = 8 per SIMD fit a CU:
-// twice the waves to fill the same memory round trips.  Same arithmetic, same selection rule, same stop rule, same hand-over of flagged
-// queries (inline replay or flag list) as ivf_fused_kernel<true, true>; results are identical.
-// ===================================================================================================
-constexpr int kW512 = 512;
-__global__ __launch_bounds__(kW512, 8) void ivf_top1_w512_kernel(IvfParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int M = p.M, MK = M * 256;
-    float *lds = reinterpret_cast<float *>(smem);
-    unsigned char *base = smem + (size_t) MK * 4;
-    constexpr int SC = kFusedMaxW + 2;
-    unsigned long long *s_sel = reinterpret_cast<unsigned long long *>(base);            // [SC]
-    unsigned long long *s_red = s_sel + SC;                                              // [2]
-    int *s_cum = reinterpret_cast<int *>(s_red + 2);                                     // [SC + 2]
-    int *s_misc = s_cum + (SC + 2);                                                      // [4]
-    int *s_len = s_misc + 4;                                                             // [SC + 2]
-    int *s_poff = s_len + (SC + 2);                                                      // [SC + 2]
-    unsigned long long *s_wsel = reinterpret_cast<unsigned long long *>(
-        smem + ((reinterpret_cast<unsigned char *>(s_poff + (SC + 2)) - smem + 7) & ~(size_t) 7));     // [8][kFusedMaxW + 1]
-    float *s_dist = reinterpret_cast<float *>(s_wsel + 8 * (kFusedMaxW + 1));            // [nlist] coarse scores
-    const int64_t bl = blockIdx.x;
-    const int tid = threadIdx.x, nlist = p.nlist, w = (int) p.w;
-    if (bl == 0 && tid == 0 && p.nflag_next) *p.nflag_next = 0;
-    auto publish = [&]() {
-        if (p.host_flag) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __threadfence_system();
-                __hip_atomic_store(&p.host_flag[p.b0 + bl], p.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    };
-    // ---- table: thread t owns entry ks = t & 255 of the subspaces m = (t >> 8), (t >> 8) + 2, ...: the subspace is wave-uniform ----
-    {
-        const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
-        const float4 *q4 = reinterpret_cast<const float4 *>(p.queries + (p.b0 + bl) * (int64_t) (M * 4));
-        const int ks = tid & 255, half = tid >> 8;
-        float4 *s_q = reinterpret_cast<float4 *>(smem + p.q_host_off);
-        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.q_host_off && tid < M) qv = q4[tid];                      // the query lives in the caller's pinned host block: fetched once
-        for (int m0 = half; m0 < M; m0 += 16) {
-            float4 cv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) cv[u] = (m0 + 2 * u < M) ? cw4[(m0 + 2 * u) * 256 + ks] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.q_host_off && m0 == half) {
-                if (tid < M) s_q[tid] = qv;
-                __syncthreads();
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (m0 + 2 * u < M) lds[(m0 + 2 * u) * 256 + ks] = fvec_l2sqr_ds4v(p.q_host_off ? s_q[m0 + 2 * u] : q4[m0 + 2 * u], cv[u]);
-        }
-    }
-    __syncthreads();
-    const int MQ = M >> 4;
-    // ---- coarse scores: two centres per thread and trip, whole codes in registers before the first lookup ----
-    for (int c0 = tid; c0 < nlist; c0 += 2 * kW512) {
-        uint4 cv[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = c0 + u * kW512;
-            const uint4 *cp = reinterpret_cast<const uint4 *>(p.centers + (size_t) (c < nlist ? c : 0) * M);
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
-                if (qd < MQ) cv[u][qd] = cp[qd];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = c0 + u * kW512;
-            if (c < nlist) s_dist[c] = adc_lds_wide(lds, cv[u], MQ, 256);
-        }
-    }
-    __syncthreads();
-    // ---- the w + 1 smallest (dist, list id) keys: every wave extracts its own `rounds` smallest (DPP minima), wave 0 merges 8 x rounds ----
-    const int rounds = (w + 1 < nlist) ? w + 1 : nlist;
-    const int wv = tid >> 6, ln = tid & 63;
-    {
-        unsigned long long last = 0ull;
-        for (int r = 0; r < rounds; ++r) {
-            unsigned long long best = ~0ull;
-            for (int c = tid; c < nlist; c += kW512) {
-                const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c;
-                if ((r == 0 || key > last) && key < best) best = key;
-            }
-            last = wave_min_u64(best);
-            if (ln == 0) s_wsel[wv * (kFusedMaxW + 1) + r] = last;
-        }
-    }
-    __syncthreads();
-    if (wv == 0) {
-        unsigned long long cand[5];                                        // 8 x 33 = 264 keys at most: up to five per lane
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int i = ln + 64 * u;
-            cand[u] = i < 8 * rounds ? s_wsel[(i / rounds) * (kFusedMaxW + 1) + (i % rounds)] : ~0ull;
-        }
-        unsigned long long prev = 0ull;
-        for (int r = 0; r < rounds; ++r) {
-            unsigned long long best = ~0ull;
-#pragma unroll
-            for (int u = 0; u < 5; ++u)
-                if ((r == 0 || cand[u] > prev) && cand[u] < best) best = cand[u];
-            prev = wave_min_u64(best);
-            if (ln == 0) s_sel[r] = prev;
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < (w < nlist ? w : nlist); c += kW512) {
-        const int no = (int) (s_sel[c] & 0xffffffffu);
-        s_len[c] = p.list_len[no];
-        s_poff[c] = (int) p.pl_off[no];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int flag = p.force_flag;
-        for (int r = 0; r + 1 < rounds; ++r)
-            if ((s_sel[r] >> 32) == (s_sel[r + 1] >> 32)) flag = 1;         // exactly tied coarse distances
-        long long cnt = 0;
-        int nv = 0;
-        bool finished = false;
-        const int wl = w < nlist ? w : nlist;
-        for (int c = 0; c < wl && !flag; ++c) {
-            const long long len = s_len[c];
-            s_cum[c] = (int) cnt;
-            if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
-            cnt += len;
-            if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
-        }
-        if (!finished) flag = 1;                                             // tail walk / empty return: exact path
-        s_cum[nv] = (int) cnt;
-        s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = flag;
-        p.flag[bl] = p.inl_scratch ? 0 : flag;
-        if (flag && p.flag_list && !p.inl_scratch) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
-        if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
-        s_red[1] = ~0ull;
-    }
-    __syncthreads();
-    if (s_misc[2]) {
-        if (p.inl_scratch) {               // the block redoes its own query (see ivf_fused_kernel)
-            __syncthreads();
-            pq64_t *s_head = reinterpret_cast<pq64_t *>(base);
-            int32_t *xmisc = reinterpret_cast<int32_t *>(s_head + p.inl_hcap);
-            if (tid == 0 && p.nflag) atomicAdd(p.nflag, 1);
-            ivf_exact_big_query(p, bl, lds, s_head, xmisc, p.inl_scratch + p.inl_per_q * (size_t) bl, tid);
-            publish();
-            return;
-        }
-        for (int c = tid; c < nlist; c += kW512) {
-            p.coarse_dist[bl * nlist + c] = s_dist[c];
-            p.coarse_id[bl * nlist + c] = c;
-        }
-        float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
-        for (int i = tid; i < MK; i += kW512) dst[i] = lds[i];
-        publish();
-        return;
-    }
-    const int ncand = s_misc[0], nv = s_misc[1];
-    float bestd = INFINITY;
-    uint32_t bestp = 0xffffffffu;
-    int32_t bestid = -1;
-    for (int p0 = tid; p0 < ncand; p0 += 2 * kW512) {
-        int32_t id[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int pos = p0 + u * kW512;
-            id[u] = -1;
-            if (pos < ncand) {
-                int lo = 0, hi = nv;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_cum[mid] <= pos) lo = mid; else hi = mid;
-                }
-                id[u] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
-            }
-        }
-        uint4 cv[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint4 *cp = reinterpret_cast<const uint4 *>(p.codes + (size_t) (id[u] < 0 ? 0 : id[u]) * M);
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
-                if (qd < MQ) cv[u][qd] = cp[qd];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {                 // ascending traversal position: strict < keeps the first minimum
-            const float d = adc_lds_wide(lds, cv[u], MQ, 256);
-            if (id[u] >= 0 && d < bestd) { bestd = d; bestp = (uint32_t) (p0 + u * kW512); bestid = id[u]; }
-        }
-    }
-    unsigned long long key = bestp == 0xffffffffu ? ~0ull : (((unsigned long long) f32_orderable(__float_as_uint(bestd)) << 32) | bestp);
-    const unsigned long long mine = key;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(key, off);
-        key = o < key ? o : key;
-    }
-    if (ln == 0 && key != ~0ull) atomicMin(&s_red[1], key);
-    __syncthreads();
-    if (mine != ~0ull && mine == s_red[1]) {
-        p.out_ids[bl] = bestid;
-        p.out_dists[bl] = bestd;
-        p.out_counts[bl] = 1;
-    }
-    publish();
-}
-static size_t ivf_w512_smem(int M, int nlist)
-{
-    constexpr int SC = kFusedMaxW + 2;
-    return (size_t) M * 256 * 4 + (size_t) SC * 8 + 16 + (size_t) (SC + 2) * 4 + 16 + (size_t) (SC + 2) * 8 + 8 + (size_t) 8 * (kFusedMaxW + 1) * 8 +
-           (size_t) nlist * 4 + 32;
-}
-bool ivf_w512_supported(int M, int Ks, int Ds, int nlist, int64_t w, int topk)
-{
-    return topk == 1 && Ds == 4 && Ks == 256 && (M & 15) == 0 && M <= 64 && nlist <= kFusedMaxNlist && w <= kFusedMaxW &&
-           ivf_w512_smem(M, nlist) <= (size_t) 40 * 1024;          // four blocks per CU: that is the point
-}
-
 // LSEL (selection in LDS): candidates' distances over the coarse scores + a small key buffer (see ivf_fused_kernel)
 constexpr int kFusedSelMaxL = 4096;
 static int ivf_fused_kcap(int topk)
@@ -1595,21 +1371,6 @@ hipError_t launch_ivf_fused(const IvfParams &p0, hipStream_t st)
     const bool gd = ivf_fused_gdist(p.M, p.Ks, p.nlist, p.w, p.topk);
     const bool lsel = ivf_fused_lsel(p.M, p.Ks, p.nlist, p.w, p.topk, p.L);
     p.kcap = lsel ? ivf_fused_kcap(p.topk) : 0;
-    if (p.w512 && p.queries && ivf_w512_supported(p.M, p.Ks, p.Ds, p.nlist, p.w, p.topk)) {      // round 4: 512 threads per query, 8 waves per SIMD
-        size_t sm = ivf_w512_smem(p.M, p.nlist);
-        if (p.q_host_off) {
-            p.q_host_off = (int) ((sm + 15) & ~(size_t) 15);
-            sm = (size_t) p.q_host_off + (size_t) p.M * 16;
-        }
-        if (p.inl_scratch) {
-            p.inl_hcap = ivf_exact_big_heap_cap(p.w, p.topk);
-            sm = std::max(sm, (size_t) p.M * 256 * 4 + (size_t) p.inl_hcap * 8 + 64);
-        }
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_top1_w512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) sm);
-        if (e != hipSuccess) return e;
-        launch_timed(ivf_top1_w512_kernel, dim3((unsigned) p.B), dim3(kW512), sm, st, p);
-        return hipGetLastError();
-    }
     size_t smem = ivf_fused_smem(p.M, p.Ks, p.nlist, p.sel_cap, p.topk, p.L, lsel, gd);
     if (p.q_host_off) {           // the query staged in LDS behind everything else (see the kernel)
         p.q_host_off = (int) ((smem + 15) & ~(size_t) 15);

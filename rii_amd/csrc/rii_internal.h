@@ -117,7 +117,6 @@ struct IvfParams {
     // round 4: ivf_fused_kernel redoes a flagged query itself (ivf_exact_big_query): one global scratch slice per query of the launch
     // group (ivf_exact_big_scratch() bytes each) and the LDS heap capacity; NULL = hand over to the flag-gated exact kernels
     unsigned char *inl_scratch = nullptr; size_t inl_per_q = 0; int inl_hcap = 0;
-    int w512 = 0;                 // 1: the common top-1 case runs ivf_top1_w512_kernel (512 threads per query) where it applies (option ivf_wide_block)
     int q_host_off = 0;           // != 0: `queries` is coherent HOST memory (Ds = 4, Ks = 256): fetched once per block into LDS (the launcher
                                   // turns the flag into the byte offset of that staging area)
 };

@@ -271,17 +271,10 @@ def test_ivf_flagged_blocks_redo_their_own_query(M, Ds):
                 for force in (0, 1):
                     g.set_option("ivf_force_exact", force)
                     res = []
-                    for inl, wide in ((1, 0), (0, 0), (1, 1), (0, 1)):
+                    for inl in (1, 0):
                         g.set_option("ivf_inline_exact", inl)
-                        g.set_option("ivf_wide_block", wide)        # (512 threads per query: top-1, Ds = 4 only; else a no-op)
                         res.append(g.query_ivf_batch(qs, topk, t, min(L, N)))
-                    g.set_option("ivf_wide_block", 0)
-                    for other in res[2:]:
-                        assert np.array_equal(other[2], res[0][2])
-                        for b in range(len(qs)):
-                            n = int(other[2][b])
-                            assert np.array_equal(other[0][b, :n], res[0][0][b, :n]) and np.array_equal(other[1][b, :n], res[0][1][b, :n]), (topk, L, force, b)
-                    (ai, ad, ac), (bi, bd, bc) = res[:2]
+                    (ai, ad, ac), (bi, bd, bc) = res
                     assert np.array_equal(ac, bc), (topk, L, force)
                     for b in range(len(qs)):
                         n = int(ac[b])
@@ -333,44 +326,3 @@ def test_async_few_queries_take_the_slice_kernel_with_device_side_tie_fallback(M
     g.set_option("slice_topk", 1)
     if scale == "sift":
         assert nties > 0                       # the fallback really ran
-
-
-@pytest.mark.parametrize("M", [16, 32, 64])
-def test_ivf_wide_block_equals_the_256_thread_kernel(M):
-    """ivf_top1_w512_kernel (option ivf_wide_block: 512 threads per query, 8 waves per SIMD) against ivf_fused_kernel<true, true>: top-1,
-    Ds = 4, Ks = 256 -- several nlist / L / w, target ids, stale lists (codes added without updating: tail walk and `not found`),
-    duplicated centres (flagged queries: inline replay and the flag-gated kernels), one-query host calls."""
-    from rii_amd import RiiGpu
-    rng = np.random.default_rng(700 + M)
-    cw = np.round(rng.random((M, 256, 4)) * 31).astype(np.float32)
-    N = 40000
-    codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
-    codes[rng.integers(0, N, 2000)] = codes[rng.integers(0, N, 2000)]
-    qs = np.round(rng.random((150, M * 4)) * 31).astype(np.float32)
-    tids = np.sort(rng.choice(N, 5000, replace=False)).astype(np.int64)
-    for nlist in (100, 1024):
-        g = RiiGpu(cw, False, simd_arch="avx512")
-        g.add_codes(codes[:30000], False)
-        g.reconfigure(nlist, 2)
-        if nlist == 100:
-            cen = g.coarse_centers_array().copy()
-            cen[1::9] = cen[0::9][:len(cen[1::9])]
-            g.set_coarse_centers(cen)
-        g.add_codes(codes[30000:], False)                 # stale lists: 10 000 codes no list knows
-        for L in (30, 400, 3000, N):
-            for t in (None, tids):
-                for inl in (1, 0):
-                    g.set_option("ivf_inline_exact", inl)
-                    g.set_option("ivf_wide_block", 0)
-                    a = g.query_ivf_batch(qs, 1, t, L)
-                    g.set_option("ivf_wide_block", 1)
-                    b = g.query_ivf_batch(qs, 1, t, L)
-                    assert np.array_equal(a[2], b[2]), (nlist, L, inl)
-                    ok = a[2] > 0
-                    assert np.array_equal(a[0][ok], b[0][ok]) and np.array_equal(a[1][ok].view(np.uint32), b[1][ok].view(np.uint32)), (nlist, L, inl)
-        g.set_option("ivf_inline_exact", 1)
-        for bq in range(0, 150, 11):                      # one query per call (the kernel fetches the query from the pinned block)
-            g.set_option("ivf_wide_block", 0)
-            want = g.query_ivf(qs[bq], 1, E, 400)
-            g.set_option("ivf_wide_block", 1)
-            assert g.query_ivf(qs[bq], 1, E, 400) == want
