@@ -326,3 +326,23 @@ def test_async_few_queries_take_the_slice_kernel_with_device_side_tie_fallback(M
     g.set_option("slice_topk", 1)
     if scale == "sift":
         assert nties > 0                       # the fallback really ran
+
+
+def test_dev_to_host_beyond_one_internal_pass():
+    """rii_query_linear_dev_to_host / _ivf_ with more queries than one internal pass holds (8192): device buffers + copies + one
+    synchronisation -- same rows as the host-pointer call."""
+    import torch
+    g, cw, codes, rng = _engine(16, 4, 20000, 99)
+    g.reconfigure(32, 2)
+    B = 9000
+    qs = rng.random((B, 64)).astype(np.float32)
+    q = torch.from_numpy(qs).cuda()
+    want = g.query_linear_batch(qs, 2, None)
+    ids, d = np.empty((B, 2), np.int64), np.empty((B, 2), np.float32)
+    g.query_linear_dev_to_host(q.data_ptr(), B, 2, 0, 0, ids, d, 0)
+    assert np.array_equal(ids, want[0]) and np.array_equal(d, want[1])
+    wi, wd, wc = g.query_ivf_batch(qs, 1, None, 700)
+    ids1, d1, cnt = np.empty((B, 1), np.int64), np.empty((B, 1), np.float32), np.empty(B, np.int64)
+    g.query_ivf_dev_to_host(q.data_ptr(), B, 1, 0, 0, 700, ids1, d1, cnt, 0)
+    ok = wc > 0
+    assert np.array_equal(cnt, wc) and np.array_equal(ids1[ok], wi[ok]) and np.array_equal(d1[ok], wd[ok])
