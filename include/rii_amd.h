@@ -283,6 +283,8 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *                      std::partial_sort emulation kernels for every query
  *   "ivf_inline_exact" 1 = a block of the fused kernel that flags its own query replays it itself [default], 0 = flag-gated exact
  *                      kernels behind every batch
+ *   "ivf_list_codes"   1 = the fused kernel reads its candidates from a second copy of the codes kept in posting order (+N*M bytes of
+ *                      device memory, rebuilt with the lists) [default], 0 = rows gathered by id.  Identical results
  *   "ivf_force_exact"  tests / measurement: 1 = every query of the fused path is flagged [0]
  *   "lanes"            scratch-buffer sets: 2 [default] or 1 (see Threading below)
  *   "timing"           0 [default] / 1 (HIP events around every kernel) / 2 (only around the dominant kernel of a step): rii_timing_read

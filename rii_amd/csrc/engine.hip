@@ -156,6 +156,8 @@ struct rii_engine : ScratchSet {
     int table_levels = 127;
     int ivf_inline_exact = 1;   // option "ivf_inline_exact" (round 4): 1 = a block of ivf_fused_kernel that flags its query (tied coarse distances, tail
                                 // walk, ties at the cut) replays it itself; 0 = the flag-gated exact kernels behind every batch (round 3)
+    int ivf_list_codes = 1;     // option "ivf_list_codes" (round 4): 1 = a second copy of the codes in POSTING order (+N*M bytes) feeds the candidate phase of
+                                // ivf_fused_kernel (contiguous rows per list, no dependent id load); 0 = rows gathered by id (round 3)
     int fused_tables = 1;       // option "fused_tables": 1 = qlut_fused_kernel + table-free top-1 re-rank (round 3), 0 = the two-launch tile path
     int ivf_force_exact = 0;    // tests: the fused kernel flags every query, so the exact LDS kernel answers all of them
     int timing = 0;
@@ -171,6 +173,7 @@ struct rii_engine : ScratchSet {
 
     // device state
     DevBuf d_codewords, d_cnorm, d_codes, d_centers, d_symtab, d_pl_off, d_pl_ids, d_list_len;
+    DevBuf d_lcodes; bool lcodes_valid = false;      // codes in posting order (option ivf_list_codes), rebuilt with the CSR
     // LDS-friendly scan order of the filter stage (scanorder.hip): codes gathered in scan order + position -> id.
     // Windows of 1024 codes are independent, so appends only (re)order the windows past `scan_cov`.
     DevBuf d_scan_codes, d_scan_perm;
@@ -341,6 +344,19 @@ int sync_lists(rii_engine *e)
                                e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->lists_dirty = false;
+    e->lcodes_valid = false;
+    return RII_OK;
+}
+
+// option ivf_list_codes: row pp of d_lcodes = the code of posting pp of the CSR id array (every id sits in exactly one list: N rows)
+int sync_list_codes(rii_engine *e, hipStream_t st)
+{
+    if (e->lcodes_valid) return RII_OK;
+    int64_t n = 0;
+    for (const auto &l : e->lists) n += (int64_t) l.size();
+    RII_TRY(e->d_lcodes.ensure((size_t) std::max<int64_t>(n, 1) * e->M));
+    HIP_TRY(launch_gather_codes_i32(e->d_codes.as<uint8_t>(), e->M, e->d_pl_ids.as<int32_t>(), n, e->d_lcodes.as<uint8_t>(), st));
+    e->lcodes_valid = true;
     return RII_OK;
 }
 
@@ -1014,6 +1030,11 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
     if (nlist < w) w = nlist;
     p.w = w;
 
+    p.lcodes = nullptr;
+    if (S == 0 && e->ivf_list_codes && e->ivf_fused) {      // unfiltered: the fused kernel reads its candidates' rows in posting order
+        RII_TRY(sync_list_codes(e, st));
+        p.lcodes = e->d_lcodes.as<uint8_t>();
+    }
     if (S != 0) {       // order-preserving filter of every list by the batch's target ids
         RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
         p.pl_ids = e->s_fids.as<int32_t>();
@@ -1217,7 +1238,7 @@ int end_on(rii_engine *e, hipStream_t st)
 void free_all(rii_engine *e)
 {
     DevBuf *bufs[] = {&e->d_codewords, &e->d_cnorm, &e->d_codes, &e->d_centers, &e->d_symtab, &e->d_pl_off,
-                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->d_fcodes};
+                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->d_fcodes, &e->d_lcodes};
     for (DevBuf *b : bufs) b->release();
     e->release_all();
     e->parked.release_all();
@@ -2545,6 +2566,9 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->ivf_fused = value ? 1 : 0;
     } else if (k == "ivf_inline_exact") {
         e->ivf_inline_exact = value ? 1 : 0;
+    } else if (k == "ivf_list_codes") {
+        e->ivf_list_codes = value ? 1 : 0;
+        if (!value) { e->d_lcodes.release(); e->lcodes_valid = false; }
     } else if (k == "ivf_force_exact") {
         e->ivf_force_exact = value ? 1 : 0;
     } else if (k == "fused_tables") {
@@ -2604,6 +2628,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_fused") return e->ivf_fused;
     if (k == "ivf_force_exact") return e->ivf_force_exact;
     if (k == "ivf_inline_exact") return e->ivf_inline_exact;
+    if (k == "ivf_list_codes") return e->ivf_list_codes;
     if (k == "fused_tables") return e->fused_tables;
     if (k == "table_levels") return e->table_levels;
     if (k == "scan_order") return e->scan_order;

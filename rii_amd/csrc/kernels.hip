@@ -483,6 +483,23 @@ __global__ void gather_codes_kernel(const uint8_t *__restrict__ codes, int M, co
         out[t] = codes[(size_t) ids[s] * M + m];
     }
 }
+// round 4: the codes in POSTING order (entry p of the CSR id array -> row p): the candidates of a list become one contiguous run
+__global__ void gather_codes_i32_kernel(const uint8_t *__restrict__ codes, int M, const int32_t *__restrict__ ids, int64_t S, uint8_t *__restrict__ out)
+{
+    const int64_t total = S * M;
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t s2 = t / M;
+        const int m = (int) (t - s2 * M);
+        out[t] = codes[(size_t) ids[s2] * M + m];
+    }
+}
+hipError_t launch_gather_codes_i32(const uint8_t *d_codes, int M, const int32_t *d_ids, int64_t S, uint8_t *d_out, hipStream_t st)
+{
+    if (S == 0) return hipSuccess;
+    const int64_t total = S * M;
+    hipLaunchKernelGGL(gather_codes_i32_kernel, dim3((unsigned) std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, st, d_codes, M, d_ids, S, d_out);
+    return hipGetLastError();
+}
 hipError_t launch_gather_codes(const uint8_t *d_codes, int M, const int64_t *d_ids, int64_t S, uint8_t *d_out,
                                hipStream_t st)
 {
@@ -1026,10 +1043,13 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     float bestd = INFINITY;
     uint32_t bestp = 0xffffffffu;
     int32_t bestid = -1;
+    // round 4 (p.lcodes): the codes also exist in POSTING order (row pp = the code of posting pp of the CSR id array), so the candidates
+    // of a list are one contiguous run: the code row is addressed from the traversal position alone -- no dependent id load in front of
+    // it, coalesced 32-byte rows instead of random gathers -- and the id is fetched for the winner only
     for (int p0 = tid; top1 && p0 < ncand; p0 += 4 * 256) {
-        int32_t id[4];
+        int32_t id[4];                                // lcodes: the posting index; else the posting's id
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                 // posting ids of up to four traversal positions: loads in flight together
+        for (int u = 0; u < 4; ++u) {                 // up to four traversal positions per thread: loads in flight together
             const int pos = p0 + u * 256;
             id[u] = -1;
             if (pos < ncand) {
@@ -1038,16 +1058,18 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                     const int mid = (lo + hi) >> 1;
                     if (s_cum[mid] <= pos) lo = mid; else hi = mid;
                 }
-                id[u] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
+                const int pp = s_poff[lo] + (pos - s_cum[lo]);
+                id[u] = p.lcodes ? pp : p.pl_ids[(size_t) pp];
             }
         }
+        const uint8_t *cbase = p.lcodes ? p.lcodes : p.codes;
         float dist[4];
         if (wide) {
             uint4 cv[4][4];
             const int MQ = p.M >> 4;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint4 *cp = reinterpret_cast<const uint4 *>(p.codes + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
+                const uint4 *cp = reinterpret_cast<const uint4 *>(cbase + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd)
                     if (qd < MQ) cv[u][qd] = cp[qd];
@@ -1056,7 +1078,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             for (int u = 0; u < 4; ++u) dist[u] = adc_lds_wide(lds, cv[u], MQ, p.Ks);
         } else {
             for (int u = 0; u < 4; ++u)
-                dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, p.codes + (size_t) id[u] * p.M, p.M, p.Ks);
+                dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, cbase + (size_t) id[u] * p.M, p.M, p.Ks);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)                   // ascending traversal position: strict < keeps the first minimum
@@ -1075,7 +1097,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
         if ((tid & 63) == 0 && key != ~0ull) atomicMin(&s_red[1], key);
         __syncthreads();
         if (mine != ~0ull && mine == s_red[1]) {
-            p.out_ids[bl] = bestid;
+            p.out_ids[bl] = p.lcodes ? p.pl_ids[(size_t) bestid] : bestid;
             p.out_dists[bl] = bestd;
             p.out_counts[bl] = 1;
         }
@@ -1102,7 +1124,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                         const int mid = (lo + hi) >> 1;
                         if (s_cum[mid] <= pos) lo = mid; else hi = mid;
                     }
-                    id[u] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
+                    id[u] = p.lcodes ? (s_poff[lo] + (pos - s_cum[lo])) : p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
                 }
             }
             float dist[4];
@@ -1111,7 +1133,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 const int MQ = p.M >> 4;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const uint4 *cp = reinterpret_cast<const uint4 *>(p.codes + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
+                    const uint4 *cp = reinterpret_cast<const uint4 *>((p.lcodes ? p.lcodes : p.codes) + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd)
                         if (qd < MQ) cv[u][qd] = cp[qd];
@@ -1120,7 +1142,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 for (int u = 0; u < 4; ++u) dist[u] = adc_lds_wide(lds, cv[u], MQ, p.Ks);
             } else {
                 for (int u = 0; u < 4; ++u)
-                    dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, p.codes + (size_t) id[u] * p.M, p.M, p.Ks);
+                    dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, (p.lcodes ? p.lcodes : p.codes) + (size_t) id[u] * p.M, p.M, p.Ks);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -1231,7 +1253,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                         const int mid = (lo + hi) >> 1;
                         if (s_cum[mid] <= pos) lo = mid; else hi = mid;
                     }
-                    id[u] = p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
+                    id[u] = p.lcodes ? (s_poff[lo] + (pos - s_cum[lo])) : p.pl_ids[(size_t) s_poff[lo] + (pos - s_cum[lo])];
                 }
             }
             float dist[4];
@@ -1240,7 +1262,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 const int MQ = p.M >> 4;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const uint4 *cp = reinterpret_cast<const uint4 *>(p.codes + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
+                    const uint4 *cp = reinterpret_cast<const uint4 *>((p.lcodes ? p.lcodes : p.codes) + (size_t) (id[u] < 0 ? 0 : id[u]) * p.M);
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd)
                         if (qd < MQ) cv[u][qd] = cp[qd];
@@ -1249,7 +1271,7 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 for (int u = 0; u < 4; ++u) dist[u] = adc_lds_wide(lds, cv[u], MQ, p.Ks);
             } else {
                 for (int u = 0; u < 4; ++u)
-                    dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, p.codes + (size_t) id[u] * p.M, p.M, p.Ks);
+                    dist[u] = id[u] < 0 ? INFINITY : adc_lds(lds, (p.lcodes ? p.lcodes : p.codes) + (size_t) id[u] * p.M, p.M, p.Ks);
             }
             const unsigned long long thr = s_kthr;
 #pragma unroll

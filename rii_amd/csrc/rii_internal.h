@@ -83,6 +83,7 @@ hipError_t launch_gather_sorted_topk(const unsigned long long *d_sorted, int64_t
                                      hipStream_t st);
 hipError_t launch_gather_codes(const uint8_t *d_codes, int M, const int64_t *d_ids, int64_t S, uint8_t *d_out,
                                hipStream_t st);
+hipError_t launch_gather_codes_i32(const uint8_t *d_codes, int M, const int32_t *d_ids, int64_t S, uint8_t *d_out, hipStream_t st);
 
 // IVF
 struct IvfParams {
@@ -91,6 +92,7 @@ struct IvfParams {
     const uint8_t *centers; int nlist;
     const int64_t *pl_off;        // [nlist+1] offsets into ids buffers
     const int32_t *pl_ids;        // ids actually traversed (filtered copy when S>0)
+    const uint8_t *lcodes = nullptr;  // round 4, ivf_fused_kernel only: the codes in the order of pl_ids (row pp = code of posting pp); NULL = gather by id
     const int32_t *list_len;      // [nlist] lengths actually traversed (filtered when S>0)
     int64_t B; int b0;            // queries [b0, b0+B) of the batch are processed by this launch group
     int topk; int64_t L; int64_t w;

@@ -346,3 +346,50 @@ def test_dev_to_host_beyond_one_internal_pass():
     g.query_ivf_dev_to_host(q.data_ptr(), B, 1, 0, 0, 700, ids1, d1, cnt, 0)
     ok = wc > 0
     assert np.array_equal(cnt, wc) and np.array_equal(ids1[ok], wi[ok]) and np.array_equal(d1[ok], wd[ok])
+
+
+@pytest.mark.parametrize("M,Ds", [(32, 4), (16, 6), (8, 16)])
+def test_ivf_posting_order_code_copy_gives_the_rows_of_the_id_gather(M, Ds):
+    """option ivf_list_codes = 1 (default): ivf_fused_kernel reads its candidates' rows from a copy of the codes kept in posting
+    order; = 0: rows gathered by id (round 3).  Same rows, bit for bit, for top-1 / selection in LDS / the streaming buffer, before
+    and after an append (the copy is rebuilt with the lists), after a reconfigure, and equal to the oracle's."""
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(90 + M)
+    cw = rng.standard_normal((M, 256, Ds)).astype(np.float32)
+    N = 40000
+    codes = rng.integers(0, 256, size=(N + 5000, M), dtype=np.uint8)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes[:N], False)
+    g.reconfigure(100, 2)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes[:N], False)
+    qs = rng.standard_normal((96, M * Ds)).astype(np.float32)
+
+    def both(topk, L):
+        res = []
+        for lc in (1, 0):
+            g.set_option("ivf_list_codes", lc)
+            assert g.get_option("ivf_list_codes") == lc
+            res.append(g.query_ivf_batch(qs, topk, None, L))
+        g.set_option("ivf_list_codes", 1)
+        (ai, ad, ac), (bi, bd, bc) = res
+        assert np.array_equal(ac, bc)
+        for b in range(len(qs)):
+            n = int(ac[b])
+            assert np.array_equal(ai[b, :n], bi[b, :n]) and np.array_equal(ad[b, :n].view(np.uint32), bd[b, :n].view(np.uint32)), (topk, L, b)
+        return res[0]
+
+    for stage in range(3):
+        for topk, L in ((1, 300), (1, 5000), (3, 800), (10, 4000), (50, 9000), (200, 20000)):
+            both(topk, L)
+        if stage == 0:
+            g.add_codes(codes[N:], True)               # append: lists and the posting-order copy follow
+        elif stage == 1:
+            g.reconfigure(300, 2)
+    o.add_codes(codes[N:], False)
+    o.set_coarse_centers(g.coarse_centers_array()) if hasattr(o, "set_coarse_centers") else None
+    if hasattr(o, "set_coarse_centers"):
+        for b in range(0, 96, 11):
+            for topk, L in ((1, 300), (10, 4000)):
+                gi, gd, gc = g.query_ivf_batch(qs[b:b + 1], topk, None, L)
+                assert_same_result((gi[0, :int(gc[0])], gd[0, :int(gc[0])]), o.query_ivf(qs[b], topk, E, L), "ivf posting-order codes")
