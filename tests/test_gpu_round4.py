@@ -351,7 +351,8 @@ def test_dev_to_host_beyond_one_internal_pass():
 @pytest.mark.parametrize("M,Ds", [(32, 4), (16, 6), (8, 16)])
 def test_ivf_posting_order_code_copy_gives_the_rows_of_the_id_gather(M, Ds):
     """option ivf_list_codes = 1 (default): ivf_fused_kernel reads its candidates' rows from a copy of the codes kept in posting
-    order; = 0: rows gathered by id (round 3).  Same rows, bit for bit, for top-1 / selection in LDS / the streaming buffer, before
+    order (a target_ids batch: the list filter compacts the rows along with the ids); = 0: rows gathered by id (round 3).  Same rows,
+    bit for bit, for top-1 / selection in LDS / the streaming buffer, with and without target ids, before
     and after an append (the copy is rebuilt with the lists), after a reconfigure, and equal to the oracle's."""
     from rii_amd import RiiGpu
     rng = np.random.default_rng(90 + M)
@@ -365,12 +366,12 @@ def test_ivf_posting_order_code_copy_gives_the_rows_of_the_id_gather(M, Ds):
     o.add_codes(codes[:N], False)
     qs = rng.standard_normal((96, M * Ds)).astype(np.float32)
 
-    def both(topk, L):
+    def both(topk, L, t=None):
         res = []
         for lc in (1, 0):
             g.set_option("ivf_list_codes", lc)
             assert g.get_option("ivf_list_codes") == lc
-            res.append(g.query_ivf_batch(qs, topk, None, L))
+            res.append(g.query_ivf_batch(qs, topk, t, L))
         g.set_option("ivf_list_codes", 1)
         (ai, ad, ac), (bi, bd, bc) = res
         assert np.array_equal(ac, bc)
@@ -382,6 +383,11 @@ def test_ivf_posting_order_code_copy_gives_the_rows_of_the_id_gather(M, Ds):
     for stage in range(3):
         for topk, L in ((1, 300), (1, 5000), (3, 800), (10, 4000), (50, 9000), (200, 20000)):
             both(topk, L)
+        nn = g.N
+        for S in (37, 4000, nn // 2):              # target ids: the filter compacts the rows along with the ids
+            t = np.sort(rng.choice(nn, S, replace=False)).astype(np.int64)
+            for topk, L in ((1, 20), (1, 900), (5, 30), (20, 2000)):
+                both(topk, min(L, S), t)
         if stage == 0:
             g.add_codes(codes[N:], True)               # append: lists and the posting-order copy follow
         elif stage == 1:

@@ -38,6 +38,27 @@ for rep in range(3):
         ids = oi.cpu().numpy().copy()
         if ref is None: ref = ids
         out.setdefault("batch_%s=%d" % (opt, v), []).append({"ms_plain": round(ms, 5), "ivf_fused_ms": round(km, 5), "ids_equal": bool((ids == ref).all())})
+# the subset form of the same step (configs[3]: |S| = 100k target ids)
+tids = torch.from_numpy(np.sort(np.random.default_rng(5).choice(N, 100_000, replace=False)).astype(np.int64)).to(dev)
+def sstep(): eng.query_ivf_dev(q.data_ptr(), B, 1, tids.data_ptr(), tids.numel(), L, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), st.cuda_stream)
+sref = None
+for rep in range(3):
+    for v in vals:
+        eng.set_option(opt, v)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.2: sstep(); torch.cuda.synchronize()
+        K = 300
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(K): sstep()
+        torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / K * 1e3
+        eng.set_option("timing", 2); eng.timing_reset()
+        for _ in range(100): sstep()
+        torch.cuda.synchronize()
+        km = eng.timing_read("ivf_fused")[0] / 100
+        eng.set_option("timing", 0)
+        ids = oi.cpu().numpy().copy()
+        if sref is None: sref = ids
+        out.setdefault("subset_%s=%d" % (opt, v), []).append({"ms_plain": round(ms, 5), "ivf_fused_ms": round(km, 5), "ids_equal": bool((ids == sref).all())})
 # README call
 rng = np.random.default_rng(0)
 X = rng.random((10000, 128)).astype(np.float32); Q = rng.random((256, 128)).astype(np.float32)
