@@ -912,6 +912,11 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     // every global load of this block is latency-exposed (one block per query, a few blocks per CU), so the gathers below
     // are issued in batches: up to four codes per thread, whole codes in registers before the first table lookup
     const bool wide = (p.M & 15) == 0 && p.M <= 64;
+    const int rounds = (w + 1 < nlist) ? w + 1 : nlist;
+    // round 4: up to 1024 lists and up to 33 picks (the common case): the keys of the four lists a thread scores stay in registers for the
+    // selection (no LDS re-reads, no barrier between scoring and selection); the coarse scores still go to s_dist for the hand-over paths
+    const bool kreg = nlist <= 4 * 256 && rounds <= kFusedMaxW + 1;
+    unsigned long long kkey[4] = {~0ull, ~0ull, ~0ull, ~0ull};
     for (int c0 = tid; c0 < nlist; c0 += 4 * 256) {
         if (wide) {
             uint4 cv[4][4];
@@ -927,38 +932,52 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = c0 + u * 256;
-                if (c < nlist) s_dist[c] = adc_lds_wide(lds, cv[u], MQ, p.Ks);
+                if (c < nlist) {
+                    const float dv = adc_lds_wide(lds, cv[u], MQ, p.Ks);
+                    s_dist[c] = dv;
+                    kkey[u] = ((unsigned long long) f32_orderable(__float_as_uint(dv)) << 32) | (uint32_t) c;
+                }
             }
         } else {
+#pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = c0 + u * 256;
-                if (c < nlist) s_dist[c] = adc_lds(lds, p.centers + (size_t) c * p.M, p.M, p.Ks);
+                if (c < nlist) {
+                    const float dv = adc_lds(lds, p.centers + (size_t) c * p.M, p.M, p.Ks);
+                    s_dist[c] = dv;
+                    kkey[u] = ((unsigned long long) f32_orderable(__float_as_uint(dv)) << 32) | (uint32_t) c;
+                }
             }
         }
     }
-    __syncthreads();
-    // ---- the w+1 smallest (dist, list id) keys, ascending: few -> rounds of block arg-min over keys strictly greater
-    // than the previous pick; many -> bitonic sort of all list keys ----
-    const int rounds = (w + 1 < nlist) ? w + 1 : nlist;
+    if (!kreg) __syncthreads();
+    // ---- the w+1 smallest (dist, list id) keys, ascending: few -> two levels of wave-wide minima; many -> bitonic sort of all
+    // list keys ----
     unsigned long long last = 0ull;
     if (rounds > kFusedMaxW + 1) {
         for (int c = tid; c < SC; c += blockDim.x)
             s_sel[c] = c < nlist ? (((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c) : ~0ull;
         rr_bitonic_sort(s_sel, tid, SC);
     }
+    bool staged = false;                  // wave 0 has already filled s_len / s_poff / s_cum / s_misc (fast form below)
     if (rounds <= kFusedMaxW + 1) {
         // Two levels, two barriers (round 2: w + 1 block-wide arg-min rounds with three barriers each, all of them exposed latency
         // in a block that has nothing else to run).  (a) Every wave extracts the `rounds` smallest keys among the lists its lanes
         // own, in ascending order, with wave-wide DPP minima (no LDS, no barrier) -- the w + 1 smallest keys of the block are among
         // the 4 x rounds found this way; (b) wave 0 extracts the `rounds` smallest of those the same way.
-
         const int wv = tid >> 6, ln = tid & 63;
         for (int r = 0; r < rounds; ++r) {
             unsigned long long best = ~0ull;
-            for (int c = tid; c < nlist; c += blockDim.x) {
-                const unsigned long long key =
-                    ((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c;
-                if ((r == 0 || key > last) && key < best) best = key;
+            if (kreg) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((r == 0 || kkey[u] > last) && kkey[u] < best) best = kkey[u];
+            } else {
+                for (int c = tid; c < nlist; c += blockDim.x) {
+                    const unsigned long long key =
+                        ((unsigned long long) f32_orderable(__float_as_uint(s_dist[c])) << 32) | (uint32_t) c;
+                    if ((r == 0 || key > last) && key < best) best = key;
+                }
             }
             last = wave_min_u64(best);                                         // ~0 when this wave's lists are exhausted
             if (ln == 0) s_wsel[wv * (kFusedMaxW + 1) + r] = last;
@@ -971,46 +990,91 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                 const int i = ln + 64 * u;                                     // i = wave * rounds + r
                 cand[u] = i < 4 * rounds ? s_wsel[(i / rounds) * (kFusedMaxW + 1) + (i % rounds)] : ~0ull;
             }
-            unsigned long long prev = 0ull;
+            unsigned long long prev = 0ull, mysel = ~0ull;                     // lane r keeps pick r
             for (int r = 0; r < rounds; ++r) {
                 unsigned long long best = ~0ull;
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
                     if ((r == 0 || cand[u] > prev) && cand[u] < best) best = cand[u];
                 prev = wave_min_u64(best);
-                if (ln == 0) s_sel[r] = prev;
+                if (ln == r) mysel = prev;
             }
+            // round 4: wave 0 goes straight on -- lane r fetches the length / offset of pick r, the stop rule of the walk (src/rii.h:
+            // 283-326) is evaluated across the lanes (prefix sums of the lengths), and ONE barrier publishes everything; before: a
+            // barrier, a block-wide fetch, a barrier, a one-lane loop over the picks, a barrier
+            const int wl = w < nlist ? w : nlist;
+            const uint32_t myhi = (uint32_t) (mysel >> 32);
+            const uint32_t nxhi = (uint32_t) __shfl_down((int) myhi, 1);
+            const bool tied = ln + 1 < rounds && myhi == nxhi;                  // exactly tied coarse distances among the w + 1 picks
+            int len = 0, off = 0;
+            if (ln < wl) {
+                const int no = (int) (mysel & 0xffffffffu);
+                len = p.list_len[no];
+                off = (int) p.pl_off[no];                                       // N < 2^31
+            }
+            int incl = len;                                                     // inclusive prefix sums (the lists are disjoint: <= N)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (ln >= o) incl += t;
+            }
+            const int excl = incl - len;
+            int flag = (p.force_flag || __ballot(tied) != 0ull) ? 1 : 0;
+            const unsigned long long hit = __ballot(ln < wl && (long long) incl >= p.L);      // first list that completes L candidates
+            int nv = 0;
+            long long cnt = 0;
+            if (hit) {
+                nv = __ffsll((long long) hit);                                  // c1 + 1
+                cnt = p.L;
+            } else if ((long long) wl == p.w) {                                 // all w lists walked: enough for topk?
+                const int tot = __shfl(incl, wl - 1);
+                if (tot >= p.topk) { nv = wl; cnt = tot; } else flag = 1;
+            } else flag = 1;                                                    // tail walk / empty return: exact path
+            if (flag) { nv = 0; cnt = 0; }
+            if (ln < wl) { s_len[ln] = len; s_poff[ln] = off; }
+            if (ln < nv) s_cum[ln] = excl;
+            if (ln == 0) {
+                s_cum[nv] = (int) cnt;
+                s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = flag;
+                p.flag[bl] = p.inl_scratch ? 0 : flag;
+                if (flag && p.flag_list && !p.inl_scratch) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
+                if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
+                s_red[1] = ~0ull;
+            }
+            if (ln < rounds) s_sel[ln] = mysel;
+        }
+        staged = true;
+    }
+    if (!staged) {
+        for (int c = tid; c < (w < nlist ? w : nlist); c += blockDim.x) {      // lengths / offsets of the lists the walk may visit
+            const int no = (int) (s_sel[c] & 0xffffffffu);
+            s_len[c] = p.list_len[no];
+            s_poff[c] = (int) p.pl_off[no];                                    // N < 2^31
         }
         __syncthreads();
-    }
-    for (int c = tid; c < (w < nlist ? w : nlist); c += blockDim.x) {      // lengths / offsets of the lists the walk may visit
-        const int no = (int) (s_sel[c] & 0xffffffffu);
-        s_len[c] = p.list_len[no];
-        s_poff[c] = (int) p.pl_off[no];                                    // N < 2^31
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int flag = p.force_flag;
-        for (int r = 0; r + 1 < rounds; ++r)
-            if ((s_sel[r] >> 32) == (s_sel[r + 1] >> 32)) flag = 1;         // exactly tied coarse distances
-        long long cnt = 0;
-        int nv = 0;
-        bool finished = false;
-        const int wl = w < nlist ? w : nlist;
-        for (int c = 0; c < wl && !flag; ++c) {
-            const long long len = s_len[c];
-            s_cum[c] = (int) cnt;
-            if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
-            cnt += len;
-            if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+        if (tid == 0) {
+            int flag = p.force_flag;
+            for (int r = 0; r + 1 < rounds; ++r)
+                if ((s_sel[r] >> 32) == (s_sel[r + 1] >> 32)) flag = 1;         // exactly tied coarse distances
+            long long cnt = 0;
+            int nv = 0;
+            bool finished = false;
+            const int wl = w < nlist ? w : nlist;
+            for (int c = 0; c < wl && !flag; ++c) {
+                const long long len = s_len[c];
+                s_cum[c] = (int) cnt;
+                if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+                cnt += len;
+                if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+            }
+            if (!finished) flag = 1;                                             // tail walk / empty return: exact path
+            s_cum[nv] = (int) cnt;
+            s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = flag;
+            p.flag[bl] = p.inl_scratch ? 0 : flag;
+            if (flag && p.flag_list && !p.inl_scratch) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
+            if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
+            s_red[1] = ~0ull;
         }
-        if (!finished) flag = 1;                                             // tail walk / empty return: exact path
-        s_cum[nv] = (int) cnt;
-        s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = flag;
-        p.flag[bl] = p.inl_scratch ? 0 : flag;
-        if (flag && p.flag_list && !p.inl_scratch) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
-        if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
-        s_red[1] = ~0ull;
     }
     __syncthreads();
     // round 4: the block that flagged its query redoes it ITSELF with the exact emulation (ivf_exact_big_query: sequences in this
@@ -1089,14 +1153,11 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             bestp == 0xffffffffu ? ~0ull
                                  : (((unsigned long long) f32_orderable(__float_as_uint(bestd)) << 32) | bestp);
         const unsigned long long mine = key;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(key, off);
-            key = o < key ? o : key;
-        }
+        key = wave_min_u64(key);                      // DPP minima (round 3's __shfl_xor ladder was twelve ds_bpermute round trips)
         if ((tid & 63) == 0 && key != ~0ull) atomicMin(&s_red[1], key);
         __syncthreads();
         if (mine != ~0ull && mine == s_red[1]) {
+            // (the id next to every row instead -- four more loads per thread -- measured slower than this one dependent load)
             p.out_ids[bl] = p.lcodes ? p.pl_ids[(size_t) bestid] : bestid;
             p.out_dists[bl] = bestd;
             p.out_counts[bl] = 1;
