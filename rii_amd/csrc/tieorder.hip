@@ -299,11 +299,34 @@ __global__ __launch_bounds__(64) void tie_replay_kernel(TcArgs p)
     __builtin_amdgcn_wave_barrier();
     wh_make_heap(heap, k, lane);
     pq64_t topv = wh_uniform(heap[0]);
-    for (int c = 0; c < p.nchunks; ++c) {
-        const int cnt = ecount[c];
+    // round 4: nothing the loop needs waits for a global round trip of its own -- the segment lengths of 64 chunks at a time sit in
+    // the lanes (one load per 64 chunks), and the first entries of the NEXT non-empty segment are requested before this segment's sifts
+    // (before: a dependent length load and a dependent first load per chunk, ~2 us x 123 chunks of a 1M-code index)
+    int cnts = 0;                                             // lane l: ecount[cbase + l]
+    int nc = 0;                                               // next chunk whose first entries are in flight / its length
+    auto cnt_of = [&](int c) { return __builtin_amdgcn_readlane(cnts, c & 63); };
+    cnts = lane < p.nchunks ? ecount[lane] : 0;
+    unsigned long long enext = 0ull;
+    {
+        const int cnt0 = cnt_of(0);
+        enext = (k + lane < cnt0) ? list[k + lane] : 0ull;
+    }
+    for (int c = 0; c < p.nchunks; c = nc) {
+        const int cnt = cnt_of(c);
         const unsigned long long *seg = list + (size_t) c * kTcChunk;
         int j0 = c == 0 ? k : 0;
-        unsigned long long e = (j0 + lane < cnt) ? seg[j0 + lane] : 0ull;
+        unsigned long long e = enext;
+        // the next chunk with entries (lengths of the following 64-chunk group fetched when the walk crosses into it)
+        nc = c + 1;
+        while (nc < p.nchunks) {
+            if ((nc & 63) == 0) cnts = nc + lane < p.nchunks ? ecount[nc + lane] : 0;
+            if (cnt_of(nc) > 0) break;
+            ++nc;
+        }
+        if (nc < p.nchunks) {
+            const int cn = cnt_of(nc);
+            enext = lane < cn ? list[(size_t) nc * kTcChunk + lane] : 0ull;
+        }
         for (; j0 < cnt; j0 += 64) {
             const unsigned long long cur = e;
             if (j0 + 64 + lane < cnt) e = seg[j0 + 64 + lane];          // next round's entries travel under this round's sifts

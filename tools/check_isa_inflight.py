@@ -16,6 +16,9 @@ kernel named on the command line (default: all fscan kernels):
   * any instruction naming a VGPR that is still pending is reported -- except the loads themselves and instructions carrying
     the marker `rii:inflight-ok` (the once-per-trip threshold refresh is read while in flight on purpose: any mix of old and
     new threshold words is valid).
+  * only loads inside inline asm (;;#ASMSTART .. ;;#ASMEND in the assembly) carry destination registers: a load the compiler issued is waited
+    for by the compiler (it still takes its slot in the queue).  (Round 4: block placement can put a cold block behind the code that
+    follows it in program order, reached and left by branches; walking such text linearly made compiler loads look pending.)
   * control flow: at a forward conditional branch the state is remembered for the target label and merged there (the state
     with more pending registers wins: the skipped block can only have waited for more); loops (backward branches) are walked
     twice so that loads issued at the end of an iteration are seen by the start of the next.
@@ -103,17 +106,24 @@ class State:
 def check_function(name, lines):
     # instruction list with labels
     insts = []
+    in_app = False                                   # between ;;#ASMSTART and ;;#ASMEND: text of an inline asm statement
     for ln in lines:
+        if ln.strip().startswith(";;#ASMSTART"):
+            in_app = True
+            continue
+        if ln.strip().startswith(";;#ASMEND"):
+            in_app = False
+            continue
         code = ln.split(";;")[0]
         m = LABEL.match(code.strip())
         if m:
-            insts.append(("label", m.group(1), ln))
+            insts.append(("label", m.group(1), ln, False))
             continue
         body, _, comment = code.partition(";")
         body = body.strip()
         if not body or body.startswith(".") or body.startswith(";"):
             continue
-        insts.append(("inst", body, comment))
+        insts.append(("inst", body, comment, in_app))
     label_pos = {x[1]: i for i, x in enumerate(insts) if x[0] == "label"}
     problems = []
     saved = {}                                       # label -> State from forward branches
@@ -125,7 +135,7 @@ def check_function(name, lines):
                 loop_heads[label_pos[m.group(2)]] = max(loop_heads.get(label_pos[m.group(2)], 0), i)
 
     def step(st, i, report):
-        kind, body, comment = insts[i]
+        kind, body, comment, hand = insts[i]
         if kind == "label":
             if body in saved and saved[body].weight() > st.weight():
                 st = saved[body].copy()
@@ -157,6 +167,9 @@ def check_function(name, lines):
         ok = OK_MARK in comment or OK_MARK in body
         if LGKM.match(mnem):
             dest = dest_regs(ops) if mnem.startswith("ds_read") else set()
+            if not hand:                             # a load the compiler issued: it places the wait itself (and keeps its slot in the queue)
+                st.lgkm.append(frozenset())
+                return st if not (touched & st.pending()) or not report or ok else (problems.append((i, body, sorted(touched & st.pending()))) or st)
             src = touched - dest
             bad = src & st.pending()
             if bad and report and not ok:
@@ -168,6 +181,12 @@ def check_function(name, lines):
             return st
         if LOAD_VM.match(mnem):
             dest = dest_regs(ops)
+            if not hand:                             # compiler-issued: only its use of registers still awaited by HAND-PLACED loads matters
+                badc = touched & st.pending()
+                if badc and report and not ok:
+                    problems.append((i, body, sorted(badc)))
+                st.vm.append(frozenset())
+                return st
             bad = (touched - dest) & st.pending()
             if bad and report and not ok:
                 problems.append((i, body, sorted(bad)))
