@@ -1976,7 +1976,6 @@ int ivf_shard_check(const rii_engine *e, int64_t B, int topk, int64_t S_global, 
     const int64_t nlist = nlist_of(e);
     if (rows > ivf_shard_max_L()) return set_err(RII_ERR_INVALID, "rows=%d: at most %d output rows per query", rows, ivf_shard_max_L());
     if (nlist == 0) return set_err(RII_ERR_STATE, "no posting lists: call reconfigure() / set_coarse_centers() first");
-    if (e->QT == 0) return set_err(RII_ERR_UNSUPPORTED, "M*Ks tables do not fit LDS");
     // the reference's preconditions, on the GLOBAL sizes (src/rii.h:252-253,271)
     if (topk < 1 || (int64_t) topk > L || L > N_global || (S_global != 0 && ((int64_t) topk > S_global || S_global > N_global)))
         return set_err(RII_ERR_INVALID, "need topk <= L <= N and topk <= len(target_ids) <= N on the whole database "
@@ -2072,7 +2071,10 @@ int linear_tie_emit_locked(rii_engine *e, const float *d_queries, int64_t nf, in
     // Cost: the emit scans the whole shard once per group of flagged queries with ~9 bytes of scratch per code and query, so
     // the group size is what fits 1 GiB of scratch (64 queries up to 1.8 M codes, ONE query per launch at a 125 M-code shard:
     // a tie-heavy batch on a Deep1B-sized shard costs nf full-shard passes -- exactness first; docs: DESIGN.md section 6).
-    const int64_t fq_max = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t) 1 << 30) / (n * 9 + 1)));
+    // Tables above the LDS budget (round 4): scan_wide_kernel writes the exact distances of the group as key rows (8 more bytes per code
+    // and query), and the chunk kernels read those instead of staging a table.
+    const bool wide = e->QT == 0;
+    const int64_t fq_max = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t) 1 << 30) / (n * (wide ? 17 : 9) + 1)));
     // work list of a group = [count | 0, 1, 2, ...]: the indices are uploaded once per engine, the count is a 4-byte memset in
     // stream order (no host synchronisation inside the loop)
     if (!e->have_ident) {
@@ -2090,10 +2092,17 @@ int linear_tie_emit_locked(rii_engine *e, const float *d_queries, int64_t nf, in
         RII_TRY(e->s_tie_chunk.ensure(linear_tie_chunked_scratch(n, cur)));
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) e->s_ident.p, cur, 1, st));
         ScopedTimer t(e, "tie", st);
+        const unsigned long long *keyrow = nullptr;
+        if (wide) {
+            RII_TRY(e->s_keys_a.ensure((size_t) cur * (size_t) n * sizeof(unsigned long long)));
+            HIP_TRY(launch_scan_wide(e->d_codes.as<uint8_t>(), n, e->M, e->Ks, e->s_lut.as<float>(), S ? d_tids : nullptr, 0, cur,
+                                     e->s_keys_a.as<unsigned long long>(), st));
+            keyrow = e->s_keys_a.as<unsigned long long>();
+        }
         HIP_TRY(launch_linear_tie_emit(e->d_codes.as<uint8_t>(), n, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, 0,
                                        e->s_ident.as<int32_t>() + 1, e->s_ident.as<int>(), S ? d_tids : nullptr, topk, cur,
                                        e->s_tie_chunk.p, S ? 1 : 0, d_bound ? d_bound + f0 : nullptr, id_offset, cap,
-                                       d_out_ids + f0 * cap, d_out_dists + f0 * cap, d_out_count + f0, st));
+                                       d_out_ids + f0 * cap, d_out_dists + f0 * cap, d_out_count + f0, st, keyrow));
     }
     return RII_OK;
 }
@@ -2108,7 +2117,7 @@ RII_API int rii_linear_tie_emit_dev(rii_engine *e, const float *d_queries, int64
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
     if (S > e->N) return set_err(RII_ERR_INVALID, "S=%lld must satisfy S <= N", (long long) S);
-    if (e->QT == 0 || !linear_tie_chunked_supported(e->M, e->Ks, topk))
+    if (e->QT == 0 ? !linear_tie_chunked_topk_ok(topk) : !linear_tie_chunked_supported(e->M, e->Ks, topk))
         return set_err(RII_ERR_UNSUPPORTED, "tie emission: topk=%d / M*Ks=%d not supported", topk, e->M * e->Ks);
     if (nf == 0) return RII_OK;
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
@@ -2381,7 +2390,7 @@ RII_API int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t i
         if (hipMemcpyAsync(&h_any, c->anyf.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
         if (!h_any) break;
         // ---- exact ties across the shards: replay (identical decisions on every rank: the flags come from identical merges) ----
-        if (e->QT == 0 || !linear_tie_chunked_supported(e->M, e->Ks, topk)) { r = set_err(RII_ERR_UNSUPPORTED, "tie replay across shards: topk=%d / M*Ks=%d not supported", topk, e->M * e->Ks); break; }
+        if (e->QT == 0 ? !linear_tie_chunked_topk_ok(topk) : !linear_tie_chunked_supported(e->M, e->Ks, topk)) { r = set_err(RII_ERR_UNSUPPORTED, "tie replay across shards: topk=%d / M*Ks=%d not supported", topk, e->M * e->Ks); break; }
         std::vector<int32_t> h_tie((size_t) B), h_sel;
         if (hipMemcpy(h_tie.data(), d_tie, (size_t) B * 4, hipMemcpyDeviceToHost) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
         for (int64_t b = 0; b < B; ++b) if (h_tie[(size_t) b]) h_sel.push_back((int32_t) b);

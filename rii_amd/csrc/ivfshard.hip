@@ -37,7 +37,9 @@ struct ShardArgs {
 
 // BIG (nlist above kShardMaxNlistLds -- the reference's default sqrt(N) is 11 k lists at a 125 M-code shard): the coarse order and
 // the cumulative counts live in global scratch, the heap of the coarse std::partial_sort (w entries) in LDS
-template <bool BIG>
+// GTAB (round 4): a table above the LDS budget (widetab.hip: M * Ks * 4 bytes > 144 KiB) is read from global memory where it lies
+// (plain [b][M * Ks], L2-resident) -- same arithmetic, same order
+template <bool BIG, bool GTAB = false>
 __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
     float *lds = reinterpret_cast<float *>(smem);
-    unsigned char *base = smem + (((size_t) MK * 4 + 15) & ~(size_t) 15);
+    const float *tab = GTAB ? p.lut + (size_t) b * MK : lds;
+    unsigned char *base = smem + (GTAB ? 0 : (((size_t) MK * 4 + 15) & ~(size_t) 15));
     const bool w_lds = p.w <= kWhSplitMaxHeap;                        // BIG: the heap of the coarse sort in LDS (walked by a wave)
     const int ncoarse = BIG ? (w_lds ? (int) p.w : 0) : nlist;        // entries of the coarse sequence kept in LDS
     pq64_t *s_head = reinterpret_cast<pq64_t *>(base);                // [ncoarse] (coarse distance, list id)
@@ -58,13 +61,13 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     unsigned long long *s_key = reinterpret_cast<unsigned long long *>(
         smem + ((reinterpret_cast<unsigned char *>(s_misc + 4) - smem + 15) & ~(size_t) 15));      // [pow2 >= L]
 
-    {
+    if constexpr (!GTAB) {
         const float *src = p.lut + (size_t) b * MK;
         for (int i = tid; i < MK; i += 256) lds[i] = src[i];
     }
     __syncthreads();
     for (int c = tid; c < nlist; c += 256) {                                          // src/rii.h:262-264
-        const pq64_t e = pq64_make(exact_adist(lds, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
+        const pq64_t e = pq64_make(exact_adist(tab, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
         if (BIG && w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
     }
     __syncthreads();
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
             const int li = pos - s_cum[lo] - before;                                  // index inside this rank's part of the list
             if (li >= 0 && li < p.list_len[no]) {
                 const int32_t id = p.pl_ids[p.pl_off[no] + li];
-                const float d = exact_adist(lds, p.codes + (size_t) id * p.M, p.M, p.Ks);
+                const float d = exact_adist(tab, p.codes + (size_t) id * p.M, p.M, p.Ks);
                 key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | (uint32_t) pos;
                 atomicAdd(&s_misc[2], 1);
             }
@@ -210,12 +213,13 @@ hipError_t launch_shard_replay(const void *d_gathered, int G, int64_t nf, int ro
 }
 
 static bool shard_big(int nlist) { return nlist > kShardMaxNlistLds; }
+static bool shard_gtab(int M, int Ks) { return lut_tile_for(M, Ks) == 0; }       // no whole table fits LDS (rii_internal.h)
 static size_t shard_smem(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
     size_t n2 = 64;
     while ((int64_t) n2 < L) n2 <<= 1;
     const size_t coarse = shard_big(nlist) ? (size_t) (w <= kWhSplitMaxHeap ? w : 0) * 8 : (size_t) nlist * 8 + (size_t) (nlist + 1) * 4;
-    return (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + coarse + 16 + 16 + n2 * 8;
+    return (shard_gtab(M, Ks) ? 0 : (((size_t) M * Ks * 4 + 15) & ~(size_t) 15)) + coarse + 16 + 16 + n2 * 8;
 }
 bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
@@ -238,7 +242,8 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
     a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_pos = d_out_pos; a.out_nloc = d_out_nloc; a.out_counts = d_out_counts;
     a.scratch = static_cast<unsigned char *>(d_scratch); a.per_block = ivf_shard_scratch_per_query(nlist);
     const size_t smem = shard_smem(M, Ks, nlist, L, w);
-    auto kern = shard_big(nlist) ? ivf_shard_kernel<true> : ivf_shard_kernel<false>;
+    auto kern = shard_gtab(M, Ks) ? (shard_big(nlist) ? ivf_shard_kernel<true, true> : ivf_shard_kernel<false, true>)
+                                  : (shard_big(nlist) ? ivf_shard_kernel<true> : ivf_shard_kernel<false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a);

@@ -300,7 +300,9 @@ hipError_t launch_scan_order(const uint8_t *d_codes, int64_t N, int M, int Ks, i
 hipError_t launch_linear_tie_emit(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                                   const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int topk, int fq,
                                   void *d_scratch, int indirect, const float *d_ext_bound, int64_t id_offset, int cap,
-                                  int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_count, hipStream_t st);
+                                  int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_count, hipStream_t st,
+                                  const unsigned long long *d_keyrow = nullptr);
+bool linear_tie_chunked_topk_ok(int topk);
 size_t linear_tie_record_bytes(int64_t nf, int cap);
 hipError_t launch_linear_shard_replay(const void *d_gathered, int G, int64_t nf, int cap, int topk, int64_t *d_out_ids,
                                       float *d_out_dists, hipStream_t st);

@@ -188,17 +188,23 @@ struct TcArgs {
     // the compacted candidate list as output instead of the replay
     const float *ext_bound = nullptr;    // [fq] (+inf = none)
     int64_t *em_ids = nullptr; float *em_dists = nullptr; int32_t *em_count = nullptr; int em_cap = 0; int64_t id_offset = 0;
+    // round 4, tables above the LDS budget (widetab.hip): the exact distances of query fi were already written by scan_wide_kernel as the
+    // key row keyrow[flag_list[fi] * n + i] = (orderable distance << 32 | i); no table is staged
+    const unsigned long long *keyrow = nullptr;
 };
 
 __device__ __forceinline__ void tc_stage(const TcArgs &p, int64_t b, float *lds, int tid)
 {
+    if (p.keyrow) return;
     const int MK = p.M * p.Ks;
     const float *src = p.lut + (size_t) (b / p.QT) * MK * p.QT + (b % p.QT);
     for (int i = tid; i < MK; i += 256) lds[i] = src[(size_t) i * p.QT];
 }
-__device__ __forceinline__ float tc_dist(const TcArgs &p, const float *lds, int64_t i)
+// orderable bits of the exact distance of position i for the query whose table (or key row) is number b
+__device__ __forceinline__ uint32_t tc_od(const TcArgs &p, const float *lds, int64_t b, int64_t i)
 {
-    return exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[i] : i) * p.M, p.M, p.Ks);
+    if (p.keyrow) return (uint32_t) (p.keyrow[(size_t) (b - p.b0) * p.n + i] >> 32);
+    return f32_orderable(__float_as_uint(exact_adist(lds, p.codes + (size_t) (p.indirect ? (int64_t) p.remap[i] : i) * p.M, p.M, p.Ks)));
 }
 
 __global__ __launch_bounds__(256) void tie_chunk_kth_kernel(TcArgs p)
@@ -207,14 +213,15 @@ __global__ __launch_bounds__(256) void tie_chunk_kth_kernel(TcArgs p)
     const int fi = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
     const int nf = *p.nflag < p.fq ? *p.nflag : p.fq;
     if (fi >= nf) return;
-    const int MK = p.M * p.Ks;
+    const int MK = p.keyrow ? 0 : p.M * p.Ks;
     float *lds = reinterpret_cast<float *>(smem);
     uint32_t *buf = reinterpret_cast<uint32_t *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));     // [kTcChunk] orderable distances
-    tc_stage(p, p.b0 + p.flag_list[fi], lds, tid);
+    const int64_t bq = p.b0 + p.flag_list[fi];
+    tc_stage(p, bq, lds, tid);
     __syncthreads();
     const int64_t s = (int64_t) c * kTcChunk;
     const int cnt = (int) ((p.n - s) < kTcChunk ? (p.n - s) : kTcChunk);
-    for (int j = tid; j < kTcChunk; j += 256) buf[j] = j < cnt ? f32_orderable(__float_as_uint(tc_dist(p, lds, s + j))) : 0xffffffffu;
+    for (int j = tid; j < kTcChunk; j += 256) buf[j] = j < cnt ? tc_od(p, lds, bq, s + j) : 0xffffffffu;
     __syncthreads();
     // k-th smallest of buf[0, cnt), exactly: histograms of the occupied range refined down to single values (cap = 0)
     __shared__ unsigned int s_hist[256];
@@ -234,7 +241,8 @@ __global__ __launch_bounds__(256) void tie_chunk_emit_kernel(TcArgs p)
     __shared__ uint32_t s_bound;
     __shared__ int s_wave[4];
     __shared__ int s_base;
-    tc_stage(p, p.b0 + p.flag_list[fi], lds, tid);
+    const int64_t bq = p.b0 + p.flag_list[fi];
+    tc_stage(p, bq, lds, tid);
     if (tid == 0) { s_bound = 0xffffffffu; s_base = 0; }
     __syncthreads();
     {
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void tie_chunk_emit_kernel(TcArgs p)
     for (int j0 = 0; j0 < cnt; j0 += 256) {                // slabs of 256 consecutive indices: order-preserving compaction
         const int j = j0 + tid;
         uint32_t od = 0xffffffffu;
-        if (j < cnt) od = f32_orderable(__float_as_uint(tc_dist(p, lds, s + j)));
+        if (j < cnt) od = tc_od(p, lds, bq, s + j);
         const bool keep = j < cnt && (bound == 0xffffffffu || od < bound);
         const unsigned long long bal = __ballot(keep);
         const int lane = tid & 63, wave = tid >> 6;
@@ -458,6 +466,7 @@ bool linear_tie_chunked_supported(int M, int Ks, int topk)
     return topk <= 2 * 64 * kWhMaxWords && topk <= kTcChunk &&
            (((size_t) M * Ks * 4 + 15) & ~(size_t) 15) + (size_t) kTcChunk * 4 + 64 <= (size_t) 160 * 1024 - 512;
 }
+bool linear_tie_chunked_topk_ok(int topk) { return topk <= 2 * 64 * kWhMaxWords && topk <= kTcChunk; }      // key-row form: no table in LDS
 int64_t linear_tie_chunks(int64_t n) { return (n + kTcChunk - 1) / kTcChunk; }
 size_t linear_tie_chunked_scratch(int64_t n, int fq) { return (size_t) fq * (size_t) linear_tie_chunks(n) * ((size_t) kTcChunk * 8 + 8); }
 
@@ -490,9 +499,11 @@ hipError_t launch_linear_tie_chunked(const uint8_t *d_codes, int64_t n, int M, i
 hipError_t launch_linear_tie_emit(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                                   const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int topk, int fq,
                                   void *d_scratch, int indirect, const float *d_ext_bound, int64_t id_offset, int cap,
-                                  int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_count, hipStream_t st)
+                                  int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_count, hipStream_t st,
+                                  const unsigned long long *d_keyrow)
 {
     TcArgs a;
+    a.keyrow = d_keyrow;
     a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.b0 = b0; a.flag_list = d_flag_list;
     a.nflag = d_nflag; a.remap = d_remap; a.indirect = indirect; a.topk = topk; a.fq = fq;
     a.nchunks = (int) linear_tie_chunks(n);
@@ -503,7 +514,7 @@ hipError_t launch_linear_tie_emit(const uint8_t *d_codes, int64_t n, int M, int 
     a.out_ids = nullptr; a.out_dists = nullptr;
     a.ext_bound = d_ext_bound; a.em_ids = d_out_ids; a.em_dists = d_out_dists; a.em_count = d_out_count; a.em_cap = cap;
     a.id_offset = id_offset;
-    const size_t tab = (((size_t) M * Ks * 4 + 15) & ~(size_t) 15);
+    const size_t tab = d_keyrow ? 0 : (((size_t) M * Ks * 4 + 15) & ~(size_t) 15);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tie_chunk_kth_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) (tab + kTcChunk * 4));
     if (e != hipSuccess) return e;

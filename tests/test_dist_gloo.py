@@ -432,6 +432,24 @@ def _worker(rank, world, port, q, use_gpu=False):
         # nlist = 5000 (above the LDS limit of the sharded kernel: coarse order in global scratch, heap in LDS) and L up to N
         _check_sharded_ivf(rd, rank, world, cw2, np.concatenate([codes2] * 5)[:7001], qs2, _GpuBatch if use_gpu else _OracleShard, use_gpu,
                            ties=True, nlist=5000)
+        # tables above the LDS budget (M = 160, Ks = 256: 160 KiB; widetab.hip): the sharded entry points used to refuse these shapes
+        # (round 4: ivf_shard_kernel<GTAB>, key-row tie emission) -- tied distances across the shards, linear and inverted index
+        rngw = np.random.default_rng(177)
+        cw3 = np.round(rngw.random((160, 256, 1)) * 3).astype(np.float32)
+        codes3 = rngw.integers(0, 6, size=(1801, 160), dtype=np.uint8)
+        codes3[rngw.integers(0, 1801, 500)] = codes3[rngw.integers(0, 1801, 500)]
+        qs3 = np.round(rngw.random((6, 160)) * 3).astype(np.float32)
+        full3 = _OracleBatch(cw3, codes3)
+        s3, e3 = rd.shard_range(1801, rank, world)
+        idx3 = rd.DbShardedIndex((_GpuBatch if use_gpu else _OracleBatch)(cw3, codes3[s3:e3]), s3, e3)
+        n_flag3 = 0
+        for topk in (1, 4, 40):
+            gi, gd = idx3.query_linear_batch(qs3, topk, None)
+            wi, wd = full3.query_linear_batch(qs3, topk, None)
+            n_flag3 += int(idx3.last_tie_flags.sum())
+            assert np.array_equal(gd.numpy().view(np.uint32), wd.view(np.uint32)) and np.array_equal(gi.numpy(), wi), "wide tables, db-sharded k=%d" % topk
+        assert n_flag3 > 0 and not bool(idx3.last_tie_overflow.any())
+        assert _check_sharded_ivf(rd, rank, world, cw3, codes3, qs3, _GpuBatch if use_gpu else _OracleShard, use_gpu, ties=True) > 0
         q.put((rank, "ok"))
     except Exception as ex:                                   # noqa: BLE001
         import traceback

@@ -399,3 +399,81 @@ def test_ivf_posting_order_code_copy_gives_the_rows_of_the_id_gather(M, Ds):
             for topk, L in ((1, 300), (10, 4000)):
                 gi, gd, gc = g.query_ivf_batch(qs[b:b + 1], topk, None, L)
                 assert_same_result((gi[0, :int(gc[0])], gd[0, :int(gc[0])]), o.query_ivf(qs[b], topk, E, L), "ivf posting-order codes")
+
+
+@pytest.mark.parametrize("M,Ds,subset", [(160, 1, False), (160, 1, True), (16, 4, False)])
+def test_tie_emission_of_wide_table_shards_replays_in_the_reference_order(M, Ds, subset):
+    """Database sharding, exact ties, tables above the LDS budget (M = 160: 160 KiB): rii_linear_tie_emit_dev used to answer
+    RII_ERR_UNSUPPORTED there; now scan_wide_kernel's key rows feed the chunk kernels.  Three shards of one database as three engines on
+    this GPU: every shard emits its candidates under the bound of the shards in front of it, the records are laid out as an all-gather
+    would, rii_linear_tie_replay_dev replays std::partial_sort over them -- the rows must be the single engine's (which replays ties
+    with tie_rows_kernel) and the oracle's, for every query, tied or not.  (M = 16: the same harness over the LDS-table form.)"""
+    import torch
+    from rii_amd import RiiGpu, core
+    rng = np.random.default_rng(1000 + M + subset)
+    cw = np.round(rng.random((M, 256, Ds)) * 7).astype(np.float32)            # integer-valued tables: exact ties everywhere
+    N = 21000
+    codes = rng.integers(0, 4, size=(N, M), dtype=np.uint8)                    # few distinct bytes: many equal distances
+    codes[rng.integers(0, N, 3000)] = codes[rng.integers(0, N, 3000)]
+    full = RiiGpu(cw, False, simd_arch="avx512")
+    full.add_codes(codes, False)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    cuts = [0, 9000, 9100, N]                                                  # a shard shorter than k among them
+    shards = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g = RiiGpu(cw, False, simd_arch="avx512")
+        g.add_codes(codes[a:b], False)
+        shards.append((g, a, b))
+    qs = np.round(rng.random((6, M * Ds)) * 7).astype(np.float32)
+    Q = torch.from_numpy(qs).cuda()
+    tids = np.sort(rng.choice(N, 6000, replace=False)).astype(np.int64) if subset else None
+    nf, cap = len(qs), 12288
+    for topk in (3, 40, 200):
+        want = full.query_linear_batch(qs, topk, tids)
+        recs = []
+        kth = []                                                                # per shard: its k-th best distance per query (+inf: fewer)
+        for g, a, b in shards:
+            tl = None if tids is None else (tids[(tids >= a) & (tids < b)] - a)
+            nloc = (b - a) if tl is None else len(tl)
+            kk = min(topk, nloc)
+            dk = np.full(nf, np.inf, np.float32)
+            if kk == topk:
+                dk = g.query_linear_batch(qs, topk, tl)[1][:, topk - 1].copy()
+            bound = np.full(nf, np.inf, np.float32)
+            for prev in kth:
+                bound = np.minimum(bound, prev)
+            kth.append(dk)
+            e_ids = torch.zeros((nf, cap), dtype=torch.int64, device="cuda")
+            e_d = torch.zeros((nf, cap), dtype=torch.float32, device="cuda")
+            e_cnt = torch.zeros((nf + (nf & 1),), dtype=torch.int32, device="cuda")
+            if nloc > 0:
+                t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).cuda()
+                bd = torch.from_numpy(bound).cuda()
+                g.linear_tie_emit_dev(Q.data_ptr(), nf, topk, t.data_ptr() if t is not None else 0, 0 if t is None else t.numel(),
+                                      bd.data_ptr(), a, cap, e_ids.data_ptr(), e_d.data_ptr(), e_cnt.data_ptr(), 0)
+            torch.cuda.synchronize()
+            assert int(e_cnt[:nf].max()) <= cap
+            rec = torch.cat([x.reshape(-1).view(torch.uint8) for x in (e_cnt, e_ids, e_d)])
+            pad = (-rec.numel()) % 16
+            if pad:
+                rec = torch.cat([rec, torch.zeros(pad, dtype=torch.uint8, device="cuda")])
+            assert rec.numel() == core.linear_tie_record_bytes(nf, cap)
+            recs.append(rec)
+        gg = torch.stack(recs).contiguous()
+        r_i = torch.empty((nf, topk), dtype=torch.int64, device="cuda")
+        r_d = torch.empty((nf, topk), dtype=torch.float32, device="cuda")
+        core.linear_tie_replay_dev(gg.data_ptr(), len(shards), nf, cap, topk, r_i.data_ptr(), r_d.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(r_i.cpu().numpy(), want[0]) and np.array_equal(r_d.cpu().numpy().view(np.uint32), want[1].view(np.uint32)), topk
+        for b in (0, 3):
+            assert_same_result((r_i[b].cpu().numpy(), r_d[b].cpu().numpy()), o.query_linear(qs[b], topk, E if tids is None else tids),
+                               "wide tie emission k=%d" % topk)
+    if not subset:                                  # and through the sharded class on one rank (merge flags -> emit -> replay behind one call)
+        from rii_amd.dist import DbShardedIndex
+        idx = DbShardedIndex(full, 0, N)
+        for topk in (3, 40):
+            ids, d = idx.query_linear_batch(Q, topk)
+            want = full.query_linear_batch(qs, topk, None)
+            assert np.array_equal(ids.cpu().numpy(), want[0]) and np.array_equal(d.cpu().numpy(), want[1]), topk
+            assert bool(idx.last_tie_flags.any()) and not bool(idx.last_tie_overflow.any())
