@@ -481,8 +481,8 @@ def readme_workload(args, torch, dev, arch):
             o["cpu_baseline"] = cb
         out[name] = o
     out["note"] = ("latency-bound: linear = ONE launch (small_topk_kernel reads the query from and writes its rows to the engine's "
-                   "pinned block, the host waits on a flag there); inverted index = pinned H2D + three launches, rows and flag "
-                   "likewise; floor of an empty launch + flag on this box 7.5 us (tools/host_latency_probe.hip); no roofline "
+                   "pinned block, the host waits on a flag there); inverted index = ONE launch too (round 4: ivf_fused_kernel fetches the query from the pinned "
+                   "block, replays a flagged query itself, rows and flag likewise); floor of an empty launch + flag on this box 7.5 us (tools/host_latency_probe.hip); no roofline "
                    "applies (the index is 320 KB)")
     return out
 
