@@ -483,7 +483,8 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
 
 // queries per table tile of the exhaustive scan for a batch of B: 1 for a single query (see launch_scan_wk; two
 // queries would walk the codes twice, which loses to one 4-query tile)
-int exact_tile_for(const rii_engine *e, int64_t B, int topk) { return (topk == 1 && B == 1) ? 1 : e->QT; }
+// top-1 over one / two queries: 4 / 8-byte table rows (scan_kernel<1 / 2>: HBM-bound on a large shard); else the engine's tile
+int exact_tile_for(const rii_engine *e, int64_t B, int topk) { return (topk == 1 && B <= 2 && e->QT >= (int) B) ? (int) B : e->QT; }
 
 void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, int64_t *chunk_len, int qt = 0)
 {
@@ -491,8 +492,10 @@ void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, i
     const int64_t tiles = (B + qt - 1) / qt;
     int64_t c = e->scan_chunks;
     if (c <= 0) {
-        // ~2 workgroups' worth of tiles per CU, but never chunks shorter than 8K codes (table staging cost)
-        const int64_t target = 2LL * e->n_cu;
+        // ~2 workgroups' worth of tiles per CU, but never chunks shorter than 8K codes (table staging cost); the one / two-query
+        // stream (scan_kernel<1 / 2>: two blocks resident per CU) runs best with four per CU (2 GB shard, B = 1: 512 chunks 4.57 TB/s,
+        // 1024: 5.38, 2048: 5.19, 4096: 4.97 -- profiles/r04_deep125m_few_queries.json)
+        const int64_t target = (qt <= 2 ? 4LL : 2LL) * e->n_cu;
         c = (target + tiles - 1) / tiles;
         const int64_t max_c = std::max<int64_t>(1, n_codes / 8192);
         c = std::max<int64_t>(1, std::min(c, max_c));

@@ -207,6 +207,28 @@ __device__ __forceinline__ void adc_words(const uint32_t (&w)[MW], const typenam
     }
 }
 
+// the same sums with the table entries of 16 subspaces at a time gathered BEFORE the first addition: sixteen LDS reads in flight instead
+// of a read -> wait -> add chain per subspace (what the compiler makes of adc_words when it is short of nothing but patience)
+template <int QT, int MW, int KST>
+__device__ __forceinline__ void adc_words_gathered(const uint32_t (&w)[MW], const typename LutT<QT>::T *__restrict__ lut,
+                                                   float (&acc)[QT])
+{
+    typedef typename LutT<QT>::T LT;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) acc[q] = 0.f;
+    constexpr int G = MW < 4 ? MW : 4;                // words per gather group (16 lookups)
+#pragma unroll
+    for (int i0 = 0; i0 < MW; i0 += G) {
+        LT v[G * 4];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i * 4 + j] = lut[((i0 + i) * 4 + j) * KST + ((w[i0 + i] >> (8 * j)) & 0xffu)];
+#pragma unroll
+        for (int t = 0; t < G * 4; ++t) acc_add<QT>(acc, v[t]);
+    }
+}
+
 template <int MW> __device__ __forceinline__ void load_code_words(const uint8_t *__restrict__ p, uint32_t (&w)[MW])
 {
     if constexpr (MW % 4 == 0) {
@@ -241,6 +263,12 @@ struct ScanArgs {
     const int32_t *perm;           // scan position -> code id (scanorder.hip) or NULL when the codes are in id order
 };
 
+// rows per thread and trip of scan_kernel (> 1: the static-table form of the one / two-query top-1 instances, at most 64 KiB of table)
+constexpr int scan_rows_per_trip(int QT, int MW, bool write_keys, bool perm)
+{
+    return (MW != 0 && !write_keys && !perm && QT <= 2 && QT * MW <= 16) ? (QT * MW <= 4 ? 8 : 4) : 1;
+}
+
 template <int QT, int MW, int KST, bool WRITE_KEYS, bool PERM = false>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
 {
@@ -251,8 +279,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
     const int tid = threadIdx.x;
     const int tile = p.tile0 + blockIdx.y;
     const size_t lut_elems = (size_t) M * Ks * QT;
-    float *lds = reinterpret_cast<float *>(smem);
-    unsigned long long *red =
+    // round 4: top-1 over one or two queries (4 / 8-byte table rows) is a pure stream on a large shard -- U rows per thread and trip are
+    // requested before the first is scored, sixteen table reads of a row are in flight before the first addition (adc_words_gathered),
+    // and the table sits in a STATIC LDS array: with its address known at compile time a lookup's address is one SDWA shift of the code
+    // byte instead of a byte extract plus a shift-add onto the dynamic-LDS base (tools/probes/stream_probe.hip: 4.7 -> 5.3 TB/s).
+    // A lane still meets its codes in ascending order, so the first minimum still wins.
+    constexpr int U = scan_rows_per_trip(QT, MW, WRITE_KEYS, PERM);
+    constexpr bool STATIC_TAB = U > 1;
+    __shared__ typename LutT<QT>::T s_tab[STATIC_TAB ? (MW ? MW : 1) * 4 * 256 : 1];
+    __shared__ unsigned long long s_red[QT];
+    float *lds = STATIC_TAB ? reinterpret_cast<float *>(s_tab) : reinterpret_cast<float *>(smem);
+    unsigned long long *red = STATIC_TAB ? s_red :
         reinterpret_cast<unsigned long long *>(smem + ((lut_elems * sizeof(float) + 15) & ~(size_t) 15));
 
     // ---- stage this tile's table: contiguous M*Ks*QT floats -> LDS (same layout) ----
@@ -279,6 +316,39 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs p)
 #pragma unroll
     for (int q = 0; q < QT; ++q) { bestd[q] = INFINITY; besti[q] = 0xffffffffu; }
 
+    // round 4: one or two queries per block are HBM-latency-bound with one 16 / 32-byte row request per thread in flight (32 waves x 1 KiB
+    // per CU against ~2 us of loaded latency = 4.2 TB/s, exactly what a 2 GB shard measured); four rows per thread are requested before
+    // the first is scored.  A lane still meets its codes in ascending order, so the first minimum still wins.
+    if constexpr (U > 1) {
+        constexpr int MWc = MW ? MW : 1;
+        int64_t n0 = c_begin + tid;
+        const int64_t full_end = c_end - (int64_t) (U - 1) * kScanThreads;      // below it all U rows of a trip exist
+        for (; n0 < full_end; n0 += (int64_t) kScanThreads * U) {
+            uint32_t w[U][MWc];
+            const uint8_t *row = p.codes + (size_t) n0 * (MWc * 4);
+#pragma unroll
+            for (int u = 0; u < U; ++u) load_code_words<MWc>(row + (size_t) u * kScanThreads * (MWc * 4), w[u]);
+            __builtin_amdgcn_sched_barrier(0);         // all U requests leave before the first row is touched (the scheduler otherwise
+                                                       // waits for row 0 with ONE request in flight and issues the others behind it)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float acc[QT];
+                adc_words_gathered<QT, MWc, KST>(w[u], lut, acc);
+#pragma unroll
+                for (int q = 0; q < QT; ++q)
+                    if (acc[q] < bestd[q]) { bestd[q] = acc[q]; besti[q] = (uint32_t) (n0 + (int64_t) u * kScanThreads); }
+            }
+        }
+        for (; n0 < c_end; n0 += kScanThreads) {       // the last, partial trip
+            uint32_t w[MWc];
+            load_code_words<MWc>(p.codes + (size_t) n0 * (MWc * 4), w);
+            float acc[QT];
+            adc_words_gathered<QT, MWc, KST>(w, lut, acc);
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+                if (acc[q] < bestd[q]) { bestd[q] = acc[q]; besti[q] = (uint32_t) n0; }
+        }
+    } else
     for (int64_t n = c_begin + tid; n < c_end; n += kScanThreads) {
         float acc[QT];
         if constexpr (MW != 0) {
@@ -359,7 +429,7 @@ static hipError_t launch_scan_t(const ScanParams &sp, int tile0, int ntiles, hip
         if (sp.perm) return launch_scan_t<QT, MW, KST, WK, true>(sp, tile0, ntiles, st);
     }
     const size_t lut_bytes = (size_t) sp.M * sp.Ks * QT * sizeof(float);
-    const size_t smem = ((lut_bytes + 15) & ~(size_t) 15) + 64;
+    const size_t smem = scan_rows_per_trip(QT, MW, WK, PERM) > 1 ? 0 : ((lut_bytes + 15) & ~(size_t) 15) + 64;      // (static table)
     auto kern = scan_kernel<QT, MW, KST, WK, PERM>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
@@ -388,6 +458,10 @@ template <bool WK> static hipError_t launch_scan_wk(const ScanParams &sp, hipStr
         if (fast && sp.QT == 1 && sp.M == 16) return launch_scan_t<1, 4, 256, false>(sp, tile0, ntiles, st);
         if (fast && sp.QT == 1 && sp.M == 32) return launch_scan_t<1, 8, 256, false>(sp, tile0, ntiles, st);
         if (fast && sp.QT == 1 && sp.M == 64) return launch_scan_t<1, 16, 256, false>(sp, tile0, ntiles, st);
+        // two queries: 8-byte rows (ds_read_b64 costs what ds_read_b32 does; a 4-query tile's 16-byte rows make the pair LDS-bound)
+        if (fast && sp.QT == 2 && sp.M == 8) return launch_scan_t<2, 2, 256, false>(sp, tile0, ntiles, st);
+        if (fast && sp.QT == 2 && sp.M == 16) return launch_scan_t<2, 4, 256, false>(sp, tile0, ntiles, st);
+        if (fast && sp.QT == 2 && sp.M == 32) return launch_scan_t<2, 8, 256, false>(sp, tile0, ntiles, st);
     }
     if (sp.QT == 4) return launch_scan_t<4, 0, 0, WK>(sp, tile0, ntiles, st);
     if (sp.QT == 2) return launch_scan_t<2, 0, 0, WK>(sp, tile0, ntiles, st);

@@ -49,3 +49,4 @@ def test_the_checker_catches_an_injected_early_read(asm_path, kernel):
     lines.insert(i + 1, "\tv_mov_b32_e32 v0, v%d" % reg)
     probs, _ = t.check_function(name, lines)
     assert probs and any(reg in p[2] for p in probs)
+

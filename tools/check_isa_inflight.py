@@ -23,7 +23,7 @@ kernel named on the command line (default: all fscan kernels):
     with more pending registers wins: the skipped block can only have waited for more); loops (backward branches) are walked
     twice so that loads issued at the end of an iteration are seen by the start of the next.
 
-usage: tools/check_isa_inflight.py [--asm file.s] [kernel-substring ...]      exit status 1 if anything is reported."""
+usage: tools/check_isa_inflight.py [--asm file.s | --src kernels.hip] [kernel-substring ...]      exit status 1 if anything is reported."""
 import os
 import re
 import subprocess
@@ -43,11 +43,11 @@ LGKM = re.compile(r"^(ds_|s_load|s_buffer_load)")
 OK_MARK = "rii:inflight-ok"
 
 
-def compile_asm():
+def compile_asm(src="fastscan.hip"):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
            "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only",
-           os.path.join(CSRC, "fastscan.hip"), "-o", out]
+           os.path.join(CSRC, src), "-o", out]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out
 
@@ -242,9 +242,12 @@ def main():
     asm = None
     if args[:1] == ["--asm"]:
         asm, args = args[1], args[2:]
+    src = "fastscan.hip"
+    if args[:1] == ["--src"]:                        # another source file of rii_amd/csrc (kernels.hip: scan_kernel's hand-placed row loads)
+        src, args = args[1], args[2:]
     if asm is None:
-        asm = compile_asm()
-    subs = args or ["fscan_mx_kernel", "fscan_mx_dual_kernel", "fscan_kernel"]
+        asm = compile_asm(src)
+    subs = args or (["fscan_mx_kernel", "fscan_mx_dual_kernel", "fscan_kernel"] if src == "fastscan.hip" else ["scan_kernel"])
     funcs = split_functions(asm)
     total, bad = 0, 0
     for name, lines in sorted(funcs.items()):

@@ -24,10 +24,11 @@ out = {"n_codes": n, "bytes": n * M}
 ref = {}
 def run(B, topk=1):
     eng.query_linear_dev(q.data_ptr(), B, topk, 0, 0, oi.data_ptr(), od.data_ptr(), st.cuda_stream)
-for name, fmb, chunks in (("exact", 33, 0), ("filter_c0", 0, 0), ("filter_c256", 0, 256), ("filter_c512", 0, 512), ("filter_c1024", 0, 1024)):
+for name, fmb, chunks in (("exact", 33, 0), ("exact_c1024", 33, 1024), ("exact_c2048", 33, 2048), ("exact_c4096", 33, 4096), ("exact_again", 33, 0), ("filter_c0", 0, 0), ("filter_c256", 0, 256), ("filter_c512", 0, 512), ("filter_c1024", 0, 1024)):
     eng.set_option("fast_min_batch", fmb); eng.set_option("scan_chunks", chunks)
     for B in (1, 2, 4, 8, 16, 32):
-        if name == "exact" and B > 8: continue
+        if name.startswith("exact") and B > 8: continue
+        if (name.startswith("exact_c") or name == "exact_again") and B > 2: continue
         for _ in range(3): run(B)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         K = 10
