@@ -522,8 +522,21 @@ def deep_shard_workload(args, torch, dev, arch, barrier):
            "value": B * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
            "uninstrumented_ms_per_step": plain / steps * 1e3, "uninstrumented_value": B * steps / plain,
            "kernel": roof["kernel"], "kernel_ms": avg_s * 1e3, "roofline": roof}
+    res_ids = out_ids.cpu().numpy().copy()
+    # one / two queries per call over the same shard (scan_kernel<1 / 2>: the exact fp32 scan as a pure HBM stream -- the code bytes
+    # are read once per call, so bytes / kernel time IS the stream rate)
+    few = {}
+    for b in (1, 2):
+        def few_step(b=b):
+            eng.query_linear_dev(q.data_ptr(), b, 1, 0, 0, out_ids.data_ptr(), out_d.data_ptr(), stream)
+        _e, fdom, _s = measure(eng, few_step, steps, 3, barrier, torch.cuda.synchronize)
+        fplain = timed_loop(few_step, steps, barrier)
+        fk = fdom["scan"][0] / steps
+        few["B%d" % b] = {"ms_per_call": fplain / steps * 1e3, "kernel": "scan_kernel<%d>" % b, "kernel_ms": fk,
+                          "stream_TBps": n * M / (fk * 1e-3) / 1e12, "hbm_frac_of_8TBps": n * M / (fk * 1e-3) / 8e12,
+                          "ids_match_batch": bool((out_ids[:b].cpu().numpy() == res_ids[:b]).all())}
+    obj["few_queries"] = few
     if not args.no_cpu_baseline:
-        res_ids = out_ids.cpu().numpy().copy()
         cb, cpu_res = cpu_baseline("linear", "full %d-code linear scan (M=16)" % n, reference_factory(eng, cw, codes, arch, False),
                                    query[:B], 1, None, 0, budget_s=3.0, thread_settings=[64, 16])
         cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, None, cpu_res)
