@@ -99,7 +99,7 @@ struct ScratchSet {
     DevBuf s_queries, s_tids, s_lut, s_best, s_out_ids, s_out_dists, s_out_counts, s_sub_codes, s_keys_a, s_keys_b,
         s_assign, s_coarse_d, s_coarse_i, s_cum, s_ncand, s_nvis, s_cand_i, s_cand_d, s_bitmap, s_fids, s_flen,
         s_hist, s_cnt, s_sample, s_qlut, s_slack, s_cand, s_cand_cnt, s_flag, s_segmin, s_thr16, s_gthr, s_qc, s_flag_list,
-        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident, s_big, s_small_done, s_tile_done;
+        s_tie_list, s_tie_hid, s_tie_hd, s_tie_chunk, s_lohi, s_fsub, s_ident, s_big, s_small_done, s_tile_done, s_tie_cnt2;
     bool have_ident = false;    // s_ident = [count | 0 .. 63]: work list of rii_linear_tie_emit_dev (every query of the call is "flagged")
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
@@ -110,6 +110,7 @@ struct ScratchSet {
     riiamd::IvfParams ivf_deferred; // host-pointer small batches: fallback kernels are launched only if a flag came back set
     bool ivf_has_deferred = false;
     int flag_parity = 0;        // which of the two flagged-query counters the next inverted-index launch group uses
+    int tie_parity = 0;         // likewise for the asynchronous few-query linear path (s_tie_cnt2: two counters, zeroed by the replay kernel)
     int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
     int qlut_levels = 63;       // quantisation levels of the byte tables of the current batch (255: signed bytes, fscan_mx_* only)
@@ -127,7 +128,7 @@ struct ScratchSet {
                           &s_keys_b, &s_assign, &s_coarse_d, &s_coarse_i, &s_cum, &s_ncand, &s_nvis, &s_cand_i, &s_cand_d,
                           &s_bitmap, &s_fids, &s_flen, &s_hist, &s_cnt, &s_sample, &s_qlut, &s_slack, &s_cand, &s_cand_cnt,
                           &s_flag, &s_segmin, &s_thr16, &s_gthr, &s_qc, &s_flag_list, &s_tie_list, &s_tie_hid, &s_tie_hd,
-                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident, &s_big, &s_small_done, &s_tile_done};
+                          &s_tie_chunk, &s_lohi, &s_fsub, &s_out_pack, &s_ident, &s_big, &s_small_done, &s_tile_done, &s_tie_cnt2};
         for (DevBuf *b : bufs) b->release();
         if (sort_temp) (void) hipFree(sort_temp);
         sort_temp = nullptr; sort_temp_bytes = 0;
@@ -552,9 +553,13 @@ int tie_list_reset(rii_engine *e, int64_t bc, hipStream_t st)
     HIP_TRY(hipMemsetAsync(e->s_tie_list.p, 0, sizeof(int32_t), st));
     return RII_OK;
 }
+// d_queries_direct != NULL: no table was built for the batch (the asynchronous few-query path): the chunk kernels build a flagged
+// query's table themselves; only valid when every flagged query takes the chunked form (bc <= 16)
 int tie_fixup(rii_engine *e, const uint8_t *d_codes_idx, int indirect, int64_t n_codes, int64_t b0, int64_t bc, int topk,
-              const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st)
+              const int64_t *d_remap, int64_t *d_out_ids, float *d_out_dists, hipStream_t st, const float *d_queries_direct = nullptr,
+              int *d_nflag = nullptr, int *d_nflag_next = nullptr)
 {
+    if (!d_nflag) d_nflag = e->s_tie_list.as<int>();
     if (!linear_tie_supported(e->M, e->Ks))
         return set_err(RII_ERR_UNSUPPORTED, "M*Ks=%d tables do not fit LDS next to the tie-order work list", e->M * e->Ks);
     // the first few flagged queries: chunk-parallel distances + one wave replaying the heap (three small launches); any
@@ -565,11 +570,13 @@ int tie_fixup(rii_engine *e, const uint8_t *d_codes_idx, int indirect, int64_t n
         RII_TRY(e->s_tie_chunk.ensure(linear_tie_chunked_scratch(n_codes, fq)));
         ScopedTimer t(e, "tie", st);
         HIP_TRY(launch_linear_tie_chunked(d_codes_idx, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt, b0,
-                                          e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>(), d_remap, d_out_ids, d_out_dists,
-                                          topk, fq, e->s_tie_chunk.p, indirect, st));
+                                          e->s_tie_list.as<int32_t>() + 1, d_nflag, d_remap, d_out_ids, d_out_dists,
+                                          topk, fq, e->s_tie_chunk.p, indirect, st, d_queries_direct,
+                                          e->d_codewords.as<float>(), e->Ds, e->arch, d_nflag_next));
         first = fq;
         if (bc <= fq) return RII_OK;
     }
+    if (d_queries_direct) return set_err(RII_ERR_STATE, "tie_fixup: table-free form needs the chunked kernels");
     const int grid = (int) std::min<int64_t>(bc - first, 2LL * e->n_cu);
     if (!linear_tie_heap_in_lds(e->M, e->Ks, topk)) {
         RII_TRY(e->s_tie_hid.ensure((size_t) grid * topk * sizeof(unsigned long long)));
@@ -955,15 +962,38 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
             RII_TRY(e->s_keys_b.ensure(std::max<size_t>(slice_topk_scratch(n_codes, B, topk), 16)));
             RII_TRY(e->s_flag.ensure(8 * sizeof(int32_t)));
             RII_TRY(ensure_small_done(e, st));
-            RII_TRY(tie_list_reset(e, B, st));
+            // four launches per call and nothing else (round 4; was: counter memset, slice kernel, table kernel, three tie kernels): the count
+            // of flagged queries alternates between two words, each zeroed by the replay kernel of the call in front of its next use,
+            // and a flagged query's exact table is built by the tie kernels' own blocks
+            const bool direct = linear_tie_chunked_supported(e->M, e->Ks, topk) && n_codes >= 4 * 8192;    // (tie_fixup's chunked form)
+            if (!direct) {
+                RII_TRY(tie_list_reset(e, B, st));
+                {
+                    ScopedTimer t(e, "scan", st);
+                    HIP_TRY(launch_slice_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, d_queries, e->d_codewords.as<float>(), e->Ds, e->arch, B, topk,
+                                              S ? d_tids : nullptr, e->s_keys_b.as<unsigned long long>(), e->s_small_done.as<unsigned int>(), d_out_ids,
+                                              d_out_dists, e->s_flag.as<int32_t>(), st, nullptr, 0, e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>()));
+                }
+                RII_TRY(build_lut(e, d_queries, B, st, false, 0));                  // the tie kernels' exact tables (B <= 8: microseconds)
+                return tie_fixup(e, e->d_codes.as<uint8_t>(), S ? 1 : 0, n_codes, 0, B, topk, S ? d_tids : nullptr, d_out_ids, d_out_dists, st);
+            }
+            RII_TRY(e->s_tie_list.ensure((size_t) (B + 1) * sizeof(int32_t)));
+            if (!e->s_tie_cnt2.p) {
+                RII_TRY(e->s_tie_cnt2.ensure(2 * sizeof(int)));
+                HIP_TRY(hipMemsetAsync(e->s_tie_cnt2.p, 0, 2 * sizeof(int), st));
+                e->tie_parity = 0;
+            }
+            int *cnt = e->s_tie_cnt2.as<int>() + e->tie_parity, *cnt_next = e->s_tie_cnt2.as<int>() + (e->tie_parity ^ 1);
+            e->tie_parity ^= 1;
             {
                 ScopedTimer t(e, "scan", st);
                 HIP_TRY(launch_slice_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, d_queries, e->d_codewords.as<float>(), e->Ds, e->arch, B, topk,
                                           S ? d_tids : nullptr, e->s_keys_b.as<unsigned long long>(), e->s_small_done.as<unsigned int>(), d_out_ids,
-                                          d_out_dists, e->s_flag.as<int32_t>(), st, nullptr, 0, e->s_tie_list.as<int32_t>() + 1, e->s_tie_list.as<int>()));
+                                          d_out_dists, e->s_flag.as<int32_t>(), st, nullptr, 0, e->s_tie_list.as<int32_t>() + 1, cnt));
             }
-            RII_TRY(build_lut(e, d_queries, B, st, false, 0));                      // the tie kernels' exact tables (B <= 8: microseconds)
-            return tie_fixup(e, e->d_codes.as<uint8_t>(), S ? 1 : 0, n_codes, 0, B, topk, S ? d_tids : nullptr, d_out_ids, d_out_dists, st);
+            e->lut_valid = false;                                                    // (no table of this batch exists)
+            return tie_fixup(e, e->d_codes.as<uint8_t>(), S ? 1 : 0, n_codes, 0, B, topk, S ? d_tids : nullptr, d_out_ids, d_out_dists, st,
+                             d_queries, cnt, cnt_next);
         }
     }
     {

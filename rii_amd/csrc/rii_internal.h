@@ -237,7 +237,9 @@ bool linear_tie_chunked_supported(int M, int Ks, int topk);
 size_t linear_tie_chunked_scratch(int64_t n, int fq);
 hipError_t launch_linear_tie_chunked(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                                      const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
-                                     float *d_out_dists, int topk, int fq, void *d_scratch, int indirect, hipStream_t st);
+                                     float *d_out_dists, int topk, int fq, void *d_scratch, int indirect, hipStream_t st,
+                                     const float *d_queries = nullptr, const float *d_codewords = nullptr, int Ds = 0, int arch = 0,
+                                     int *d_nflag_next = nullptr);
 hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
                                   int32_t *d_flag_list, int *d_nflag, hipStream_t st);
 

@@ -191,12 +191,21 @@ struct TcArgs {
     // round 4, tables above the LDS budget (widetab.hip): the exact distances of query fi were already written by scan_wide_kernel as the
     // key row keyrow[flag_list[fi] * n + i] = (orderable distance << 32 | i); no table is staged
     const unsigned long long *keyrow = nullptr;
+    // round 4, the asynchronous few-query path (engine.hip: query_linear_dev, slice_topk_kernel): no table was built for the batch -- a
+    // flagged query's block builds it here (RiiCpp::DTable, the arithmetic of lut_build_kernel) instead of a table launch behind EVERY call
+    const float *queries = nullptr; const float *codewords = nullptr; int Ds = 0, arch = 0;
+    int *nflag_next = nullptr;           // the counter of the NEXT call (two alternate): zeroed by tie_replay_kernel -- no memset per call
 };
 
 __device__ __forceinline__ void tc_stage(const TcArgs &p, int64_t b, float *lds, int tid)
 {
     if (p.keyrow) return;
     const int MK = p.M * p.Ks;
+    if (p.queries) {
+        const float *q = p.queries + b * (int64_t) (p.M * p.Ds);
+        for (int i = tid; i < MK; i += 256) lds[i] = fvec_l2sqr_any(q + (size_t) (i / p.Ks) * p.Ds, p.codewords + (size_t) i * p.Ds, p.Ds, p.arch);
+        return;
+    }
     const float *src = p.lut + (size_t) (b / p.QT) * MK * p.QT + (b % p.QT);
     for (int i = tid; i < MK; i += 256) lds[i] = src[(size_t) i * p.QT];
 }
@@ -293,6 +302,7 @@ __global__ __launch_bounds__(64) void tie_replay_kernel(TcArgs p)
     pq64_t *heap = reinterpret_cast<pq64_t *>(smem);       // [topk]
     const int fi = blockIdx.x, lane = threadIdx.x;
     const int nf = *p.nflag < p.fq ? *p.nflag : p.fq;
+    if (p.nflag_next && fi == 0 && lane == 0) *p.nflag_next = 0;      // (its last reader, the previous call's replay, is behind us in stream order)
     if (fi >= nf) return;
     const int k = p.topk;
     const int64_t b = p.b0 + p.flag_list[fi];
@@ -472,9 +482,11 @@ size_t linear_tie_chunked_scratch(int64_t n, int fq) { return (size_t) fq * (siz
 
 hipError_t launch_linear_tie_chunked(const uint8_t *d_codes, int64_t n, int M, int Ks, const float *d_lut, int QT, int64_t b0,
                                      const int32_t *d_flag_list, const int *d_nflag, const int64_t *d_remap, int64_t *d_out_ids,
-                                     float *d_out_dists, int topk, int fq, void *d_scratch, int indirect, hipStream_t st)
+                                     float *d_out_dists, int topk, int fq, void *d_scratch, int indirect, hipStream_t st,
+                                     const float *d_queries, const float *d_codewords, int Ds, int arch, int *d_nflag_next)
 {
     TcArgs a;
+    a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch; a.nflag_next = d_nflag_next;
     a.codes = d_codes; a.n = n; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.b0 = b0; a.flag_list = d_flag_list;
     a.nflag = d_nflag; a.remap = d_remap; a.indirect = indirect; a.topk = topk; a.fq = fq;
     a.nchunks = (int) linear_tie_chunks(n);
