@@ -111,6 +111,7 @@ struct ScratchSet {
     bool ivf_has_deferred = false;
     int flag_parity = 0;        // which of the two flagged-query counters the next inverted-index launch group uses
     int tie_parity = 0;         // likewise for the asynchronous few-query linear path (s_tie_cnt2: two counters, zeroed by the replay kernel)
+    bool tie_cnt_dirty = false; // a call failed between its slice kernel and its replay kernel: both counters are zeroed again first
     int lut_qt = 0;             // layout of the fp32 tables currently in s_lut: queries per interleaved tile (1 = plain)
     bool qlut_ready = false;    // the quantised tables of the current batch were produced by the fused table kernel
     int qlut_levels = 63;       // quantisation levels of the byte tables of the current batch (255: signed bytes, fscan_mx_* only)
@@ -978,13 +979,15 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
                 return tie_fixup(e, e->d_codes.as<uint8_t>(), S ? 1 : 0, n_codes, 0, B, topk, S ? d_tids : nullptr, d_out_ids, d_out_dists, st);
             }
             RII_TRY(e->s_tie_list.ensure((size_t) (B + 1) * sizeof(int32_t)));
-            if (!e->s_tie_cnt2.p) {
+            if (!e->s_tie_cnt2.p || e->tie_cnt_dirty) {
                 RII_TRY(e->s_tie_cnt2.ensure(2 * sizeof(int)));
                 HIP_TRY(hipMemsetAsync(e->s_tie_cnt2.p, 0, 2 * sizeof(int), st));
                 e->tie_parity = 0;
+                e->tie_cnt_dirty = false;
             }
             int *cnt = e->s_tie_cnt2.as<int>() + e->tie_parity, *cnt_next = e->s_tie_cnt2.as<int>() + (e->tie_parity ^ 1);
             e->tie_parity ^= 1;
+            e->tie_cnt_dirty = true;                                                 // until the replay kernel of this call is enqueued
             {
                 ScopedTimer t(e, "scan", st);
                 HIP_TRY(launch_slice_topk(e->d_codes.as<uint8_t>(), n_codes, e->M, e->Ks, d_queries, e->d_codewords.as<float>(), e->Ds, e->arch, B, topk,
@@ -992,8 +995,10 @@ int query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int topk,
                                           d_out_dists, e->s_flag.as<int32_t>(), st, nullptr, 0, e->s_tie_list.as<int32_t>() + 1, cnt));
             }
             e->lut_valid = false;                                                    // (no table of this batch exists)
-            return tie_fixup(e, e->d_codes.as<uint8_t>(), S ? 1 : 0, n_codes, 0, B, topk, S ? d_tids : nullptr, d_out_ids, d_out_dists, st,
-                             d_queries, cnt, cnt_next);
+            RII_TRY(tie_fixup(e, e->d_codes.as<uint8_t>(), S ? 1 : 0, n_codes, 0, B, topk, S ? d_tids : nullptr, d_out_ids, d_out_dists, st,
+                              d_queries, cnt, cnt_next));
+            e->tie_cnt_dirty = false;
+            return RII_OK;
         }
     }
     {
