@@ -358,6 +358,7 @@ int sync_list_codes(rii_engine *e, hipStream_t st)
     for (const auto &l : e->lists) n += (int64_t) l.size();
     RII_TRY(e->d_lcodes.ensure((size_t) std::max<int64_t>(n, 1) * e->M));
     HIP_TRY(launch_gather_codes_i32(e->d_codes.as<uint8_t>(), e->M, e->d_pl_ids.as<int32_t>(), n, e->d_lcodes.as<uint8_t>(), st));
+    HIP_TRY(hipStreamSynchronize(st));        // engine-level state (like the CSR itself): a call on the other lane's stream may read it next
     e->lcodes_valid = true;
     return RII_OK;
 }
@@ -497,7 +498,8 @@ void pick_chunks(const rii_engine *e, int64_t n_codes, int64_t B, int *chunks, i
         // ~2 workgroups' worth of tiles per CU, but never chunks shorter than 8K codes (table staging cost); the one / two-query
         // stream (scan_kernel<1 / 2>: two blocks resident per CU) runs best with four per CU (2 GB shard, B = 1: 512 chunks 4.57 TB/s,
         // 1024: 5.38, 2048: 5.19, 4096: 4.97 -- profiles/r04_deep125m_few_queries.json)
-        const int64_t target = (qt <= 2 ? 4LL : 2LL) * e->n_cu;
+        const bool stream_form = qt <= 2 && (size_t) qt * e->M * e->Ks * sizeof(float) <= ((size_t) 64 << 10);     // (its static-table instances)
+        const int64_t target = (stream_form ? 4LL : 2LL) * e->n_cu;
         c = (target + tiles - 1) / tiles;
         const int64_t max_c = std::max<int64_t>(1, n_codes / 8192);
         c = std::max<int64_t>(1, std::min(c, max_c));
