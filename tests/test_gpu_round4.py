@@ -477,3 +477,37 @@ def test_tie_emission_of_wide_table_shards_replays_in_the_reference_order(M, Ds,
             want = full.query_linear_batch(qs, topk, None)
             assert np.array_equal(ids.cpu().numpy(), want[0]) and np.array_equal(d.cpu().numpy(), want[1]), topk
             assert bool(idx.last_tie_flags.any()) and not bool(idx.last_tie_overflow.any())
+
+
+@pytest.mark.parametrize("M,Ds", [(8, 4), (16, 6), (32, 4), (64, 2), (12, 3)])
+def test_one_and_two_query_exact_scan_trips_and_tails(M, Ds):
+    """scan_kernel<1> / <2> (round 4: U rows per thread and trip behind a scheduling barrier, gathered table reads, static LDS table,
+    8-byte rows for two queries): top-1 of one and two queries over index sizes around the trip boundaries (1024 x U codes per block and
+    trip, chunks that end inside a trip, a chunk shorter than one trip), with duplicated codes (first minimum) and target ids, against the
+    oracle and against the batch path."""
+    from rii_amd import RiiGpu
+    rng = np.random.default_rng(4000 + M)
+    cw = np.round(rng.random((M, 256, Ds)) * 9).astype(np.float32)            # integer-valued: equal distances happen
+    Nmax = 70001
+    codes = rng.integers(0, 256, size=(Nmax, M), dtype=np.uint8)
+    codes[rng.integers(0, Nmax, 9000)] = codes[rng.integers(0, Nmax, 9000)]
+    qs = np.round(rng.random((4, M * Ds)) * 9).astype(np.float32)
+    for N in (1, 63, 1023, 1025, 4096, 8191, 8193, 32768 + 5, Nmax):
+        g = RiiGpu(cw, False, simd_arch="avx512")
+        g.add_codes(codes[:N], False)
+        g.set_option("slice_topk", 0)                                         # (the few-query slice kernel ...
+        g.set_option("small_topk", 0)                                         #  ... and the one-launch small-index kernel would take these calls)
+        o = O.OracleRii(cw, False, simd_arch="avx512")
+        o.add_codes(codes[:N], False)
+        tids = np.sort(rng.choice(N, max(1, N // 3), replace=False)).astype(np.int64)
+        for t in (None, tids):
+            for B in (1, 2):
+                ids, d = g.query_linear_batch(qs[:B], 1, t)
+                for b in range(B):
+                    assert_same_result((ids[b], d[b]), o.query_linear(qs[b], 1, E if t is None else t), "N=%d B=%d b=%d" % (N, B, b))
+            for nchunks in (1, 7, 64):                                        # chunk boundaries inside a trip
+                g.set_option("scan_chunks", nchunks)
+                ids, d = g.query_linear_batch(qs[:2], 1, t)
+                for b in range(2):
+                    assert_same_result((ids[b], d[b]), o.query_linear(qs[b], 1, E if t is None else t), "N=%d chunks=%d b=%d" % (N, nchunks, b))
+            g.set_option("scan_chunks", 0)
