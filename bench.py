@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-host-call", action="store_true")
     ap.add_argument("--no-fresh", action="store_true",
                     help="skip the extra measurement with a different query batch every step")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="skip the rocprofv3 --pmc passes of a short copy of this run (HBM traffic and LDS counters of the dominant "
+                         "kernel, measured live on rank 0 at N = 1; without them the committed profiles/*.json tables are quoted)")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra two-stream measurement (reported beside `value`, never as it)")
     ap.add_argument("--no-others", action="store_true",
@@ -188,6 +191,51 @@ def profile_table(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return {}
+
+
+def live_counters(kernel_sub, shape_args, budget_s=75.0):
+    """HBM traffic and LDS counters of the dominant kernel measured in THIS run: a short copy of the same command (3 steps, no side
+    measurements) under `rocprofv3 --pmc`, one pass per counter group as the MI355X guide prescribes (no trace domain next to --pmc).
+    Returns {} when rocprofv3 is missing, a pass fails or the budget runs out -- the caller then quotes the committed tables."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {}
+    groups = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"))
+    out, t_end = {}, time.perf_counter() + budget_s
+    env = dict(os.environ, TMPDIR="/tmp")
+    for grp in groups:
+        left = t_end - time.perf_counter()
+        if left < 10.0:
+            break
+        d = tempfile.mkdtemp(prefix="rii_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", *grp, "--kernel-include-regex", kernel_sub, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--preheat", "0", "--no-cpu-baseline",
+               "--no-host-call", "--no-others", "--no-fresh", "--no-pipelined", "--no-live-counters"] + list(shape_args)
+        try:
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)             # the group this call started, nothing else
+                pr.wait()
+                shutil.rmtree(d, ignore_errors=True)
+                break
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            per = {}
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if kernel_sub in r["Kernel_Name"]:
+                        per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+                        per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+            for c, dv in per.items():
+                out[c] = sum(dv.values()) / len(dv)           # per launch: mean over the dispatches, instances summed
+                out["_dispatches"] = len(dv)
+        except Exception:
+            pass
+        shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def filter_kernel_name(scan_mx, M):
@@ -969,6 +1017,27 @@ def main():
             roof = roofline_scan(filter_kernel_name(args.scan_mx, M) if filt else "scan_kernel", B, n_scanned, M, Ks, avg_s, k_n,
                                  args.steps, filt, 1 if args.scan_mx or not filt else 2, key)
         roof.update(extra)
+        if world == 1 and not args.no_live_counters:
+            shape = ["--workload", args.workload, "--batch", str(B), "--topk", str(topk), "--scan-mode", str(args.scan_mode),
+                     "--scan-mx", str(args.scan_mx), "--scan-order", str(args.scan_order), "--lut-mode", args.lut_mode]
+            lc = live_counters(roof["kernel"], shape)
+            if "FETCH_SIZE" in lc and "WRITE_SIZE" in lc:
+                # counters are in KB; FETCH_SIZE reports half of a wide coalesced stream on gfx950 (MI355X guide): doubled
+                traffic = int((2.0 * lc["FETCH_SIZE"] + lc["WRITE_SIZE"]) * 1024.0)
+                roof["traffic_from_profiles"] = roof.get("traffic")
+                roof["traffic"] = traffic
+                roof["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a 3-step copy of this command, run by "
+                                          "bench.py itself (%d dispatches of the kernel); (2 x FETCH_SIZE + WRITE_SIZE) x 1024" % lc.get("_dispatches", 0))
+                if isinstance(roof.get("hbm"), dict) and avg_s > 0:
+                    roof["hbm"]["traffic_bytes"] = traffic
+                    roof["hbm"]["achieved"] = traffic / avg_s / 1e9
+                    roof["hbm"]["frac"] = roof["hbm"]["achieved"] / HBM_PEAK_GBPS
+            if lc.get("SQ_LDS_IDX_ACTIVE") and lc.get("SQ_INSTS_LDS"):
+                roof["counters_live"] = {"lds_conflict_frac": lc.get("SQ_LDS_BANK_CONFLICT", 0.0) / lc["SQ_LDS_IDX_ACTIVE"],
+                                         "lds_cycles_per_read": lc["SQ_LDS_IDX_ACTIVE"] / lc["SQ_INSTS_LDS"],
+                                         "lds_insts": lc["SQ_INSTS_LDS"], "valu_insts": lc.get("SQ_INSTS_VALU"),
+                                         "wave_wait_frac": (lc.get("SQ_WAIT_ANY", 0.0) / lc["SQ_WAVE_CYCLES"]) if lc.get("SQ_WAVE_CYCLES") else None,
+                                         "source": "live rocprofv3 --pmc pass of this run"}
         line = {
             "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
