@@ -202,7 +202,7 @@ def live_counters(kernel_sub, shape_args, budget_s=75.0):
     if not exe:
         return {}
     groups = (("FETCH_SIZE",), ("WRITE_SIZE",),
-              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"))
+              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"))
     out, t_end = {}, time.perf_counter() + budget_s
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
@@ -1041,6 +1041,14 @@ def main():
                                          "lds_insts": lc["SQ_INSTS_LDS"], "valu_insts": lc.get("SQ_INSTS_VALU"),
                                          "wave_wait_frac": (lc.get("SQ_WAIT_ANY", 0.0) / lc["SQ_WAVE_CYCLES"]) if lc.get("SQ_WAVE_CYCLES") else None,
                                          "source": "live rocprofv3 --pmc pass of this run"}
+                if lc.get("GRBM_GUI_ACTIVE") and avg_s > 0:
+                    # shader cycles of one launch (the counter sums the 8 XCDs) over the launch time of the timed region: the clock the
+                    # chip held under this kernel -- `frac` is quoted against the NOMINAL 2.4 GHz, boxes of the pool hold 2.0 - 2.2
+                    cyc = lc["GRBM_GUI_ACTIVE"] / 8.0
+                    ghz = cyc / avg_s / 1e9
+                    roof["counters_live"].update({"gpu_cycles_per_launch": cyc, "shader_clock_ghz": ghz,
+                                                  "lds_busy": lc["SQ_LDS_IDX_ACTIVE"] / 256.0 / cyc,
+                                                  "frac_at_held_clock": roof["frac"] * 2.4 / ghz if ghz > 0 else None})
         line = {
             "metric": "queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
