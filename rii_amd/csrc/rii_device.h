@@ -388,12 +388,11 @@ __device__ __forceinline__ pq64_t wh_adjust_heap(pq64_t *h, int hole0, int len, 
     unsigned int choices = 0u;
     if constexpr (NW == 1) {
         const unsigned long long w = W[0];
-        while (n < ninner) {
-            const unsigned int right = 1u - (unsigned int) ((w >> n) & 1ull);
-            n = 2 * n + 1 + (int) right;
-            choices = (choices << 1) | right;
+        while (n < ninner) {                                // (the choices are read off the node number afterwards: half the scalar
+            n = 2 * n + 2 - (int) ((w >> n) & 1ull);        //  instructions per level of the round-3 loop, which is a seventh of a sift)
             ++L;
         }
+        choices = (unsigned int) (n + 1) - (((unsigned int) hole0 + 1u) << L);
     } else {                                                // word r lives in lane r: fetched with a scalar lane index
         int wlo = 0, whi = 0;
 #pragma unroll
