@@ -639,7 +639,10 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
             // ~13K codes, tools/chunk_sweep.py).  Pick the c that minimises the product (63 tiles: 4 chunks = 252 blocks in
             // one round, not 5 = 315 in two; 188 tiles: 4 chunks = 3 rounds of a quarter, not one round of everything);
             // never chunks shorter than 8 slabs or more than 128 of them (every chunk starts from its own thresholds)
-            const int64_t cmax = std::max<int64_t>(1, std::min<int64_t>(128, n_codes / 8192));
+            // (at most 64: with one to three query tiles the product below keeps asking for more, shorter chunks, but every chunk block
+            //  stages its tile's 128 KiB of tables and converges its own thresholds -- measured, N = 1M: B = 16 73.7 us with 122 chunks,
+            //  58.1 with 64; B = 32 89.6 -> 71.7; B = 48 81.5 -> 72.4; tools/r4_small_batch_chunks.py)
+            const int64_t cmax = std::max<int64_t>(1, std::min<int64_t>(64, n_codes / 8192));
             const double per_block = 13000.0;
             double best_cost = 1e300;
             c = 1;
