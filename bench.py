@@ -55,9 +55,13 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--n-base", type=int, default=1_000_000)
     ap.add_argument("--M", type=int, default=32)
-    ap.add_argument("--workload", default="linear", choices=["linear", "ivf", "subset", "subset-ivf", "deep"],
+    ap.add_argument("--workload", default="linear", choices=["linear", "ivf", "subset", "subset-ivf", "deep", "deep-ivf"],
                     help="linear/ivf/subset/subset-ivf: BASELINE configs[1..3] (SIFT1M-shaped, index replicated, queries "
-                         "sharded); deep: configs[4] shape (D=96, M=16, --n-base codes PER GPU, database sharded)")
+                         "sharded); deep: configs[4] shape (D=96, M=16, --n-base codes PER GPU, database sharded); deep-ivf: the same "
+                         "shards searched through the database-sharded inverted index (nlist = sqrt(N_global), L = N_global / nlist: "
+                         "the reference's billion-scale setting, examples/benchmark/run_sift1b.py:105-106)")
+    ap.add_argument("--nlist", type=int, default=0, help="inverted-index workloads: coarse lists (0 = 1024; deep-ivf: sqrt(N_global))")
+    ap.add_argument("--L", type=int, default=0, help="inverted-index workloads: candidates per query (0 = L0 = round(N / nlist))")
     ap.add_argument("--topk", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-call", action="store_true")
@@ -323,7 +327,7 @@ def timed_loop(fn, steps, barrier):
     return time.perf_counter() - t0
 
 
-DOMINANT = ("scan", "ivf_fused", "ivf_scan")
+DOMINANT = ("scan", "ivf_fused", "ivf_scan", "ivf_shard")
 OTHER_KERNELS = ("lut", "quant", "rerank", "kth", "tie", "select", "gather", "ivf_exact", "ivf_coarse", "ivf_plan", "ivf_scan",
                  "ivf_select")
 
@@ -487,8 +491,96 @@ def sharded_world1_workload(eng, args, torch, dev, stream, t_q, B, topk, barrier
                 res[name]["rows_match_plain"] = bool(torch.equal(oi, ri) and torch.equal(od, rdd))
         res["query_sharded"]["added_us"] = (res["query_sharded"]["ms_per_step"] - res["plain"]["ms_per_step"]) * 1e3
         res["db_sharded"]["added_us"] = (res["db_sharded"]["ms_per_step"] - res["plain"]["ms_per_step"]) * 1e3
+        # the inverted index the same three ways (round 5): plain rii_query_ivf_dev (ivf_fused_kernel), query-sharded (the same kernel +
+        # all-gather + unpack) and DATABASE-sharded (rii_query_ivf_dbsharded_dev: list lengths -> all-gather -> ivf_shard_kernel ->
+        # pack -> all-gather -> merge -> finish; a different kernel: the walk is global, so the fused one-query kernel does not apply)
+        if eng.nlist > 0:
+            nl = eng.nlist
+            L = int(np.round(N / nl))
+            oc = torch.empty((b,), dtype=torch.int64, device=dev)
+            rc = torch.empty((b,), dtype=torch.int64, device=dev)
+
+            def iplain():
+                eng.query_ivf_dev(q.data_ptr(), b, topk, 0, 0, L, ri.data_ptr(), rdd.data_ptr(), rc.data_ptr(), stream)
+
+            def iqsh():
+                comm.query_ivf_qsharded_dev(eng, q.data_ptr(), b, topk, 0, 0, L, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), stream)
+
+            def idbsh():
+                comm.query_ivf_dbsharded_dev(eng, 0, N, q.data_ptr(), b, topk, 0, 0, 0, L, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), 0, stream)
+
+            ires = {"nlist": nl, "L": L}
+            for name, fn in (("plain", iplain), ("query_sharded", iqsh), ("db_sharded", idbsh)):
+                preheat(fn, torch.cuda.synchronize, 0.05)
+                ms = min(timed_loop(fn, K, barrier) for _ in range(2)) / K * 1e3
+                ires[name] = {"ms_per_step": ms, "value": b / ms * 1e3, "unit": "queries/s"}
+                if name != "plain":
+                    ires[name]["rows_match_plain"] = bool(torch.equal(oi, ri) and torch.equal(od, rdd) and torch.equal(oc, rc))
+                    ires[name]["added_us"] = (ms - ires["plain"]["ms_per_step"]) * 1e3
+            res["ivf"] = ires
         out["batch_%d" % b] = res
     return out
+
+
+def mfma_tables_workload(eng, args, torch, dev, stream, q_dev, B, M, Ks, Ds, barrier):
+    """north_star: "MFMA used only for the batched (Q x Ks) x Ds sub-distance table build where it is a true dense contraction".  Engine
+    option lut_mode = "mfma": lut_build_mfma_kernel (v_mfma_f32_16x16x4_f32: -2 q.c on the matrix cores, |q|^2 + |c|^2 added in fp32)
+    writes the fp32 tables, the SAME filter scan and re-rank follow (tables quantised by lut_quantize_kernel).  Not the default: the
+    expansion rounds differently from fvec_L2sqr (src/distance.h:117-252), so distances agree to 1e-4 relative instead of bit for bit.
+    One row: the step, the table kernel's time and flop rate against the fp32 matrix peak, and the agreement with the exact mode."""
+    oi = torch.empty((B, 1), dtype=torch.int64, device=dev)
+    od = torch.empty((B, 1), dtype=torch.float32, device=dev)
+
+    def step():
+        eng.query_linear_dev(q_dev.data_ptr(), B, 1, 0, 0, oi.data_ptr(), od.data_ptr(), stream)
+
+    step()
+    torch.cuda.synchronize()
+    ids_e, d_e = oi.cpu().numpy().copy(), od.cpu().numpy().copy()
+    eng.set_option("lut_mode", "mfma")
+    try:
+        elapsed, dom, shares = measure(eng, step, args.steps, max(args.warmup, 2), barrier, torch.cuda.synchronize)
+        ids_m, d_m = oi.cpu().numpy().copy(), od.cpu().numpy().copy()
+    finally:
+        eng.set_option("lut_mode", "exact")
+    flops = 2.0 * B * M * Ks * Ds
+    lut_ms = shares.get("lut_ms_per_step")
+    peak = 157.3                                                  # TFLOP/s, fp32 matrix (MI355X guide)
+    ach = (flops / (lut_ms * 1e-3) / 1e12) if lut_ms else None
+    return {"config": "linear top-1, batch=%d, tables on the matrix cores (lut_mode=mfma), same filter scan + re-rank" % B,
+            "ms_per_step": elapsed / args.steps * 1e3, "value": B * args.steps / elapsed, "unit": "queries/s",
+            "table_kernel": "lut_build_mfma_kernel", "table_kernel_ms": lut_ms, "quantise_ms": shares.get("quant_ms_per_step"),
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
+                         "flops_per_launch": flops, "traffic": None,
+                         "note": "2 x B x M x Ks x Ds = %.0f MFLOP per batch: a launch-latency-sized problem, so the matrix pipe cannot be "
+                                 "the bound (SURVEY 8d); counters: profiles/r05_mfma_*" % (flops / 1e6)},
+            "ids_equal_exact_mode": float((ids_m == ids_e).mean()),
+            "max_rel_distance_error_vs_exact_mode": float(np.max(np.abs(d_m - d_e) / np.maximum(np.abs(d_e), 1.0)))}
+
+
+def modulo_lists(n, nlist):
+    """A synthetic posting-list partition of n codes for the throughput legs that cannot afford the N x nlist x M assignment pass of
+    a real build (64 M codes x 8 k lists = 8e15 table lookups): code i goes to list i mod nlist, ids ascending inside a list
+    (src/rii.h:356-358).  The codes of those legs are uniform random bytes, so any partition is as good as the nearest-centre one for
+    what is measured (the walk, the candidate scoring, the selection); the SAME lists go to the CPU baseline.  -> (off, ids) CSR."""
+    rows = (n + nlist - 1) // nlist
+    grid = np.arange(rows * nlist, dtype=np.int64).reshape(rows, nlist).T.reshape(-1)      # list-major: j, j + nlist, j + 2 nlist, ...
+    ids = grid[grid < n].astype(np.int32)
+    lens = np.full(nlist, n // nlist, np.int64)
+    lens[:n % nlist] += 1
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return off, ids
+
+
+def roofline_ivf_shard(kernel, B, nlist, M, L, avg_s, launches, steps):
+    """Database-sharded inverted index: per query the shard kernel reads the nlist coarse centres (M bytes each) and, of the L
+    candidates of the global walk, the ids (4 B) and codes (M B) of those this rank owns -- SURVEY 8(d)'s IVF form with the rank's
+    share; HBM-form figure (the working set of a batch is L2-resident: what binds the kernel is latency / issue, like ivf_fused)."""
+    alg = B * (nlist * M + L * (M + 4))
+    r = roofline_hbm(kernel, alg, avg_s, launches, steps, None)
+    r["note"] = ("algorithmic bytes = B x (nlist x M centre bytes + L x (M + 4) candidate bytes); one block per query: table staged, "
+                 "coarse scores, std::partial_sort of the coarse order by wave 0, the global walk by one lane, then the owned candidates")
+    return r
 
 
 def readme_workload(args, torch, dev, arch):
@@ -591,8 +683,179 @@ def deep_shard_workload(args, torch, dev, arch, barrier):
                                    query[:B], 1, None, 0, budget_s=3.0, thread_settings=[64, 16])
         cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, None, cpu_res)
         obj["cpu_baseline"] = cb
+    # the same shard through the DATABASE-SHARDED INVERTED INDEX (round 5): nlist = sqrt(N), L = N / nlist, one-rank communicator
+    try:
+        from rii_amd import dist as rd
+        nl = int(np.round(np.sqrt(n)))
+        obj["ivf_dbsharded"] = deep_ivf_on(eng, rd.get_comm(), args, torch, dev, barrier, q, n, n, 0, 1, nl, int(np.round(n / nl)), 1, steps,
+                                           cw, codes, arch)
+    except Exception as ex:                                      # noqa: BLE001
+        obj["ivf_dbsharded"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     del eng
     return obj
+
+
+def ref_harness_workload(args, torch, dev, arch, barrier, base_codes_src):
+    """The reference's OWN SIFT1M harness configuration (examples/benchmark/ann_methods.py:19-34, run_sift1m.py:60-61): Rii(M=64,
+    nlist=1000, L=5000), recall@1, one query per call -- measured both the harness's way (p50 of one-query host-pointer calls,
+    run_sift1m.py:26-28) and as a batch of 1024, beside the real reference on the host cores."""
+    from rii_amd import RiiGpu
+    from rii_amd import bench_data as bd
+    N, D, M, Ks, nlist, L, topk = args.n_base, 128, 64, 256, 1000, 5000, 1
+    B = args.batch
+    base, train, query, gt = base_codes_src()
+    cw = bd.train_pq(train, M, Ks, iters=10, seed=123, device=dev)
+    codes = bd.encode_pq(base, cw, device=dev)
+    eng = RiiGpu(cw, False, simd_arch=arch, device=dev.index)
+    eng.add_codes(codes, False)
+    eng.reconfigure(nlist, 5)
+    q = torch.from_numpy(np.ascontiguousarray(query[:B])).to(dev)
+    oi = torch.empty((B, topk), dtype=torch.int64, device=dev)
+    od = torch.empty((B, topk), dtype=torch.float32, device=dev)
+    oc = torch.empty((B,), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.query_ivf_dev(q.data_ptr(), B, topk, 0, 0, L, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), stream)
+
+    elapsed, dom, shares = measure(eng, step, args.steps, max(args.warmup, 2), barrier, torch.cuda.synchronize)
+    plain = timed_loop(step, args.steps, barrier)
+    res_ids, res_cnt = oi.cpu().numpy().copy(), oc.cpu().numpy().copy()
+    kname = "ivf_fused" if dom["ivf_fused"][1] else "ivf_scan"
+    k_ms, k_n = dom[kname]
+    avg_s = (k_ms / max(args.steps, 1)) * 1e-3
+    w = min(nlist, int(np.round(L * nlist / N)) + 3)
+    roof = roofline_ivf(B, nlist, M, Ks, D // M, w, N // nlist, L, avg_s, k_n, args.steps, None)
+    roof["kernel"] = kname + "_kernel"
+    roof.update(shares)
+    E = np.array([], np.int64)
+    ts, one_ids = [], []
+    for qq in query[:20]:
+        eng.query_ivf(qq, topk, E, L)
+    for qq in query[:256]:
+        t0 = time.perf_counter()
+        r = eng.query_ivf(qq, topk, E, L)
+        ts.append(time.perf_counter() - t0)
+        one_ids.append(r[0])
+    ts = np.array(ts) * 1e3
+    obj = {"config": "the reference's SIFT1M harness setting (examples/benchmark/ann_methods.py:19-34): SIFT1M-shaped, D=128 M=64 Ks=256, "
+                     "N=%d, nlist=%d, L=%d, topk=1" % (N, nlist, L),
+           "batch_%d" % B: {"value": B * args.steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / args.steps * 1e3,
+                            "uninstrumented_ms_per_step": plain / args.steps * 1e3, "kernel": roof["kernel"], "kernel_ms": avg_s * 1e3},
+           "one_query_per_call": {"p50_ms": float(np.percentile(ts, 50)), "p99_ms": float(np.percentile(ts, 99)), "value": 1e3 / float(ts.mean()),
+                                  "unit": "queries/s", "what": "host pointers, one synchronisation per call (run_sift1m.py:26-28's loop)",
+                                  "ids_match_batch": bool(all(list(one_ids[b]) == list(res_ids[b, :int(res_cnt[b])]) for b in range(len(one_ids))))},
+           "recall_at_1": float(bd.recall_at_r(res_ids, gt[:B], 1)), "roofline": roof}
+    if not args.no_cpu_baseline:
+        cb, cpu_res = cpu_baseline("ivf", "inverted index M=64 nlist=%d L=%d" % (nlist, L), reference_factory(eng, cw, codes, arch, True),
+                                   query[:B], topk, None, L, budget_s=3.0)
+        cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, res_cnt, cpu_res)
+        obj["cpu_baseline"] = cb
+    del eng
+    return obj
+
+
+def deep_ivf_on(eng, comm, args, torch, dev, barrier, q, n_shard, n_global, rank, world, nlist, L, topk, steps, cw, codes, arch):
+    """The database-sharded inverted index over this rank's Deep1B-shaped shard, ONE rii_query_ivf_dbsharded_dev call per step (list
+    lengths -> all-gather -> ivf_shard kernel -> pack -> all-gather -> merge -> finish).  Lists: modulo_lists() over the local ids,
+    centres: nlist random codes, the same on every rank.  -> (object, rows)"""
+    B, M = q.shape[0], eng.M
+    centers = np.random.default_rng(4242).integers(0, 256, size=(nlist, M), dtype=np.uint8)
+    off, ids = modulo_lists(n_shard, nlist)
+    eng.set_posting_lists(centers, off, ids)
+    oi = torch.empty((B, topk), dtype=torch.int64, device=dev)
+    od = torch.empty((B, topk), dtype=torch.float32, device=dev)
+    oc = torch.empty((B,), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        comm.query_ivf_dbsharded_dev(eng, rank * n_shard, n_global, q.data_ptr(), B, topk, 0, 0, 0, L, oi.data_ptr(), od.data_ptr(),
+                                     oc.data_ptr(), 0, stream)
+
+    elapsed, dom, shares = measure(eng, step, steps, 2, barrier, torch.cuda.synchronize, heat=8)
+    plain = timed_loop(step, steps, barrier)
+    k_ms, k_n = dom["ivf_shard"]
+    avg_s = (k_ms / max(steps, 1)) * 1e-3
+    roof = roofline_ivf_shard("ivf_shard_any_kernel" if L > 8192 else "ivf_shard_kernel", B, nlist, M, L, avg_s, k_n, steps)
+    roof.update(shares)
+    obj = {"config": "Deep1B-shaped database-sharded inverted index: D=96 M=16 Ks=256, %d codes per GPU (%d in all), nlist=%d "
+                     "(= sqrt(N)), L=%d (= N / nlist), batch=%d, topk=%d" % (n_shard, n_global, nlist, L, B, topk),
+           "value": B * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+           "uninstrumented_ms_per_step": plain / steps * 1e3, "kernel": roof["kernel"], "kernel_ms": avg_s * 1e3, "roofline": roof,
+           "lists": "synthetic partition (code i -> list i mod nlist; uniform random codes and centres): a real build's assignment "
+                    "pass is N x nlist x M = %.1e table lookups" % (float(n_global) * nlist * M)}
+    res_ids, res_cnt = oi.cpu().numpy().copy(), oc.cpu().numpy().copy()
+    if world == 1 and not args.no_cpu_baseline:
+        # the C oracle ("port"): the real reference takes posting lists through py::pickle's python lists only (src/main.cpp:39-52) --
+        # 64 M python ints -- or through its own reconfigure (hours on this shape); the oracle is pinned to it bit for bit by tests/
+        from oracle import oracle as O
+        o = O.OracleRii(cw, False, simd_arch=arch)
+        o.codes = codes
+        o.set_csr(centers, off, ids)
+        E = np.array([], np.int64)
+        qh = q.cpu().numpy()
+        nq = min(16, B)
+        o.query_ivf(qh[0], topk, E, L)
+        t0 = time.perf_counter()
+        cpu_res = [o.query_ivf(qh[b], topk, E, L)[0] for b in range(nq)]
+        dt = time.perf_counter() - t0
+        cb = {"value": nq / dt, "unit": "queries/s", "ms_per_query": dt / nq * 1e3, "cores": 1, "kind": "port",
+              "sample": "one query per call, inverted index nlist=%d L=%d over %d codes, %d queries (QueryIvf is single-threaded by "
+                        "design, src/rii.h:244-326)" % (nlist, L, n_shard, nq)}
+        cb["ids_match_gpu"], cb["queries_compared"] = ids_match(res_ids, res_cnt, cpu_res)
+        obj["cpu_baseline"] = cb
+    return obj
+
+
+def main_deep_ivf(args, world, rank, local, dev, arch):
+    """`--workload deep-ivf`: BASELINE configs[4]'s shards searched the way the reference searches a billion vectors
+    (examples/benchmark/run_sift1b.py:105-106: nlist = sqrt(N), L = N / nlist) -- the database-sharded inverted index through
+    rii_query_ivf_dbsharded_dev, --n-base codes PER GPU."""
+    import torch
+    import torch.distributed as dist
+    from rii_amd import RiiGpu
+    from rii_amd import bench_data as bd
+    from rii_amd import dist as rd
+    B, M, Ks, D = args.batch, 16, 256, 96
+    n_shard = args.n_base
+    n_global = n_shard * world
+    nlist = args.nlist if args.nlist > 0 else int(np.round(np.sqrt(n_global)))
+    L = args.L if args.L > 0 else int(np.round(n_global / nlist))
+    _, train, query = bd.sift_like(n_base=1, n_train=50_000, n_query=B, D=D, seed=99)
+    cw = bd.train_pq(train, M, Ks, iters=5, seed=123, device=dev)
+    codes = np.random.default_rng(1000 + rank).integers(0, 256, size=(n_shard, M), dtype=np.uint8)
+    eng = RiiGpu(cw, False, simd_arch=arch, device=local)
+    eng.add_codes(codes, False)
+    q = torch.from_numpy(np.ascontiguousarray(query[:B])).to(dev)
+    use_dist = dist.is_initialized()
+    comm = rd.get_comm()
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    obj = deep_ivf_on(eng, comm, args, torch, dev, barrier, q, n_shard, n_global, rank, world, nlist, L, args.topk, args.steps, cw, codes, arch)
+    elapsed_ms = obj["ms_per_step"]
+    if use_dist:
+        t = torch.tensor([elapsed_ms], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_ms = float(t.item())
+    if rank == 0:
+        line = {"metric": "queries/sec", "value": B / elapsed_ms * 1e3, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": obj["config"], "global_batch": B,
+                           "parallelism": "database-sharded x%d: ONE rii_query_ivf_dbsharded_dev call per step (two RCCL all-gathers + device "
+                                          "merge in the timed region; top-1 never synchronises with the host)" % world},
+                "recall_at_1": None, "roofline": obj["roofline"], "uninstrumented_ms_per_step": obj["uninstrumented_ms_per_step"],
+                "lists": obj["lists"]}
+        if "cpu_baseline" in obj:
+            line["cpu_baseline"] = obj["cpu_baseline"]
+        print(json.dumps(line))
+    rd.close_comms()
+    if use_dist:
+        dist.destroy_process_group()
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -700,6 +963,8 @@ def main():
     arch = host_simd_arch()
     if args.workload == "deep":
         return main_deep(args, world, rank, local, dev, arch)
+    if args.workload == "deep-ivf":
+        return main_deep_ivf(args, world, rank, local, dev, arch)
 
     # ---------------- inputs (synthetic, seeded): rank 0 builds, everyone receives ----------------
     N = args.n_base
@@ -713,6 +978,8 @@ def main():
         t_codes = torch.from_numpy(codes).to(dev)
         t_q = torch.from_numpy(np.ascontiguousarray(query[:nq])).to(dev)
         t_gt = torch.from_numpy(gt).to(dev)
+        # (the `others.ref_harness` leg re-encodes the same vectors with M = 64: kept for the default invocation only)
+        keep_vectors = (base, train, query) if (world == 1 and not args.no_others and args.workload == "linear" and args.topk == 1) else None
         del base, train
     else:
         t_cw = torch.empty((M, Ks, D // M), dtype=torch.float32, device=dev)
@@ -745,9 +1012,10 @@ def main():
     topk = args.topk
     ivf = args.workload in ("ivf", "subset-ivf")
     S, L, d_tids, h_tids = 0, 0, 0, None
+    nlist_main = args.nlist if args.nlist > 0 else 1024
     if ivf:
-        eng.reconfigure(1024, 5)
-        L = int(np.round(N / 1024))
+        eng.reconfigure(nlist_main, 5)
+        L = args.L if args.L > 0 else int(np.round(N / nlist_main))
     if args.workload in ("subset", "subset-ivf"):
         h_tids = np.sort(np.random.default_rng(7).choice(N, min(100_000, N), replace=False)).astype(np.int64)
         tids = torch.from_numpy(h_tids).to(dev)
@@ -1011,8 +1279,8 @@ def main():
         avg_s = (k_ms / max(args.steps, 1)) * 1e-3          # top-k runs the scan kernel twice per step: charged together
         key = workload_key(args.workload, args.scan_mode, args.scan_mx, M, n_scanned, B, topk)
         if ivf:
-            w = min(1024, int(np.round(L * 1024 / (S if S else N))) + 3)
-            roof = roofline_ivf(B, 1024, M, Ks, D // M, w, N // 1024, L, avg_s, k_n, args.steps,
+            w = min(nlist_main, int(np.round(L * nlist_main / (S if S else N))) + 3)
+            roof = roofline_ivf(B, nlist_main, M, Ks, D // M, w, N // nlist_main, L, avg_s, k_n, args.steps,
                                 profile_table("traffic.json").get(key, {}).get("hbm_bytes_per_launch"))
         else:
             filt = bool(args.scan_mode and (topk > 1 or B >= eng.get_option("fast_min_batch")))
@@ -1022,7 +1290,7 @@ def main():
         if world == 1 and not args.no_live_counters:
             shape = ["--workload", args.workload, "--batch", str(B), "--topk", str(topk), "--scan-mode", str(args.scan_mode),
                      "--scan-mx", str(args.scan_mx), "--scan-order", str(args.scan_order), "--lut-mode", args.lut_mode,
-                     "--n-base", str(N)]
+                     "--n-base", str(N), "--M", str(M), "--nlist", str(args.nlist), "--L", str(args.L)]
             lc = live_counters(roof["kernel"], shape)
             if "FETCH_SIZE" in lc and "WRITE_SIZE" in lc:
                 # counters are in KB; FETCH_SIZE reports half of a wide coalesced stream on gfx950 (MI355X guide): doubled
@@ -1054,7 +1322,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "SIFT1M-shaped %s search, D=128 M=%d Ks=256, N=%d, batch=%d per GPU, topk=%d%s%s"
-                                   % (args.workload, M, N, B, topk, (", nlist=1024 L=%d" % L) if L else "",
+                                   % (args.workload, M, N, B, topk, (", nlist=%d L=%d" % (nlist_main, L)) if L else "",
                                       (", |target_ids|=%d" % S) if S else ""),
                        "global_batch": B * world,
                        "parallelism": "query-sharded x%d, index replicated; value: no exchange step (results stay with the "
@@ -1100,7 +1368,8 @@ def main():
             line["pipelined"] = pipe
         if world == 1 and not args.no_cpu_baseline:
             what = {"linear": "full %d-code linear scan" % N, "subset": "linear scan of %d target ids" % S,
-                    "ivf": "inverted index nlist=1024 L=%d" % L, "subset-ivf": "inverted index nlist=1024 L=%d over %d target ids" % (L, S)}
+                    "ivf": "inverted index nlist=%d L=%d" % (nlist_main, L),
+                    "subset-ivf": "inverted index nlist=%d L=%d over %d target ids" % (nlist_main, L, S)}
             try:
                 cb, cpu_res = cpu_baseline("ivf" if ivf else "linear", what[args.workload], reference_factory(eng, cw, codes, arch, ivf),
                                            my_q.cpu().numpy(), topk, h_tids, L)
@@ -1122,7 +1391,12 @@ def main():
                 others[name] = guarded(sift_workload, name, eng, args, torch, dev, stream, my_q, cw, codes, barrier, arch, N, M, Ks,
                                        D // M, B, topk)
             others["sharded_world1"] = guarded(sharded_world1_workload, eng, args, torch, dev, stream, t_q, B, topk, barrier, out_ids)
+            others["mfma_tables"] = guarded(mfma_tables_workload, eng, args, torch, dev, stream, my_q, B, M, Ks, D // M, barrier)
             others["readme_n10k"] = guarded(readme_workload, args, torch, dev, arch)
+
+            def harness_data():                                  # the main measurement's vectors and ground truth
+                return keep_vectors[0], keep_vectors[1], keep_vectors[2], t_gt.cpu().numpy()
+            others["ref_harness"] = guarded(ref_harness_workload, args, torch, dev, arch, barrier, harness_data)
             if args.deep_shard > 0:
                 others["deep_shard"] = guarded(deep_shard_workload, args, torch, dev, arch, barrier)
             others["seconds_spent"] = time.perf_counter() - t_oth

@@ -67,8 +67,12 @@ int rii_clear(rii_engine *e);
 
 /* State import: what the reference does through py::pickle's set-state (src/main.cpp:39-52).
  * rii_set_coarse_centers replaces the centres and rebuilds all posting lists by coarse assignment
- * (src/rii.h:150-155); rii_set_state installs centres, codes and lists verbatim. */
+ * (src/rii.h:150-155); rii_set_state installs centres, codes and lists verbatim; rii_set_posting_lists (round 5) installs centres
+ * and lists verbatim over the codes already added (ids ascending inside a list is the caller's contract, src/rii.h:356-358; the
+ * ids are range-checked): lists built elsewhere -- a cached index as in examples/benchmark/run_sift1b.py:73-99, another rank --
+ * without the N x nlist x M assignment pass. */
 int rii_set_coarse_centers(rii_engine *e, const uint8_t *centers, int64_t nlist);
+int rii_set_posting_lists(rii_engine *e, const uint8_t *centers, int64_t nlist, const int64_t *pl_off, const int32_t *pl_ids);
 int rii_set_state(rii_engine *e, const uint8_t *centers, int64_t nlist, const uint8_t *codes, int64_t N,
                   const int64_t *pl_off, const int32_t *pl_ids);
 
@@ -104,6 +108,9 @@ int rii_query_linear_dev(rii_engine *e, const float *d_queries, int64_t B, int t
 int rii_query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids,
                       int64_t S, int64_t L, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts,
                       void *stream);
+/* (Memory: the first unfiltered inverted-index query after the lists change builds a posting-order copy of the codes -- option
+ * "ivf_list_codes", another N * M bytes of HBM, one synchronisation of the stream; where that allocation does not fit the kernels
+ * gather the candidates' rows by id instead, same results.) */
 
 /* Queries resident in HBM, results delivered to the HOST (NEW): the batched form of what the reference's caller observes --
  * the rows are host-visible when the call returns (src/main.cpp:17-27 return Python lists) -- and what SURVEY 8d's metric times
@@ -130,7 +137,12 @@ int rii_query_ivf_dev_to_host(rii_engine *e, const float *d_queries, int64_t B, 
  * ({}, {}) (identical on every rank).  Merging the G records under (distance, position) gives the reference's answer for
  * top-1 and for top-k whenever the k+1 smallest distances are pairwise different.  S_global / N_global: sizes of the whole
  * target set / database (they fix `w`, src/rii.h:266-277).  Any nlist <= N (above 4096 lists the coarse order of a
- * query lives in global scratch); L <= 8192 (the candidate keys of a query are sorted in LDS). */
+ * query lives in global scratch).  Any L <= N (round 5; the reference's billion-scale run uses L = N / nlist = sqrt(N) ~ 31.6 k,
+ * examples/benchmark/run_sift1b.py:105-106): up to 8192 candidate keys of a query are sorted in LDS at once; above that the rank's
+ * own candidates pass through an LDS selection buffer with a running bound.  `rows` (0 = topk + 1): the rows a launch can SELECT are
+ * bounded by rii_ivf_shard_max_select_rows() (8193 while L <= 8192, ~7.6 k above); rows >= L always works and returns EVERY owned
+ * candidate -- in (distance, position) order while L <= 8192, at the slot of its traversal position (row j = position j, other
+ * ranks' slots padded) above that: the replay below rebuilds the sequence by position either way. */
 int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64_t S, int64_t S_global, int32_t *d_out_len,
                              void *stream);
 int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S,
@@ -144,6 +156,16 @@ int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64_t B, in
  * the reference's order, tied distances included, identically on every rank.  Stateless; nf = number of such queries. */
 int rii_ivf_shard_replay_dev(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
                              float *d_out_dists, void *stream);
+/* rows > 8192 (round 5): the rebuilt sequences live in caller-provided device scratch of rii_ivf_shard_replay_scratch_bytes(nf, rows)
+ * bytes (0 while they fit LDS), the heap of std::partial_sort in LDS while topk <= 1024, walked by one lane over global memory above.
+ * A query without candidates (the reference's ({}, {})) gets ids -1 / distances +inf.  With rows = L for EVERY query of a batch this
+ * is the whole answer (no merge, no tie flags): the collect-all route rii_query_ivf_dbsharded_dev takes for very large topk. */
+int64_t rii_ivf_shard_replay_scratch_bytes(int64_t nf, int rows);
+int rii_ivf_shard_replay_ex_dev(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
+                                float *d_out_dists, void *d_scratch, int64_t scratch_bytes, void *stream);
+/* Largest `rows` rii_query_ivf_shard_dev selects per query for this engine's shape and (L, N_global, S_global); callers that need
+ * more rows per query ask for rows = L instead (every owned candidate).  The same on every rank. */
+int rii_ivf_shard_max_select_rows(const rii_engine *e, int64_t L, int64_t N_global, int64_t S_global);
 
 /* Database-sharded LINEAR search, exact ties (NEW; tieorder.hip).  The merge below orders bit-equal distances of different
  * shards by id; the reference's order is what std::partial_sort (src/rii.h:234-235) makes of all N distances in index order.
@@ -186,7 +208,15 @@ int rii_merge_topk_ex_dev(const void *d_gathered, int G, int64_t B, int k, int k
  * RII_ERR_HIP.  Rank 0 (or anyone) calls rii_comm_unique_id and hands the RII_COMM_ID_BYTES bytes to every rank by whatever means
  * the host program has (MPI, a file, torch.distributed); every rank then calls rii_comm_init (collective).  The sharded calls below
  * enqueue  engine kernels -> ONE ncclAllGather of pre-sized records -> unpack / merge kernel  on `stream` (NULL = the engine's);
- * the calls that use one communicator must be issued in the same order on every rank, one stream at a time. */
+ * the calls that use one communicator must be issued in the same order on every rank, one stream at a time, with the same
+ * batch / topk / L / target-set arguments (every decision that leads to a collective is taken from those alone).
+ * Failures (round 5): a rank whose OWN part of a call fails (its engine call, an allocation, a bad local argument) still takes part in
+ * the batch's all-gather and returns its error afterwards; its peers return from the same call too -- query sharding: the failed
+ * rank's rows read ids -1 / distances NaN / counts -1; database sharding: every record carries a 16-byte header {int64 id offset,
+ * int32 status} and a non-zero status poisons the whole batch on every rank (ids -2, distances NaN), the top-k paths (which read one
+ * word per batch anyway) also return RII_ERR_STATE -- so the ranks stay in step and the communicator stays usable.  Only when a
+ * collective ITSELF fails (or a rank cannot allocate its exchange records) is the communicator marked unusable: every later call on
+ * it returns RII_ERR_STATE; destroy it. */
 #define RII_COMM_ID_BYTES 128
 typedef struct rii_comm rii_comm;
 int rii_comm_unique_id(void *id_out /* RII_COMM_ID_BYTES */);
@@ -224,7 +254,10 @@ int rii_qshard_unpack_dev(const void *d_gathered, int64_t B, int G, int k, int c
  * marked in d_out_overflow [B] int32, or NULL).  top-1 is asynchronous on the stream; top-k synchronises once per batch (the host
  * reads one word: is any query flagged?).  d_tids_local: this rank's share of the target ids as LOCAL ids, S_local of them; S_global =
  * size of the whole target set, 0 = none (a rank may own none of the targets: S_local == 0, S_global != 0).
- * G <= 64; topk > 1: G * (topk + 1) <= 8192 and topk <= 1024 for the replay. */
+ * Any G, any topk (round 5): the shards' first ids travel in the record headers (nothing cached per communicator: two differently
+ * sharded indices may share one); G * (topk + 1) > 8192 rows per query are merged in global scratch instead of LDS; the exact-tie
+ * replay walks heaps of up to 1024 entries -- a flagged query with topk > 1024 keeps the (distance, id) order among its exactly tied
+ * distances and is marked in d_out_overflow, like a candidate list above tie_cap. */
 int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset, const float *d_queries, int64_t B, int topk,
                                    const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t *d_out_ids,
                                    float *d_out_dists, int32_t *d_out_tie, int32_t *d_out_overflow, int tie_cap, void *stream);
@@ -236,7 +269,10 @@ int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset
  * std::partial_sort (src/rii.h:312-313) replayed on the rebuilt sequence.  Coarse centres replicated (rii_set_coarse_centers on every
  * rank), posting lists over this rank's codes [id_offset, id_offset + N_local); N_global = codes of the whole database.  Outputs: GLOBAL
  * ids, distances, counts (topk, or 0 where the reference returns ({}, {})), identical on every rank.  top-1 is asynchronous on the
- * stream; top-k synchronises once per batch.  L <= 8192, G * (topk + 1) <= 8192. */
+ * stream; top-k synchronises once per batch.  Any L <= N_global, any topk <= L, any G (round 5): see rii_query_ivf_shard_dev for the
+ * shard kernel above L = 8192; the exact-tie replay gathers the flagged queries' candidates in groups of at most 512 MiB; topk + 1
+ * rows beyond what a launch selects take the collect-all route (every candidate of every query gathered group by group, the replay is
+ * the answer; d_out_tie is zero then). */
 int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset, int64_t N_global, const float *d_queries, int64_t B,
                                 int topk, const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t L,
                                 int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, int32_t *d_out_tie, void *stream);

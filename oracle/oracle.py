@@ -147,7 +147,15 @@ class OracleRii(object):
             self._D = symmetric_tables(self.codewords, self.arch)
         return self._D
 
+    def set_csr(self, centers, off, ids):
+        """Centres and posting lists handed over in CSR form (large synthetic indices: no python list per posting)."""
+        self.centers = np.ascontiguousarray(centers, np.uint8)
+        self._csr_given = (np.ascontiguousarray(off, np.int64), np.ascontiguousarray(ids, np.int32))
+        self._lists = None
+
     def _csr(self):
+        if getattr(self, "_csr_given", None) is not None and self._lists is None:
+            return self._csr_given
         off = np.zeros(self.nlist + 1, np.int64)
         for i, l in enumerate(self._lists):
             off[i + 1] = off[i] + len(l)

@@ -109,6 +109,7 @@ def _lib():
         "rii_clear": (c_int, [c_vp]),
         "rii_set_coarse_centers": (c_int, [c_vp, u8p, c_i64]),
         "rii_set_state": (c_int, [c_vp, u8p, c_i64, u8p, c_i64, i64p, i32p]),
+        "rii_set_posting_lists": (c_int, [c_vp, u8p, c_i64, i64p, i32p]),
         "rii_get_N": (c_i64, [c_vp]),
         "rii_get_nlist": (c_i64, [c_vp]),
         "rii_get_M": (c_int, [c_vp]),
@@ -132,6 +133,9 @@ def _lib():
         "rii_query_ivf_shard_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int,
                                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "rii_ivf_shard_replay_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+        "rii_ivf_shard_replay_scratch_bytes": (c_i64, [c_i64, c_int]),
+        "rii_ivf_shard_replay_ex_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+        "rii_ivf_shard_max_select_rows": (c_int, [c_vp, c_i64, c_i64, c_i64]),
         "rii_linear_tie_emit_dev": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
         "rii_linear_tie_record_bytes": (c_i64, [c_i64, c_int]),
         "rii_linear_tie_replay_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -191,10 +195,16 @@ def merge_topk_ex_dev(d_gathered, G, B, k, k_out, id_offsets, d_out_keys, d_out_
                                         stream or None))
 
 
-def ivf_shard_replay_dev(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, stream=0):
-    """std::partial_sort replayed over the gathered candidate sequences of nf tie-flagged queries (include/rii_amd.h)."""
-    _check(_lib().rii_ivf_shard_replay_dev(d_gathered, int(G), int(nf), int(rows), int(topk), d_out_ids, d_out_dists,
-                                           stream or None))
+def ivf_shard_replay_scratch_bytes(nf, rows):
+    """Bytes of device scratch rii_ivf_shard_replay_ex_dev needs (0 while the rebuilt sequences fit LDS: rows <= 8192)."""
+    return int(_lib().rii_ivf_shard_replay_scratch_bytes(int(nf), int(rows)))
+
+
+def ivf_shard_replay_dev(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, stream=0, d_scratch=0, scratch_bytes=0):
+    """std::partial_sort replayed over the gathered candidate sequences of nf queries (include/rii_amd.h); any `rows` when the caller
+    hands ivf_shard_replay_scratch_bytes(nf, rows) bytes of device scratch."""
+    _check(_lib().rii_ivf_shard_replay_ex_dev(d_gathered, int(G), int(nf), int(rows), int(topk), d_out_ids, d_out_dists,
+                                              d_scratch or None, int(scratch_bytes), stream or None))
 
 
 def linear_tie_record_bytes(nf, cap):
@@ -225,11 +235,15 @@ class Comm(object):
         _check(_lib().rii_comm_init(ctypes.c_char_p(comm_id), int(rank), int(nranks), int(device), ctypes.byref(self._h)))
         self.rank, self.size = int(rank), int(nranks)
 
+    def close(self):
+        """rii_comm_destroy (synchronises the device, destroys the RCCL communicator).  Idempotent."""
+        if getattr(self, "_h", None):
+            _lib().rii_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                _lib().rii_comm_destroy(self._h)
-                self._h = ctypes.c_void_p()
+            self.close()
         except Exception:
             pass
 
@@ -356,6 +370,15 @@ class RiiGpu(object):
         assert c.ndim == 2 and c.shape[1] == self.M
         _check(_lib().rii_set_coarse_centers(self._h, _ptr(c, ctypes.c_uint8), c.shape[0]))
 
+    def set_posting_lists(self, centers, pl_off, pl_ids):
+        """Centres [nlist, M] and posting lists in CSR form (pl_off int64 [nlist + 1], pl_ids int32, ascending inside a list)
+        installed verbatim over the codes already added (rii_set_posting_lists: the lists half of the pickle set-state)."""
+        c = np.ascontiguousarray(centers, dtype=np.uint8)
+        off = np.ascontiguousarray(pl_off, dtype=np.int64)
+        ids = np.ascontiguousarray(pl_ids, dtype=np.int32)
+        assert c.ndim == 2 and c.shape[1] == self.M and off.shape == (c.shape[0] + 1,) and ids.shape == (int(off[-1]),)
+        _check(_lib().rii_set_posting_lists(self._h, _ptr(c, ctypes.c_uint8), c.shape[0], _ptr(off, ctypes.c_int64), _ptr(ids, ctypes.c_int32)))
+
     # ---- helpers ----
     @staticmethod
     def _as_query_batch(q, D):
@@ -424,6 +447,10 @@ class RiiGpu(object):
 
     def ivf_list_lengths_dev(self, d_tids, S, S_global, d_out_len, stream=0):
         _check(_lib().rii_ivf_list_lengths_dev(self._h, d_tids or None, int(S), int(S_global), d_out_len, stream or None))
+
+    def ivf_shard_max_select_rows(self, L, N_global, S_global=0):
+        """Largest `rows` query_ivf_shard_dev selects per query at this shape; more rows per query: ask for rows = L."""
+        return int(_lib().rii_ivf_shard_max_select_rows(self._h, int(L), int(N_global), int(S_global)))
 
     def query_ivf_shard_dev(self, d_queries, B, topk, d_tids, S, S_global, L, N_global, d_glen, G, rank, d_out_ids,
                             d_out_dists, d_out_pos, d_out_nloc, d_out_counts, stream=0, rows=0):

@@ -152,32 +152,36 @@ hipError_t launch_qshard_unpack(const void *d_gathered, int64_t B, int G, int k,
 struct CommOffsets {
     int64_t off[64];
 };
+// hdr != 0: the records carry the 16-byte header of merge.hip ({int64 id offset, int32 status}): offsets read from there (any G), and a
+// rank that failed poisons every row on every rank (id -2, distance NaN)
 __global__ __launch_bounds__(256) void merge_top1_kernel(const unsigned char *__restrict__ gathered, int G, int64_t B, size_t rec,
-                                                         CommOffsets offs, int64_t *__restrict__ out_ids, float *__restrict__ out_dists)
+                                                         CommOffsets offs, int64_t *__restrict__ out_ids, float *__restrict__ out_dists, int hdr)
 {
     const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     uint32_t best_d = 0xffffffffu;
     int64_t best_id = INT64_MAX;
+    int bad = 0;
     for (int g = 0; g < G; ++g) {
-        const unsigned char *p = gathered + rec * (size_t) g;
+        const unsigned char *h = gathered + rec * (size_t) g, *p = h + hdr;
         int64_t id = reinterpret_cast<const int64_t *>(p)[b];
         const uint32_t d = f32_orderable(__float_as_uint(reinterpret_cast<const float *>(p + (size_t) B * 8)[b]));
-        if (!(id < 0 || id >= INT64_MAX / 2)) id += offs.off[g];         // padding keys stay what they are
+        if (hdr) bad |= reinterpret_cast<const int32_t *>(h)[2];
+        if (!(id < 0 || id >= INT64_MAX / 2)) id += hdr ? *reinterpret_cast<const int64_t *>(h) : offs.off[g];   // padding keys stay what they are
         if (d < best_d || (d == best_d && id < best_id)) { best_d = d; best_id = id; }
     }
-    out_ids[b] = best_id;
-    out_dists[b] = __uint_as_float(f32_unorderable(best_d));
+    out_ids[b] = bad ? (int64_t) -2 : best_id;
+    out_dists[b] = bad ? __uint_as_float(0x7fc00000u) : __uint_as_float(f32_unorderable(best_d));
 }
 hipError_t launch_merge_top1(const void *d_gathered, int G, int64_t B, const int64_t *id_offsets, int64_t *d_out_ids, float *d_out_dists,
-                             hipStream_t st)
+                             hipStream_t st, int hdr)
 {
     if (B == 0) return hipSuccess;
-    if (G > 64) return hipErrorInvalidValue;
+    if (G > 64 && !hdr) return hipErrorInvalidValue;
     CommOffsets offs;
     for (int g = 0; g < 64; ++g) offs.off[g] = (id_offsets && g < G) ? id_offsets[g] : 0;
     hipLaunchKernelGGL(merge_top1_kernel, dim3((unsigned) ((B + 255) / 256)), dim3(256), 0, st, static_cast<const unsigned char *>(d_gathered), G, B,
-                       merge_record_bytes(B, 1, 0), offs, d_out_ids, d_out_dists);
+                       merge_record_bytes(B, 1, 0) + (size_t) hdr, offs, d_out_ids, d_out_dists, hdr);
     return hipGetLastError();
 }
 
@@ -192,7 +196,7 @@ hipError_t launch_merge_top1(const void *d_gathered, int G, int64_t B, const int
 __global__ __launch_bounds__(256) void tie_prepare_kernel(const unsigned char *__restrict__ gathered, size_t rec, int rank, int64_t B, int rows,
                                                           int topk, const int32_t *__restrict__ fsel, int nf, const float *__restrict__ queries,
                                                           int D, float *__restrict__ qf, float *__restrict__ bound)
-{
+{   // (gathered = the first rank's rows, rec = the stride of the ranks: the caller has stepped over a record header, if any)
     const int f = blockIdx.x;
     if (f >= nf) return;
     const int64_t b = fsel[f];
@@ -207,11 +211,11 @@ __global__ __launch_bounds__(256) void tie_prepare_kernel(const unsigned char *_
     }
 }
 hipError_t launch_tie_prepare(const void *d_gathered, int rank, int64_t B, int rows, int topk, const int32_t *d_fsel, int nf,
-                              const float *d_queries, int D, float *d_qf, float *d_bound, hipStream_t st)
+                              const float *d_queries, int D, float *d_qf, float *d_bound, hipStream_t st, int hdr)
 {
     if (nf == 0) return hipSuccess;
-    hipLaunchKernelGGL(tie_prepare_kernel, dim3((unsigned) nf), dim3(256), 0, st, static_cast<const unsigned char *>(d_gathered),
-                       merge_record_bytes(B, rows, 0), rank, B, rows, topk, d_fsel, nf, d_queries, D, d_qf, d_bound);
+    hipLaunchKernelGGL(tie_prepare_kernel, dim3((unsigned) nf), dim3(256), 0, st, static_cast<const unsigned char *>(d_gathered) + hdr,
+                       merge_record_bytes(B, rows, 0) + (size_t) hdr, rank, B, rows, topk, d_fsel, nf, d_queries, D, d_qf, d_bound);
     return hipGetLastError();
 }
 

@@ -241,7 +241,7 @@ int64_t nlist_of(const rii_engine *e) { return e->M ? (int64_t) (e->centers.size
 bool timer_wanted(const rii_engine *e, const char *name)
 {
     if (e->timing == 1) return true;
-    if (e->timing == 2) return !strcmp(name, "scan") || !strcmp(name, "ivf_fused") || !strcmp(name, "ivf_scan");
+    if (e->timing == 2) return !strcmp(name, "scan") || !strcmp(name, "ivf_fused") || !strcmp(name, "ivf_scan") || !strcmp(name, "ivf_shard");
     return false;
 }
 hipEvent_t timer_event(rii_engine *e)
@@ -1075,8 +1075,10 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
 
     p.lcodes = nullptr;
     if (S == 0 && e->ivf_list_codes && e->ivf_fused) {      // unfiltered: the fused kernel reads its candidates' rows in posting order
-        RII_TRY(sync_list_codes(e, st));
-        p.lcodes = e->d_lcodes.as<uint8_t>();
+        // (a second N * M bytes of HBM, built on the first unfiltered query after the lists change; where it does not fit the kernel
+        //  gathers the rows by id as before -- the copy is an optimisation, never a precondition)
+        if (sync_list_codes(e, st) == RII_OK) p.lcodes = e->d_lcodes.as<uint8_t>();
+        else (void) hipGetLastError();
     }
     if (S != 0) {       // order-preserving filter of every list by the batch's target ids
         RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
@@ -1391,6 +1393,27 @@ RII_API int rii_set_coarse_centers(rii_engine *e, const uint8_t *centers, int64_
     for (auto &l : e->lists) l.reserve((size_t) (e->N / nlist));
     e->lists_dirty = true;
     return update_posting_lists(e, 0, e->N);
+}
+
+// Centres and posting lists as given (the lists half of the pickle set-state, src/main.cpp:39-52), the codes untouched: an index
+// whose lists were built elsewhere -- another rank, a cached file (examples/benchmark/run_sift1b.py:73-99), a synthetic partition.
+RII_API int rii_set_posting_lists(rii_engine *e, const uint8_t *centers, int64_t nlist, const int64_t *pl_off, const int32_t *pl_ids)
+{
+    if (!e || !centers || nlist <= 0 || !pl_off || (pl_off[nlist] > 0 && !pl_ids)) return set_err(RII_ERR_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> guard(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(begin_exclusive(e));
+    if (pl_off[0] != 0) return set_err(RII_ERR_INVALID, "pl_off[0] must be 0");
+    for (int64_t i = 0; i < nlist; ++i)
+        if (pl_off[i + 1] < pl_off[i]) return set_err(RII_ERR_INVALID, "pl_off must be non-decreasing");
+    for (int64_t j = 0; j < pl_off[nlist]; ++j)
+        if (pl_ids[j] < 0 || (int64_t) pl_ids[j] >= e->N) return set_err(RII_ERR_INVALID, "posting id %d out of range [0, %lld)", pl_ids[j], (long long) e->N);
+    e->centers.assign(centers, centers + (size_t) nlist * e->M);
+    RII_TRY(upload_centers(e));
+    e->lists.assign((size_t) nlist, std::vector<int32_t>());
+    for (int64_t i = 0; i < nlist; ++i) e->lists[(size_t) i].assign(pl_ids + pl_off[i], pl_ids + pl_off[i + 1]);
+    e->lists_dirty = true;
+    return RII_OK;
 }
 
 RII_API int rii_set_state(rii_engine *e, const uint8_t *centers, int64_t nlist, const uint8_t *codes, int64_t N,
@@ -2014,23 +2037,30 @@ int ivf_list_lengths_locked(rii_engine *e, const int64_t *d_tids, int64_t S, int
     HIP_TRY(hipMemcpyAsync(d_out_len, src, (size_t) nlist * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return RII_OK;
 }
-int ivf_shard_check(const rii_engine *e, int64_t B, int topk, int64_t S_global, int64_t L, int64_t N_global, int rows, int64_t *w_out)
+int ivf_shard_w(const rii_engine *e, int64_t S_global, int64_t L, int64_t N_global)
+{
+    // w of src/rii.h:266-277 from the global sizes
+    const int64_t nlist = nlist_of(e);
+    const double wd = (S_global == 0) ? std::round((double) L * (double) nlist / (double) N_global)
+                                      : std::round((double) L * (double) nlist / (double) S_global);
+    int64_t w = (int64_t) (size_t) wd + 3;
+    if (nlist < w) w = nlist;
+    return (int) w;
+}
+int ivf_shard_check(const rii_engine *e, int64_t B, int topk, int64_t S_global, int64_t L, int64_t N_global, int64_t rows, int64_t *w_out)
 {
     const int64_t nlist = nlist_of(e);
-    if (rows > ivf_shard_max_L()) return set_err(RII_ERR_INVALID, "rows=%d: at most %d output rows per query", rows, ivf_shard_max_L());
     if (nlist == 0) return set_err(RII_ERR_STATE, "no posting lists: call reconfigure() / set_coarse_centers() first");
     // the reference's preconditions, on the GLOBAL sizes (src/rii.h:252-253,271)
     if (topk < 1 || (int64_t) topk > L || L > N_global || (S_global != 0 && ((int64_t) topk > S_global || S_global > N_global)))
         return set_err(RII_ERR_INVALID, "need topk <= L <= N and topk <= len(target_ids) <= N on the whole database "
                                         "(topk=%d, L=%lld, N=%lld, S=%lld)", topk, (long long) L, (long long) N_global, (long long) S_global);
-    // w of src/rii.h:266-277 from the global sizes
-    const double wd = (S_global == 0) ? std::round((double) L * (double) nlist / (double) N_global)
-                                      : std::round((double) L * (double) nlist / (double) S_global);
-    int64_t w = (int64_t) (size_t) wd + 3;
-    if (nlist < w) w = nlist;
-    if (!ivf_shard_supported(e->M, e->Ks, (int) nlist, L, w))
-        return set_err(RII_ERR_UNSUPPORTED, "sharded inverted index: L=%lld must be <= %d (the candidate keys of a query are sorted in LDS)",
-                       (long long) L, ivf_shard_max_L());
+    if (L > (int64_t) INT32_MAX - 1) return set_err(RII_ERR_INVALID, "L=%lld: traversal positions are 32-bit", (long long) L);
+    const int64_t w = ivf_shard_w(e, S_global, L, N_global);
+    // any L (round 5): `rows` best owned candidates per query while they fit the selection buffer, or every owned candidate (rows >= L)
+    if (rows < 1 || rows > (int64_t) INT32_MAX - 1 || !ivf_shard_supported(e->M, e->Ks, (int) nlist, L, w, (int) rows))
+        return set_err(RII_ERR_INVALID, "rows=%lld: at most %d selected rows per query at this shape, or rows >= L = %lld (every owned candidate)",
+                       (long long) rows, ivf_shard_max_select_rows(e->M, e->Ks, (int) nlist, L, w), (long long) L);
     *w_out = w;
     return RII_OK;
 }
@@ -2047,8 +2077,8 @@ int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk,
         pl_ids = e->s_fids.as<int32_t>();
         list_len = e->s_flen.as<int32_t>();
     }
-    // nlist past the LDS limit: coarse order + cumulative counts of a query in global scratch, <= 256 MiB per launch
-    const size_t per_q = ivf_shard_scratch_per_query((int) nlist);
+    // nlist or L past the LDS limits: coarse order + cumulative counts of a query in global scratch, <= 256 MiB per launch
+    const size_t per_q = ivf_shard_scratch_per_query(e->M, e->Ks, (int) nlist, L, w);
     const int64_t step = per_q ? std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, ((int64_t) 256 << 20) / (int64_t) per_q)) : kMaxBatch;
     if (per_q) RII_TRY(e->s_big.ensure(per_q * (size_t) std::min<int64_t>(step, B)));
     for (int64_t b0 = 0; b0 < B; b0 += step) {
@@ -2058,7 +2088,7 @@ int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk,
         ScopedTimer t(e, "ivf_shard", st);
         HIP_TRY(launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
                                  e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
-                                 d_out_ids + b0 * rows, d_out_dists + b0 * rows, d_out_pos + b0 * rows,
+                                 d_out_ids + b0 * (int64_t) rows, d_out_dists + b0 * (int64_t) rows, d_out_pos + b0 * (int64_t) rows,
                                  d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st));
     }
     return RII_OK;
@@ -2089,13 +2119,32 @@ RII_API int rii_query_ivf_shard_dev(rii_engine *e, const float *d_queries, int64
     return r2;
 }
 
+RII_API int rii_ivf_shard_max_select_rows(const rii_engine *e, int64_t L, int64_t N_global, int64_t S_global)
+{
+    if (!e || L < 1 || N_global < 1 || S_global < 0 || nlist_of(e) == 0) return -1;
+    return ivf_shard_max_select_rows(e->M, e->Ks, (int) nlist_of(e), L, ivf_shard_w(e, S_global, L, N_global));
+}
+RII_API int64_t rii_ivf_shard_replay_scratch_bytes(int64_t nf, int rows)
+{
+    return (nf < 0 || rows < 1) ? -1 : (int64_t) shard_replay_scratch(nf, rows);
+}
+RII_API int rii_ivf_shard_replay_ex_dev(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
+                                        float *d_out_dists, void *d_scratch, int64_t scratch_bytes, void *stream)
+{
+    if (!d_gathered || G < 1 || nf < 0 || rows < 1 || topk < 1 || topk > rows || (nf > 0 && (!d_out_ids || !d_out_dists)))
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    const size_t need = shard_replay_scratch(nf, rows);
+    if (need && (!d_scratch || scratch_bytes < (int64_t) need))
+        return set_err(RII_ERR_INVALID, "rows=%d: the candidate sequences need %lld bytes of scratch (rii_ivf_shard_replay_scratch_bytes)", rows, (long long) need);
+    HIP_TRY(launch_shard_replay(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, d_scratch, (hipStream_t) stream));
+    return RII_OK;
+}
 RII_API int rii_ivf_shard_replay_dev(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
                                      float *d_out_dists, void *stream)
 {
-    if (!d_gathered || G < 1 || nf < 0 || rows < 1 || rows > ivf_shard_max_L() || topk < 1 || topk > rows || (nf > 0 && (!d_out_ids || !d_out_dists)))
-        return set_err(RII_ERR_INVALID, "bad arguments");
-    HIP_TRY(launch_shard_replay(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, (hipStream_t) stream));
-    return RII_OK;
+    if (rows >= 1 && nf >= 0 && shard_replay_scratch(nf, rows) != 0)
+        return set_err(RII_ERR_INVALID, "rows=%d: sequences past the LDS budget need scratch: call rii_ivf_shard_replay_ex_dev", rows);
+    return rii_ivf_shard_replay_ex_dev(d_gathered, G, nf, rows, topk, d_out_ids, d_out_dists, nullptr, 0, stream);
 }
 
 // Database-sharded linear search, exact ties (not in the reference; kernels and argument: tieorder.hip).
@@ -2205,7 +2254,7 @@ RII_API int rii_merge_topk_ex_dev(const void *d_gathered, int G, int64_t B, int 
         return set_err(RII_ERR_INVALID, "bad arguments");
     if ((int64_t) G * k > merge_topk_max_keys())
         return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d keys per query exceeds %d", G, k, merge_topk_max_keys());
-    if (k == 1 && k_out == 1 && !payload && !d_out_tie && G <= 64) {        // one row per rank: one thread per query (comm.hip)
+    if (k == 1 && k_out == 1 && !payload && !d_out_tie && !d_out_any && G <= 64) {   // one row per rank: one thread per query (comm.hip)
         HIP_TRY(launch_merge_top1(d_gathered, G, B, id_offsets, d_out_keys, d_out_dists, (hipStream_t) stream));
         return RII_OK;
     }
@@ -2236,9 +2285,15 @@ RII_API int rii_qshard_unpack_dev(const void *d_gathered, int64_t B, int G, int 
 struct rii_comm {
     void *nccl = nullptr;
     int rank = 0, G = 1, device = 0;
-    DevBuf rec, gathered, tmp_i, tmp_d, mi, md, tie, anyf, fsel, qf, bound, rec2, gg, r_i, r_d, starts_dev;
-    std::vector<int64_t> starts;          // first global id of every rank's shard (database sharding), all-gathered once per id_offset
-    int64_t my_start = -1;
+    DevBuf rec, gathered, tmp_i, tmp_d, mi, md, tie, anyf, fsel, qf, bound, rec2, gg, r_i, r_d, lens, status_dev, seq;
+    // round 5: every record of the database-sharded calls starts with a kRecHeader-byte header {int64 id offset of this rank's shard,
+    // int32 status}: the offsets travel with the rows (nothing cached that another index on the same communicator could leave stale,
+    // no collective that only some ranks issue), and so does a rank-local failure.  What this rank last wrote into the header of
+    // c->rec (a rank-local cache of a rank-local write):
+    void *hdr_at = nullptr;
+    int64_t hdr_offset = -1;
+    int hdr_status = -1;
+    bool broken = false;                  // a collective itself failed: the ranks may be out of step, every later call is refused
     std::mutex mu;
 };
 
@@ -2275,7 +2330,7 @@ RII_API void rii_comm_destroy(rii_comm *c)
     (void) hipDeviceSynchronize();
     comm_destroy(c->nccl);
     DevBuf *bufs[] = {&c->rec, &c->gathered, &c->tmp_i, &c->tmp_d, &c->mi, &c->md, &c->tie, &c->anyf, &c->fsel, &c->qf, &c->bound,
-                      &c->rec2, &c->gg, &c->r_i, &c->r_d, &c->starts_dev};
+                      &c->rec2, &c->gg, &c->r_i, &c->r_d, &c->lens, &c->status_dev, &c->seq};
     for (DevBuf *b : bufs) b->release();
     delete c;
 }
@@ -2285,15 +2340,64 @@ RII_API int rii_comm_size(const rii_comm *c) { return c ? c->G : 0; }
 namespace {
 int comm_gather(rii_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st)
 {
-    if (const char *err = comm_all_gather(c->nccl, d_send, d_recv, bytes, st)) return set_err(RII_ERR_HIP, "ncclAllGather: %s", err);
+    if (const char *err = comm_all_gather(c->nccl, d_send, d_recv, bytes, st)) {
+        c->broken = true;                      // the ranks may be out of step from here on
+        return set_err(RII_ERR_HIP, "ncclAllGather: %s (the communicator is unusable after a failed collective: destroy it)", err);
+    }
     return RII_OK;
 }
-// shared tail of the query-sharded calls: this rank's rows are in c->rec
-int qshard_exchange(rii_comm *c, int64_t B, int topk, int counts, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st)
+int comm_usable(const rii_comm *c)
 {
+    if (c->broken) return set_err(RII_ERR_STATE, "this communicator saw a failed collective: the ranks may be out of step; destroy it");
+    return RII_OK;
+}
+// the header of c->rec: written when it changes only (one small host-to-device copy; the common case is "same shard, status 0")
+int comm_set_header(rii_comm *c, int64_t id_offset, int status, hipStream_t st)
+{
+    if (c->hdr_at == c->rec.p && c->hdr_offset == id_offset && c->hdr_status == status) return RII_OK;
+    struct { int64_t off; int32_t status, pad; } h = {id_offset, status, 0};
+    static_assert(sizeof(h) == kRecHeader, "record header");
+    c->hdr_at = nullptr;
+    HIP_TRY(hipMemcpyAsync(c->rec.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));         // (`h` lives on this stack frame)
+    c->hdr_at = c->rec.p; c->hdr_offset = id_offset; c->hdr_status = status;
+    return RII_OK;
+}
+// Collective agreement for the RARE phases that talk to the host anyway (exact-tie replays, the collect-all route): every rank
+// contributes its local return code behind ONE 4-byte all-gather, so a rank-local failure (an allocation that did not fit, ...)
+// makes every rank return an error from the same call instead of leaving its peers inside the next all-gather.
+int comm_agree(rii_comm *c, int local_rc, hipStream_t st)
+{
+    const std::string local_msg = g_err;
+    int32_t mine = local_rc;
+    std::vector<int32_t> all((size_t) c->G, 0);
+    if (c->status_dev.ensure((size_t) (c->G + 1) * sizeof(int32_t)) != RII_OK) {
+        c->broken = true;                      // cannot even take part: the peers will wait in their all-gather
+        return set_err(RII_ERR_HIP, "no memory for the status exchange (the communicator is unusable)");
+    }
+    int32_t *sd = c->status_dev.as<int32_t>();
+    if (hipMemcpyAsync(sd + c->G, &mine, 4, hipMemcpyHostToDevice, st) != hipSuccess) { c->broken = true; return set_err(RII_ERR_HIP, "copy failed"); }
+    RII_TRY(comm_gather(c, sd + c->G, sd, 4, st));
+    if (hipMemcpyAsync(all.data(), sd, (size_t) c->G * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        c->broken = true;
+        return set_err(RII_ERR_HIP, "copy failed");
+    }
+    if (local_rc != RII_OK) { g_err = local_msg; return local_rc; }
+    for (int g = 0; g < c->G; ++g)
+        if (all[(size_t) g] != RII_OK) return set_err(RII_ERR_STATE, "rank %d failed this sharded call (code %d); every rank returns, the communicator stays in step", g, (int) all[(size_t) g]);
+    return RII_OK;
+}
+// shared tail of the query-sharded calls: this rank's rows are in c->rec.  A rank whose own engine call failed (local_rc) still takes
+// part -- its rows go out as all-ones bytes (ids -1, counts -1, distances NaN), so its peers return from the same call with those
+// rows poisoned instead of waiting in the all-gather -- and returns its error afterwards
+int qshard_exchange(rii_comm *c, int local_rc, int64_t B, int topk, int counts, int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, hipStream_t st)
+{
+    const std::string local_msg = g_err;
     const size_t rec_bytes = qshard_record_bytes(B, c->G, topk, counts);
+    if (local_rc != RII_OK && hipMemsetAsync(c->rec.p, 0xff, rec_bytes, st) != hipSuccess) { c->broken = true; return set_err(RII_ERR_HIP, "memset failed"); }
     RII_TRY(comm_gather(c, c->rec.p, c->gathered.p, rec_bytes, st));
     HIP_TRY(launch_qshard_unpack(c->gathered.p, B, c->G, topk, counts, d_out_ids, d_out_dists, d_out_counts, st));
+    if (local_rc != RII_OK) { g_err = local_msg; return local_rc; }
     return RII_OK;
 }
 }  // namespace
@@ -2307,19 +2411,23 @@ RII_API int rii_query_linear_qsharded_dev(rii_engine *e, rii_comm *c, const floa
     std::lock_guard<std::mutex> gc(c->mu);
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    RII_TRY(check_query_args(e, B, topk, S));
+    RII_TRY(comm_usable(c));
+    RII_TRY(check_query_args(e, B, topk, S));        // (the index is replicated: the same outcome on every rank)
     if (B == 0) return RII_OK;
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     const int64_t s0 = qshard_begin(B, c->G, c->rank), n = qshard_begin(B, c->G, c->rank + 1) - s0, nmax = (B + c->G - 1) / c->G;
     const size_t rec_bytes = qshard_record_bytes(B, c->G, topk, 0);
-    RII_TRY(c->rec.ensure(rec_bytes));
-    RII_TRY(c->gathered.ensure(rec_bytes * (size_t) c->G));
+    if (c->rec.ensure(rec_bytes) != RII_OK || c->gathered.ensure(rec_bytes * (size_t) c->G) != RII_OK) {
+        c->broken = true;
+        return set_err(RII_ERR_HIP, "no memory for the exchange records (the communicator is unusable: the peers wait in their all-gather)");
+    }
+    c->hdr_at = nullptr;                       // (the record of this call starts where the database-sharded calls keep their header)
     RII_TRY(begin_on(e, st));
     int r = RII_OK;
     if (n > 0)
         r = query_linear_dev(e, d_queries + s0 * (int64_t) (e->M * e->Ds), n, topk, d_tids, S, c->rec.as<int64_t>(),
                              reinterpret_cast<float *>(c->rec.as<unsigned char>() + (size_t) nmax * topk * 8), st);
-    if (r == RII_OK) r = qshard_exchange(c, B, topk, 0, d_out_ids, d_out_dists, nullptr, st);
+    r = qshard_exchange(c, r, B, topk, 0, d_out_ids, d_out_dists, nullptr, st);
     const std::string msg = g_err;
     const int r2 = end_on(e, st);
     if (r != RII_OK) { g_err = msg; return r; }
@@ -2333,14 +2441,18 @@ RII_API int rii_query_ivf_qsharded_dev(rii_engine *e, rii_comm *c, const float *
     std::lock_guard<std::mutex> gc(c->mu);
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(comm_usable(c));
     RII_TRY(check_query_args(e, B, topk, S));
     RII_TRY(check_ivf_args(e, topk, L));
     if (B == 0) return RII_OK;
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
     const int64_t s0 = qshard_begin(B, c->G, c->rank), n = qshard_begin(B, c->G, c->rank + 1) - s0, nmax = (B + c->G - 1) / c->G;
     const size_t rec_bytes = qshard_record_bytes(B, c->G, topk, 1);
-    RII_TRY(c->rec.ensure(rec_bytes));
-    RII_TRY(c->gathered.ensure(rec_bytes * (size_t) c->G));
+    if (c->rec.ensure(rec_bytes) != RII_OK || c->gathered.ensure(rec_bytes * (size_t) c->G) != RII_OK) {
+        c->broken = true;
+        return set_err(RII_ERR_HIP, "no memory for the exchange records (the communicator is unusable: the peers wait in their all-gather)");
+    }
+    c->hdr_at = nullptr;
     RII_TRY(begin_on(e, st));
     int r = RII_OK;
     unsigned char *rp = c->rec.as<unsigned char>();
@@ -2348,7 +2460,7 @@ RII_API int rii_query_ivf_qsharded_dev(rii_engine *e, rii_comm *c, const float *
         r = query_ivf_dev(e, d_queries + s0 * (int64_t) (e->M * e->Ds), n, topk, d_tids, S, L, reinterpret_cast<int64_t *>(rp),
                           reinterpret_cast<float *>(rp + (size_t) nmax * topk * 8 + (size_t) nmax * 8),
                           reinterpret_cast<int64_t *>(rp + (size_t) nmax * topk * 8), st);
-    if (r == RII_OK) r = qshard_exchange(c, B, topk, 1, d_out_ids, d_out_dists, d_out_counts, st);
+    r = qshard_exchange(c, r, B, topk, 1, d_out_ids, d_out_dists, d_out_counts, st);
     const std::string msg = g_err;
     const int r2 = end_on(e, st);
     if (r != RII_OK) { g_err = msg; return r; }
@@ -2364,6 +2476,12 @@ RII_API int rii_query_ivf_qsharded_dev(rii_engine *e, rii_comm *c, const float *
 // wave per query replays the library's heap (tieorder.hip).  Top-1 is asynchronous on the stream; top-k reads ONE word per batch
 // on the host (is any query flagged?) and is synchronous only in that.  d_tids_local: this rank's share of the target ids as
 // LOCAL ids (S_global = size of the whole target set, 0 = none; a rank may own none: S_local == 0).
+//
+// Collectives and failures (round 5): every decision that leads to a collective is taken from arguments that are the same
+// on every rank; everything rank-local (this shard's size, allocations, the engine's own call) is folded into `lr` and the rank STILL
+// takes part in the batch's all-gather, with a non-zero status in its record header -- the merge kernels of every rank then poison
+// the batch (ids -2, distances NaN) and the top-k path returns RII_ERR_STATE everywhere; the rare replay phase agrees on a status
+// word first (comm_agree).  The ranks stay in step; only a failed collective itself marks the communicator unusable.
 RII_API int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset, const float *d_queries, int64_t B, int topk,
                                            const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t *d_out_ids,
                                            float *d_out_dists, int32_t *d_out_tie, int32_t *d_out_overflow, int tie_cap, void *stream)
@@ -2375,86 +2493,99 @@ RII_API int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t i
     std::lock_guard<std::mutex> gc(c->mu);
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    if (S_local > e->N) return set_err(RII_ERR_INVALID, "S_local=%lld must satisfy S <= N", (long long) S_local);
-    if (c->G > 64) return set_err(RII_ERR_UNSUPPORTED, "database sharding over %d ranks: at most 64", c->G);
+    RII_TRY(comm_usable(c));
     if (B == 0) return RII_OK;
     const int G = c->G;
     const int rows = topk == 1 ? 1 : topk + 1;
-    if (topk > 1 && (int64_t) G * rows > merge_topk_max_keys())
-        return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d rows per query exceeds %d keys", G, rows, merge_topk_max_keys());
+    if ((int64_t) G * rows >= ((int64_t) 1 << 31)) return set_err(RII_ERR_INVALID, "G * (topk + 1) = %lld rows per query", (long long) G * rows);
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
+    const size_t rec_bytes = merge_record_bytes(B, rows, 0), stride = rec_bytes + kRecHeader;
+    // without its own record and the gathered ones a rank cannot take part at all
+    if (c->rec.ensure(stride) != RII_OK || c->gathered.ensure(stride * (size_t) G) != RII_OK) {
+        c->broken = true;
+        return set_err(RII_ERR_HIP, "no memory for the exchange records (the communicator is unusable: the peers wait in their all-gather)");
+    }
+    // ---- rank-local from here: failures go into lr, the collective below is issued regardless ----
+    int lr = RII_OK;
+    if (S_local > e->N) lr = set_err(RII_ERR_INVALID, "S_local=%lld must satisfy S <= N", (long long) S_local);
     const int64_t n_local = S_global ? S_local : e->N;
     const int k_local = (int) std::min<int64_t>(rows, n_local);
-    const size_t rec_bytes = merge_record_bytes(B, rows, 0);
-    RII_TRY(c->rec.ensure(rec_bytes));
-    RII_TRY(c->gathered.ensure(rec_bytes * (size_t) G));
-    int64_t *rec_i = c->rec.as<int64_t>();
-    float *rec_d = reinterpret_cast<float *>(c->rec.as<unsigned char>() + (size_t) B * rows * 8);
+    const size_t msc = merge_topk_scratch(G, B, rows);
+    if (lr == RII_OK && topk > 1 &&
+        ((lr = c->mi.ensure((size_t) B * rows * 8)) != RII_OK || (lr = c->md.ensure((size_t) B * rows * 4)) != RII_OK ||
+         (lr = c->tie.ensure((size_t) B * 4)) != RII_OK || (lr = c->anyf.ensure(16)) != RII_OK || (msc && (lr = c->seq.ensure(msc)) != RII_OK))) {}
+    if (lr == RII_OK && k_local > 0 && k_local < rows &&
+        ((lr = c->tmp_i.ensure((size_t) B * k_local * 8)) != RII_OK || (lr = c->tmp_d.ensure((size_t) B * k_local * 4)) != RII_OK)) {}
+    int64_t *rec_i = reinterpret_cast<int64_t *>(c->rec.as<unsigned char>() + kRecHeader);
+    float *rec_d = reinterpret_cast<float *>(c->rec.as<unsigned char>() + kRecHeader + (size_t) B * rows * 8);
     RII_TRY(begin_on(e, st));
     int r = RII_OK;
     do {
-        // the shards' first ids, all-gathered once (and again if this rank is handed another offset)
-        if (c->my_start != id_offset || (int) c->starts.size() != G) {
-            if ((r = c->starts_dev.ensure((size_t) (G + 1) * sizeof(int64_t))) != RII_OK) break;
-            int64_t *sd = c->starts_dev.as<int64_t>();
-            if (hipMemcpyAsync(sd + G, &id_offset, sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
-            if ((r = comm_gather(c, sd + G, sd, sizeof(int64_t), st)) != RII_OK) break;
-            c->starts.assign((size_t) G, 0);
-            if (hipMemcpyAsync(c->starts.data(), sd, (size_t) G * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
-            c->my_start = id_offset;
-        }
-        if (k_local == rows) {                 // the engine writes its LOCAL ids and distances straight into the record
-            if ((r = query_linear_dev(e, d_queries, B, rows, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, rec_i, rec_d, st)) != RII_OK) break;
-        } else {                               // fewer local codes / targets than rows: padding rows (key 2^62, distance +inf)
-            if (launch_fill_pad(rec_i, rec_d, B * rows, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "fill failed"); break; }
-            if (k_local > 0) {
-                if ((r = c->tmp_i.ensure((size_t) B * k_local * 8)) != RII_OK || (r = c->tmp_d.ensure((size_t) B * k_local * 4)) != RII_OK) break;
-                if ((r = query_linear_dev(e, d_queries, B, k_local, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, c->tmp_i.as<int64_t>(),
-                                          c->tmp_d.as<float>(), st)) != RII_OK) break;
-                if (launch_copy_cols(c->tmp_i.as<int64_t>(), c->tmp_d.as<float>(), B, k_local, rows, k_local, rec_i, rec_d, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        if (lr == RII_OK) {
+            if (k_local == rows) {                 // the engine writes its LOCAL ids and distances straight into the record
+                lr = query_linear_dev(e, d_queries, B, rows, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, rec_i, rec_d, st);
+            } else {                               // fewer local codes / targets than rows: padding rows (key 2^62, distance +inf)
+                if (launch_fill_pad(rec_i, rec_d, B * rows, st) != hipSuccess) lr = set_err(RII_ERR_HIP, "fill failed");
+                if (lr == RII_OK && k_local > 0) {
+                    lr = query_linear_dev(e, d_queries, B, k_local, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, c->tmp_i.as<int64_t>(),
+                                          c->tmp_d.as<float>(), st);
+                    if (lr == RII_OK && launch_copy_cols(c->tmp_i.as<int64_t>(), c->tmp_d.as<float>(), B, k_local, rows, k_local, rec_i, rec_d, st) != hipSuccess)
+                        lr = set_err(RII_ERR_HIP, "copy failed");
+                }
             }
         }
-        if ((r = comm_gather(c, c->rec.p, c->gathered.p, rec_bytes, st)) != RII_OK) break;
+        const std::string local_msg = g_err;
+        if (comm_set_header(c, id_offset, lr != RII_OK ? 1 : 0, st) != RII_OK) { c->broken = true; r = RII_ERR_HIP; break; }
+        if ((r = comm_gather(c, c->rec.p, c->gathered.p, stride, st)) != RII_OK) break;
+        if (lr != RII_OK) { g_err = local_msg; r = lr; break; }         // the peers learn it from this rank's header
         if (d_out_overflow && hipMemsetAsync(d_out_overflow, 0, (size_t) B * sizeof(int32_t), st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
         if (topk == 1) {
             if (d_out_tie && hipMemsetAsync(d_out_tie, 0, (size_t) B * sizeof(int32_t), st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
-            if (launch_merge_top1(c->gathered.p, G, B, c->starts.data(), d_out_ids, d_out_dists, st) != hipSuccess) r = set_err(RII_ERR_HIP, "merge failed");
+            if (launch_merge_top1(c->gathered.p, G, B, nullptr, d_out_ids, d_out_dists, st, kRecHeader) != hipSuccess) r = set_err(RII_ERR_HIP, "merge failed");
             break;
         }
-        if ((r = c->mi.ensure((size_t) B * rows * 8)) != RII_OK || (r = c->md.ensure((size_t) B * rows * 4)) != RII_OK ||
-            (r = c->tie.ensure((size_t) B * 4)) != RII_OK || (r = c->anyf.ensure(16)) != RII_OK) break;
         int32_t *d_tie = d_out_tie ? d_out_tie : c->tie.as<int32_t>();
         if (hipMemsetAsync(c->anyf.p, 0, 4, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
-        if (launch_merge_topk(c->gathered.p, G, B, rows, rows, 0, c->mi.as<int64_t>(), c->md.as<float>(), nullptr, st, c->starts.data(), rows,
-                              d_tie, c->anyf.as<int32_t>()) != hipSuccess ||
+        if (launch_merge_topk(c->gathered.p, G, B, rows, rows, 0, c->mi.as<int64_t>(), c->md.as<float>(), nullptr, st, nullptr, rows,
+                              d_tie, c->anyf.as<int32_t>(), kRecHeader, c->seq.p) != hipSuccess ||
             launch_copy_cols(c->mi.as<int64_t>(), c->md.as<float>(), B, rows, topk, topk, d_out_ids, d_out_dists, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "merge failed"); break; }
         int32_t h_any = 0;                     // the batch's one host read
         if (hipMemcpyAsync(&h_any, c->anyf.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        if (h_any & 2) { r = set_err(RII_ERR_STATE, "a peer rank failed this sharded call (its rows are poisoned: ids -2, distances NaN)"); break; }
         if (!h_any) break;
         // ---- exact ties across the shards: replay (identical decisions on every rank: the flags come from identical merges) ----
-        if (e->QT == 0 ? !linear_tie_chunked_topk_ok(topk) : !linear_tie_chunked_supported(e->M, e->Ks, topk)) { r = set_err(RII_ERR_UNSUPPORTED, "tie replay across shards: topk=%d / M*Ks=%d not supported", topk, e->M * e->Ks); break; }
+        if (e->QT == 0 ? !linear_tie_chunked_topk_ok(topk) : !linear_tie_chunked_supported(e->M, e->Ks, topk)) {
+            // a heap deeper than the replay kernels walk (topk > 1024): the flagged queries keep the (distance, id) order among exactly
+            // tied distances and say so, like a candidate list above tie_cap (d_out_overflow; the shape is the same on every rank)
+            if (d_out_overflow && hipMemcpyAsync(d_out_overflow, d_tie, (size_t) B * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                r = set_err(RII_ERR_HIP, "copy failed");
+            break;
+        }
         std::vector<int32_t> h_tie((size_t) B), h_sel;
         if (hipMemcpy(h_tie.data(), d_tie, (size_t) B * 4, hipMemcpyDeviceToHost) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
         for (int64_t b = 0; b < B; ++b) if (h_tie[(size_t) b]) h_sel.push_back((int32_t) b);
         const int nf = (int) h_sel.size();
         const int cap = tie_cap > 0 ? tie_cap : 12288;
-        if ((int64_t) G * cap >= ((int64_t) 1 << 32)) { r = set_err(RII_ERR_INVALID, "tie_cap too large"); break; }
+        if ((int64_t) G * cap >= ((int64_t) 1 << 32)) { r = set_err(RII_ERR_INVALID, "tie_cap too large"); break; }      // (same arguments on every rank)
         const int D = e->M * e->Ds;
         const size_t rec2 = linear_tie_record_bytes(nf, cap);
-        if ((r = c->fsel.ensure((size_t) nf * 4)) != RII_OK || (r = c->qf.ensure((size_t) nf * D * 4)) != RII_OK || (r = c->bound.ensure((size_t) nf * 4)) != RII_OK ||
-            (r = c->rec2.ensure(rec2)) != RII_OK || (r = c->gg.ensure(rec2 * (size_t) G)) != RII_OK || (r = c->r_i.ensure((size_t) nf * topk * 8)) != RII_OK ||
-            (r = c->r_d.ensure((size_t) nf * topk * 4)) != RII_OK) break;
-        if (hipMemcpyAsync(c->fsel.p, h_sel.data(), (size_t) nf * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
-        if (launch_tie_prepare(c->gathered.p, c->rank, B, rows, topk, c->fsel.as<int32_t>(), nf, d_queries, D, c->qf.as<float>(), c->bound.as<float>(), st) != hipSuccess) { r = set_err(RII_ERR_HIP, "launch failed"); break; }
+        int l2 = RII_OK;                       // rank-local again, agreed on before the second all-gather
+        if ((l2 = c->fsel.ensure((size_t) nf * 4)) != RII_OK || (l2 = c->qf.ensure((size_t) nf * D * 4)) != RII_OK || (l2 = c->bound.ensure((size_t) nf * 4)) != RII_OK ||
+            (l2 = c->rec2.ensure(rec2)) != RII_OK || (l2 = c->gg.ensure(rec2 * (size_t) G)) != RII_OK || (l2 = c->r_i.ensure((size_t) nf * topk * 8)) != RII_OK ||
+            (l2 = c->r_d.ensure((size_t) nf * topk * 4)) != RII_OK) {}
         unsigned char *r2p = c->rec2.as<unsigned char>();
         const size_t cnt_bytes = ((size_t) nf * 4 + 7) / 8 * 8;
-        if (hipMemsetAsync(r2p, 0, rec2, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
+        if (l2 == RII_OK && (hipMemcpyAsync(c->fsel.p, h_sel.data(), (size_t) nf * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+            l2 = set_err(RII_ERR_HIP, "copy failed");
+        if (l2 == RII_OK && launch_tie_prepare(c->gathered.p, c->rank, B, rows, topk, c->fsel.as<int32_t>(), nf, d_queries, D, c->qf.as<float>(), c->bound.as<float>(), st,
+                                               kRecHeader) != hipSuccess) l2 = set_err(RII_ERR_HIP, "launch failed");
+        if (l2 == RII_OK && hipMemsetAsync(r2p, 0, rec2, st) != hipSuccess) l2 = set_err(RII_ERR_HIP, "memset failed");
         // a rank whose share of the target ids is EMPTY contributes nothing (S = 0 would mean "no target set" to the engine)
-        if (!(S_global != 0 && S_local == 0))
-            if ((r = linear_tie_emit_locked(e, c->qf.as<float>(), nf, topk, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, c->bound.as<float>(), id_offset, cap,
-                                            reinterpret_cast<int64_t *>(r2p + cnt_bytes), reinterpret_cast<float *>(r2p + cnt_bytes + (size_t) nf * cap * 8),
-                                            reinterpret_cast<int32_t *>(r2p), st)) != RII_OK) break;
+        if (l2 == RII_OK && !(S_global != 0 && S_local == 0))
+            l2 = linear_tie_emit_locked(e, c->qf.as<float>(), nf, topk, S_global ? d_tids_local : nullptr, S_global ? S_local : 0, c->bound.as<float>(), id_offset, cap,
+                                        reinterpret_cast<int64_t *>(r2p + cnt_bytes), reinterpret_cast<float *>(r2p + cnt_bytes + (size_t) nf * cap * 8),
+                                        reinterpret_cast<int32_t *>(r2p), st);
+        if ((r = comm_agree(c, l2, st)) != RII_OK) break;
         if ((r = comm_gather(c, r2p, c->gg.p, rec2, st)) != RII_OK) break;
         if (launch_linear_shard_replay(c->gg.p, G, nf, cap, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), st) != hipSuccess ||
             launch_tie_scatter(c->gg.p, G, nf, cap, topk, c->fsel.as<int32_t>(), c->r_i.as<int64_t>(), c->r_d.as<float>(), d_out_ids, d_out_dists, d_out_overflow, st) != hipSuccess)
@@ -2472,6 +2603,16 @@ RII_API int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t i
 // it owns (k + 1 rows per query); (3) ONE all-gather of (position, global id, distance) rows, merged under (distance, position);
 // (4) queries whose k + 1 best distances tie exactly (d_out_tie) are redone with ALL candidates gathered (rows = L) and
 // std::partial_sort replayed on the rebuilt sequence.  top-1 is asynchronous; top-k reads one word per batch on the host.
+//
+// Round 5: any L and any topk <= L.  The reference's own billion-scale run uses L = N / nlist = sqrt(N) ~ 31.6 k
+// (examples/benchmark/run_sift1b.py:105-106): the shard kernel selects its k + 1 rows through an LDS buffer with a running bound
+// (ivf_shard_any_kernel), the replay of (4) rebuilds sequences of any length in global scratch (shard_replay_any_kernel), in groups of
+// flagged queries that keep the gathered rows under kShardGatherBudget.  k + 1 rows beyond what a launch can select (> ~7.6 k):
+// the collect-all route -- every rank sends EVERY candidate it owns (rows = L, by position), in groups of queries, and
+// std::partial_sort replayed on the rebuilt sequence IS the reference's answer (no merge, no flags).
+// Failures: see rii_query_linear_dbsharded_dev.
+constexpr size_t kShardGatherBudget = (size_t) 512 << 20;
+
 RII_API int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_offset, int64_t N_global, const float *d_queries, int64_t B,
                                         int topk, const int64_t *d_tids_local, int64_t S_local, int64_t S_global, int64_t L,
                                         int64_t *d_out_ids, float *d_out_dists, int64_t *d_out_counts, int32_t *d_out_tie, void *stream)
@@ -2482,76 +2623,138 @@ RII_API int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_o
     std::lock_guard<std::mutex> gc(c->mu);
     std::lock_guard<std::mutex> guard(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    RII_TRY(comm_usable(c));
     const int G = c->G;
-    const int k1 = topk + 1;
+    const int64_t nlist = nlist_of(e);
+    // (the shape -- M, Ks, nlist, the centres -- is the same on every rank by contract, and so is everything derived from it)
     int64_t w = 0;
-    RII_TRY(ivf_shard_check(e, B, topk, S_global, L, N_global, k1, &w));
-    if ((int64_t) G * k1 > merge_topk_max_keys())
-        return set_err(RII_ERR_UNSUPPORTED, "merge of %d x %d rows per query exceeds %d keys", G, k1, merge_topk_max_keys());
+    RII_TRY(ivf_shard_check(e, B, topk, S_global, L, N_global, L, &w));                    // (rows = L is always served)
+    const int64_t k1 = (int64_t) topk + 1;
+    const bool collect_all = k1 > (int64_t) ivf_shard_max_select_rows(e->M, e->Ks, (int) nlist, L, w) || (int64_t) G * k1 >= ((int64_t) 1 << 31);
     if (B == 0) return RII_OK;
     hipStream_t st = stream ? (hipStream_t) stream : e->stream;
-    const int64_t nlist = nlist_of(e);
     const int D = e->M * e->Ds;
+    const size_t lens_bytes = (size_t) nlist * sizeof(int32_t);
+    if (c->lens.ensure((size_t) (G + 1) * lens_bytes + 64) != RII_OK) {
+        c->broken = true;
+        return set_err(RII_ERR_HIP, "no memory for the exchange records (the communicator is unusable: the peers wait in their all-gather)");
+    }
+    int32_t *glen = c->lens.as<int32_t>(), *mylen = glen + (size_t) G * nlist;
+    // groups of queries whose gathered every-candidate rows (G x L x 20 bytes each) stay under the budget: the exact-tie replay, and
+    // the whole batch on the collect-all route
+    const int64_t per_q_all = (int64_t) G * L * 20;
+    const int64_t group = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t) kShardGatherBudget / std::max<int64_t>(per_q_all, 1)));
     RII_TRY(begin_on(e, st));
     int r = RII_OK;
     do {
-        // (1) list lengths of every rank
-        if ((r = c->starts_dev.ensure((size_t) (G + 1) * (size_t) nlist * sizeof(int32_t) + 64)) != RII_OK) break;
-        int32_t *glen = c->starts_dev.as<int32_t>(), *mylen = glen + (size_t) G * nlist;
-        c->my_start = -1;                      // (the buffer is shared with the shard-offset cache of the linear call)
-        if ((r = ivf_list_lengths_locked(e, d_tids_local, S_local, S_global, mylen, st)) != RII_OK) break;
-        if ((r = comm_gather(c, mylen, glen, (size_t) nlist * sizeof(int32_t), st)) != RII_OK) break;
+        int lr = RII_OK;                       // rank-local outcome; the collectives below are issued regardless
+        // (1) list lengths of every rank (a rank that failed sends zeros: an empty shard, a consistent walk on every peer)
+        lr = ivf_list_lengths_locked(e, d_tids_local, S_local, S_global, mylen, st);
+        if (lr != RII_OK && hipMemsetAsync(mylen, 0, lens_bytes, st) != hipSuccess) { c->broken = true; r = RII_ERR_HIP; break; }
+        std::string local_msg = g_err;
+        if ((r = comm_gather(c, mylen, glen, lens_bytes, st)) != RII_OK) break;
+        if (collect_all) {
+            // ---- every candidate of every query, group by group; the replay is the answer ----
+            const size_t nr = (size_t) group * (size_t) L, rec2 = merge_record_bytes(group, (int) L, 1);
+            if (lr == RII_OK &&
+                ((lr = c->tmp_i.ensure(nr * 8)) != RII_OK || (lr = c->tmp_d.ensure(nr * 4)) != RII_OK || (lr = c->qf.ensure(nr * 4 + (size_t) group * 4)) != RII_OK ||
+                 (lr = c->rec2.ensure(rec2)) != RII_OK || (lr = c->gg.ensure(rec2 * (size_t) G)) != RII_OK ||
+                 (lr = c->seq.ensure(std::max<size_t>(shard_replay_scratch(group, (int) L), 16))) != RII_OK)) {}
+            if (lr != RII_OK) local_msg = g_err;
+            g_err = local_msg;
+            if ((r = comm_agree(c, lr, st)) != RII_OK) break;
+            if (d_out_tie && hipMemsetAsync(d_out_tie, 0, (size_t) B * sizeof(int32_t), st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
+            for (int64_t b0 = 0; b0 < B && r == RII_OK; b0 += group) {
+                const int64_t nb = std::min<int64_t>(group, B - b0);
+                const size_t n = (size_t) nb * (size_t) L, recb = merge_record_bytes(nb, (int) L, 1);
+                int32_t *pos = c->qf.as<int32_t>(), *nloc = pos + n;
+                int l2 = ivf_shard_locked(e, d_queries + b0 * D, nb, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, (int) L, c->tmp_i.as<int64_t>(),
+                                          c->tmp_d.as<float>(), pos, nloc, d_out_counts + b0, st);
+                if (l2 == RII_OK && launch_ivf_pack(c->tmp_i.as<int64_t>(), pos, c->tmp_d.as<float>(), (int64_t) n, id_offset, c->rec2.p, st) != hipSuccess)
+                    l2 = set_err(RII_ERR_HIP, "pack failed");
+                if ((r = comm_agree(c, l2, st)) != RII_OK) break;
+                if ((r = comm_gather(c, c->rec2.p, c->gg.p, recb, st)) != RII_OK) break;
+                if (launch_shard_replay(c->gg.p, G, nb, (int) L, topk, d_out_ids + b0 * topk, d_out_dists + b0 * topk, c->seq.p, st) != hipSuccess)
+                    r = set_err(RII_ERR_HIP, "replay launch failed");
+            }
+            break;
+        }
         // (2) this rank's k + 1 best candidates per query
-        const size_t n1 = (size_t) B * k1;
-        if ((r = c->tmp_i.ensure(n1 * 8)) != RII_OK || (r = c->tmp_d.ensure(n1 * 4)) != RII_OK || (r = c->qf.ensure(n1 * 4 + (size_t) B * 4)) != RII_OK ||
-            (r = c->bound.ensure((size_t) B * 8)) != RII_OK) break;
+        const size_t n1 = (size_t) B * (size_t) k1;
+        const size_t rec_bytes = merge_record_bytes(B, (int) k1, 1), stride = rec_bytes + kRecHeader;
+        if (c->rec.ensure(stride) != RII_OK || c->gathered.ensure(stride * (size_t) G) != RII_OK) {
+            c->broken = true;
+            r = set_err(RII_ERR_HIP, "no memory for the exchange records (the communicator is unusable: the peers wait in their all-gather)");
+            break;
+        }
+        const size_t msc = merge_topk_scratch(G, B, (int) k1);
+        if (lr == RII_OK &&
+            ((lr = c->tmp_i.ensure(n1 * 8)) != RII_OK || (lr = c->tmp_d.ensure(n1 * 4)) != RII_OK || (lr = c->qf.ensure(n1 * 4 + (size_t) B * 4)) != RII_OK ||
+             (lr = c->bound.ensure((size_t) B * 8)) != RII_OK || (lr = c->mi.ensure(n1 * 8)) != RII_OK || (lr = c->md.ensure(n1 * 4)) != RII_OK ||
+             (lr = c->r_i.ensure(n1 * 8)) != RII_OK || (lr = c->tie.ensure((size_t) B * 4)) != RII_OK || (lr = c->anyf.ensure(16)) != RII_OK ||
+             (msc && (lr = c->seq.ensure(msc)) != RII_OK))) {}
         int32_t *pos = c->qf.as<int32_t>(), *nloc = pos + n1;
         int64_t *cnt = c->bound.as<int64_t>();
-        if ((r = ivf_shard_locked(e, d_queries, B, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, k1, c->tmp_i.as<int64_t>(),
-                                  c->tmp_d.as<float>(), pos, nloc, cnt, st)) != RII_OK) break;
+        if (lr == RII_OK)
+            lr = ivf_shard_locked(e, d_queries, B, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, (int) k1, c->tmp_i.as<int64_t>(),
+                                  c->tmp_d.as<float>(), pos, nloc, cnt, st);
         // (3) one all-gather + merge under (distance, position), the global ids as payload
-        const size_t rec_bytes = merge_record_bytes(B, k1, 1);
-        if ((r = c->rec.ensure(rec_bytes)) != RII_OK || (r = c->gathered.ensure(rec_bytes * (size_t) G)) != RII_OK ||
-            (r = c->mi.ensure(n1 * 8)) != RII_OK || (r = c->md.ensure(n1 * 4)) != RII_OK || (r = c->r_i.ensure(n1 * 8)) != RII_OK ||
-            (r = c->tie.ensure((size_t) B * 4)) != RII_OK || (r = c->anyf.ensure(16)) != RII_OK) break;
         int32_t *d_tie = d_out_tie ? d_out_tie : c->tie.as<int32_t>();
-        if (launch_ivf_pack(c->tmp_i.as<int64_t>(), pos, c->tmp_d.as<float>(), (int64_t) n1, id_offset, c->rec.p, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "pack failed"); break; }
-        if ((r = comm_gather(c, c->rec.p, c->gathered.p, rec_bytes, st)) != RII_OK) break;
+        if (lr == RII_OK && launch_ivf_pack(c->tmp_i.as<int64_t>(), pos, c->tmp_d.as<float>(), (int64_t) n1, id_offset, c->rec.as<unsigned char>() + kRecHeader, st) != hipSuccess)
+            lr = set_err(RII_ERR_HIP, "pack failed");
+        if (lr != RII_OK) local_msg = g_err;
+        if (comm_set_header(c, 0, lr != RII_OK ? 1 : 0, st) != RII_OK) { c->broken = true; r = RII_ERR_HIP; break; }
+        if ((r = comm_gather(c, c->rec.p, c->gathered.p, stride, st)) != RII_OK) break;
+        if (lr != RII_OK) { g_err = local_msg; r = lr; break; }          // the peers learn it from this rank's header
         if (hipMemsetAsync(c->anyf.p, 0, 8, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
         // (keys = positions -> r_i, payload = ids -> mi; the merge's own OR of the flags goes to the second word: the finishing kernel
         //  recomputes it over the queries that were found)
-        if (launch_merge_topk(c->gathered.p, G, B, k1, k1, 1, c->r_i.as<int64_t>(), c->md.as<float>(), c->mi.as<int64_t>(), st, nullptr, k1, d_tie,
-                              c->anyf.as<int32_t>() + 1) != hipSuccess ||
-            launch_ivf_finish(c->mi.as<int64_t>(), c->md.as<float>(), cnt, B, k1, topk, d_out_ids, d_out_dists, d_out_counts, d_tie, c->anyf.as<int32_t>(), st) != hipSuccess) {
+        if (launch_merge_topk(c->gathered.p, G, B, (int) k1, (int) k1, 1, c->r_i.as<int64_t>(), c->md.as<float>(), c->mi.as<int64_t>(), st, nullptr, (int) k1, d_tie,
+                              c->anyf.as<int32_t>() + 1, kRecHeader, c->seq.p) != hipSuccess ||
+            launch_ivf_finish(c->mi.as<int64_t>(), c->md.as<float>(), cnt, B, (int) k1, topk, d_out_ids, d_out_dists, d_out_counts, d_tie, c->anyf.as<int32_t>(), st) != hipSuccess) {
             r = set_err(RII_ERR_HIP, "merge failed");
             break;
         }
         if (topk == 1) break;
-        int32_t h_any = 0;                     // the batch's one host read
-        if (hipMemcpyAsync(&h_any, c->anyf.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
-        if (!h_any) break;
+        int32_t h_any[2] = {0, 0};             // the batch's one host read
+        if (hipMemcpyAsync(h_any, c->anyf.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
+        if (h_any[1] & 2) { r = set_err(RII_ERR_STATE, "a peer rank failed this sharded call (its rows are poisoned: ids -2, distances NaN)"); break; }
+        if (!h_any[0]) break;
         // (4) exact ties among the k + 1 best: every rank sends ALL the candidates it owns for those queries, the sequence is rebuilt by
-        //     position and std::partial_sort (src/rii.h:312-313) replayed on it -- identically on every rank
+        //     position and std::partial_sort (src/rii.h:312-313) replayed on it -- identically on every rank, group by group
         std::vector<int32_t> h_tie((size_t) B), h_sel;
         if (hipMemcpy(h_tie.data(), d_tie, (size_t) B * 4, hipMemcpyDeviceToHost) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
         for (int64_t b = 0; b < B; ++b) if (h_tie[(size_t) b]) h_sel.push_back((int32_t) b);
         const int nf = (int) h_sel.size(), rows = (int) L;
-        if (rows > ivf_shard_max_L()) { r = set_err(RII_ERR_UNSUPPORTED, "tie replay of the sharded inverted index: L=%lld must be <= %d", (long long) L, ivf_shard_max_L()); break; }
-        const size_t nr = (size_t) nf * rows, rec2 = merge_record_bytes(nf, rows, 1);
-        if ((r = c->fsel.ensure((size_t) nf * 4)) != RII_OK || (r = c->rec2.ensure(rec2 + (size_t) nf * D * 4 + 64)) != RII_OK || (r = c->gg.ensure(rec2 * (size_t) G)) != RII_OK ||
-            (r = c->tmp_i.ensure(nr * 8)) != RII_OK || (r = c->tmp_d.ensure(nr * 4)) != RII_OK || (r = c->qf.ensure(nr * 4 + (size_t) nf * 4)) != RII_OK ||
-            (r = c->bound.ensure((size_t) nf * 8)) != RII_OK || (r = c->r_i.ensure((size_t) nf * topk * 8)) != RII_OK || (r = c->r_d.ensure((size_t) nf * topk * 4)) != RII_OK) break;
-        float *qsel = reinterpret_cast<float *>(c->rec2.as<unsigned char>() + ((rec2 + 63) & ~(size_t) 63));
-        if (hipMemcpyAsync(c->fsel.p, h_sel.data(), (size_t) nf * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { r = set_err(RII_ERR_HIP, "copy failed"); break; }
-        if (launch_gather_rows(d_queries, c->fsel.as<int32_t>(), nf, D, qsel, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "launch failed"); break; }
-        int32_t *fpos = c->qf.as<int32_t>(), *fnloc = fpos + nr;
-        if ((r = ivf_shard_locked(e, qsel, nf, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, rows, c->tmp_i.as<int64_t>(), c->tmp_d.as<float>(),
-                                  fpos, fnloc, c->bound.as<int64_t>(), st)) != RII_OK) break;
-        if (launch_ivf_pack(c->tmp_i.as<int64_t>(), fpos, c->tmp_d.as<float>(), (int64_t) nr, id_offset, c->rec2.p, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "pack failed"); break; }
-        if ((r = comm_gather(c, c->rec2.p, c->gg.p, rec2, st)) != RII_OK) break;
-        if (launch_shard_replay(c->gg.p, G, nf, rows, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), st) != hipSuccess ||
-            launch_scatter_rows(c->fsel.as<int32_t>(), nf, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), d_out_ids, d_out_dists, st) != hipSuccess)
-            r = set_err(RII_ERR_HIP, "replay launch failed");
+        const int fgroup = (int) std::min<int64_t>(nf, group);
+        const size_t nr = (size_t) fgroup * rows, rec2 = merge_record_bytes(fgroup, rows, 1);
+        int l2 = RII_OK;
+        if ((l2 = c->fsel.ensure((size_t) nf * 4)) != RII_OK || (l2 = c->rec2.ensure(rec2 + (size_t) fgroup * D * 4 + 64)) != RII_OK || (l2 = c->gg.ensure(rec2 * (size_t) G)) != RII_OK ||
+            (l2 = c->tmp_i.ensure(nr * 8)) != RII_OK || (l2 = c->tmp_d.ensure(nr * 4)) != RII_OK || (l2 = c->qf.ensure(nr * 4 + (size_t) fgroup * 4)) != RII_OK ||
+            (l2 = c->bound.ensure((size_t) fgroup * 8)) != RII_OK || (l2 = c->r_i.ensure((size_t) fgroup * topk * 8)) != RII_OK || (l2 = c->r_d.ensure((size_t) fgroup * topk * 4)) != RII_OK ||
+            (l2 = c->seq.ensure(std::max<size_t>(shard_replay_scratch(fgroup, rows), 16))) != RII_OK) {}
+        if (l2 == RII_OK && (hipMemcpyAsync(c->fsel.p, h_sel.data(), (size_t) nf * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+            l2 = set_err(RII_ERR_HIP, "copy failed");
+        if ((r = comm_agree(c, l2, st)) != RII_OK) break;
+        for (int f0 = 0; f0 < nf && r == RII_OK; f0 += fgroup) {
+            const int nfc = std::min(fgroup, nf - f0);
+            const size_t nrc = (size_t) nfc * rows, recc = merge_record_bytes(nfc, rows, 1);
+            float *qsel = reinterpret_cast<float *>(c->rec2.as<unsigned char>() + ((rec2 + 63) & ~(size_t) 63));
+            const int32_t *fsel = c->fsel.as<int32_t>() + f0;
+            int32_t *fpos = c->qf.as<int32_t>(), *fnloc = fpos + nrc;
+            int l3 = RII_OK;
+            if (launch_gather_rows(d_queries, fsel, nfc, D, qsel, st) != hipSuccess) l3 = set_err(RII_ERR_HIP, "launch failed");
+            if (l3 == RII_OK)
+                l3 = ivf_shard_locked(e, qsel, nfc, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, rows, c->tmp_i.as<int64_t>(), c->tmp_d.as<float>(),
+                                      fpos, fnloc, c->bound.as<int64_t>(), st);
+            if (l3 == RII_OK && launch_ivf_pack(c->tmp_i.as<int64_t>(), fpos, c->tmp_d.as<float>(), (int64_t) nrc, id_offset, c->rec2.p, st) != hipSuccess)
+                l3 = set_err(RII_ERR_HIP, "pack failed");
+            if ((r = comm_agree(c, l3, st)) != RII_OK) break;
+            if ((r = comm_gather(c, c->rec2.p, c->gg.p, recc, st)) != RII_OK) break;
+            if (launch_shard_replay(c->gg.p, G, nfc, rows, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), c->seq.p, st) != hipSuccess ||
+                launch_scatter_rows(fsel, nfc, topk, c->r_i.as<int64_t>(), c->r_d.as<float>(), d_out_ids, d_out_dists, st) != hipSuccess)
+                r = set_err(RII_ERR_HIP, "replay launch failed");
+        }
     } while (0);
     const std::string msg = g_err;
     const int r2 = end_on(e, st);

@@ -154,6 +154,183 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Any L (round 5).  The reference's own billion-scale run asks for L = N / nlist = sqrt(N) ~ 31.6 k candidates per query
+// (examples/benchmark/run_sift1b.py:105-106, rii/rii.py:143) -- four times what the kernel above sorts in LDS.  Here the coarse order
+// and the cumulative counts always live in global scratch (the BIG layout above), the walk visits the visited lists one after the
+// other and every thread takes candidates THIS RANK OWNS only (offsets [before_r, before_r + len_r) of a global list clipped to the
+// list's share of L: no per-position search), and one of two things happens to a scored candidate:
+//   rows = k + 1 (selection): its key (distance, position) joins an LDS buffer of `nbuf` keys if it beats the current bound; a full
+//       buffer is sorted, cut back to its k + 1 best and the (k + 1)-th key becomes the bound -- positions are unique, so whatever
+//       order the atomics hand out slots in, the sorted prefix is the same.  Needs rows + 512 <= nbuf.
+//   rows = L (every owned candidate: exact-tie replay, and the collect-all route of large k): the row goes to slot `position` of the
+//       query's output; the slots of candidates other ranks own are padding.  No order, no sort: the replay rebuilds by position.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kShardAnyBuf = 8192;       // most keys the selection buffer holds (64 KiB)
+constexpr int kShardGroup = 256;         // visited lists whose descriptors are staged per round
+
+template <bool GTAB>
+__global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbuf, int collect)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int MK = p.M * p.Ks;
+    const int nlist = p.nlist;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    float *lds = reinterpret_cast<float *>(smem);
+    const float *tab = GTAB ? p.lut + (size_t) b * MK : lds;
+    unsigned char *base = smem + (GTAB ? 0 : (((size_t) MK * 4 + 15) & ~(size_t) 15));
+    const bool w_lds = p.w <= kWhSplitMaxHeap;
+    pq64_t *s_head = reinterpret_cast<pq64_t *>(base);                               // [w] when the coarse heap is walked by a wave
+    int32_t *s_misc = reinterpret_cast<int32_t *>(s_head + (w_lds ? p.w : 0));       // [8]: ncand, nv, owned, buffered
+    int32_t *s_lpos = s_misc + 8, *s_lown = s_lpos + kShardGroup;                   // staged list descriptors
+    int64_t *s_loff = reinterpret_cast<int64_t *>(smem + ((reinterpret_cast<unsigned char *>(s_lown + kShardGroup) - smem + 15) & ~(size_t) 15));
+    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_loff + kShardGroup);        // [nbuf] (selection only)
+    unsigned char *mine = p.scratch + p.per_block * blockIdx.x;
+    pq64_t *s_coarse = reinterpret_cast<pq64_t *>(mine);                             // [nlist] the whole coarse order
+    int32_t *s_cum = reinterpret_cast<int32_t *>(mine + (size_t) nlist * 8);         // [nlist + 1] cumulative GLOBAL counts
+
+    if constexpr (!GTAB) {
+        const float *src = p.lut + (size_t) b * MK;
+        for (int i = tid; i < MK; i += 256) lds[i] = src[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < nlist; c += 256) {                                          // src/rii.h:262-264
+        const pq64_t e = pq64_make(exact_adist(tab, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
+        if (w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
+    }
+    __syncthreads();
+    if (w_lds) {                                                                      // src/rii.h:279-280
+        if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);
+        __syncthreads();
+        for (int c = tid; c < (int) p.w; c += 256) s_coarse[c] = s_head[c];
+    } else if (tid == 0) {
+        pq64_partial_sort(s_coarse, (long) p.w, (long) nlist);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        long long cnt = 0;
+        int nv = 0;
+        bool finished = false;
+        for (int c = 0; c < nlist; ++c) {                                             // src/rii.h:286-321, global lengths
+            const int no = (int) pq64_id(s_coarse[c]);
+            long long len = 0;
+            for (int g = 0; g < p.G; ++g) len += p.glen[(size_t) g * nlist + no];
+            s_cum[c] = (int) cnt;
+            if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+            cnt += len;
+            if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+        }
+        if (!finished) { cnt = 0; nv = 0; }
+        s_cum[nv] = (int) cnt;
+        s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = 0; s_misc[3] = 0;
+        p.out_counts[b] = finished ? p.topk : 0;                                      // src/rii.h:324-325 when 0
+    }
+    const int rows = p.rows;
+    if (collect)                                                                       // padding everywhere first; owned rows overwrite it
+        for (int j = tid; j < rows; j += 256) {
+            p.out_ids[b * rows + j] = -1;
+            p.out_dists[b * rows + j] = INFINITY;
+            p.out_pos[b * rows + j] = INT32_MAX;
+        }
+    __syncthreads();
+    const int nv = s_misc[1];
+    unsigned long long thr = ~0ull;                                                   // selection: keys at or above it cannot make the cut
+    int owned = 0;
+    auto flush = [&]() {                                                              // all threads; barriers inside
+        const int n = s_misc[3];
+        int n2 = 64;
+        while (n2 < n) n2 <<= 1;
+        for (int i = n + tid; i < n2; i += 256) s_key[i] = ~0ull;
+        rr_bitonic_sort(s_key, tid, n2);
+        const int kept = n < rows ? n : rows;
+        if (kept == rows) thr = s_key[rows - 1];
+        __syncthreads();
+        if (tid == 0) s_misc[3] = kept;
+        __syncthreads();
+    };
+    for (int c0 = 0; c0 < nv; c0 += kShardGroup) {
+        __syncthreads();
+        if (tid < kShardGroup) {                                                      // this rank's part of visited list c0 + tid
+            int no = 0, lpos = 0, own = 0;
+            int64_t off = 0;
+            const int c = c0 + tid;
+            if (c < nv) {
+                no = (int) pq64_id(s_coarse[c]);
+                const int cum = s_cum[c], take = s_cum[c + 1] - cum;                 // the list's share of the L candidates
+                int before = 0;
+                for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
+                const int mylen = p.list_len[no];
+                own = take - before < mylen ? take - before : mylen;
+                own = own > 0 ? own : 0;
+                lpos = cum + before;
+                off = p.pl_off[no];
+            }
+            s_lpos[tid] = lpos; s_lown[tid] = own; s_loff[tid] = off;
+        }
+        __syncthreads();
+        const int ng = nv - c0 < kShardGroup ? nv - c0 : kShardGroup;
+        for (int l = 0; l < ng; ++l) {
+            const int own = s_lown[l];
+            if (own == 0) continue;
+            const int lpos = s_lpos[l];
+            const int32_t *ids = p.pl_ids + s_loff[l];
+            for (int base_li = 0; base_li < own; base_li += 256) {
+                // a thread reads the fill behind its own insertion of the round before, not behind everyone's: up to 256 entries
+                // short of the truth, hence 512; the OR makes the decision the block's
+                if (!collect && __syncthreads_or(s_misc[3] + 512 > nbuf)) flush();
+                const int li = base_li + tid;
+                if (li < own) {
+                    const int32_t id = ids[li];
+                    const float d = exact_adist(tab, p.codes + (size_t) id * p.M, p.M, p.Ks);
+                    const int pos = lpos + li;
+                    ++owned;
+                    if (collect) {
+                        p.out_ids[b * rows + pos] = id;
+                        p.out_dists[b * rows + pos] = d;
+                        p.out_pos[b * rows + pos] = pos;
+                    } else {
+                        const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | (uint32_t) pos;
+                        if (key < thr) s_key[atomicAdd(&s_misc[3], 1)] = key;
+                    }
+                }
+            }
+        }
+    }
+    atomicAdd(&s_misc[2], owned);
+    __syncthreads();
+    const int nown = s_misc[2];
+    if (collect) {
+        if (tid == 0) p.out_nloc[b] = nown < rows ? nown : rows;
+        return;
+    }
+    flush();
+    const int nloc = s_misc[3];                                                        // = min(owned, rows)
+    if (tid == 0) p.out_nloc[b] = nloc;
+    for (int j = tid; j < rows; j += 256) {
+        int64_t id = -1;
+        float d = INFINITY;
+        int32_t pos = INT32_MAX;
+        if (j < nloc) {
+            const unsigned long long key = s_key[j];
+            pos = (int32_t) (key & 0xffffffffu);
+            d = __uint_as_float(f32_unorderable((uint32_t) (key >> 32)));
+            int lo = 0, hi = nv;                                                      // the list holding traversal position pos
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+            }
+            const int no = (int) pq64_id(s_coarse[lo]);
+            int before = 0;
+            for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
+            id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo] - before)];
+        }
+        p.out_ids[b * rows + j] = id;
+        p.out_dists[b * rows + j] = d;
+        p.out_pos[b * rows + j] = pos;
+    }
+}
+
 // Tie replay for the database-sharded inverted index: when two of the merged k+1 best distances are bit-equal the reference's
 // answer is what std::partial_sort (src/rii.h:312-313) makes of the WHOLE candidate sequence in traversal order.  Every rank
 // then sends all the candidates it owns for that query (rows = L) and every rank rebuilds the sequence by position and
@@ -199,10 +376,79 @@ __global__ __launch_bounds__(256) void shard_replay_kernel(const unsigned char *
     }
 }
 
+// The same replay for sequences that do not fit LDS (rows > 8192, round 5): the rebuilt sequence and the ids live in global scratch
+// (16 bytes per row and query), the heap of std::partial_sort in LDS and walked by a wave while topk <= 1024 (wh_partial_sort_split:
+// a tail entry is read once, at its own step), by one lane over global memory above that (the single engine's last resort as well:
+// ivf_select_kernel).  `middle` = min(topk, candidates): a query the reference answers with ({}, {}) has no candidates at all.
+__global__ __launch_bounds__(256) void shard_replay_any_kernel(const unsigned char *__restrict__ gathered, int G, int64_t nf, int rows,
+                                                               int topk, unsigned char *__restrict__ scratch, int64_t *__restrict__ out_ids,
+                                                               float *__restrict__ out_dists)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pq64_t *head = reinterpret_cast<pq64_t *>(smem);                    // [topk] when topk <= kWhSplitMaxHeap
+    __shared__ int s_n;
+    const int64_t f = blockIdx.x;
+    const int tid = threadIdx.x;
+    pq64_t *seq = reinterpret_cast<pq64_t *>(scratch + (size_t) f * rows * 16);
+    int64_t *sid = reinterpret_cast<int64_t *>(seq + rows);
+    const int64_t n = nf * rows;
+    const size_t rec = ((size_t) n * 20 + 15) / 16 * 16;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int g = 0; g < G; ++g) {
+        const unsigned char *base = gathered + rec * g;
+        const int64_t *pos = reinterpret_cast<const int64_t *>(base);
+        const int64_t *gid = reinterpret_cast<const int64_t *>(base + (size_t) n * 8);
+        const float *dd = reinterpret_cast<const float *>(base + (size_t) n * 16);
+        for (int j = tid; j < rows; j += 256) {
+            const int64_t ps = pos[f * rows + j];
+            if (ps >= 0 && ps < rows) {
+                seq[ps] = pq64_make(dd[f * rows + j], (uint32_t) ps);
+                sid[ps] = gid[f * rows + j];
+                ++mine;
+            }
+        }
+    }
+    atomicAdd(&s_n, mine);
+    __syncthreads();
+    const int ncand = s_n;                                  // positions are dense: every candidate is owned by exactly one rank
+    const int middle = topk < ncand ? topk : ncand;
+    const bool in_lds = topk <= kWhSplitMaxHeap;
+    if (in_lds) {
+        for (int j = tid; j < middle; j += 256) head[j] = seq[j];
+        __syncthreads();
+        if (tid < 64) wh_partial_sort_split(head, seq + middle, middle, ncand, tid);
+    } else if (tid == 0) {
+        pq64_partial_sort(seq, (long) middle, (long) ncand);
+    }
+    __syncthreads();
+    for (int j = tid; j < topk; j += 256) {
+        int64_t id = -1;
+        float d = INFINITY;
+        if (j < middle) {
+            const pq64_t e = in_lds ? head[j] : seq[j];
+            id = sid[pq64_id(e)];
+            d = pq64_dist(e);
+        }
+        out_ids[f * topk + j] = id;
+        out_dists[f * topk + j] = d;
+    }
+}
+
+size_t shard_replay_scratch(int64_t nf, int rows) { return rows > kShardMaxL ? (size_t) nf * (size_t) rows * 16 : 0; }
+
 hipError_t launch_shard_replay(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
-                               float *d_out_dists, hipStream_t st)
+                               float *d_out_dists, void *d_scratch, hipStream_t st)
 {
     if (nf == 0) return hipSuccess;
+    if (rows > kShardMaxL) {                                // sequences in global scratch (shard_replay_scratch() bytes)
+        if (!d_scratch) return hipErrorInvalidValue;
+        const size_t smem = topk <= kWhSplitMaxHeap ? (size_t) topk * 8 : 0;
+        hipLaunchKernelGGL(shard_replay_any_kernel, dim3((unsigned) nf), dim3(256), smem, st, static_cast<const unsigned char *>(d_gathered),
+                           G, nf, rows, topk, static_cast<unsigned char *>(d_scratch), d_out_ids, d_out_dists);
+        return hipGetLastError();
+    }
     const size_t smem = (size_t) rows * 16;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(shard_replay_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
@@ -221,14 +467,41 @@ static size_t shard_smem(int M, int Ks, int nlist, int64_t L, int64_t w)
     const size_t coarse = shard_big(nlist) ? (size_t) (w <= kWhSplitMaxHeap ? w : 0) * 8 : (size_t) nlist * 8 + (size_t) (nlist + 1) * 4;
     return (shard_gtab(M, Ks) ? 0 : (((size_t) M * Ks * 4 + 15) & ~(size_t) 15)) + coarse + 16 + 16 + n2 * 8;
 }
-bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w)
+// the kernel with every working set of a query in LDS (L <= 8192 candidate keys sorted at once)
+static bool shard_lds_ok(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
     if (L > kShardMaxL) return false;
     return shard_smem(M, Ks, nlist, L, w) <= (size_t) 160 * 1024 - 512;
 }
-int ivf_shard_max_L() { return kShardMaxL; }
-// BIG: bytes of global scratch per query of a launch, and how many queries one launch may take
-size_t ivf_shard_scratch_per_query(int nlist) { return shard_big(nlist) ? ((size_t) nlist * 12 + 4 + 63) / 64 * 64 : 0; }
+// ivf_shard_any_kernel: LDS without the selection buffer, and the buffer that fits next to it (a power of two)
+static size_t shard_any_fixed(int M, int Ks, int64_t w)
+{
+    return (shard_gtab(M, Ks) ? 0 : (((size_t) M * Ks * 4 + 15) & ~(size_t) 15)) + (size_t) (w <= kWhSplitMaxHeap ? w : 0) * 8 + 8 * 4 +
+           2 * kShardGroup * 4 + 16 + kShardGroup * 8;
+}
+static int shard_any_nbuf(int M, int Ks, int64_t w)
+{
+    const size_t avail = (size_t) 160 * 1024 - 512 - shard_any_fixed(M, Ks, w);
+    int nbuf = kShardAnyBuf;
+    while (nbuf > 64 && (size_t) nbuf * 8 > avail) nbuf >>= 1;
+    return nbuf;
+}
+// rows per query a launch can select (rows = k + 1 form); anything up to L is served by the collect form (rows >= L)
+int ivf_shard_max_select_rows(int M, int Ks, int nlist, int64_t L, int64_t w)
+{
+    if (shard_lds_ok(M, Ks, nlist, L, w)) return kShardMaxL + 1;
+    return shard_any_nbuf(M, Ks, w) - 512;
+}
+bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w, int rows)
+{
+    if (shard_lds_ok(M, Ks, nlist, L, w)) return rows <= kShardMaxL + 1;      // (rows = k + 1 with k = L = 8192)
+    return rows <= shard_any_nbuf(M, Ks, w) - 512 || (int64_t) rows >= L;
+}
+// bytes of global scratch per query of a launch (coarse order + cumulative counts), 0: everything fits LDS
+size_t ivf_shard_scratch_per_query(int M, int Ks, int nlist, int64_t L, int64_t w)
+{
+    return (shard_big(nlist) || !shard_lds_ok(M, Ks, nlist, L, w)) ? ((size_t) nlist * 12 + 4 + 63) / 64 * 64 : 0;
+}
 
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
@@ -240,7 +513,18 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
     a.codes = d_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.centers = d_centers; a.nlist = nlist; a.pl_off = d_pl_off;
     a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w; a.rows = rows;
     a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_pos = d_out_pos; a.out_nloc = d_out_nloc; a.out_counts = d_out_counts;
-    a.scratch = static_cast<unsigned char *>(d_scratch); a.per_block = ivf_shard_scratch_per_query(nlist);
+    a.scratch = static_cast<unsigned char *>(d_scratch); a.per_block = ivf_shard_scratch_per_query(M, Ks, nlist, L, w);
+    if (!shard_lds_ok(M, Ks, nlist, L, w)) {               // any L: coarse order in global scratch, selection buffer or collect form
+        const int nbuf = shard_any_nbuf(M, Ks, w);
+        const int collect = rows > nbuf - 512 ? 1 : 0;
+        if (collect && (int64_t) rows < L) return hipErrorInvalidValue;
+        const size_t smem = shard_any_fixed(M, Ks, w) + (collect ? 0 : (size_t) nbuf * 8);
+        auto kern = shard_gtab(M, Ks) ? ivf_shard_any_kernel<true> : ivf_shard_any_kernel<false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, nbuf, collect);
+        return hipGetLastError();
+    }
     const size_t smem = shard_smem(M, Ks, nlist, L, w);
     auto kern = shard_gtab(M, Ks) ? (shard_big(nlist) ? ivf_shard_kernel<true, true> : ivf_shard_kernel<false, true>)
                                   : (shard_big(nlist) ? ivf_shard_kernel<true> : ivf_shard_kernel<false>);

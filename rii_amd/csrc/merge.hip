@@ -24,20 +24,45 @@ struct MergeOffsets {
     int64_t off[kMergeMaxRanks];
 };
 
-__global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__restrict__ gathered, int G, int64_t B, int k, int k_out,
+// hdr != 0 (the sharded entry points of engine.hip, round 5): every rank's record is preceded by a 16-byte header {int64 id offset
+// of the rank's shard, int32 status, pad} -- the offsets travel WITH the rows (no cached copy on any rank that a re-sharded index
+// could leave stale, no collective that only some ranks issue) and so does a rank's failure: a non-zero status in any header
+// poisons every row of the batch on EVERY rank (ids kPeerFailedId, distances NaN) and raises bit 1 of *out_any.
+constexpr int64_t kPeerFailedId = -2;
+__global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__restrict__ gathered_raw, int G, int64_t B, int k, int k_out,
                                                          int payload, int64_t *__restrict__ out_ids, float *__restrict__ out_dists,
                                                          int64_t *__restrict__ out_payload, MergeOffsets offs, int tie_cols,
-                                                         int32_t *__restrict__ out_tie, int32_t *__restrict__ out_any)
+                                                         int32_t *__restrict__ out_tie, int32_t *__restrict__ out_any, int hdr,
+                                                         unsigned long long *__restrict__ gkeys, int64_t b0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *key = reinterpret_cast<unsigned long long *>(smem);        // (orderable dist << 32 | g * k + j)
-    const int64_t b = blockIdx.x;
+    const int64_t b = blockIdx.x + b0;
     const int tid = threadIdx.x;
     const int n = G * k;
     int n2 = 64;
     while (n2 < n) n2 <<= 1;
+    // (orderable dist << 32 | g * k + j); more than kMergeMaxKeys of them (round 5: any G x k): the same sort over a slice of global
+    // scratch -- a block's barrier orders its own global accesses
+    unsigned long long *key = gkeys ? gkeys + (size_t) blockIdx.x * (size_t) n2 : reinterpret_cast<unsigned long long *>(smem);
     const int64_t Bk = B * k;
-    const size_t rec = mrg_rec_bytes(Bk, payload);           // rii_merge_record_bytes
+    const size_t rec = mrg_rec_bytes(Bk, payload) + (size_t) hdr;        // rii_merge_record_bytes (+ the header): the stride of the ranks
+    const unsigned char *gathered = gathered_raw + hdr;
+    if (hdr) {
+        int bad = 0;
+        for (int g = tid; g < G; g += 256) bad |= reinterpret_cast<const int32_t *>(gathered_raw + rec * g)[2];
+        if (__syncthreads_or(bad)) {
+            for (int j = tid; j < k_out; j += 256) {
+                out_ids[b * k_out + j] = kPeerFailedId;
+                out_dists[b * k_out + j] = __uint_as_float(0x7fc00000u);
+                if (payload) out_payload[b * k_out + j] = kPeerFailedId;
+            }
+            if (tid == 0) {
+                if (out_tie) out_tie[b] = 0;
+                if (out_any) atomicOr(out_any, 2);
+            }
+            return;
+        }
+    }
     for (int i = tid; i < n2; i += 256) {
         unsigned long long kk = ~0ull;
         if (i < n) {
@@ -51,7 +76,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__
         if (s >= (uint32_t) n) return INT64_MAX;
         const int g = (int) (s / (uint32_t) k), j = (int) (s - (uint32_t) g * k);
         const int64_t v = mrg_ids(gathered, rec, g)[b * k + j];
-        return (v < 0 || v >= INT64_MAX / 2) ? v : v + offs.off[g];      // padding keys (-1 / huge) stay what they are
+        if (v < 0 || v >= INT64_MAX / 2) return v;                      // padding keys (-1 / huge) stay what they are
+        return v + (hdr ? *reinterpret_cast<const int64_t *>(gathered_raw + rec * g) : offs.off[g]);
     };
     for (int size = 2; size <= n2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -101,16 +127,42 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const unsigned char *__
 
 int merge_topk_max_keys() { return kMergeMaxKeys; }
 
+// queries per launch when the keys live in global scratch (<= 512 MiB of it), and the scratch a merge of B queries needs (0: LDS)
+static int64_t merge_group(int G, int64_t B, int k)
+{
+    size_t n2 = 64;
+    while (n2 < (size_t) G * (size_t) k) n2 <<= 1;
+    return std::max<int64_t>(1, std::min<int64_t>(B, (int64_t) (((size_t) 512 << 20) / (n2 * 8))));
+}
+size_t merge_topk_scratch(int G, int64_t B, int k)
+{
+    if ((int64_t) G * k <= kMergeMaxKeys) return 0;
+    size_t n2 = 64;
+    while (n2 < (size_t) G * (size_t) k) n2 <<= 1;
+    return (size_t) merge_group(G, B, k) * n2 * 8;
+}
+
 size_t merge_record_bytes(int64_t B, int k, int payload) { return mrg_rec_bytes(B * k, payload); }
 
 hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_ids,
                              float *d_out_dists, int64_t *d_out_payload, hipStream_t st, const int64_t *id_offsets, int tie_cols,
-                             int32_t *d_out_tie, int32_t *d_out_any)
+                             int32_t *d_out_tie, int32_t *d_out_any, int hdr, void *d_scratch)
 {
     if (B == 0) return hipSuccess;
     if (G > kMergeMaxRanks && id_offsets) return hipErrorInvalidValue;
     MergeOffsets offs;
     for (int g = 0; g < kMergeMaxRanks; ++g) offs.off[g] = (id_offsets && g < G) ? id_offsets[g] : 0;
+    if ((int64_t) G * k > kMergeMaxKeys) {                   // keys in global scratch (merge_topk_scratch() bytes), group by group
+        if (!d_scratch) return hipErrorInvalidValue;
+        const int64_t group = merge_group(G, B, k);
+        for (int64_t b0 = 0; b0 < B; b0 += group) {
+            const int64_t nb = std::min<int64_t>(group, B - b0);
+            hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned) nb), dim3(256), 0, st, static_cast<const unsigned char *>(d_gathered), G, B, k, k_out,
+                               payload, d_out_ids, d_out_dists, d_out_payload, offs, tie_cols, d_out_tie, d_out_any, hdr,
+                               static_cast<unsigned long long *>(d_scratch), b0);
+        }
+        return hipGetLastError();
+    }
     int n2 = 64;
     while (n2 < G * k) n2 <<= 1;
     const size_t smem = (size_t) n2 * 8;
@@ -119,7 +171,7 @@ hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, in
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned) B), dim3(256), smem, st,
                        static_cast<const unsigned char *>(d_gathered), G, B, k, k_out, payload, d_out_ids, d_out_dists, d_out_payload,
-                       offs, tie_cols, d_out_tie, d_out_any);
+                       offs, tie_cols, d_out_tie, d_out_any, hdr, static_cast<unsigned long long *>(nullptr), (int64_t) 0);
     return hipGetLastError();
 }
 

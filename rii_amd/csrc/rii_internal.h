@@ -243,16 +243,19 @@ hipError_t launch_linear_tie_chunked(const uint8_t *d_codes, int64_t n, int M, i
 hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc, int64_t n_codes, int topk,
                                   int32_t *d_flag_list, int *d_nflag, hipStream_t st);
 
-// ivfshard.hip: inverted-index search over a database-sharded index (global stop rule from all-gathered list lengths)
-bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w);
-int ivf_shard_max_L();
-size_t ivf_shard_scratch_per_query(int nlist);       // global scratch per query of a launch (0: everything fits LDS)
+// ivfshard.hip: inverted-index search over a database-sharded index (global stop rule from all-gathered list lengths).  Any L
+// (round 5): rows = k + 1 best owned candidates per query while rows <= ivf_shard_max_select_rows(), or rows >= L = EVERY owned
+// candidate at the slot of its traversal position (exact-tie replay; the collect-all route of large k)
+bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w, int rows);
+int ivf_shard_max_select_rows(int M, int Ks, int nlist, int64_t L, int64_t w);
+size_t ivf_shard_scratch_per_query(int M, int Ks, int nlist, int64_t L, int64_t w);   // global scratch per query of a launch (0: everything fits LDS)
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st);
+size_t shard_replay_scratch(int64_t nf, int rows);    // bytes of d_scratch launch_shard_replay needs (0: the sequences fit LDS)
 hipError_t launch_shard_replay(const void *d_gathered, int G, int64_t nf, int rows, int topk, int64_t *d_out_ids,
-                               float *d_out_dists, hipStream_t st);
+                               float *d_out_dists, void *d_scratch, hipStream_t st);
 
 // merge.hip: database sharding, k-way merge of the gathered per-shard top-k rows under (dist, id)
 int merge_topk_max_keys();
@@ -261,7 +264,13 @@ size_t merge_record_bytes(int64_t B, int k, int payload);
 // tie flags over the first tie_cols merged distances (d_out_any must be zeroed by the caller)
 hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_ids,
                              float *d_out_dists, int64_t *d_out_payload, hipStream_t st, const int64_t *id_offsets = nullptr,
-                             int tie_cols = 0, int32_t *d_out_tie = nullptr, int32_t *d_out_any = nullptr);
+                             int tie_cols = 0, int32_t *d_out_tie = nullptr, int32_t *d_out_any = nullptr, int hdr = 0,
+                             void *d_scratch = nullptr);
+// G * k above merge_topk_max_keys(): the keys are sorted in d_scratch (merge_topk_scratch() bytes) instead of LDS -- any G, any k
+size_t merge_topk_scratch(int G, int64_t B, int k);
+// hdr = kRecHeader: every rank's record is preceded by {int64 id offset of its shard, int32 status, pad} (merge.hip); a non-zero
+// status on any rank poisons every row of the batch on every rank (id -2, distance NaN; bit 1 of *d_out_any)
+constexpr int kRecHeader = 16;
 
 // smalltopk.hip: a small batch over a small index, one launch
 // d_lut == NULL: every block builds its exact table from d_queries and the codebook itself (no table launch).
@@ -320,9 +329,9 @@ size_t qshard_record_bytes(int64_t B, int G, int k, int counts);
 hipError_t launch_qshard_unpack(const void *d_gathered, int64_t B, int G, int k, int counts, int64_t *d_out_ids, float *d_out_dists,
                                 int64_t *d_out_counts, hipStream_t st);
 hipError_t launch_merge_top1(const void *d_gathered, int G, int64_t B, const int64_t *id_offsets, int64_t *d_out_ids, float *d_out_dists,
-                             hipStream_t st);
+                             hipStream_t st, int hdr = 0);
 hipError_t launch_tie_prepare(const void *d_gathered, int rank, int64_t B, int rows, int topk, const int32_t *d_fsel, int nf,
-                              const float *d_queries, int D, float *d_qf, float *d_bound, hipStream_t st);
+                              const float *d_queries, int D, float *d_qf, float *d_bound, hipStream_t st, int hdr = 0);
 hipError_t launch_tie_scatter(const void *d_gg, int G, int nf, int cap, int topk, const int32_t *d_fsel, const int64_t *d_r_ids,
                               const float *d_r_d, int64_t *d_out_ids, float *d_out_dists, int32_t *d_overflow, hipStream_t st);
 hipError_t launch_copy_cols(const int64_t *d_in_i, const float *d_in_d, int64_t B, int in_stride, int out_stride, int ncols, int64_t *d_out_i,

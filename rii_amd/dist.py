@@ -30,9 +30,10 @@ import torch
 import torch.distributed as dist
 
 
-def world():
+def world(group=None):
+    """(rank, size) inside `group` (default: the whole world; no process group: one rank)."""
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
 
 
@@ -116,7 +117,7 @@ def _as_tensor(a, dtype, device):
 def _all_gather_bytes(rec, group=None):
     """One collective: every rank's byte record, concatenated in rank order -> uint8 [W, len(rec)].  Runs the collective
     whenever a process group exists (world size 1 included, so that a single-GPU box exercises RCCL too)."""
-    rank, w = world()
+    rank, w = world(group)
     if not (dist.is_available() and dist.is_initialized()):
         return rec.reshape(1, -1)
     out = torch.empty(w * rec.numel(), dtype=torch.uint8, device=rec.device)
@@ -158,7 +159,7 @@ def allgather_merge_topk(local_ids, local_dists, topk, id_offset=0, group=None):
     if id_offset:
         ids = torch.where(torch.isfinite(d), ids + int(id_offset), ids)
     B, k = ids.shape
-    rank, w = world()
+    rank, w = world(group)
     if dev.type == "cuda" and w * k <= 8192:
         from . import core
         nrec = core.merge_record_bytes(B, k)
@@ -192,7 +193,7 @@ def allgather_query_shards(local_ids, local_dists, group=None, local_counts=None
     ids = _as_tensor(local_ids, torch.int64, dev)
     d = _as_tensor(local_dists, torch.float32, dev)
     cnt = None if local_counts is None else _as_tensor(local_counts, torch.int64, dev).reshape(-1)
-    rank, w = world()
+    rank, w = world(group)
     n, k = ids.shape
     nmax = n if rows is None else int(max(rows))
     if nmax > n:                                           # pad the short slice: equal shapes for the all-gather
@@ -240,16 +241,15 @@ def _use_c_comm():
 
 def get_comm(group=None):
     """The process's rii_comm for `group` (default: the whole world; none initialised: one rank), created on first use -- rank 0 of
-    the group draws the id (rii_comm_unique_id) and torch.distributed carries its 128 bytes to the others."""
+    the group draws the id (rii_comm_unique_id) and torch.distributed carries its 128 bytes to the others.  The cache is keyed on
+    the group OBJECT (which the key keeps alive: a destroyed group's id() cannot come back as another group's); close_comms()
+    destroys the communicators explicitly -- call it before destroy_process_group() rather than leaving it to interpreter exit."""
     from . import core
     dev = torch.cuda.current_device()
-    if dist.is_available() and dist.is_initialized():
-        rank, w = dist.get_rank(group), dist.get_world_size(group)
-    else:
-        rank, w = 0, 1
-    key = (id(group) if group is not None else 0, dev, rank, w)
+    rank, w = world(group)
+    key = (group, dev)
     c = _COMMS.get(key)
-    if c is None:
+    if c is None or c.rank != rank or c.size != w:
         if w > 1 or (dist.is_available() and dist.is_initialized()):
             box = [core.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
@@ -258,6 +258,12 @@ def get_comm(group=None):
             cid = core.comm_unique_id()
         c = _COMMS[key] = core.Comm(cid, rank, w, dev)
     return c
+
+
+def close_comms():
+    """Destroy every cached communicator (collective per communicator: call it on every rank, before destroy_process_group())."""
+    for key in list(_COMMS):
+        _COMMS.pop(key).close()
 
 
 class DbShardedIndex(object):
@@ -278,12 +284,13 @@ class DbShardedIndex(object):
 
     TIE_CAP = 12288          # rows of a flagged query's candidate list per rank (8192 = one unbounded chunk, + the bounded rest)
     MERGE_MAX_KEYS = 8192    # G * (k + 1) rows per query the device merge sorts in LDS (rii_merge_topk_ex_dev); above: torch merge
+    GATHER_BUDGET = 512 << 20    # bytes of gathered every-candidate rows (G x L x 20 per query) per group of queries (inverted index)
 
     def all_starts(self):
         """First global id of every rank's shard, in rank order (one tiny all-gather, cached): the merge kernel adds them to the
         LOCAL ids the engines wrote, so no rank rewrites its own rows."""
         if getattr(self, "_all_starts", None) is None:
-            rank, w = world()
+            rank, w = world(self.group)
             if dist.is_available() and dist.is_initialized():
                 t = torch.tensor([self.start], dtype=torch.int64, device=_comm_device())
                 out = torch.empty(w, dtype=torch.int64, device=t.device)
@@ -345,8 +352,8 @@ class DbShardedIndex(object):
         """Device engines: ONE library call -- engine kernels -> record -> ncclAllGather -> merge kernel (+ the exact-tie replay) are
         enqueued by rii_query_linear_dbsharded_dev (round 4).  Shapes beyond the merge kernel's limits (G x (k + 1) > 8192 rows, more
         than 64 ranks) and host collectives ("gloo") keep the torch path below."""
-        rank, G = world()
-        if _use_c_comm() and G <= 64 and (topk == 1 or G * rows <= self.MERGE_MAX_KEYS) and self.MERGE_MAX_KEYS >= 8192:
+        rank, G = world(self.group)
+        if _use_c_comm() and self.MERGE_MAX_KEYS >= 8192:       # (any G, any topk since round 5; the class attribute is the tests' lever)
             dev = torch.device("cuda", torch.cuda.current_device())
             comm = get_comm(self.group)
             with _engine_stream() as sh:
@@ -455,7 +462,7 @@ class DbShardedIndex(object):
     def _tie_bound(self, gd, fsel, topk):
         """bound of this rank = the smallest k-th distance any EARLIER shard reported (an earlier shard's codes come first in the
         reference's index order, so the heap top is already at or below it when this shard's first code is visited)."""
-        rank, G = world()
+        rank, G = world(self.group)
         bound = torch.full((fsel.numel(),), float("inf"), dtype=torch.float32, device=fsel.device)
         for s in range(rank):
             bound = torch.minimum(bound, gd[s][fsel, topk - 1])           # +inf when shard s holds fewer than k codes
@@ -552,15 +559,16 @@ class DbShardedIndex(object):
         counts [B]) on every rank; counts[b] == 0 where the reference returns ({}, {}).  Queries whose merged k+1 best
         distances hold an exact tie (`last_tie_flags`) are redone exactly: every rank sends all the candidates it owns
         and std::partial_sort is replayed over the rebuilt candidate sequence (rii_ivf_shard_replay_dev)."""
-        rank, w = world()
+        rank, w = world(self.group)
         B = Q.shape[0]
         k1 = topk + 1
         tl, _ = self._local_targets(target_ids, topk)
         S_global = 0 if target_ids is None else len(target_ids)
         N_global = self.total_codes()
         dev = _comm_device()
-        if _is_device_engine(self.engine) and _use_c_comm() and w * k1 <= self.MERGE_MAX_KEYS and self.MERGE_MAX_KEYS >= 8192:
-            # ONE library call (round 4): list lengths -> all-gather -> the shard's walk -> all-gather -> merge (+ the exact-tie replay)
+        if _is_device_engine(self.engine) and _use_c_comm() and self.MERGE_MAX_KEYS >= 8192:
+            # ONE library call (round 4): list lengths -> all-gather -> the shard's walk -> all-gather -> merge (+ the exact-tie replay);
+            # any L, any topk, any number of ranks (round 5)
             dev = torch.device("cuda", torch.cuda.current_device())
             comm = get_comm(self.group)
             with _engine_stream() as sh:
@@ -577,6 +585,8 @@ class DbShardedIndex(object):
             _handoff(self.last_tie_flags)
             return _handoff(ids, d, cnt)
         if _is_device_engine(self.engine):
+            # real engines under a host collective ("gloo": the tests' two ranks on one GPU): the same protocol, driven from here
+            from . import core
             with _engine_stream() as sh:
                 t = None if tl is None else torch.from_numpy(np.ascontiguousarray(tl)).to(dev)
                 nlist = self.engine.nlist
@@ -585,6 +595,39 @@ class DbShardedIndex(object):
                                                  lens.data_ptr(), sh)
                 glen = _all_gather_bytes(lens.view(torch.uint8), self.group).view(torch.int32).reshape(-1, nlist).contiguous()
                 q = _as_tensor(Q, torch.float32, dev)
+                rows = int(L)
+                group = max(1, min(B, self.GATHER_BUDGET // max(w * rows * 20, 1)))       # queries whose every-candidate rows stay under the budget
+
+                def every_candidate(qq):
+                    """rows = L for the queries qq: every rank's owned candidates gathered, std::partial_sort replayed on the rebuilt
+                    sequences (rii_ivf_shard_replay_ex_dev) -> (ids, dists, counts) of those queries."""
+                    nf = int(qq.shape[0])
+                    ri = torch.empty((nf, topk), dtype=torch.int64, device=dev)
+                    rd = torch.empty((nf, topk), dtype=torch.float32, device=dev)
+                    rc = torch.empty((nf,), dtype=torch.int64, device=dev)
+                    for f0 in range(0, nf, group):
+                        nfc = min(group, nf - f0)
+                        fi = torch.empty((nfc, rows), dtype=torch.int64, device=dev)
+                        fd = torch.empty((nfc, rows), dtype=torch.float32, device=dev)
+                        fp = torch.empty((nfc, rows), dtype=torch.int32, device=dev)
+                        fn = torch.empty((nfc,), dtype=torch.int32, device=dev)
+                        qc = qq[f0:f0 + nfc].contiguous()
+                        self.engine.query_ivf_shard_dev(qc.data_ptr(), nfc, topk, 0 if t is None else t.data_ptr(),
+                                                        0 if t is None else t.numel(), S_global, L, N_global, glen.data_ptr(),
+                                                        glen.shape[0], rank, fi.data_ptr(), fd.data_ptr(), fp.data_ptr(),
+                                                        fn.data_ptr(), rc[f0:f0 + nfc].data_ptr(), sh, rows=rows)
+                        g = _all_gather_bytes(_pack([fp.to(torch.int64), torch.where(fi >= 0, fi + self.start, fi), fd]), self.group)
+                        nsc = core.ivf_shard_replay_scratch_bytes(nfc, rows)
+                        scratch = torch.empty(max(nsc, 16), dtype=torch.uint8, device=dev)
+                        core.ivf_shard_replay_dev(g.data_ptr(), g.shape[0], nfc, rows, topk, ri[f0:f0 + nfc].data_ptr(), rd[f0:f0 + nfc].data_ptr(), sh,
+                                                  scratch.data_ptr(), nsc)
+                    return ri, rd, rc
+
+                if k1 > self.engine.ivf_shard_max_select_rows(L, N_global, S_global):
+                    # more rows per query than a launch selects: the collect-all route, the replay IS the answer
+                    out_i, out_d, cnt = every_candidate(q)
+                    self.last_tie_flags = torch.zeros(B, dtype=torch.bool, device=dev)
+                    return _handoff(out_i, out_d, cnt)
                 ids = torch.empty((B, k1), dtype=torch.int64, device=dev)
                 d = torch.empty((B, k1), dtype=torch.float32, device=dev)
                 pos = torch.empty((B, k1), dtype=torch.int32, device=dev)
@@ -597,22 +640,7 @@ class DbShardedIndex(object):
                 out_i, out_d, cnt = self._merge_ivf(ids, d, pos, cnt, topk)
                 flagged = torch.nonzero(self.last_tie_flags).flatten()
                 if flagged.numel():                           # exact ties among the k+1 best: replay the heap (same on all ranks)
-                    nf, rows = int(flagged.numel()), int(L)
-                    qf = q[flagged].contiguous()
-                    fi = torch.empty((nf, rows), dtype=torch.int64, device=dev)
-                    fd = torch.empty((nf, rows), dtype=torch.float32, device=dev)
-                    fp = torch.empty((nf, rows), dtype=torch.int32, device=dev)
-                    fn = torch.empty((nf,), dtype=torch.int32, device=dev)
-                    fc = torch.empty((nf,), dtype=torch.int64, device=dev)
-                    self.engine.query_ivf_shard_dev(qf.data_ptr(), nf, topk, 0 if t is None else t.data_ptr(),
-                                                    0 if t is None else t.numel(), S_global, L, N_global, glen.data_ptr(),
-                                                    glen.shape[0], rank, fi.data_ptr(), fd.data_ptr(), fp.data_ptr(),
-                                                    fn.data_ptr(), fc.data_ptr(), sh, rows=rows)
-                    g = _all_gather_bytes(_pack([fp.to(torch.int64), torch.where(fi >= 0, fi + self.start, fi), fd]), self.group)
-                    ri = torch.empty((nf, topk), dtype=torch.int64, device=dev)
-                    rd = torch.empty((nf, topk), dtype=torch.float32, device=dev)
-                    from . import core
-                    core.ivf_shard_replay_dev(g.data_ptr(), g.shape[0], nf, rows, topk, ri.data_ptr(), rd.data_ptr(), sh)
+                    ri, rd, _ = every_candidate(q[flagged].contiguous())
                     out_i[flagged] = ri
                     out_d[flagged] = rd
                 out = (out_i, out_d, cnt)
@@ -620,29 +648,47 @@ class DbShardedIndex(object):
         lens = np.asarray(self.engine.ivf_list_lengths(tl), np.int32)
         glen = _all_gather_bytes(torch.from_numpy(lens).view(torch.uint8), self.group).view(torch.int32).reshape(-1, len(lens))
         Qh = np.asarray(Q)
+        rows = int(L)
+        group = max(1, min(B, self.GATHER_BUDGET // max(w * rows * 20, 1)))
+
+        def every_candidate(Qs):
+            """host tensors (gloo): rows = L for the queries Qs, gathered, the engine replays std::partial_sort on the rebuilt sequences"""
+            nf = Qs.shape[0]
+            ri = np.empty((nf, topk), np.int64)
+            rdd = np.empty((nf, topk), np.float32)
+            rc = np.empty((nf,), np.int64)
+            for f0 in range(0, nf, group):
+                fi, fd, fp, _, fc = self.engine.query_ivf_shard(Qs[f0:f0 + group], topk, tl, S_global, L, N_global, glen.numpy(), rank, rows=rows)
+                nfc = fi.shape[0]
+                fi = torch.from_numpy(np.ascontiguousarray(fi))
+                g = _all_gather_bytes(_pack([torch.from_numpy(np.ascontiguousarray(fp)).to(torch.int64),
+                                             torch.where(fi >= 0, fi + self.start, fi), torch.from_numpy(np.ascontiguousarray(fd))]), self.group)
+                n = nfc * rows
+                gp = np.stack([_field(g, r, 0, n, torch.int64).reshape(nfc, rows).numpy() for r in range(g.shape[0])])
+                gi = np.stack([_field(g, r, n * 8, n, torch.int64).reshape(nfc, rows).numpy() for r in range(g.shape[0])])
+                gd = np.stack([_field(g, r, n * 16, n, torch.float32).reshape(nfc, rows).numpy() for r in range(g.shape[0])])
+                ri[f0:f0 + nfc], rdd[f0:f0 + nfc] = self.engine.ivf_shard_replay(gp, gi, gd, topk)
+                rc[f0:f0 + nfc] = fc
+            return ri, rdd, rc
+
+        max_sel = getattr(self.engine, "ivf_shard_max_select_rows", None)
+        if max_sel is not None and k1 > max_sel(L, N_global, S_global):
+            ri, rdd, rc = every_candidate(Qh)              # collect-all: the replay is the answer
+            self.last_tie_flags = torch.zeros(B, dtype=torch.bool)
+            return torch.from_numpy(ri), torch.from_numpy(rdd), torch.from_numpy(rc)
         ids, d, pos, nloc, cnt = self.engine.query_ivf_shard(Qh, topk, tl, S_global, L, N_global, glen.numpy(), rank)
         out_i, out_d, cnt = self._merge_ivf(torch.from_numpy(np.ascontiguousarray(ids)), torch.from_numpy(np.ascontiguousarray(d)),
                                             torch.from_numpy(np.ascontiguousarray(pos)), torch.from_numpy(np.ascontiguousarray(cnt)), topk)
         flagged = torch.nonzero(self.last_tie_flags).flatten()
         if flagged.numel():                                   # host tensors (gloo): same protocol, the engine replays
-            nf, rows = int(flagged.numel()), int(L)
-            fi, fd, fp, _, _ = self.engine.query_ivf_shard(Qh[flagged.numpy()], topk, tl, S_global, L, N_global, glen.numpy(), rank,
-                                                           rows=rows)
-            fi = torch.from_numpy(np.ascontiguousarray(fi))
-            g = _all_gather_bytes(_pack([torch.from_numpy(np.ascontiguousarray(fp)).to(torch.int64),
-                                         torch.where(fi >= 0, fi + self.start, fi), torch.from_numpy(np.ascontiguousarray(fd))]), self.group)
-            n = nf * rows
-            gp = np.stack([_field(g, r, 0, n, torch.int64).reshape(nf, rows).numpy() for r in range(g.shape[0])])
-            gi = np.stack([_field(g, r, n * 8, n, torch.int64).reshape(nf, rows).numpy() for r in range(g.shape[0])])
-            gd = np.stack([_field(g, r, n * 16, n, torch.float32).reshape(nf, rows).numpy() for r in range(g.shape[0])])
-            ri, rd = self.engine.ivf_shard_replay(gp, gi, gd, topk)
+            ri, rdd, _ = every_candidate(Qh[flagged.numpy()])
             out_i[flagged] = torch.from_numpy(np.ascontiguousarray(ri))
-            out_d[flagged] = torch.from_numpy(np.ascontiguousarray(rd))
+            out_d[flagged] = torch.from_numpy(np.ascontiguousarray(rdd))
         return out_i, out_d, cnt
 
     def _merge_ivf(self, ids, d, pos, cnt, topk):
         """all-gather of the per-rank (position, global id, dist) rows + merge under (dist, position)."""
-        rank, w = world()
+        rank, w = world(self.group)
         B, k1 = ids.shape
         dev = ids.device
         gid = torch.where(ids >= 0, ids + self.start, ids)                  # local -> global ids, -1 stays
@@ -690,7 +736,7 @@ class QueryShardedIndex(object):
         self.engine, self.group = engine, group
 
     def _slices(self, B):
-        rank, w = world()
+        rank, w = world(self.group)
         rows = [shard_range(B, r, w)[1] - shard_range(B, r, w)[0] for r in range(w)]
         return shard_range(B, rank, w), rows
 

@@ -67,6 +67,24 @@ def test_no_gpu_means_loud_failure_not_fallback():
         RiiGpu(np.zeros((2, 4, 3), np.float32), False)
 
 
+def test_comm_init_refuses_bad_ranks_without_touching_a_device():
+    """rii_comm_init validates (id, rank, nranks) before any HIP / RCCL call: a wrong world description is an error code, not a
+    hang inside ncclCommInitRank (a DUPLICATE rank cannot be seen by one process alone: RCCL's own rendezvous reports it)."""
+    from rii_amd import core
+    lib = core._lib()
+    out = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(core.COMM_ID_BYTES)
+    for rank, nranks in ((0, 0), (-1, 2), (2, 2), (5, 1), (0, -3)):
+        assert lib.rii_comm_init(ident, rank, nranks, 0, ctypes.byref(out)) == -1, (rank, nranks)      # RII_ERR_INVALID
+        assert not out.value
+    assert lib.rii_comm_init(None, 0, 1, 0, ctypes.byref(out)) == -1
+    assert lib.rii_comm_init(ident, 0, 1, 0, None) == -1
+    assert lib.rii_comm_rank(None) == -1 and lib.rii_comm_size(None) == 0
+    # the stateless helpers of the sharded protocol answer without a device as well
+    assert lib.rii_ivf_shard_replay_scratch_bytes(3, 8192) == 0 and lib.rii_ivf_shard_replay_scratch_bytes(3, 8193) == 3 * 8193 * 16
+    assert lib.rii_ivf_shard_max_select_rows(None, 100, 1000, 0) == -1
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under rii_amd/ may import, include, link or load it."""
     pkg = os.path.join(ROOT, "rii_amd")

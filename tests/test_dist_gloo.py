@@ -119,14 +119,9 @@ class _OracleShard(_OracleBatch):
         total = glen.sum(0)
         before = glen[:rank].sum(0)
         pair = np.dtype([("id", "<u8"), ("dist", "<f4")], align=True)
+        codes = np.asarray(o.codes)
         for b in range(B):
             dt = O.dtable(o.codewords, Q[b], o.arch)
-
-            def adist(code):
-                acc = np.float32(0)
-                for m in range(o.M):
-                    acc = np.float32(acc + dt[m, code[m]])
-                return acc
             coarse = np.zeros(nlist, pair)
             coarse["id"] = np.arange(nlist)
             cacc = np.zeros(nlist, np.float32)               # sequential fp32 adds over m, all centres at once
@@ -135,15 +130,21 @@ class _OracleShard(_OracleBatch):
                 cacc = (cacc + dt[m, cen[:, m]]).astype(np.float32)
             coarse["dist"] = cacc
             O.lib().oracle_partial_sort(coarse.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(w), ctypes.c_size_t(nlist))
-            c_cnt, finished, mine = 0, False, []
+            c_cnt, finished = 0, False
+            m_d, m_p, m_i = [], [], []                       # this rank's candidates: distance, traversal position, local id
             for c in range(nlist):
                 no = int(coarse["id"][c])
                 ln = int(total[no])
                 take = min(ln, L - c_cnt)
-                for li, lid in enumerate(lists[no]):
-                    o_glob = int(before[no]) + li
-                    if o_glob < take:
-                        mine.append((adist(o.codes[lid]), c_cnt + o_glob, int(lid)))
+                lst = lists[no]
+                own = lst[:max(0, min(len(lst), take - int(before[no])))]          # offsets before + li < take
+                if len(own):
+                    acc = np.zeros(len(own), np.float32)
+                    for m in range(o.M):                     # RiiCpp::ADist: sequential fp32 adds over m
+                        acc = (acc + dt[m, codes[own, m]]).astype(np.float32)
+                    m_d.append(acc)
+                    m_p.append(c_cnt + int(before[no]) + np.arange(len(own), dtype=np.int64))
+                    m_i.append(own)
                 if c_cnt + ln >= L:
                     c_cnt, finished = L, True
                     break
@@ -151,13 +152,13 @@ class _OracleShard(_OracleBatch):
                 if c + 1 == w and c_cnt >= topk:
                     finished = True
                     break
-            if not finished:
-                mine = []
             cnt[b] = topk if finished else 0
-            mine.sort(key=lambda t: (t[0], t[1]))
-            nloc[b] = min(len(mine), k1)
-            for j, (d_, p_, i_) in enumerate(mine[:k1]):
-                ids[b, j], dd[b, j], pos[b, j] = i_, d_, p_
+            if finished and m_d:
+                md_, mp_, mi_ = np.concatenate(m_d), np.concatenate(m_p), np.concatenate(m_i)
+                order = np.lexsort((mp_, md_))[:k1]           # ascending by (distance, position)
+                n = len(order)
+                nloc[b] = n
+                ids[b, :n], dd[b, :n], pos[b, :n] = mi_[order], md_[order], mp_[order]
         return ids, dd, pos, nloc, cnt
 
     def ivf_shard_replay(self, gp, gi, gd, topk):
@@ -177,9 +178,11 @@ class _OracleShard(_OracleBatch):
             seq["id"][ps] = ps
             seq["dist"][ps] = gd[:, f, :][ok]
             ids[ps] = gi[:, f, :][ok]
-            O.lib().oracle_partial_sort(seq.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(topk), ctypes.c_size_t(n))
-            ri[f] = ids[seq["id"][:topk].astype(np.int64)]
-            rd[f] = seq["dist"][:topk]
+            mid = min(topk, n)                                # (a query the reference answers with ({}, {}) has no candidates)
+            O.lib().oracle_partial_sort(seq.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(mid), ctypes.c_size_t(n))
+            ri[f], rd[f] = -1, np.inf
+            ri[f, :mid] = ids[seq["id"][:mid].astype(np.int64)]
+            rd[f, :mid] = seq["dist"][:mid]
         return ri, rd
 
 
@@ -259,13 +262,18 @@ class _GpuBatch(object):
         dbuf = buf.cuda()
         ri = torch.empty((nf, topk), dtype=torch.int64, device="cuda")
         rd = torch.empty((nf, topk), dtype=torch.float32, device="cuda")
+        nsc = core.ivf_shard_replay_scratch_bytes(nf, rows)           # rows > 8192: the rebuilt sequences live in global scratch
+        scratch = torch.empty(max(nsc, 16), dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
-        core.ivf_shard_replay_dev(dbuf.data_ptr(), G, nf, rows, topk, ri.data_ptr(), rd.data_ptr())
+        core.ivf_shard_replay_dev(dbuf.data_ptr(), G, nf, rows, topk, ri.data_ptr(), rd.data_ptr(), 0, scratch.data_ptr(), nsc)
         torch.cuda.synchronize()
         return ri.cpu().numpy(), rd.cpu().numpy()
 
+    def ivf_shard_max_select_rows(self, L, N_global, S_global=0):
+        return self.g.ivf_shard_max_select_rows(L, N_global, S_global)
 
-def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties=False, nlist=40):
+
+def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties=False, nlist=40, big_cases=None):
     """Database-sharded inverted index against the single-index oracle on the concatenated database, incl. target ids,
     ranks without targets, stale lists (tail walk into the unsorted coarse order, `not found`)."""
     from oracle import oracle as O
@@ -281,7 +289,7 @@ def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties
     Q = qs[:6]
     E = np.array([], np.int64)
     n_tied = 0
-    for stale in ((False,) if ties else (False, True)):
+    for stale in ((False,) if (ties or big_cases is not None) else (False, True)):
         local = make_local(cw, codes[s:e])
         n_listed = (e - s) // 9 if stale else None
         local.set_coarse_centers(centers, n_listed)
@@ -303,6 +311,8 @@ def _check_sharded_ivf(rd, rank, world, cw, codes, qs, make_local, use_gpu, ties
         cases = [(1, 75, None), (1, 400, None), (5, 300, None), (3, 3, None), (10, N, None), (7, 200, sub), (2, 9, low), (1, 40, low)]
         if nlist != 40:
             cases = [(1, 3, None), (4, 60, None), (2, N, None), (3, 30, sub)]
+        if big_cases is not None:
+            cases = big_cases
         if stale:
             cases += [(20, 100, None), (20, 40, None), (3, 30, None), (12, 50, None), (1, 51, None)]
         n_empty = 0
@@ -432,6 +442,18 @@ def _worker(rank, world, port, q, use_gpu=False):
         # nlist = 5000 (above the LDS limit of the sharded kernel: coarse order in global scratch, heap in LDS) and L up to N
         _check_sharded_ivf(rd, rank, world, cw2, np.concatenate([codes2] * 5)[:7001], qs2, _GpuBatch if use_gpu else _OracleShard, use_gpu,
                            ties=True, nlist=5000)
+        # round 5: L past the 8192 keys the shard kernel sorts in LDS -- the reference's billion-scale run asks for L = sqrt(N) ~ 31.6 k
+        # (examples/benchmark/run_sift1b.py:105-106) -- with topk up to thousands: selection buffer, sequences rebuilt in global
+        # scratch, and the collect-all route (topk + 1 above what a launch selects); integer-valued data: exact ties everywhere
+        nbig = 40001
+        codes_big = np.concatenate([codes2] * 27)[:nbig].copy()
+        codes_big[:, 0] = np.random.default_rng(5).integers(0, 16, nbig)
+        sub_big = np.sort(np.random.default_rng(6).choice(nbig, 30000, replace=False)).astype(np.int64)
+        big = [(1, 8193, None), (10, 8193, None), (10, 32000, None), (1, 32000, None), (2000, 32000, None), (10, nbig, None),
+               (2000, nbig, None), (7, 20000, sub_big), (8100, 9000, None)]
+        n_tied_big = _check_sharded_ivf(rd, rank, world, cw2, codes_big, qs2[:3], _GpuBatch if use_gpu else _OracleShard, use_gpu,
+                                        ties=True, big_cases=big)
+        assert n_tied_big > 0
         # tables above the LDS budget (M = 160, Ks = 256: 160 KiB; widetab.hip): the sharded entry points used to refuse these shapes
         # (round 4: ivf_shard_kernel<GTAB>, key-row tie emission) -- tied distances across the shards, linear and inverted index
         rngw = np.random.default_rng(177)

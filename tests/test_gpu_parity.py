@@ -441,18 +441,31 @@ def test_gpu_state_loads_into_the_real_reference():
 
 
 def test_gpu_mfma_lut_within_tolerance():
-    """north_star: distances within 1e-4 (relative) when the table is built on the matrix cores."""
+    """north_star: distances within 1e-4 (relative) when the table is built on the matrix cores -- against the ORACLE's table
+    (RiiCpp::DTable, src/rii.h:361-373), not against the engine's own exact mode; the batch is large enough for the default
+    filter path (lut_build_mfma_kernel -> lut_quantize_kernel -> fscan_mx_kernel -> re-rank from the matrix-core table)."""
     from rii_amd import RiiGpu
     cw, codes, qs = make_problem(77, 32, 256, 4, 20000, "sift")
+    Q = np.concatenate([qs, qs + 1.0, qs * 0.5, qs + 3.0]).astype(np.float32)            # 64 queries: above fast_min_batch
     g = RiiGpu(cw, False)
     g.add_codes(codes, False)
-    exact = g.dtable(qs[:16])
-    ids_e, d_e = g.query_linear_batch(qs[:16], 1, None)
+    want = np.stack([O.dtable(cw, Q[b], "avx512") for b in range(16)]).reshape(16, -1)
+    ids_e, d_e = g.query_linear_batch(Q, 1, None)
     g.set_option("lut_mode", "mfma")
-    approx = g.dtable(qs[:16])
-    ids_m, d_m = g.query_linear_batch(qs[:16], 1, None)
-    rel = np.abs(approx - exact) / np.maximum(np.abs(exact), 1.0)
+    approx = g.dtable(Q[:16]).reshape(16, -1)
+    ids_m, d_m = g.query_linear_batch(Q, 1, None)
+    g.set_option("timing", 1)
+    g.timing_reset()
+    g.query_linear_batch(Q, 1, None)
+    assert g.timing_read("quant")[1] > 0 and g.timing_read("scan")[1] > 0      # the filter path ran on the matrix-core tables
+    g.set_option("timing", 0)
+    rel = np.abs(approx - want) / np.maximum(np.abs(want), 1.0)
     assert rel.max() < 1e-4, rel.max()
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    for b in range(0, 64, 7):
+        wi, wd = o.query_linear(Q[b], 1, np.array([], np.int64))
+        assert abs(float(d_m[b, 0]) - wd[0]) <= 1e-4 * max(abs(wd[0]), 1.0), (b, d_m[b, 0], wd[0])
     assert np.allclose(d_m, d_e, rtol=1e-4)
     assert (ids_m == ids_e).mean() >= 0.9          # tie-tolerant: near-ties may flip under different rounding
 

@@ -1,0 +1,267 @@
+"""Round 5, GPU: the database-sharded entry points without their round-4 limits -- the inverted index at any L and any topk
+(the reference's billion-scale run asks for L = sqrt(N) ~ 31.6 k: examples/benchmark/run_sift1b.py:105-106), the merge of
+more than 8192 rows per query, record headers instead of cached shard offsets, rank-local failures that keep the ranks in
+step -- through a ONE-rank communicator behind the C ABI (RCCL; the two-rank decomposition of the same kernels is
+tests/test_dist_gloo.py::test_world2_sharded_real_engines_match_single_index).  Everything is compared with the CPU oracle
+on the whole database, ids and distance bits, exact ties included."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import make_problem
+
+pytestmark = pytest.mark.gpu
+E = np.array([], np.int64)
+
+
+def _tied_problem(n):
+    """integer-valued codebooks and queries + duplicated codes: exactly tied distances everywhere"""
+    rng = np.random.default_rng(77)
+    cw = np.round(rng.random((8, 16, 4)) * 3).astype(np.float32)
+    codes = rng.integers(0, 16, size=(n, 8), dtype=np.uint8)
+    codes[rng.integers(0, n, n // 4)] = codes[rng.integers(0, n, n // 4)]
+    qs = np.round(rng.random((6, 32)) * 3).astype(np.float32)
+    return cw, codes, qs
+
+
+def _pair(cw, codes, nlist, it=2):
+    from rii_amd import RiiGpu
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    o.reconfigure(nlist, it)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.set_coarse_centers(np.array(o.coarse_centers, np.uint8))
+    assert g.posting_lists == o.posting_lists
+    return g, o
+
+
+def _check_ivf(idx, o, qs, topk, L, tids=None):
+    import torch
+    gi, gd, gc = idx.query_ivf_batch(torch.from_numpy(qs).cuda(), topk, tids, L)
+    gi, gd, gc = gi.cpu().numpy(), gd.cpu().numpy(), gc.cpu().numpy()
+    tied = 0
+    for b in range(qs.shape[0]):
+        wi, wd = o.query_ivf(qs[b], topk, E if tids is None else tids, L)
+        what = "sharded ivf k=%d L=%d b=%d" % (topk, L, b)
+        assert int(gc[b]) == len(wi), what
+        n = len(wi)
+        assert np.array_equal(gd[b, :n].view(np.uint32), np.asarray(wd, np.float32).view(np.uint32)), what
+        assert list(gi[b, :n]) == list(wi), what
+        tied += int(len(set(wd)) < n)
+    return tied
+
+
+def test_sharded_ivf_any_L_any_topk_through_the_c_abi():
+    """L in {8193, 32 k, N} x topk in {1, 10, 2000}: the selection-buffer kernel (ivf_shard_any_kernel), sequences rebuilt in global
+    scratch for the exact-tie replay (shard_replay_any_kernel, heaps of 10 in LDS / of 2000 walked by one lane), target ids, the
+    collect-all route (topk + 1 above what a launch selects) and the global-scratch merge (G x (k + 1) > 8192 rows)."""
+    from rii_amd import dist as rd
+    n = 40001
+    cw, codes, qs = _tied_problem(n)
+    g, o = _pair(cw, codes, 40)
+    idx = rd.DbShardedIndex(g, 0, n)
+    sub = np.sort(np.random.default_rng(6).choice(n, 30000, replace=False)).astype(np.int64)
+    tied = 0
+    for topk, L, t in ((1, 8193, None), (10, 8193, None), (10, 32000, None), (1, 32000, None), (2000, 32000, None), (10, n, None),
+                       (2000, n, None), (7, 20000, sub), (8100, 9000, None), (8192, 8192, None), (1, 977, None), (5, 8192, None)):
+        tied += _check_ivf(idx, o, qs[:3], topk, L, t)
+    assert tied > 0
+    assert g.ivf_shard_max_select_rows(32000, n) < 8100 + 1 <= 9000       # (8100, 9000) really took the collect-all route
+    # untied data at a shape with real tables (M = 16, Ks = 256) and many lists: nlist above the LDS limit of the coarse order too
+    cwu, codesu, qsu = make_problem(8, 16, 256, 6, 30000, "unit")
+    gu, ou = _pair(cwu, codesu, 173, it=1)
+    iu = rd.DbShardedIndex(gu, 0, 30000)
+    for topk, L in ((1, 9000), (10, 20000), (1500, 30000)):
+        assert _check_ivf(iu, ou, qsu[:4], topk, L) == 0
+    assert not bool(iu.last_tie_flags.any())
+
+
+def test_shard_kernel_two_fake_ranks_any_L_and_the_replay_by_position():
+    """rii_query_ivf_shard_dev for ranks 0 and 1 of 2 on ONE GPU (two engines, the list lengths exchanged by hand), L = 20 000:
+    selection rows merged on the host under (distance, position) = the oracle's top-1 / top-10 wherever no tie decides; rows = L =
+    every owned candidate at the slot of its traversal position, rebuilt and replayed by rii_ivf_shard_replay_ex_dev = the
+    oracle's answer, ties included."""
+    import torch
+    from rii_amd import RiiGpu, core
+    n = 30001
+    cw, codes, qs = _tied_problem(n)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    o.reconfigure(30, 2)
+    cen = np.array(o.coarse_centers, np.uint8)
+    cut = n // 2 + 7
+    engs = []
+    for s, e in ((0, cut), (cut, n)):
+        ge = RiiGpu(cw, False, simd_arch="avx512")
+        ge.add_codes(codes[s:e], False)
+        ge.set_coarse_centers(cen)
+        engs.append((ge, s))
+    nl = 30
+    lens = []
+    for ge, _ in engs:
+        t = torch.empty(nl, dtype=torch.int32, device="cuda")
+        ge.ivf_list_lengths_dev(0, 0, 0, t.data_ptr())
+        ge.synchronize()
+        lens.append(t)
+    glen = torch.stack(lens).contiguous()
+    L, B = 20000, 4
+    q = torch.from_numpy(qs[:B]).cuda()
+    for topk in (1, 10):
+        rows = L
+        recs = []
+        for r, (ge, s) in enumerate(engs):
+            ids = torch.empty((B, rows), dtype=torch.int64, device="cuda")
+            d = torch.empty((B, rows), dtype=torch.float32, device="cuda")
+            pos = torch.empty((B, rows), dtype=torch.int32, device="cuda")
+            nloc = torch.empty((B,), dtype=torch.int32, device="cuda")
+            cnt = torch.empty((B,), dtype=torch.int64, device="cuda")
+            ge.query_ivf_shard_dev(q.data_ptr(), B, topk, 0, 0, 0, L, n, glen.data_ptr(), 2, r, ids.data_ptr(), d.data_ptr(), pos.data_ptr(),
+                                   nloc.data_ptr(), cnt.data_ptr(), 0, rows)
+            ge.synchronize()
+            p, i, dd = pos.cpu().numpy(), ids.cpu().numpy(), d.cpu().numpy()
+            own = p != np.iinfo(np.int32).max
+            assert (p[own] == np.nonzero(own)[1]).all(), "rows = L above 8192: slot j holds traversal position j"
+            assert int(own.sum()) == int(nloc.sum().item())
+            assert (cnt.cpu().numpy() == topk).all()
+            recs.append((p.astype(np.int64), np.where(i >= 0, i + s, i), dd))
+        assert ((recs[0][0] != np.iinfo(np.int32).max).astype(int) + (recs[1][0] != np.iinfo(np.int32).max).astype(int) == 1).all(), \
+            "every one of the L positions is owned by exactly one rank"
+        nrec = (B * rows * 20 + 15) // 16 * 16
+        buf = torch.zeros((2, nrec), dtype=torch.uint8)
+        for r in range(2):
+            buf[r, :B * rows * 8] = torch.from_numpy(np.ascontiguousarray(recs[r][0])).reshape(-1).view(torch.uint8)
+            buf[r, B * rows * 8:B * rows * 16] = torch.from_numpy(np.ascontiguousarray(recs[r][1])).reshape(-1).view(torch.uint8)
+            buf[r, B * rows * 16:B * rows * 20] = torch.from_numpy(np.ascontiguousarray(recs[r][2])).reshape(-1).view(torch.uint8)
+        dbuf = buf.cuda()
+        nsc = core.ivf_shard_replay_scratch_bytes(B, rows)
+        assert nsc == B * rows * 16
+        scratch = torch.empty(nsc, dtype=torch.uint8, device="cuda")
+        ri = torch.empty((B, topk), dtype=torch.int64, device="cuda")
+        rdd = torch.empty((B, topk), dtype=torch.float32, device="cuda")
+        with pytest.raises(Exception):
+            core.ivf_shard_replay_dev(dbuf.data_ptr(), 2, B, rows, topk, ri.data_ptr(), rdd.data_ptr())     # no scratch: refused, not a fault
+        core.ivf_shard_replay_dev(dbuf.data_ptr(), 2, B, rows, topk, ri.data_ptr(), rdd.data_ptr(), 0, scratch.data_ptr(), nsc)
+        torch.cuda.synchronize()
+        for b in range(B):
+            wi, wd = o.query_ivf(qs[b], topk, E, L)
+            assert list(ri[b].cpu().numpy()) == list(wi) and np.array_equal(rdd[b].cpu().numpy().view(np.uint32), np.asarray(wd, np.float32).view(np.uint32))
+        # the selection form (k + 1 rows per rank) merged by hand: the same distances, the same ids wherever the k + 1 best differ
+        k1 = topk + 1
+        sel = []
+        for r, (ge, s) in enumerate(engs):
+            ids = torch.empty((B, k1), dtype=torch.int64, device="cuda")
+            d = torch.empty((B, k1), dtype=torch.float32, device="cuda")
+            pos = torch.empty((B, k1), dtype=torch.int32, device="cuda")
+            nloc = torch.empty((B,), dtype=torch.int32, device="cuda")
+            cnt = torch.empty((B,), dtype=torch.int64, device="cuda")
+            ge.query_ivf_shard_dev(q.data_ptr(), B, topk, 0, 0, 0, L, n, glen.data_ptr(), 2, r, ids.data_ptr(), d.data_ptr(), pos.data_ptr(),
+                                   nloc.data_ptr(), cnt.data_ptr())
+            ge.synchronize()
+            sel.append((d.cpu().numpy(), pos.cpu().numpy().astype(np.int64), np.where(ids.cpu().numpy() >= 0, ids.cpu().numpy() + s, -1)))
+            for b in range(B):            # rows ascending by (distance, position), drawn from the every-candidate record
+                assert list(zip(sel[-1][0][b], sel[-1][1][b])) == sorted(zip(sel[-1][0][b], sel[-1][1][b]))
+                mine = sorted(zip(recs[r][2][b][recs[r][0][b] < L], recs[r][0][b][recs[r][0][b] < L]))[:k1]
+                assert [x[1] for x in mine] == list(sel[-1][1][b][:len(mine)])
+        for b in range(B):
+            allrows = sorted((float(sel[r][0][b][j]), int(sel[r][1][b][j]), int(sel[r][2][b][j])) for r in range(2) for j in range(k1))
+            wi, wd = o.query_ivf(qs[b], topk, E, L)
+            assert [x[0] for x in allrows[:topk]] == [float(x) for x in wd]
+            if len({x[0] for x in allrows[:k1]}) == k1:
+                assert [x[2] for x in allrows[:topk]] == list(wi)
+
+
+def test_linear_dbsharded_large_topk_headers_and_local_failures():
+    """rii_query_linear_dbsharded_dev over a one-rank communicator: G x (k + 1) > 8192 rows merged in global scratch; the shard's
+    first id travels in the record header (two differently placed indices on ONE communicator, alternating: ADVICE r4); a heap
+    deeper than the replay kernels walk keeps the (distance, id) order and says so; a rank-local failure returns its error and
+    leaves the communicator usable."""
+    import torch
+    from rii_amd import RiiGpu, core
+    from rii_amd import dist as rd
+    cw, codes, qs = make_problem(6, 16, 256, 6, 12000, "unit")
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    comm = rd.get_comm()
+    Q = torch.from_numpy(qs[:5]).cuda()
+    for topk in (9000, 1, 40):
+        oi = torch.empty((5, topk), dtype=torch.int64, device="cuda")
+        od = torch.empty((5, topk), dtype=torch.float32, device="cuda")
+        tie = torch.empty(5, dtype=torch.int32, device="cuda")
+        ovf = torch.empty(5, dtype=torch.int32, device="cuda")
+        for start in (0, 1_000_000, 0, 77):                       # the offset of THIS call, whatever the previous call used
+            comm.query_linear_dbsharded_dev(g, start, Q.data_ptr(), 5, topk, 0, 0, 0, oi.data_ptr(), od.data_ptr(), tie.data_ptr(), ovf.data_ptr())
+            torch.cuda.synchronize()
+            for b in range(5):
+                wi, wd = o.query_linear(qs[b], topk, E)
+                assert list(oi[b].cpu().numpy() - start) == list(wi), (topk, start, b)
+                assert np.array_equal(od[b].cpu().numpy().view(np.uint32), np.asarray(wd, np.float32).view(np.uint32))
+            assert int(tie.sum().item()) == 0 and int(ovf.sum().item()) == 0
+    # exact ties under a heap of 2000: (distance, id) order kept, flagged as overflow -- never an error
+    cwt, codest, qst = _tied_problem(9000)
+    gt = RiiGpu(cwt, False, simd_arch="avx512")
+    gt.add_codes(codest, False)
+    ot = O.OracleRii(cwt, False, simd_arch="avx512")
+    ot.add_codes(codest, False)
+    Qt = torch.from_numpy(qst[:3]).cuda()
+    oi = torch.empty((3, 2000), dtype=torch.int64, device="cuda")
+    od = torch.empty((3, 2000), dtype=torch.float32, device="cuda")
+    tie = torch.empty(3, dtype=torch.int32, device="cuda")
+    ovf = torch.empty(3, dtype=torch.int32, device="cuda")
+    comm.query_linear_dbsharded_dev(gt, 0, Qt.data_ptr(), 3, 2000, 0, 0, 0, oi.data_ptr(), od.data_ptr(), tie.data_ptr(), ovf.data_ptr())
+    torch.cuda.synchronize()
+    assert int(tie.sum().item()) == 3 and torch.equal(tie, ovf)
+    for b in range(3):
+        wi, wd = ot.query_linear(qst[b], 2000, E)
+        assert np.array_equal(od[b].cpu().numpy().view(np.uint32), np.asarray(wd, np.float32).view(np.uint32))
+        gi = oi[b].cpu().numpy()
+        assert list(gi) == [i for _, i in sorted(zip(od[b].cpu().numpy().tolist(), gi.tolist()))]
+    # a rank-local failure (more local target ids than local codes): this rank's error, the communicator stays in step and usable
+    bad = torch.zeros(12001, dtype=torch.int64, device="cuda")
+    oi = torch.empty((5, 1), dtype=torch.int64, device="cuda")
+    od = torch.empty((5, 1), dtype=torch.float32, device="cuda")
+    with pytest.raises(Exception, match="S_local"):
+        comm.query_linear_dbsharded_dev(g, 0, Q.data_ptr(), 5, 1, bad.data_ptr(), 12001, 20000, oi.data_ptr(), od.data_ptr())
+    comm.query_linear_dbsharded_dev(g, 0, Q.data_ptr(), 5, 1, 0, 0, 0, oi.data_ptr(), od.data_ptr())
+    torch.cuda.synchronize()
+    for b in range(5):
+        assert list(oi[b].cpu().numpy()) == o.query_linear(qs[b], 1, E)[0]
+    # the query-sharded calls write their rows where the header lives: the next database-sharded call must put it back
+    qi = torch.empty((5, 3), dtype=torch.int64, device="cuda")
+    qd = torch.empty((5, 3), dtype=torch.float32, device="cuda")
+    comm.query_linear_qsharded_dev(g, Q.data_ptr(), 5, 3, 0, 0, qi.data_ptr(), qd.data_ptr())
+    comm.query_linear_dbsharded_dev(g, 500, Q.data_ptr(), 5, 1, 0, 0, 0, oi.data_ptr(), od.data_ptr())
+    torch.cuda.synchronize()
+    for b in range(5):
+        assert list(oi[b].cpu().numpy() - 500) == o.query_linear(qs[b], 1, E)[0]
+        assert list(qi[b].cpu().numpy()) == o.query_linear(qs[b], 3, E)[0]
+
+
+def test_set_posting_lists_installs_a_given_partition():
+    """rii_set_posting_lists: centres + CSR lists over the codes already added, no assignment pass -- the inverted index then walks
+    exactly those lists (oracle with the same CSR), and bad ids are refused."""
+    from rii_amd import RiiGpu
+    import bench
+    cw, codes, qs = make_problem(11, 16, 256, 6, 20000, "unit")
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    nlist = 141
+    cen = np.random.default_rng(4).integers(0, 256, size=(nlist, 16), dtype=np.uint8)
+    off, ids = bench.modulo_lists(20000, nlist)
+    g.set_posting_lists(cen, off, ids)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    o.set_csr(cen, off, ids)
+    assert g.nlist == nlist and g.posting_lists[3][:3] == [3, 3 + nlist, 3 + 2 * nlist]
+    for topk, L in ((1, 142), (5, 1000), (3, 20000)):
+        gi, gd, gc = g.query_ivf_batch(qs[:6], topk, E, L)
+        for b in range(6):
+            wi, wd = o.query_ivf(qs[b], topk, E, L)
+            assert int(gc[b]) == len(wi) and list(gi[b, :len(wi)]) == list(wi)
+            assert np.array_equal(gd[b, :len(wi)].view(np.uint32), np.asarray(wd, np.float32).view(np.uint32))
+    ids_bad = ids.copy()
+    ids_bad[5] = 20000
+    with pytest.raises(Exception, match="out of range"):
+        g.set_posting_lists(cen, off, ids_bad)
