@@ -168,8 +168,13 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kShardAnyBuf = 8192;       // most keys the selection buffer holds (64 KiB)
 constexpr int kShardGroup = 256;         // visited lists whose descriptors are staged per round
+constexpr int kShardUnroll = 4;          // candidates a thread scores per round: their ids, then their code rows, are in flight together
+constexpr int kShardRound = 256 * kShardUnroll;
 
-template <bool GTAB>
+// CLDS: the coarse order and the cumulative counts of the query in LDS (nlist <= kShardMaxNlistLds), else in global scratch.
+// TOP1: rows == 2 (top-1: the best two owned candidates): every thread keeps its two smallest keys in registers, the block's two
+//       smallest come out of two DPP minima per wave and eight keys in LDS -- no buffer, no sort, no atomics.
+template <bool GTAB, bool CLDS, bool TOP1>
 __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbuf, int collect)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -180,15 +185,17 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     float *lds = reinterpret_cast<float *>(smem);
     const float *tab = GTAB ? p.lut + (size_t) b * MK : lds;
     unsigned char *base = smem + (GTAB ? 0 : (((size_t) MK * 4 + 15) & ~(size_t) 15));
-    const bool w_lds = p.w <= kWhSplitMaxHeap;
-    pq64_t *s_head = reinterpret_cast<pq64_t *>(base);                               // [w] when the coarse heap is walked by a wave
-    int32_t *s_misc = reinterpret_cast<int32_t *>(s_head + (w_lds ? p.w : 0));       // [8]: ncand, nv, owned, buffered
+    const bool w_lds = CLDS || p.w <= kWhSplitMaxHeap;
+    const int nhead = CLDS ? nlist : (w_lds ? (int) p.w : 0);
+    pq64_t *s_head = reinterpret_cast<pq64_t *>(base);                               // CLDS: the whole order; else the heap of the coarse sort
+    int32_t *s_cum_lds = reinterpret_cast<int32_t *>(s_head + nhead);                // CLDS: [nlist + 1]
+    int32_t *s_misc = s_cum_lds + (CLDS ? nlist + 1 : 0);                            // [8]: ncand, nv, owned, buffered
     int32_t *s_lpos = s_misc + 8, *s_lown = s_lpos + kShardGroup;                   // staged list descriptors
     int64_t *s_loff = reinterpret_cast<int64_t *>(smem + ((reinterpret_cast<unsigned char *>(s_lown + kShardGroup) - smem + 15) & ~(size_t) 15));
-    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_loff + kShardGroup);        // [nbuf] (selection only)
-    unsigned char *mine = p.scratch + p.per_block * blockIdx.x;
-    pq64_t *s_coarse = reinterpret_cast<pq64_t *>(mine);                             // [nlist] the whole coarse order
-    int32_t *s_cum = reinterpret_cast<int32_t *>(mine + (size_t) nlist * 8);         // [nlist + 1] cumulative GLOBAL counts
+    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_loff + kShardGroup);        // [nbuf] (selection) / [8] (TOP1)
+    unsigned char *mine = CLDS ? nullptr : p.scratch + p.per_block * blockIdx.x;
+    pq64_t *s_coarse = CLDS ? s_head : reinterpret_cast<pq64_t *>(mine);                            // [nlist] the whole coarse order
+    int32_t *s_cum = CLDS ? s_cum_lds : reinterpret_cast<int32_t *>(mine + (size_t) nlist * 8);    // [nlist + 1] cumulative GLOBAL counts
 
     if constexpr (!GTAB) {
         const float *src = p.lut + (size_t) b * MK;
@@ -197,10 +204,12 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     __syncthreads();
     for (int c = tid; c < nlist; c += 256) {                                          // src/rii.h:262-264
         const pq64_t e = pq64_make(exact_adist(tab, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
-        if (w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
+        if (!CLDS && w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
     }
     __syncthreads();
-    if (w_lds) {                                                                      // src/rii.h:279-280
+    if constexpr (CLDS) {
+        if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);               // src/rii.h:279-280 (wave 0)
+    } else if (w_lds) {
         if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);
         __syncthreads();
         for (int c = tid; c < (int) p.w; c += 256) s_coarse[c] = s_head[c];
@@ -236,6 +245,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     __syncthreads();
     const int nv = s_misc[1];
     unsigned long long thr = ~0ull;                                                   // selection: keys at or above it cannot make the cut
+    unsigned long long b0 = ~0ull, b1 = ~0ull;                                        // TOP1: this thread's two smallest keys
     int owned = 0;
     auto flush = [&]() {                                                              // all threads; barriers inside
         const int n = s_misc[3];
@@ -252,11 +262,11 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     for (int c0 = 0; c0 < nv; c0 += kShardGroup) {
         __syncthreads();
         if (tid < kShardGroup) {                                                      // this rank's part of visited list c0 + tid
-            int no = 0, lpos = 0, own = 0;
+            int lpos = 0, own = 0;
             int64_t off = 0;
             const int c = c0 + tid;
             if (c < nv) {
-                no = (int) pq64_id(s_coarse[c]);
+                const int no = (int) pq64_id(s_coarse[c]);
                 const int cum = s_cum[c], take = s_cum[c + 1] - cum;                 // the list's share of the L candidates
                 int before = 0;
                 for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
@@ -275,23 +285,38 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             if (own == 0) continue;
             const int lpos = s_lpos[l];
             const int32_t *ids = p.pl_ids + s_loff[l];
-            for (int base_li = 0; base_li < own; base_li += 256) {
-                // a thread reads the fill behind its own insertion of the round before, not behind everyone's: up to 256 entries
-                // short of the truth, hence 512; the OR makes the decision the block's
-                if (!collect && __syncthreads_or(s_misc[3] + 512 > nbuf)) flush();
-                const int li = base_li + tid;
-                if (li < own) {
-                    const int32_t id = ids[li];
-                    const float d = exact_adist(tab, p.codes + (size_t) id * p.M, p.M, p.Ks);
-                    const int pos = lpos + li;
+            for (int base_li = 0; base_li < own; base_li += kShardRound) {
+                // a thread reads the fill behind its own insertions of the round before, not behind everyone's: up to one round
+                // short of the truth, hence two rounds of slack; the OR makes the decision the block's
+                if (!TOP1 && !collect && __syncthreads_or(s_misc[3] + 2 * kShardRound > nbuf)) flush();
+                int32_t idv[kShardUnroll];
+#pragma unroll
+                for (int u = 0; u < kShardUnroll; ++u) {                              // the ids of the round first ...
+                    const int li = base_li + u * 256 + tid;
+                    idv[u] = li < own ? ids[li] : -1;
+                }
+                float dv[kShardUnroll];
+#pragma unroll
+                for (int u = 0; u < kShardUnroll; ++u)                                // ... then their rows (independent gathers in flight)
+                    dv[u] = idv[u] >= 0 ? exact_adist(tab, p.codes + (size_t) idv[u] * p.M, p.M, p.Ks) : 0.f;
+#pragma unroll
+                for (int u = 0; u < kShardUnroll; ++u) {
+                    if (idv[u] < 0) continue;
+                    const int pos = lpos + base_li + u * 256 + tid;
                     ++owned;
                     if (collect) {
-                        p.out_ids[b * rows + pos] = id;
-                        p.out_dists[b * rows + pos] = d;
+                        p.out_ids[b * rows + pos] = idv[u];
+                        p.out_dists[b * rows + pos] = dv[u];
                         p.out_pos[b * rows + pos] = pos;
                     } else {
-                        const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | (uint32_t) pos;
-                        if (key < thr) s_key[atomicAdd(&s_misc[3], 1)] = key;
+                        const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(dv[u])) << 32) | (uint32_t) pos;
+                        if constexpr (TOP1) {
+                            if (key < b1) {
+                                if (key < b0) { b1 = b0; b0 = key; } else b1 = key;
+                            }
+                        } else {
+                            if (key < thr) s_key[atomicAdd(&s_misc[3], 1)] = key;
+                        }
                     }
                 }
             }
@@ -304,7 +329,25 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
         if (tid == 0) p.out_nloc[b] = nown < rows ? nown : rows;
         return;
     }
-    flush();
+    if constexpr (TOP1) {
+        // the wave's smallest key, then -- the lane that held it falls back on its second -- the wave's second smallest
+        const unsigned long long m0 = wave_min_u64(b0);
+        const unsigned long long m1 = wave_min_u64(b0 == m0 ? b1 : b0);              // (keys are unique: one lane holds m0)
+        if ((tid & 63) == 0) { s_key[2 * (tid >> 6)] = m0; s_key[2 * (tid >> 6) + 1] = m1; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long k0 = ~0ull, k1 = ~0ull;
+            for (int i = 0; i < 8; ++i) {
+                const unsigned long long k = s_key[i];
+                if (k < k1) { if (k < k0) { k1 = k0; k0 = k; } else k1 = k; }
+            }
+            s_key[0] = k0; s_key[1] = k1;
+            s_misc[3] = nown < 2 ? nown : 2;
+        }
+        __syncthreads();
+    } else {
+        flush();
+    }
     const int nloc = s_misc[3];                                                        // = min(owned, rows)
     if (tid == 0) p.out_nloc[b] = nloc;
     for (int j = tid; j < rows; j += 256) {
@@ -474,33 +517,54 @@ static bool shard_lds_ok(int M, int Ks, int nlist, int64_t L, int64_t w)
     return shard_smem(M, Ks, nlist, L, w) <= (size_t) 160 * 1024 - 512;
 }
 // ivf_shard_any_kernel: LDS without the selection buffer, and the buffer that fits next to it (a power of two)
-static size_t shard_any_fixed(int M, int Ks, int64_t w)
+static size_t shard_any_misc() { return 8 * 4 + 2 * kShardGroup * 4 + 16 + kShardGroup * 8; }
+static size_t shard_tab_bytes(int M, int Ks) { return shard_gtab(M, Ks) ? 0 : (((size_t) M * Ks * 4 + 15) & ~(size_t) 15); }
+// the coarse order of the query in LDS: up to kShardMaxNlistLds lists, and only next to a table that leaves room for it and a
+// 1024-key buffer
+static bool shard_any_clds(int M, int Ks, int nlist)
 {
-    return (shard_gtab(M, Ks) ? 0 : (((size_t) M * Ks * 4 + 15) & ~(size_t) 15)) + (size_t) (w <= kWhSplitMaxHeap ? w : 0) * 8 + 8 * 4 +
-           2 * kShardGroup * 4 + 16 + kShardGroup * 8;
+    return !shard_big(nlist) &&
+           shard_tab_bytes(M, Ks) + (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 + shard_any_misc() + 1024 * 8 <= (size_t) 160 * 1024 - 512;
 }
-static int shard_any_nbuf(int M, int Ks, int64_t w)
+static size_t shard_any_fixed(int M, int Ks, int nlist, int64_t w)
 {
-    const size_t avail = (size_t) 160 * 1024 - 512 - shard_any_fixed(M, Ks, w);
+    const size_t coarse = shard_any_clds(M, Ks, nlist) ? (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 : (size_t) (w <= kWhSplitMaxHeap ? w : 0) * 8;
+    return shard_tab_bytes(M, Ks) + coarse + shard_any_misc();
+}
+static int shard_any_nbuf(int M, int Ks, int nlist, int64_t w)
+{
+    const size_t avail = (size_t) 160 * 1024 - 512 - shard_any_fixed(M, Ks, nlist, w);
     int nbuf = kShardAnyBuf;
     while (nbuf > 64 && (size_t) nbuf * 8 > avail) nbuf >>= 1;
     return nbuf;
+}
+static int shard_any_max_rows(int M, int Ks, int nlist, int64_t w)
+{
+    const int r = shard_any_nbuf(M, Ks, nlist, w) - 2 * kShardRound;                 // two rounds of slack (see the kernel)
+    return r > 2 ? r : 2;                                                             // (rows = 2: the register path, no buffer)
 }
 // rows per query a launch can select (rows = k + 1 form); anything up to L is served by the collect form (rows >= L)
 int ivf_shard_max_select_rows(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
     if (shard_lds_ok(M, Ks, nlist, L, w)) return kShardMaxL + 1;
-    return shard_any_nbuf(M, Ks, w) - 512;
+    return shard_any_max_rows(M, Ks, nlist, w);
 }
 bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w, int rows)
 {
     if (shard_lds_ok(M, Ks, nlist, L, w)) return rows <= kShardMaxL + 1;      // (rows = k + 1 with k = L = 8192)
-    return rows <= shard_any_nbuf(M, Ks, w) - 512 || (int64_t) rows >= L;
+    return rows <= shard_any_max_rows(M, Ks, nlist, w) || (int64_t) rows >= L;
+}
+// which kernel: top-1 (rows = 2) always takes the register path of ivf_shard_any_kernel (sorting L keys to keep two of them is what
+// the 8192-key kernel would do); other row counts the 8192-key kernel while everything fits, else the selection buffer / collect form
+static bool shard_use_any(int M, int Ks, int nlist, int64_t L, int64_t w, int rows)
+{
+    if (rows == 2 && L > 2 && shard_any_fixed(M, Ks, nlist, w) + 64 <= (size_t) 160 * 1024 - 512) return true;
+    return !shard_lds_ok(M, Ks, nlist, L, w);
 }
 // bytes of global scratch per query of a launch (coarse order + cumulative counts), 0: everything fits LDS
 size_t ivf_shard_scratch_per_query(int M, int Ks, int nlist, int64_t L, int64_t w)
 {
-    return (shard_big(nlist) || !shard_lds_ok(M, Ks, nlist, L, w)) ? ((size_t) nlist * 12 + 4 + 63) / 64 * 64 : 0;
+    return (shard_big(nlist) || !shard_any_clds(M, Ks, nlist)) ? ((size_t) nlist * 12 + 4 + 63) / 64 * 64 : 0;
 }
 
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
@@ -514,12 +578,17 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
     a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w; a.rows = rows;
     a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_pos = d_out_pos; a.out_nloc = d_out_nloc; a.out_counts = d_out_counts;
     a.scratch = static_cast<unsigned char *>(d_scratch); a.per_block = ivf_shard_scratch_per_query(M, Ks, nlist, L, w);
-    if (!shard_lds_ok(M, Ks, nlist, L, w)) {               // any L: coarse order in global scratch, selection buffer or collect form
-        const int nbuf = shard_any_nbuf(M, Ks, w);
-        const int collect = rows > nbuf - 512 ? 1 : 0;
+    if (shard_use_any(M, Ks, nlist, L, w, rows)) {          // any L: register path (top-1), selection buffer, or collect form
+        const bool top1 = rows == 2 && L > 2;
+        const int nbuf = shard_any_nbuf(M, Ks, nlist, w);
+        const int collect = (!top1 && rows > shard_any_max_rows(M, Ks, nlist, w)) ? 1 : 0;
         if (collect && (int64_t) rows < L) return hipErrorInvalidValue;
-        const size_t smem = shard_any_fixed(M, Ks, w) + (collect ? 0 : (size_t) nbuf * 8);
-        auto kern = shard_gtab(M, Ks) ? ivf_shard_any_kernel<true> : ivf_shard_any_kernel<false>;
+        const size_t smem = shard_any_fixed(M, Ks, nlist, w) + (top1 ? 64 : (collect ? 0 : (size_t) nbuf * 8));
+        const bool gt = shard_gtab(M, Ks), cl = shard_any_clds(M, Ks, nlist);
+        auto kern = top1 ? (gt ? (cl ? ivf_shard_any_kernel<true, true, true> : ivf_shard_any_kernel<true, false, true>)
+                               : (cl ? ivf_shard_any_kernel<false, true, true> : ivf_shard_any_kernel<false, false, true>))
+                         : (gt ? (cl ? ivf_shard_any_kernel<true, true, false> : ivf_shard_any_kernel<true, false, false>)
+                               : (cl ? ivf_shard_any_kernel<false, true, false> : ivf_shard_any_kernel<false, false, false>));
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, nbuf, collect);
