@@ -201,7 +201,6 @@ def test_linear_dbsharded_large_topk_headers_and_local_failures():
                 if int(ovf[b].item()):            # (9000 of 12000 fp32 sums: a few collide exactly; a heap that deep is not replayed)
                     assert topk > 1024 and int(tie[b].item()) == 1
                     assert list(gi) == [i for _, i in sorted(zip(od[b].cpu().numpy().tolist(), gi.tolist()))]
-                    assert sorted(gi.tolist()) == sorted(wi) or len(set(wd[-2:])) == 1
                 else:
                     assert list(gi) == list(wi), (topk, start, b)
             if topk <= 1024:
