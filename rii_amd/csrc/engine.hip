@@ -156,6 +156,8 @@ struct rii_engine : ScratchSet {
     // profiles/r03_levels_ab.json): 63 -> 124 candidates per query, 127 -> 40, 255 -> 20; the scan itself is 3 % SLOWER with 255 (signed
     // bytes: more switching in the matrix core under a power-limited clock), so 127 -- non-negative bytes, no bias -- is the default.
     int table_levels = 127;
+    int ivf_dbg_stop = 0;       // measurement only: ivf_quad_kernel returns after phase 1 .. 3 (wrong rows; tools/r5_ivf_phases.py)
+    int ivf_quad = 1;           // option "ivf_quad" (round 5): 1 = top-1 batches of >= 16 queries over <= 1024 lists run four queries per block (ivf_quad_kernel)
     int ivf_inline_exact = 1;   // option "ivf_inline_exact" (round 4): 1 = a block of ivf_fused_kernel that flags its query (tied coarse distances, tail
                                 // walk, ties at the cut) replays it itself; 0 = the flag-gated exact kernels behind every batch (round 3)
     int ivf_list_codes = 1;     // option "ivf_list_codes" (round 4): 1 = a second copy of the codes in POSTING order (+N*M bytes) feeds the candidate phase of
@@ -1156,8 +1158,15 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             // common case answered in one launch; queries whose answer could hinge on std::partial_sort's internal
             // order raise flag[b] and are redone by the exact emulation kernels below (which skip the others)
             if (defer && e->spin_flag) { p.host_flag = e->spin_flag; p.host_seq = e->spin_seq; }
+            // round 5: four queries per block (tables interleaved: one 16-byte LDS read scores a centre for four queries) for the
+            // batched top-1 case; one-query calls, host-resident queries / flags and the other shapes keep the one-query blocks
+            // (from 768 queries: below that one-query blocks have CUs -- and each CU's LDS -- to themselves and finish their 16 us chain
+            //  before the 21 us chain of a four-query block; measured 16 / 64 / ... / 4096 queries: tools/r5_ivf_phases.py)
+            const bool quad = e->ivf_quad && p.queries && !p.q_host_off && !p.host_flag && p.B >= (e->ivf_quad > 1 ? 1 : 768) &&
+                              ivf_quad_supported(e->M, e->Ks, e->Ds, (int) nlist, w, topk);
+            p.kcap = quad ? e->ivf_dbg_stop : 0;
             ScopedTimer t(e, "ivf_fused", st, true);
-            HIP_TRY(launch_ivf_fused(p, st));
+            HIP_TRY(quad ? launch_ivf_quad(p, st) : launch_ivf_fused(p, st));
             p.host_flag = nullptr;                   // (the deferred fallback re-uses p: nothing after this launch publishes)
             if (defer) {
                 e->spin_used = e->spin_flag != nullptr;
@@ -2819,6 +2828,10 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->scan_mode = (int) value;
     } else if (k == "ivf_fused") {
         e->ivf_fused = value ? 1 : 0;
+    } else if (k == "ivf_dbg_stop") {
+        e->ivf_dbg_stop = (int) value;
+    } else if (k == "ivf_quad") {
+        e->ivf_quad = value < 0 ? 0 : (int) std::min<int64_t>(value, 2);        // 2: at every batch size (tests)
     } else if (k == "ivf_inline_exact") {
         e->ivf_inline_exact = value ? 1 : 0;
     } else if (k == "ivf_list_codes") {
@@ -2883,6 +2896,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_fused") return e->ivf_fused;
     if (k == "ivf_force_exact") return e->ivf_force_exact;
     if (k == "ivf_inline_exact") return e->ivf_inline_exact;
+    if (k == "ivf_quad") return e->ivf_quad;
     if (k == "ivf_list_codes") return e->ivf_list_codes;
     if (k == "fused_tables") return e->fused_tables;
     if (k == "table_levels") return e->table_levels;

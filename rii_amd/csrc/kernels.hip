@@ -1464,6 +1464,326 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
     }
 }
 
+// ===================================================================================================
+// ivf_quad_kernel (round 5): FOUR queries per block of 1024 threads, top-1, Ds = 4, Ks = 256, M = 16 / 32, nlist <= 1024, w <= 32.
+//
+// ivf_fused_kernel keeps four one-query blocks on a CU; their coarse phase is 4 x nlist x M random 4-byte LDS reads (ds_read_b32:
+// 32 banks, ~3.4 distinct rows on the busiest bank per 32-lane pass -- profiles/r04_ivf_pmc.json: 59 % of the LDS cycles of that
+// kernel are bank conflicts) and every block reads the whole codebook and all the centres.  Here the four tables are interleaved
+// [m][ks][query] in 16-byte rows:
+//   tables   thread (ks, quarter of the subspaces): M / 4 codeword loads instead of M, the entry of all four queries from each
+//            (the same eleven fp32 operations per entry, fvec_L2sqr's order), one 16-byte row written per entry -- conflict-free;
+//   coarse   thread = centre: its code is read ONCE and every one of its M lookups is one ds_read_b128 that returns the entries of
+//            all four queries (sequential fp32 adds over m per query, src/rii.h:375-384): a quarter of the LDS instructions, on
+//            the 64-bank 16-byte path;
+//   select   every wave extracts the w + 1 smallest keys of its 64 centres per query (DPP minima), then ONE WAVE PER QUERY merges
+//            the sixteen waves' picks and evaluates the stop rule of the walk (src/rii.h:283-326) across its lanes -- the four
+//            queries' selections run side by side;
+//   scan     lane l of every wave works for query l mod 4 (the four queries' rows of a table entry lie in four different banks:
+//            neighbouring lanes never collide), four candidates per thread in flight, first minimum in traversal order.
+// A query whose answer could hinge on std::partial_sort's internals (exactly tied coarse distances among the w + 1 picks, a walk
+// past list w) is flagged exactly as in ivf_fused_kernel and redone by the block afterwards with ivf_exact_big_query (its table
+// de-interleaved through registers), or handed to the flag-gated exact kernels when no scratch slice was given.
+// ===================================================================================================
+constexpr int kQuadThreads = 1024;
+constexpr int kQuadQ = 4;
+constexpr int kQuadMaxNlist = 1024;
+constexpr int kQuadR = kFusedMaxW + 1;             // picks per query (w + 1 <= 33)
+
+__global__ __launch_bounds__(kQuadThreads) void ivf_quad_kernel(IvfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = p.M, MK = M * 256;
+    float4 *lds4 = reinterpret_cast<float4 *>(smem);                                     // [MK] rows of four queries' entries
+    float *ldsf = reinterpret_cast<float *>(smem);
+    unsigned char *base = smem + (size_t) MK * 16;
+    unsigned long long *s_wsel = reinterpret_cast<unsigned long long *>(base);           // [4][16][kQuadR] the waves' picks
+    unsigned long long *s_sel = s_wsel + kQuadQ * 16 * kQuadR;                           // [4][kQuadR + 1] the block's picks
+    unsigned long long *s_red = s_sel + kQuadQ * (kQuadR + 1);                           // [4] best (distance, position)
+    int *s_cum = reinterpret_cast<int *>(s_red + kQuadQ);                                // [4][kQuadR + 1]
+    int *s_poff = s_cum + kQuadQ * (kQuadR + 1);                                         // [4][kQuadR + 1]
+    int *s_misc = s_poff + kQuadQ * (kQuadR + 1);                                        // [4][4]: ncand, nv, flag
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nlist = p.nlist, w = (int) p.w;
+    const int64_t q0 = (int64_t) blockIdx.x * kQuadQ;                                    // first query of the block (within the launch group)
+    const int nq = (int) (p.B - q0 < kQuadQ ? p.B - q0 : kQuadQ);                        // live queries (the last block may hold fewer)
+    if (blockIdx.x == 0 && tid == 0 && p.nflag_next) *p.nflag_next = 0;
+    // the code of this thread's centre is requested before anything else: its L2 round trip passes behind the table phase instead of
+    // in front of the coarse scores (-1.3 us of the block's dependent chain)
+    const int MQ = M >> 4;                                                              // 16-byte pieces of a code
+    uint4 cen[2];
+    {
+        const uint4 *cp = reinterpret_cast<const uint4 *>(p.centers + (size_t) (tid < nlist ? tid : 0) * M);
+        cen[0] = cp[0];
+        cen[1] = MQ > 1 ? cp[1] : make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    // ---- tables: thread = (ks, quarter of the subspaces) ----
+    {
+        const int ks = tid & 255, mg = tid >> 8, mper = M >> 2;                          // (mg is wave-uniform: scalar query loads)
+        const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
+        const float4 *qv[kQuadQ];
+#pragma unroll
+        for (int q = 0; q < kQuadQ; ++q)
+            qv[q] = reinterpret_cast<const float4 *>(p.queries + (p.b0 + q0 + (q < nq ? q : 0)) * (int64_t) (M * 4));
+        float4 cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cv[u] = u < mper ? cw4[(mg * mper + u) * 256 + ks] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < mper) {
+                const int m = mg * mper + u;
+                float4 row;
+                row.x = fvec_l2sqr_ds4v(qv[0][m], cv[u]);
+                row.y = fvec_l2sqr_ds4v(qv[1][m], cv[u]);
+                row.z = fvec_l2sqr_ds4v(qv[2][m], cv[u]);
+                row.w = fvec_l2sqr_ds4v(qv[3][m], cv[u]);
+                lds4[m * 256 + ks] = row;
+            }
+        }
+    }
+    __syncthreads();
+    if (p.kcap == 1) return;                              // (measurement only -- option "ivf_dbg_stop": the phases' shares, tools/r5_ivf_phases.py)
+    // ---- coarse scores: thread = centre, four queries per lookup ----
+    const int rounds = (w + 1 < nlist) ? w + 1 : nlist;
+    unsigned long long kkey[kQuadQ] = {~0ull, ~0ull, ~0ull, ~0ull};
+    if (tid < nlist) {
+        const uint4 (&cvv)[2] = cen;
+        float acc[kQuadQ] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+            if (qd < MQ) {
+                const uint32_t wds[4] = {cvv[qd].x, cvv[qd].y, cvv[qd].z, cvv[qd].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 row = lds4[((qd * 4 + i) * 4 + j) * 256 + ((wds[i] >> (8 * j)) & 0xffu)];
+                        acc[0] = __fadd_rn(acc[0], row.x);
+                        acc[1] = __fadd_rn(acc[1], row.y);
+                        acc[2] = __fadd_rn(acc[2], row.z);
+                        acc[3] = __fadd_rn(acc[3], row.w);
+                    }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kQuadQ; ++q) kkey[q] = ((unsigned long long) f32_orderable(__float_as_uint(acc[q])) << 32) | (uint32_t) tid;
+    }
+    // ---- level 1: the `rounds` smallest keys of this wave's 64 centres, per query, ascending (the four queries' DPP ladders in
+    // lockstep: wave_min_u64_x4) ----
+    {
+        unsigned long long mykey[kQuadQ] = {kkey[0], kkey[1], kkey[2], kkey[3]};
+        for (int r = 0; r < rounds; ++r) {
+            unsigned long long got[kQuadQ] = {mykey[0], mykey[1], mykey[2], mykey[3]};
+            wave_min_u64_x4(got);                                                       // ~0 when the wave's centres are exhausted
+#pragma unroll
+            for (int q = 0; q < kQuadQ; ++q) {
+                if (mykey[q] == got[q]) mykey[q] = ~0ull;                               // (keys are distinct: one lane gives its key up)
+                if (lane == 0) s_wsel[(q * 16 + wave) * kQuadR + r] = got[q];
+            }
+        }
+    }
+    __syncthreads();
+    if (p.kcap == 2) return;
+    // ---- level 2 + stop rule: wave q for query q ----
+    if (wave < kQuadQ) {
+        const int q = wave;
+        const int ncnd = 16 * rounds;                                                   // <= 528 keys: up to nine per lane
+        unsigned long long mysel = ~0ull;                                               // lane r keeps pick r
+        auto merge = [&](auto ns) {
+            constexpr int NS = decltype(ns)::value;
+            unsigned long long cand[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int i = lane + 64 * u;                                            // i = wave' * rounds + r
+                cand[u] = i < ncnd ? s_wsel[(q * 16 + i / rounds) * kQuadR + (i % rounds)] : ~0ull;
+            }
+            for (int r = 0; r < rounds; ++r) {
+                unsigned long long best = cand[0];
+#pragma unroll
+                for (int u = 1; u < NS; ++u) best = cand[u] < best ? cand[u] : best;
+                const unsigned long long got = wave_min_u64(best);
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+                    if (cand[u] == got) cand[u] = ~0ull;
+                if (lane == r) mysel = got;
+            }
+        };
+        if (ncnd <= 128) merge(std::integral_constant<int, 2>{}); else merge(std::integral_constant<int, 9>{});
+        // the stop rule of the walk across the lanes (the wave-0 code of ivf_fused_kernel, per query)
+        const int wl = w < nlist ? w : nlist;
+        const uint32_t myhi = (uint32_t) (mysel >> 32);
+        const uint32_t nxhi = (uint32_t) __shfl_down((int) myhi, 1);
+        const bool tied = lane + 1 < rounds && myhi == nxhi;                             // exactly tied coarse distances among the w + 1 picks
+        int len = 0, off = 0;
+        if (lane < wl) {
+            const int no = (int) (mysel & 0xffffffffu);
+            len = p.list_len[no];
+            off = (int) p.pl_off[no];                                                   // N < 2^31
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int excl = incl - len;
+        int flag = (p.force_flag || __ballot(tied) != 0ull) ? 1 : 0;
+        const unsigned long long hit = __ballot(lane < wl && (long long) incl >= p.L);    // first list that completes L candidates
+        int nv = 0;
+        long long cnt = 0;
+        if (hit) {
+            nv = __ffsll((long long) hit);
+            cnt = p.L;
+        } else if ((long long) wl == p.w) {                                             // all w lists walked: enough for topk?
+            const int tot = __shfl(incl, wl - 1);
+            if (tot >= p.topk) { nv = wl; cnt = tot; } else flag = 1;
+        } else flag = 1;                                                                // tail walk / empty return: exact path
+        if (flag) { nv = 0; cnt = 0; }
+        if (q >= nq) { flag = 0; nv = 0; cnt = 0; }                                     // (padding query of the last block)
+        if (lane < wl) s_poff[q * (kQuadR + 1) + lane] = off;
+        if (lane < nv) s_cum[q * (kQuadR + 1) + lane] = excl;
+        if (lane == 0) {
+            s_cum[q * (kQuadR + 1) + nv] = (int) cnt;
+            s_misc[q * 4 + 0] = (int) cnt; s_misc[q * 4 + 1] = nv; s_misc[q * 4 + 2] = flag;
+            s_red[q] = ~0ull;
+            if (q < nq) {
+                const int64_t bl = q0 + q;
+                p.flag[bl] = p.inl_scratch ? 0 : flag;
+                if (flag && p.flag_list && !p.inl_scratch) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
+                if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
+            }
+        }
+    }
+    __syncthreads();
+    if (p.kcap == 3) return;
+    // ---- candidates: lane l works for query l mod 4; thread j = tid / 4 of its query takes positions j, j + 256, ... ----
+    {
+        const int q = tid & 3, j = tid >> 2;
+        const int ncand = s_misc[q * 4 + 0], nv = s_misc[q * 4 + 1];
+        const int *cum = s_cum + q * (kQuadR + 1), *poff = s_poff + q * (kQuadR + 1);
+        float bestd = INFINITY;
+        uint32_t bestp = 0xffffffffu;
+        int32_t bestid = -1;
+        const uint8_t *cbase = p.lcodes ? p.lcodes : p.codes;
+        for (int p0 = j; p0 < ncand; p0 += 4 * 256) {
+            int32_t id[4];                                // lcodes: the posting index; else the posting's id
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pos = p0 + u * 256;
+                id[u] = -1;
+                if (pos < ncand) {
+                    int lo = 0, hi = nv;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (cum[mid] <= pos) lo = mid; else hi = mid;
+                    }
+                    const int pp = poff[lo] + (pos - cum[lo]);
+                    id[u] = p.lcodes ? pp : p.pl_ids[(size_t) pp];
+                }
+            }
+            uint4 cvv[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint4 *cp = reinterpret_cast<const uint4 *>(cbase + (size_t) (id[u] < 0 ? 0 : id[u]) * M);
+                cvv[u][0] = cp[0];
+                cvv[u][1] = MQ > 1 ? cp[1] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float dist = 0.f;
+#pragma unroll
+                for (int qd = 0; qd < 2; ++qd) {
+                    if (qd < MQ) {
+                        const uint32_t wds[4] = {cvv[u][qd].x, cvv[u][qd].y, cvv[u][qd].z, cvv[u][qd].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                dist = __fadd_rn(dist, ldsf[(((qd * 4 + i) * 4 + jj) * 256 + ((wds[i] >> (8 * jj)) & 0xffu)) * 4 + q]);
+                    }
+                }
+                // ascending traversal position: strict < keeps the first minimum
+                if (id[u] >= 0 && dist < bestd) { bestd = dist; bestp = (uint32_t) (p0 + u * 256); bestid = id[u]; }
+            }
+        }
+        const unsigned long long mine = bestp == 0xffffffffu ? ~0ull : (((unsigned long long) f32_orderable(__float_as_uint(bestd)) << 32) | bestp);
+        {                                                 // the wave's minimum per query (its lanes with l mod 4 == qq), in lockstep
+            unsigned long long got[kQuadQ];
+#pragma unroll
+            for (int qq = 0; qq < kQuadQ; ++qq) got[qq] = q == qq ? mine : ~0ull;
+            wave_min_u64_x4(got);
+#pragma unroll
+            for (int qq = 0; qq < kQuadQ; ++qq)
+                if (lane == 0 && got[qq] != ~0ull) atomicMin(&s_red[qq], got[qq]);
+        }
+        __syncthreads();
+        if (mine != ~0ull && mine == s_red[q]) {          // (distance, position) keys are distinct: one winner per query
+            const int64_t bl = q0 + q;
+            p.out_ids[bl] = p.lcodes ? p.pl_ids[(size_t) bestid] : bestid;
+            p.out_dists[bl] = bestd;
+            p.out_counts[bl] = 1;
+        }
+    }
+    // ---- flagged queries (rare): this block redoes them exactly, or hands their tables to the flag-gated exact kernels ----
+    const int f0 = s_misc[2], f1 = s_misc[6], f2 = s_misc[10], f3 = s_misc[14];
+    if (!(f0 | f1 | f2 | f3)) return;
+    {
+        // the flagged queries' tables out of the interleaved rows, through registers (MK / 1024 entries per thread and query)
+        float keep[kQuadQ][8];
+        const int per = MK / kQuadThreads;                // 8 (M = 32) or 4 (M = 16)
+#pragma unroll
+        for (int q = 0; q < kQuadQ; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                keep[q][u] = (u < per && s_misc[q * 4 + 2]) ? ldsf[(size_t) (tid + kQuadThreads * u) * 4 + q] : 0.f;
+        __syncthreads();                                  // every thread has read what it needs of the tables and the selection state
+        for (int q = 0; q < kQuadQ; ++q) {
+            const int fl = q == 0 ? f0 : q == 1 ? f1 : q == 2 ? f2 : f3;
+            if (!fl) continue;
+            const int64_t bl = q0 + q;
+            if (p.inl_scratch) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < per) ldsf[tid + kQuadThreads * u] = q == 0 ? keep[0][u] : q == 1 ? keep[1][u] : q == 2 ? keep[2][u] : keep[3][u];
+                pq64_t *s_head = reinterpret_cast<pq64_t *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));
+                int32_t *xmisc = reinterpret_cast<int32_t *>(s_head + p.inl_hcap);
+                __syncthreads();
+                if (tid == 0) { p.flag[bl] = 0; if (p.nflag) atomicAdd(p.nflag, 1); }       // (the counter: statistics only)
+                ivf_exact_big_query(p, bl, ldsf, s_head, xmisc, p.inl_scratch + p.inl_per_q * (size_t) bl, tid);
+                __syncthreads();
+            } else {
+                float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < per) dst[tid + kQuadThreads * u] = q == 0 ? keep[0][u] : q == 1 ? keep[1][u] : q == 2 ? keep[2][u] : keep[3][u];
+            }
+        }
+    }
+}
+
+static size_t ivf_quad_smem(int M) { return (size_t) M * 256 * 16 + (size_t) kQuadQ * 16 * kQuadR * 8 + (size_t) kQuadQ * (kQuadR + 1) * 8 + kQuadQ * 8 +
+                                            2 * (size_t) kQuadQ * (kQuadR + 1) * 4 + kQuadQ * 4 * 4 + 64; }
+bool ivf_quad_supported(int M, int Ks, int Ds, int nlist, int64_t w, int topk)
+{
+    return topk == 1 && Ds == 4 && Ks == 256 && (M == 16 || M == 32) && nlist <= kQuadMaxNlist && nlist >= 1 && w <= kFusedMaxW &&
+           ivf_quad_smem(M) <= (size_t) 160 * 1024 - 512;
+}
+hipError_t launch_ivf_quad(const IvfParams &p0, hipStream_t st)
+{
+    if (p0.B == 0) return hipSuccess;
+    IvfParams p = p0;                                    // (p.kcap: the caller's debug stop, 0 = none)
+    size_t smem = ivf_quad_smem(p.M);
+    if (p.inl_scratch) {          // the flagged queries' exact replay: plain table + heap over the (dead) interleaved rows
+        p.inl_hcap = ivf_exact_big_heap_cap(p.w, p.topk);
+        smem = std::max(smem, (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15) + (size_t) p.inl_hcap * 8 + 64);
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_quad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    launch_timed(ivf_quad_kernel, dim3((unsigned) ((p.B + kQuadQ - 1) / kQuadQ)), dim3(kQuadThreads), smem, st, p);
+    return hipGetLastError();
+}
+
 // LSEL (selection in LDS): candidates' distances over the coarse scores + a small key buffer (see ivf_fused_kernel)
 constexpr int kFusedSelMaxL = 4096;
 static int ivf_fused_kcap(int topk)

@@ -164,6 +164,37 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long ke
     return ((unsigned long long) mh << 32) | ml;
 }
 
+// Four independent minima at once (round 5: ivf_quad_kernel selects for four queries side by side): the same DPP ladder with the four
+// chains written in lockstep, so every step's four instructions are independent and fill each other's DPP / VALU wait states --
+// four dependent ladders one after the other cost a wave four times the latency of one.
+__device__ __forceinline__ void wave_min_u32_l63_x4(uint32_t (&v)[4])
+{
+#define RII_MIN_STEP4(CTRL, ROWS)                                                                              \
+    {                                                                                                          \
+        uint32_t o[4];                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
+            o[q] = (uint32_t) __builtin_amdgcn_update_dpp((int) 0xffffffffu, (int) v[q], CTRL, ROWS, 0xf, false); \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) v[q] = o[q] < v[q] ? o[q] : v[q];                        \
+    }
+    RII_MIN_STEP4(0x111, 0xf) RII_MIN_STEP4(0x112, 0xf) RII_MIN_STEP4(0x114, 0xf) RII_MIN_STEP4(0x118, 0xf)
+    RII_MIN_STEP4(0x142, 0xa) RII_MIN_STEP4(0x143, 0xc)
+#undef RII_MIN_STEP4
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (uint32_t) __builtin_amdgcn_readlane((int) v[q], 63);
+}
+__device__ __forceinline__ void wave_min_u64_x4(unsigned long long (&key)[4])
+{
+    uint32_t hi[4], mh[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mh[q] = hi[q] = (uint32_t) (key[q] >> 32);
+    wave_min_u32_l63_x4(mh);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lo[q] = hi[q] == mh[q] ? (uint32_t) (key[q] & 0xffffffffu) : 0xffffffffu;
+    wave_min_u32_l63_x4(lo);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) key[q] = ((unsigned long long) mh[q] << 32) | lo[q];
+}
+
 // ---- block-local streaming top-k support (256 threads): LDS key buffer + bitonic sort ----
 constexpr int kRrBuf = 2048;             // LDS key buffer; supports topk <= kRrBuf / 2
 

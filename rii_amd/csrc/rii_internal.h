@@ -126,6 +126,10 @@ hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
 bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk);
 int ivf_fused_sel_cap(int nlist, int64_t w);
 hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st);
+// round 5: four queries per block (tables interleaved [m][ks][query]: one ds_read_b128 scores a centre for four queries); top-1,
+// Ds = 4, Ks = 256, M = 16 / 32, nlist <= 1024, w <= 32; same IvfParams, same flag protocol, no host_flag / q_host_off
+bool ivf_quad_supported(int M, int Ks, int Ds, int nlist, int64_t w, int topk);
+hipError_t launch_ivf_quad(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_select(const IvfParams &p, hipStream_t st);

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.util import make_problem
+from tests.util import make_problem, assert_same_result
 
 pytestmark = pytest.mark.gpu
 E = np.array([], np.int64)
@@ -271,3 +271,47 @@ def test_set_posting_lists_installs_a_given_partition():
     ids_bad[5] = 20000
     with pytest.raises(Exception, match="out of range"):
         g.set_posting_lists(cen, off, ids_bad)
+
+
+@pytest.mark.parametrize("M,scale,nlist", [(32, "sift", 1024), (16, "sift", 300), (32, "unit", 64), (16, "unit", 1), (32, "sift", 37)])
+def test_ivf_quad_kernel_equals_one_query_blocks_and_the_oracle(M, scale, nlist):
+    """ivf_quad_kernel (four queries per block, tables interleaved [m][ks][query]) against ivf_fused_kernel (option ivf_quad = 0) and
+    the oracle: ragged batches (the last block holds 1 - 3 padding queries), every w the shape allows (L from a handful to N),
+    target ids, integer-valued data (exactly tied coarse distances -> flagged queries, replayed inside the block and -- option
+    ivf_inline_exact = 0 -- by the flag-gated exact kernels), every query flagged (ivf_force_exact), rows gathered by id
+    (ivf_list_codes = 0)."""
+    from rii_amd import RiiGpu
+    N = 30011
+    cw, codes, qs = make_problem(900 + M + nlist, M, 256, 4, N, scale, dup=2000 if scale == "sift" else 0)
+    rng = np.random.default_rng(5)
+    Q = np.concatenate([qs, rng.permutation(qs.reshape(-1)).reshape(qs.shape), qs * 0.5, qs[:13] + 1.0]).astype(np.float32)      # 61 queries
+    if scale == "sift":
+        Q = np.round(Q)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    o.reconfigure(nlist, 2)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.set_coarse_centers(np.array(o.coarse_centers, np.uint8))
+    assert g.posting_lists == o.posting_lists
+    tids = np.sort(rng.choice(N, 9000, replace=False)).astype(np.int64)
+    L0 = max(1, N // nlist)
+    n_flagged = 0
+    for B in (61, 16, 33):
+        for L, t in ((L0, None), (max(1, L0 // 3), None), (min(N, 20 * L0), None), (min(9000, 5 * L0), tids), (N, None)):
+            want = [o.query_ivf(Q[b], 1, E if t is None else t, L) for b in range(B)]
+            res = {}
+            for quad, inline, lc, force in ((2, 1, 1, 0), (0, 1, 1, 0), (2, 0, 1, 0), (2, 1, 0, 0), (2, 1, 1, 1), (2, 0, 1, 1)):
+                g.set_option("ivf_quad", quad)
+                g.set_option("ivf_inline_exact", inline)
+                g.set_option("ivf_list_codes", lc)
+                g.set_option("ivf_force_exact", force)
+                gi, gd, gc = g.query_ivf_batch(Q[:B], 1, t, L)
+                res[(quad, inline, lc, force)] = (gi.copy(), gd.copy(), gc.copy())
+                for b in range(B):
+                    n = int(gc[b])
+                    assert_same_result((gi[b, :n], gd[b, :n]), want[b], "ivf quad=%d inline=%d lcodes=%d force=%d M=%d nlist=%d B=%d L=%d b=%d"
+                                       % (quad, inline, lc, force, M, nlist, B, L, b))
+            g.set_option("timing", 0)
+    for k, v in (("ivf_quad", 1), ("ivf_inline_exact", 1), ("ivf_list_codes", 1), ("ivf_force_exact", 0)):
+        g.set_option(k, v)
