@@ -202,6 +202,17 @@ int rii_merge_topk_ex_dev(const void *d_gathered, int G, int64_t B, int k, int k
                           int64_t *d_out_keys, float *d_out_dists, int64_t *d_out_payload, int tie_cols, int32_t *d_out_tie,
                           int32_t *d_out_any, void *stream);
 
+/* The same merge over records that carry a 16-byte header {int64 id offset of the rank's shard, int32 status, int32 pad} in front of
+ * their rows (round 5: the form the sharded entry points below exchange; rii_merge_hdr_record_bytes() = rii_merge_record_bytes() + 16):
+ * any G, any k -- more than 8192 rows per query are sorted in `d_scratch` (rii_merge_hdr_scratch_bytes(), 0 below that) --, the
+ * offsets are read from the headers and added to the non-padding keys, a non-zero status in ANY header poisons every row (keys /
+ * payloads -2, distances NaN; bit 1 of *d_out_any).  Stateless. */
+int64_t rii_merge_hdr_record_bytes(int64_t B, int k, int payload);
+int64_t rii_merge_hdr_scratch_bytes(int G, int64_t B, int k);
+int rii_merge_topk_hdr_dev(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_keys, float *d_out_dists,
+                           int64_t *d_out_payload, int tie_cols, int32_t *d_out_tie, int32_t *d_out_any, void *d_scratch,
+                           int64_t scratch_bytes, void *stream);
+
 /* ---- Multi-GPU behind the C ABI (NEW, round 4; not in the reference: it has no multi-device code) ----
  * One rii_comm per process and GPU = one RCCL communicator (over xGMI inside a node).  RCCL is bound at run time (dlopen of the
  * copy already in the process -- PyTorch-ROCm ships one -- else the system's librccl.so.1); without it rii_comm_init fails with
@@ -325,6 +336,8 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *   "ivf_list_codes"   1 = the fused kernel reads its candidates from a second copy of the codes kept in posting order (+N*M bytes of
  *                      device memory, rebuilt with the lists) [default], 0 = rows gathered by id.  Identical results
  *   "ivf_force_exact"  tests / measurement: 1 = every query of the fused path is flagged [0]
+ *   "ivf_dbg_stop"     measurement only: ivf_quad_kernel returns after its table (1) / coarse (2) / selection (3) phase -- the rows are
+ *                      NOT answers then (tools/r5_ivf_phases.py) [0]
  *   "lanes"            scratch-buffer sets: 2 [default] or 1 (see Threading below)
  *   "timing"           0 [default] / 1 (HIP events around every kernel) / 2 (only around the dominant kernel of a step): rii_timing_read
  * Read-only (rii_get_option): "lut_tile", "n_cu", "cand_total", "cand_max" (debug counters of the last filter pass; synchronise).

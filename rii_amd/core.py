@@ -142,6 +142,9 @@ def _lib():
         "rii_merge_record_bytes": (c_i64, [c_i64, c_int, c_int]),
         "rii_merge_topk_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
         "rii_merge_topk_ex_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, i64p, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+        "rii_merge_hdr_record_bytes": (c_i64, [c_i64, c_int, c_int]),
+        "rii_merge_hdr_scratch_bytes": (c_i64, [c_int, c_i64, c_int]),
+        "rii_merge_topk_hdr_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
         "rii_comm_unique_id": (c_int, [c_vp]),
         "rii_comm_init": (c_int, [c_vp, c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
         "rii_comm_destroy": (None, [c_vp]),
@@ -193,6 +196,22 @@ def merge_topk_ex_dev(d_gathered, G, B, k, k_out, id_offsets, d_out_keys, d_out_
     _check(_lib().rii_merge_topk_ex_dev(d_gathered, int(G), int(B), int(k), int(k_out), int(bool(d_out_payload)), off, d_out_keys,
                                         d_out_dists, d_out_payload or None, int(tie_cols), d_out_tie or None, d_out_any or None,
                                         stream or None))
+
+
+def merge_hdr_record_bytes(B, k, payload=False):
+    return int(_lib().rii_merge_hdr_record_bytes(int(B), int(k), int(bool(payload))))
+
+
+def merge_hdr_scratch_bytes(G, B, k):
+    return int(_lib().rii_merge_hdr_scratch_bytes(int(G), int(B), int(k)))
+
+
+def merge_topk_hdr_dev(d_gathered, G, B, k, k_out, d_out_keys, d_out_dists, d_out_payload=0, tie_cols=0, d_out_tie=0, d_out_any=0,
+                       d_scratch=0, scratch_bytes=0, stream=0):
+    """rii_merge_topk_hdr_dev: the merge of records with the {id offset, status} header (any G, any k)."""
+    _check(_lib().rii_merge_topk_hdr_dev(d_gathered, int(G), int(B), int(k), int(k_out), int(bool(d_out_payload)), d_out_keys, d_out_dists,
+                                         d_out_payload or None, int(tie_cols), d_out_tie or None, d_out_any or None, d_scratch or None,
+                                         int(scratch_bytes), stream or None))
 
 
 def ivf_shard_replay_scratch_bytes(nf, rows):

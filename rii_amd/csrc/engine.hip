@@ -2272,6 +2272,31 @@ RII_API int rii_merge_topk_ex_dev(const void *d_gathered, int G, int64_t B, int 
     return RII_OK;
 }
 
+// The merge of records that carry the 16-byte header {int64 id offset of the rank's shard, int32 status, pad} in front of the rows
+// (round 5): what rii_query_linear_dbsharded_dev / rii_query_ivf_dbsharded_dev run behind their all-gather, for callers that run the
+// collective themselves -- any G, any k (more than 8192 rows per query are sorted in d_scratch: rii_merge_hdr_scratch_bytes()), the
+// shard offsets read from the headers, a non-zero status anywhere poisons every row (ids -2, distances NaN; bit 1 of *d_out_any).
+RII_API int64_t rii_merge_hdr_record_bytes(int64_t B, int k, int payload) { return (B < 0 || k < 1) ? -1 : (int64_t) merge_record_bytes(B, k, payload) + kRecHeader; }
+RII_API int64_t rii_merge_hdr_scratch_bytes(int G, int64_t B, int k) { return (G < 1 || B < 0 || k < 1) ? -1 : (int64_t) merge_topk_scratch(G, B, k); }
+RII_API int rii_merge_topk_hdr_dev(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_keys, float *d_out_dists,
+                                   int64_t *d_out_payload, int tie_cols, int32_t *d_out_tie, int32_t *d_out_any, void *d_scratch,
+                                   int64_t scratch_bytes, void *stream)
+{
+    if (!d_gathered || G < 1 || B < 0 || k < 1 || k_out < 1 || (int64_t) k_out > (int64_t) G * k || (int64_t) G * k >= ((int64_t) 1 << 31) ||
+        (B > 0 && (!d_out_keys || !d_out_dists)) || (payload && B > 0 && !d_out_payload) || tie_cols < 0 || tie_cols > k_out)
+        return set_err(RII_ERR_INVALID, "bad arguments");
+    const size_t need = merge_topk_scratch(G, B, k);
+    if (need && (!d_scratch || scratch_bytes < (int64_t) need))
+        return set_err(RII_ERR_INVALID, "%d x %d rows per query need %lld bytes of scratch (rii_merge_hdr_scratch_bytes)", G, k, (long long) need);
+    if (k == 1 && k_out == 1 && !payload && !d_out_tie && !d_out_any) {            // one row per rank: one thread per query (comm.hip)
+        HIP_TRY(launch_merge_top1(d_gathered, G, B, nullptr, d_out_keys, d_out_dists, (hipStream_t) stream, kRecHeader));
+        return RII_OK;
+    }
+    HIP_TRY(launch_merge_topk(d_gathered, G, B, k, k_out, payload, d_out_keys, d_out_dists, d_out_payload, (hipStream_t) stream, nullptr, tie_cols,
+                              d_out_tie, d_out_any, kRecHeader, d_scratch));
+    return RII_OK;
+}
+
 // Query sharding, for callers that run the collective themselves: the record of a rank and the unpack of the G gathered records
 // (what rii_query_*_qsharded_dev do internally).  Stateless.
 RII_API int64_t rii_qshard_begin(int64_t B, int G, int rank) { return (G < 1 || rank < 0 || rank > G || B < 0) ? -1 : qshard_begin(B, G, rank); }

@@ -1669,6 +1669,35 @@ __device__ __forceinline__ void fs_mx_pattern(int i, v4i_t &a, int &idx)
 }
 
 typedef const __attribute__((address_space(3))) v4i_t *fs_lds_row_t;
+// A fresh accumulator for the sparse matrix instruction (it accumulates in place: D = A x B + D).  Round 5: two v_pk_mov_b32 (one
+// 64-bit register pair each) instead of the four v_mov_b32 the compiler writes for `acc = zero` -- per group of 16 codes that is
+// 2 of 14 (M = 32) / 4 of 20 (two M = 16 tiles) vector instructions fewer on an issue port that is co-limiting with the LDS.
+#ifndef RII_PK_ZERO
+#define RII_PK_ZERO 1
+#endif
+typedef int fs_v2i_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4i_t fs_acc_init(const v4i_t &zero)
+{
+#if RII_PK_ZERO
+    const fs_v2i_t zl = __builtin_shufflevector(zero, zero, 0, 1), zh = __builtin_shufflevector(zero, zero, 2, 3);
+    fs_v2i_t lo, hi;
+    asm volatile("v_pk_mov_b32 %0, %2, %2 op_sel:[0,1]\n\tv_pk_mov_b32 %1, %3, %3 op_sel:[0,1]" : "=v"(lo), "=v"(hi) : "v"(zl), "v"(zh));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+#else
+    return zero;
+#endif
+}
+// the same from the inline constant 0 (tables with unsigned bytes: no bias, no zero registers kept)
+__device__ __forceinline__ v4i_t fs_acc_init0()
+{
+#if RII_PK_ZERO
+    fs_v2i_t lo, hi;
+    asm volatile("v_pk_mov_b32 %0, 0, 0\n\tv_pk_mov_b32 %1, 0, 0" : "=v"(lo), "=v"(hi));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+#else
+    return v4i_t{0, 0, 0, 0};
+#endif
+}
 // The lookups are the code bytes themselves (one byte per row to fetch).  The LDS address of the row of lookup t is
 //     (half << 16) | (ks << 8) | (slot << 4)          (rotated layout: row = half * 4096 + ks * 16 + slot, 16 bytes each;
 // dynamic LDS starts at address 0 in this kernel); half and slot depend on the lane and on t only, so they sit in T registers per
@@ -1733,10 +1762,10 @@ template <int T> __device__ __forceinline__ void fs_mx_issue_hot(const typename 
 // one group: the rows in r[] (already waited for) go through the matrix core pair by pair, and as soon as a pair has been
 // issued its registers take the rows of the group two ahead (lookups wn) -- the reads travel under the remaining matrix
 // instructions and the whole next group
-template <int T> __device__ __forceinline__ v4i_t fs_mx_reduce_refill(v4i_t (&r)[T], const typename FsMxW<T>::V &wn, const uint32_t (&C)[T],
+template <int T, bool Z0 = false> __device__ __forceinline__ v4i_t fs_mx_reduce_refill(v4i_t (&r)[T], const typename FsMxW<T>::V &wn, const uint32_t (&C)[T],
                                                                       const v4i_t &spa, int spidx, const v4i_t &zero)
 {
-    v4i_t acc = zero;
+    v4i_t acc = Z0 ? fs_acc_init0() : fs_acc_init(zero);
     {
         const v8i_t b = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3, 4, 5, 6, 7);
         acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, acc, spidx, 0, 0);
@@ -1877,7 +1906,7 @@ template <int U, int PENDING> __device__ __forceinline__ void fs_mx_step8(v2i_t 
 template <int PENDING> __device__ __forceinline__ v4i_t fs_mx_group8(v2i_t (&r)[16], const u32x4 &wn, const uint32_t (&K)[6], const v4i_t &spa, int spidx,
                                                                      const v4i_t &zero)
 {
-    v4i_t acc = zero;
+    v4i_t acc = fs_acc_init(zero);
     fs_mx_step8<0, PENDING>(r, acc, wn, K, spa, spidx);
     fs_mx_step8<1, PENDING>(r, acc, wn, K, spa, spidx);
     fs_mx_step8<2, PENDING>(r, acc, wn, K, spa, spidx);
@@ -2297,12 +2326,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                         auto settle = [&](const v4i_t &a, uint32_t nn) { if (MODE == 1) take_min(a); else judge(a, thr, nn); };
                         fs_mx_vmwait<3>(q[2]);
                         fs_mx_wait<T>(ra);                                    // group 0 (the T younger reads are group 1's)
-                        const v4i_t acc0 = fs_mx_reduce_refill<T>(ra, q[2], C, spa, spidx, zz);   // ... refilled with group 2's rows
+                        const v4i_t acc0 = fs_mx_reduce_refill<T, ZLIT>(ra, q[2], C, spa, spidx, zz);   // ... refilled with group 2's rows
                         fs_mx_load<2 * S>(q[2], pn);
                         if constexpr (ZLIT) settle(accp, np); else settle(acc0, n);
                         fs_mx_vmwait<3>(q[3]);
                         fs_mx_wait<T>(rb);                                    // group 1
-                        const v4i_t acc1 = fs_mx_reduce_refill<T>(rb, q[3], C, spa, spidx, zz);
+                        const v4i_t acc1 = fs_mx_reduce_refill<T, ZLIT>(rb, q[3], C, spa, spidx, zz);
                         fs_mx_load<3 * S>(q[3], pn);
                         if constexpr (ZLIT) settle(acc0, n); else settle(acc1, n + 16);
                         // thresholds: re-read once per trip, straight into the registers group 2 may still be comparing against -- any mix
@@ -2310,12 +2339,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_kernel(FsArgs p)
                         if constexpr (MODE == 0) asm volatile("ds_read_b128 %0, %1 ; rii:inflight-ok (tools/check_isa_inflight.py)" : "+v"(thr) : "v"(thr_addr));
                         fs_mx_vmwait<3>(q[0]);
                         fs_mx_wait<(MODE == 0) ? T + 1 : T>(ra);              // group 2 (younger: group 3's rows and the thresholds)
-                        const v4i_t acc2 = fs_mx_reduce_refill<T>(ra, q[0], C, spa, spidx, zz);   // next trip's group 0
+                        const v4i_t acc2 = fs_mx_reduce_refill<T, ZLIT>(ra, q[0], C, spa, spidx, zz);   // next trip's group 0
                         fs_mx_load<0>(q[0], pnn);
                         if constexpr (ZLIT) settle(acc1, n + 16); else settle(acc2, n + 32);
                         fs_mx_vmwait<3>(q[1]);
                         fs_mx_wait<T>(rb);                                    // group 3 (and the thresholds: older than group 2's refills)
-                        const v4i_t acc3 = fs_mx_reduce_refill<T>(rb, q[1], C, spa, spidx, zz);
+                        const v4i_t acc3 = fs_mx_reduce_refill<T, ZLIT>(rb, q[1], C, spa, spidx, zz);
                         fs_mx_load<S>(q[1], pnn);
                         if constexpr (ZLIT) { settle(acc2, n + 32); accp = acc3; np = n + 48; } else settle(acc3, n + 48);
                         adopt(false);
@@ -2477,7 +2506,7 @@ __device__ __forceinline__ void fs_mx_issue_hot_dual(uint32_t w, const uint32_t 
 __device__ __forceinline__ void fs_mx_reduce_refill_dual(v4i_t (&r)[8], uint32_t wn, const uint32_t (&C)[8], const v4i_t &spa, int spidx,
                                                          const v4i_t &zero, v4i_t &accA, v4i_t &accB)
 {
-    accA = zero;
+    accA = fs_acc_init(zero);
     {
         const v8i_t b = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3, 4, 5, 6, 7);
         accA = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, accA, spidx, 0, 0);
@@ -2488,7 +2517,7 @@ __device__ __forceinline__ void fs_mx_reduce_refill_dual(v4i_t (&r)[8], uint32_t
         accA = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, accA, spidx, 0, 0);
         fs_mx_issue2<2>(wn, C[2], C[3], r[2], r[3]);
     }
-    accB = zero;
+    accB = fs_acc_init(zero);
     {
         const v8i_t b = __builtin_shufflevector(r[4], r[5], 0, 1, 2, 3, 4, 5, 6, 7);
         accB = __builtin_amdgcn_smfmac_i32_16x16x128_i8(spa, b, accB, spidx, 0, 0);

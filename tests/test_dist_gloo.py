@@ -657,28 +657,45 @@ def test_bench_runs_under_torchrun_world1_with_rccl():
         assert line["strong"][form]["ms_per_step"] > 0 and line["strong"][form]["results_match_single_engine"] is True, line["strong"]
 
 
-def _bench_two_ranks(cmd_prefix, extra_env):
+def _bench_two_ranks(cmd_prefix, extra_env, world=2, n_base=100000, batch=1024, timeout=300):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RII_BENCH_BACKEND="gloo", RII_BENCH_DEVICE="0", **extra_env)
     env.pop("WORLD_SIZE", None)
-    cmd = cmd_prefix(sys.executable, os.path.join(root, "bench.py")) + ["--gpus", "2", "--steps", "2", "--warmup", "1", "--n-base",
-                                                                        "100000", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    cmd = cmd_prefix(sys.executable, os.path.join(root, "bench.py")) + ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-base",
+                                                                        str(n_base), "--batch", str(batch), "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2048 and line["scaling"] == "weak"
+    assert line["n_gpus"] == world and line["config"]["global_batch"] == batch * world and line["scaling"] == "weak"
     assert line["with_gather"]["ms_per_step"] > 0 and line["value"] > 0
-    # strong scaling: ONE global batch of 1024 over the two ranks, both decompositions, answers equal to the single engine's
+    # strong scaling: ONE global batch over the ranks (ragged slices when it does not divide), both decompositions, answers equal to
+    # the single engine's
     st = line["strong"]
-    assert st["query_sharded"]["rows_per_rank"] == [512, 512] and st["query_sharded"]["results_match_single_engine"] is True
-    assert st["db_sharded"]["codes_per_rank"] == 50000 and st["db_sharded"]["results_match_single_engine"] is True
+    from rii_amd.dist import shard_range
+    assert st["query_sharded"]["rows_per_rank"] == [shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world)]
+    assert st["query_sharded"]["results_match_single_engine"] is True, st["query_sharded"]
+    assert st["db_sharded"]["codes_per_rank"] == shard_range(n_base, 0, world)[1] and st["db_sharded"]["results_match_single_engine"] is True, st["db_sharded"]
     assert st["query_sharded"]["ms_per_step"] > 0 and st["db_sharded"]["ms_per_step"] > 0
     return line
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_preflight_on_one_gpu():
+    """The driver's 8-GPU launch line (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`) rehearsed on the one GPU of the test
+    box (collectives on gloo, a reduced index and a batch that does NOT divide by eight: ragged query slices, shards of unequal
+    size): the broadcast of the inputs, strong.query_sharded / strong.db_sharded with results_match_single_engine, one JSON line --
+    inside a fraction of the driver's time limit."""
+    import time
+    t0 = time.time()
+    line = _bench_two_ranks(lambda py, bench: [py, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                                               "127.0.0.1", "--master-port", str(_free_port()), bench], {}, world=8, n_base=60001, batch=1020, timeout=600)
+    assert time.time() - t0 < 600
+    assert line["strong"]["query_sharded"]["rows_per_rank"] == [128, 128, 128, 128, 127, 127, 127, 127]
 
 
 @pytest.mark.gpu

@@ -315,3 +315,64 @@ def test_ivf_quad_kernel_equals_one_query_blocks_and_the_oracle(M, scale, nlist)
             g.set_option("timing", 0)
     for k, v in (("ivf_quad", 1), ("ivf_inline_exact", 1), ("ivf_list_codes", 1), ("ivf_force_exact", 0)):
         g.set_option(k, v)
+
+
+def test_header_merge_for_many_fake_ranks():
+    """rii_merge_topk_hdr_dev = what the database-sharded entry points run behind their all-gather, on records built by hand for
+    G = 2 ... 70 fake ranks: shard offsets read from the 16-byte record headers (more than the 64 by-value offsets of round 4), the
+    one-thread-per-query top-1 form, the LDS sort, the global-scratch sort (G x k > 8192 rows), exact ties across ranks ordered by
+    global id, padding rows, tie flags -- and a non-zero status in one header poisoning the whole batch on every rank."""
+    import torch
+    from rii_amd import core
+    rng = np.random.default_rng(12)
+    for G, B, k in ((2, 5, 1), (3, 4, 7), (8, 3, 2000), (70, 6, 1), (70, 2, 3), (5, 2, 1700)):
+        offs = np.sort(rng.choice(10**9, G, replace=False)).astype(np.int64)
+        ids = np.stack([np.sort(rng.choice(50000, (B, k)), axis=1) for _ in range(G)]).astype(np.int64)          # local ids
+        d = np.sort(rng.integers(0, 40, size=(G, B, k)).astype(np.float32), axis=2)                             # many exact ties across ranks
+        pad = rng.random((G, B, k)) < 0.05                                                                       # padding rows: key 2^62, +inf
+        pad[:, :, 0] = False
+        d[pad] = np.inf
+        ids[pad] = np.iinfo(np.int64).max // 2
+        d = np.sort(d, axis=2)
+        rec = core.merge_hdr_record_bytes(B, k)
+        assert rec == core.merge_record_bytes(B, k) + 16
+        buf = torch.zeros((G, rec), dtype=torch.uint8)
+        for g in range(G):
+            buf[g, :8] = torch.from_numpy(offs[g:g + 1]).view(torch.uint8)
+            buf[g, 16:16 + B * k * 8] = torch.from_numpy(np.ascontiguousarray(ids[g])).reshape(-1).view(torch.uint8)
+            buf[g, 16 + B * k * 8:16 + B * k * 12] = torch.from_numpy(np.ascontiguousarray(d[g])).reshape(-1).view(torch.uint8)
+        dbuf = buf.cuda()
+        k_out = k if k == 1 else min(G * k, k + 1)
+        oi = torch.empty((B, k_out), dtype=torch.int64, device="cuda")
+        od = torch.empty((B, k_out), dtype=torch.float32, device="cuda")
+        tie = torch.empty(B, dtype=torch.int32, device="cuda")
+        anyf = torch.zeros(1, dtype=torch.int32, device="cuda")
+        nsc = core.merge_hdr_scratch_bytes(G, B, k)
+        assert (nsc > 0) == (G * k > 8192)
+        scratch = torch.empty(max(nsc, 16), dtype=torch.uint8, device="cuda")
+        if k == 1:
+            core.merge_topk_hdr_dev(dbuf.data_ptr(), G, B, 1, 1, oi.data_ptr(), od.data_ptr())
+        else:
+            core.merge_topk_hdr_dev(dbuf.data_ptr(), G, B, k, k_out, oi.data_ptr(), od.data_ptr(), tie_cols=k_out, d_out_tie=tie.data_ptr(),
+                                    d_out_any=anyf.data_ptr(), d_scratch=scratch.data_ptr(), scratch_bytes=nsc)
+        torch.cuda.synchronize()
+        for b in range(B):
+            rows = sorted((float(d[g, b, j]), int(ids[g, b, j] + (0 if pad[g, b, j] else offs[g]))) for g in range(G) for j in range(k))[:k_out]
+            assert [r[0] for r in rows] == od[b].cpu().tolist(), (G, B, k, b)
+            assert [r[1] for r in rows] == oi[b].cpu().tolist(), (G, B, k, b)
+            if k > 1:
+                want_tie = int(any(rows[j][0] == rows[j + 1][0] and np.isfinite(rows[j + 1][0]) for j in range(k_out - 1)))
+                assert int(tie[b].item()) == want_tie
+        # one rank reports a failure: every row of the batch is poisoned, bit 1 of the word says so
+        buf[G // 2, 8:12] = torch.tensor([7], dtype=torch.int32).view(torch.uint8)
+        dbuf = buf.cuda()
+        anyf.zero_()
+        if k == 1:
+            core.merge_topk_hdr_dev(dbuf.data_ptr(), G, B, 1, 1, oi.data_ptr(), od.data_ptr())
+        else:
+            core.merge_topk_hdr_dev(dbuf.data_ptr(), G, B, k, k_out, oi.data_ptr(), od.data_ptr(), tie_cols=k_out, d_out_tie=tie.data_ptr(),
+                                    d_out_any=anyf.data_ptr(), d_scratch=scratch.data_ptr(), scratch_bytes=nsc)
+        torch.cuda.synchronize()
+        assert bool((oi == -2).all()) and bool(torch.isnan(od).all())
+        if k > 1:
+            assert int(anyf.item()) & 2 and int(tie.sum().item()) == 0
