@@ -579,7 +579,8 @@ def roofline_ivf_shard(kernel, B, nlist, M, L, avg_s, launches, steps):
     alg = B * (nlist * M + L * (M + 4))
     r = roofline_hbm(kernel, alg, avg_s, launches, steps, None)
     r["note"] = ("algorithmic bytes = B x (nlist x M centre bytes + L x (M + 4) candidate bytes); one block per query: table staged, "
-                 "coarse scores, std::partial_sort of the coarse order by wave 0, the global walk by one lane, then the owned candidates")
+                 "coarse scores, std::partial_sort of the coarse order by wave 0, the global walk by one lane, then the owned candidates "
+                 "(rows read from the posting-order copy of the codes: one coalesced run per visited list)")
     return r
 
 
@@ -776,7 +777,7 @@ def deep_ivf_on(eng, comm, args, torch, dev, barrier, q, n_shard, n_global, rank
     plain = timed_loop(step, steps, barrier)
     k_ms, k_n = dom["ivf_shard"]
     avg_s = (k_ms / max(steps, 1)) * 1e-3
-    roof = roofline_ivf_shard("ivf_shard_any_kernel" if L > 8192 else "ivf_shard_kernel", B, nlist, M, L, avg_s, k_n, steps)
+    roof = roofline_ivf_shard("ivf_shard_any_kernel" if (L > 8192 or topk == 1) else "ivf_shard_kernel", B, nlist, M, L, avg_s, k_n, steps)
     roof.update(shares)
     obj = {"config": "Deep1B-shaped database-sharded inverted index: D=96 M=16 Ks=256, %d codes per GPU (%d in all), nlist=%d "
                      "(= sqrt(N)), L=%d (= N / nlist), batch=%d, topk=%d" % (n_shard, n_global, nlist, L, B, topk),

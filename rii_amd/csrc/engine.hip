@@ -2086,6 +2086,13 @@ int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk,
         pl_ids = e->s_fids.as<int32_t>();
         list_len = e->s_flen.as<int32_t>();
     }
+    // unfiltered lists: the posting-order copy of the codes (option ivf_list_codes, shared with the fused kernels) makes a list's
+    // candidates one coalesced run; where it does not fit the kernel gathers by id
+    const uint8_t *lcodes = nullptr;
+    if (S_global == 0 && e->ivf_list_codes) {
+        if (sync_list_codes(e, st) == RII_OK) lcodes = e->d_lcodes.as<uint8_t>();
+        else (void) hipGetLastError();
+    }
     // nlist or L past the LDS limits: coarse order + cumulative counts of a query in global scratch, <= 256 MiB per launch
     const size_t per_q = ivf_shard_scratch_per_query(e->M, e->Ks, (int) nlist, L, w);
     const int64_t step = per_q ? std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, ((int64_t) 256 << 20) / (int64_t) per_q)) : kMaxBatch;
@@ -2093,12 +2100,15 @@ int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk,
     for (int64_t b0 = 0; b0 < B; b0 += step) {
         const int64_t cur = std::min<int64_t>(step, B - b0);
         const int64_t D = (int64_t) e->M * e->Ds;
-        RII_TRY(build_lut(e, d_queries + b0 * D, cur, st, false, 1));
+        // round 5: the any-L kernel builds its query's exact table itself (exact mode): no table launch, no table round trip
+        const bool own_tables = e->lut_mode == RII_LUT_EXACT && ivf_shard_builds_tables(e->M, e->Ks, (int) nlist, L, w, rows);
+        if (!own_tables) RII_TRY(build_lut(e, d_queries + b0 * D, cur, st, false, 1));
         ScopedTimer t(e, "ivf_shard", st);
-        HIP_TRY(launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
+        HIP_TRY(launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, own_tables ? nullptr : e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
                                  e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
                                  d_out_ids + b0 * (int64_t) rows, d_out_dists + b0 * (int64_t) rows, d_out_pos + b0 * (int64_t) rows,
-                                 d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st));
+                                 d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st,
+                                 own_tables ? d_queries + b0 * D : nullptr, e->d_codewords.as<float>(), e->Ds, e->arch, lcodes));
     }
     return RII_OK;
 }

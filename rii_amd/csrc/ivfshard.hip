@@ -33,6 +33,12 @@ struct ShardArgs {
     int rows;                            // output rows per query: topk + 1, or L (every owned candidate: tie replay)
     int64_t *out_ids; float *out_dists; int32_t *out_pos; int32_t *out_nloc; int64_t *out_counts;
     unsigned char *scratch; size_t per_block;      // BIG: [nlist] pq64 + [nlist + 1] int32 per block
+    // round 5, ivf_shard_any_kernel: non-NULL = the block builds its query's exact table itself from (queries, codewords) -- no table
+    // launch in front of the kernel, no 4 M Ks bytes per query written to and read back from global memory (as ivf_fused_kernel does)
+    const float *queries = nullptr; const float *codewords = nullptr; int Ds = 0, arch = 0;
+    // round 5, ivf_shard_any_kernel: the codes in POSTING order (row pp = the code of posting pp of pl_ids: the engine's lcodes copy,
+    // unfiltered lists only) -- a list's candidates are one contiguous, coalesced run instead of one random 64-byte HBM sector each
+    const uint8_t *lcodes = nullptr;
 };
 
 // BIG (nlist above kShardMaxNlistLds -- the reference's default sqrt(N) is 11 k lists at a 125 M-code shard): the coarse order and
@@ -198,13 +204,47 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     int32_t *s_cum = CLDS ? s_cum_lds : reinterpret_cast<int32_t *>(mine + (size_t) nlist * 8);    // [nlist + 1] cumulative GLOBAL counts
 
     if constexpr (!GTAB) {
-        const float *src = p.lut + (size_t) b * MK;
-        for (int i = tid; i < MK; i += 256) lds[i] = src[i];
+        if (p.queries) {                                                              // RiiCpp::DTable, src/rii.h:361-373 (fvec_L2sqr's order)
+            const float *q = p.queries + b * (int64_t) (p.M * p.Ds);
+            if (p.Ds == 4 && p.Ks == 256) {                                           // thread = ks: the sub-vector is block-uniform, 16 loads in flight
+                const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
+                const float4 *q4 = reinterpret_cast<const float4 *>(q);
+                for (int m0 = 0; m0 < p.M; m0 += 16) {
+                    float4 cv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) cv[u] = (m0 + u < p.M) ? cw4[(m0 + u) * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (m0 + u < p.M) lds[(m0 + u) * 256 + tid] = fvec_l2sqr_ds4v(q4[m0 + u], cv[u]);
+                }
+            } else {
+                for (int m = 0; m < p.M; ++m) {
+                    const float *qm = q + (size_t) m * p.Ds;
+                    const float *cm = p.codewords + (size_t) m * p.Ks * p.Ds;
+                    for (int ks = tid; ks < p.Ks; ks += 256) lds[m * p.Ks + ks] = fvec_l2sqr_any(qm, cm + (size_t) ks * p.Ds, p.Ds, p.arch);
+                }
+            }
+        } else {
+            const float *src = p.lut + (size_t) b * MK;
+            for (int i = tid; i < MK; i += 256) lds[i] = src[i];
+        }
     }
     __syncthreads();
-    for (int c = tid; c < nlist; c += 256) {                                          // src/rii.h:262-264
-        const pq64_t e = pq64_make(exact_adist(tab, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
-        if (!CLDS && w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
+    for (int c0 = tid; c0 < nlist; c0 += 4 * 256) {                                   // src/rii.h:262-264; four centres' codes in flight per thread
+        float dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 256;
+            dv[u] = c < nlist ? exact_adist(tab, p.centers + (size_t) c * p.M, p.M, p.Ks) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 256;
+            if (c < nlist) {
+                const pq64_t e = pq64_make(dv[u], (uint32_t) c);
+                if (!CLDS && w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
+            }
+        }
     }
     __syncthreads();
     if constexpr (CLDS) {
@@ -285,20 +325,24 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             if (own == 0) continue;
             const int lpos = s_lpos[l];
             const int32_t *ids = p.pl_ids + s_loff[l];
+            const uint8_t *lrows = p.lcodes ? p.lcodes + (size_t) s_loff[l] * p.M : nullptr;
             for (int base_li = 0; base_li < own; base_li += kShardRound) {
                 // a thread reads the fill behind its own insertions of the round before, not behind everyone's: up to one round
                 // short of the truth, hence two rounds of slack; the OR makes the decision the block's
                 if (!TOP1 && !collect && __syncthreads_or(s_misc[3] + 2 * kShardRound > nbuf)) flush();
                 int32_t idv[kShardUnroll];
 #pragma unroll
-                for (int u = 0; u < kShardUnroll; ++u) {                              // the ids of the round first ...
-                    const int li = base_li + u * 256 + tid;
-                    idv[u] = li < own ? ids[li] : -1;
+                for (int u = 0; u < kShardUnroll; ++u) {                              // the ids of the round first (posting-order rows: only
+                    const int li = base_li + u * 256 + tid;                            //  the collect form needs them at all) ...
+                    idv[u] = li < own ? ((lrows && !collect) ? 0 : ids[li]) : -1;
                 }
                 float dv[kShardUnroll];
 #pragma unroll
-                for (int u = 0; u < kShardUnroll; ++u)                                // ... then their rows (independent gathers in flight)
-                    dv[u] = idv[u] >= 0 ? exact_adist(tab, p.codes + (size_t) idv[u] * p.M, p.M, p.Ks) : 0.f;
+                for (int u = 0; u < kShardUnroll; ++u) {                              // ... then their rows (independent loads in flight)
+                    const int li = base_li + u * 256 + tid;
+                    const uint8_t *row = lrows ? lrows + (size_t) li * p.M : p.codes + (size_t) idv[u] * p.M;
+                    dv[u] = idv[u] >= 0 ? exact_adist(tab, row, p.M, p.Ks) : 0.f;
+                }
 #pragma unroll
                 for (int u = 0; u < kShardUnroll; ++u) {
                     if (idv[u] < 0) continue;
@@ -567,13 +611,20 @@ size_t ivf_shard_scratch_per_query(int M, int Ks, int nlist, int64_t L, int64_t 
     return (shard_big(nlist) || !shard_any_clds(M, Ks, nlist)) ? ((size_t) nlist * 12 + 4 + 63) / 64 * 64 : 0;
 }
 
+// true: launch_ivf_shard will run the kernel that builds its tables itself when handed (queries, codewords) instead of d_lut
+bool ivf_shard_builds_tables(int M, int Ks, int nlist, int64_t L, int64_t w, int rows)
+{
+    return !shard_gtab(M, Ks) && shard_use_any(M, Ks, nlist, L, w, rows);
+}
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
-                            int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st)
+                            int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st,
+                            const float *d_queries, const float *d_codewords, int Ds, int arch, const uint8_t *d_lcodes)
 {
     if (B == 0) return hipSuccess;
     ShardArgs a;
+    a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch; a.lcodes = d_lcodes;
     a.codes = d_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.centers = d_centers; a.nlist = nlist; a.pl_off = d_pl_off;
     a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w; a.rows = rows;
     a.out_ids = d_out_ids; a.out_dists = d_out_dists; a.out_pos = d_out_pos; a.out_nloc = d_out_nloc; a.out_counts = d_out_counts;
