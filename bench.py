@@ -933,6 +933,8 @@ def main_deep(args, world, rank, local, dev, arch):
 
 def main():
     global PREHEAT_S
+    t_start = time.perf_counter()
+    wall = {}
     args = parse()
     PREHEAT_S = max(0.0, args.preheat)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1078,6 +1080,7 @@ def main():
     # first exactly what the contract's wording gives from an idle GPU (W warm-up + K timed steps, clocks still ramping) ...
     for _ in range(args.warmup):
         step()
+    wall["setup_s"] = time.perf_counter() - t_start          # imports, synthetic data, codebooks, encoding, ground truth, index upload
     cold = timed_loop(step, args.steps, barrier)
     # ... then the steady state: pre-heat, W warm-up steps, K timed steps (this is `value`)
     elapsed, dom, extra = measure(eng, step, args.steps, args.warmup, barrier, torch.cuda.synchronize)
@@ -1292,7 +1295,9 @@ def main():
             shape = ["--workload", args.workload, "--batch", str(B), "--topk", str(topk), "--scan-mode", str(args.scan_mode),
                      "--scan-mx", str(args.scan_mx), "--scan-order", str(args.scan_order), "--lut-mode", args.lut_mode,
                      "--n-base", str(N), "--M", str(M), "--nlist", str(args.nlist), "--L", str(args.L)]
+            t_lc = time.perf_counter()
             lc = live_counters(roof["kernel"], shape)
+            wall["live_counters_s"] = time.perf_counter() - t_lc
             if "FETCH_SIZE" in lc and "WRITE_SIZE" in lc:
                 # counters are in KB; FETCH_SIZE reports half of a wide coalesced stream on gfx950 (MI355X guide): doubled
                 traffic = int((2.0 * lc["FETCH_SIZE"] + lc["WRITE_SIZE"]) * 1024.0)
@@ -1371,6 +1376,7 @@ def main():
             what = {"linear": "full %d-code linear scan" % N, "subset": "linear scan of %d target ids" % S,
                     "ivf": "inverted index nlist=%d L=%d" % (nlist_main, L),
                     "subset-ivf": "inverted index nlist=%d L=%d over %d target ids" % (nlist_main, L, S)}
+            t_cb = time.perf_counter()
             try:
                 cb, cpu_res = cpu_baseline("ivf" if ivf else "linear", what[args.workload], reference_factory(eng, cw, codes, arch, ivf),
                                            my_q.cpu().numpy(), topk, h_tids, L)
@@ -1378,6 +1384,7 @@ def main():
             except Exception as ex:                              # noqa: BLE001 -- the measured line above must still be printed
                 cb = {"error": "%s: %s" % (type(ex).__name__, ex)}
             line["cpu_baseline"] = cb
+            wall["cpu_baseline_s"] = time.perf_counter() - t_cb
         # every other BASELINE config in the same process (default invocation only: the SIFT-shaped legs reuse this index)
         if world == 1 and not use_dist and not args.no_others and args.workload == "linear" and topk == 1:
             others = {}
@@ -1402,6 +1409,9 @@ def main():
                 others["deep_shard"] = guarded(deep_shard_workload, args, torch, dev, arch, barrier)
             others["seconds_spent"] = time.perf_counter() - t_oth
             line["others"] = others
+            wall["others_s"] = others["seconds_spent"]
+        wall["total_s"] = time.perf_counter() - t_start
+        line["wall_clock"] = wall
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -567,8 +567,10 @@ static size_t shard_tab_bytes(int M, int Ks) { return shard_gtab(M, Ks) ? 0 : ((
 // 1024-key buffer
 static bool shard_any_clds(int M, int Ks, int nlist)
 {
+    // ... and only while FOUR blocks still fit a CU (40 KiB each): a 1024-query batch is then one round of blocks, not two -- above
+    // that the order goes to global scratch (its tail is read eight slices ahead: two round trips for 1024 lists)
     return !shard_big(nlist) &&
-           shard_tab_bytes(M, Ks) + (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 + shard_any_misc() + 1024 * 8 <= (size_t) 160 * 1024 - 512;
+           shard_tab_bytes(M, Ks) + (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 + shard_any_misc() + 64 <= (size_t) 40 * 1024 - 128;
 }
 static size_t shard_any_fixed(int M, int Ks, int nlist, int64_t w)
 {
