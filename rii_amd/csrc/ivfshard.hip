@@ -17,6 +17,7 @@
 #include "rii_internal.h"
 #include "rii_device.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace riiamd {
 
@@ -188,14 +189,16 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     const int nlist = p.nlist;
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
+    const int dbg = collect >> 8;                          // measurement only (env RII_SHARD_DBG_STOP, tools/r5_sharded_ivf.py): return after a phase
+    collect &= 0xff;
     float *lds = reinterpret_cast<float *>(smem);
     const float *tab = GTAB ? p.lut + (size_t) b * MK : lds;
     unsigned char *base = smem + (GTAB ? 0 : (((size_t) MK * 4 + 15) & ~(size_t) 15));
     const bool w_lds = CLDS || p.w <= kWhSplitMaxHeap;
     const int nhead = CLDS ? nlist : (w_lds ? (int) p.w : 0);
     pq64_t *s_head = reinterpret_cast<pq64_t *>(base);                               // CLDS: the whole order; else the heap of the coarse sort
-    int32_t *s_cum_lds = reinterpret_cast<int32_t *>(s_head + nhead);                // CLDS: [nlist + 1]
-    int32_t *s_misc = s_cum_lds + (CLDS ? nlist + 1 : 0);                            // [8]: ncand, nv, owned, buffered
+    int32_t *s_cum_lds = reinterpret_cast<int32_t *>(s_head + nhead);                // CLDS: [nlist + 1]; else [nhead + 2]: the counts of the first w lists
+    int32_t *s_misc = s_cum_lds + (CLDS ? nlist + 1 : nhead + 2);                    // [8]: ncand, nv, owned, buffered
     int32_t *s_lpos = s_misc + 8, *s_lown = s_lpos + kShardGroup;                   // staged list descriptors
     int64_t *s_loff = reinterpret_cast<int64_t *>(smem + ((reinterpret_cast<unsigned char *>(s_lown + kShardGroup) - smem + 15) & ~(size_t) 15));
     unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_loff + kShardGroup);        // [nbuf] (selection) / [8] (TOP1)
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
         }
     }
     __syncthreads();
+    if (dbg == 1) return;
     for (int c0 = tid; c0 < nlist; c0 += 4 * 256) {                                   // src/rii.h:262-264; four centres' codes in flight per thread
         float dv[4];
 #pragma unroll
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
         }
     }
     __syncthreads();
+    if (dbg == 2) return;
     if constexpr (CLDS) {
         if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);               // src/rii.h:279-280 (wave 0)
     } else if (w_lds) {
@@ -257,21 +262,29 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
         pq64_partial_sort(s_coarse, (long) p.w, (long) nlist);
     }
     __syncthreads();
+    if (dbg == 3) return;
+    // the order's first w entries (the sorted heap) and the counts up to list w are read from LDS wherever the order itself lives in
+    // global scratch: the walk leaves them only for stale lists (tail walk), and every such read was a dependent L2 round trip of
+    // the block's chain
+    const int nlds = CLDS ? nlist : nhead;
+    auto order_at = [&](int c) -> pq64_t { return (CLDS || c < nlds) ? s_head[c] : s_coarse[c]; };
+    auto cum_at = [&](int c) -> int { return (CLDS || c <= nlds) ? s_cum_lds[c] : s_cum[c]; };
+    auto cum_set = [&](int c, int v) { if (CLDS || c <= nlds) s_cum_lds[c] = v; if (!CLDS) s_cum[c] = v; };
     if (tid == 0) {
         long long cnt = 0;
         int nv = 0;
         bool finished = false;
         for (int c = 0; c < nlist; ++c) {                                             // src/rii.h:286-321, global lengths
-            const int no = (int) pq64_id(s_coarse[c]);
+            const int no = (int) pq64_id(order_at(c));
             long long len = 0;
             for (int g = 0; g < p.G; ++g) len += p.glen[(size_t) g * nlist + no];
-            s_cum[c] = (int) cnt;
+            cum_set(c, (int) cnt);
             if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
             cnt += len;
             if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
         }
         if (!finished) { cnt = 0; nv = 0; }
-        s_cum[nv] = (int) cnt;
+        cum_set(nv, (int) cnt);
         s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = 0; s_misc[3] = 0;
         p.out_counts[b] = finished ? p.topk : 0;                                      // src/rii.h:324-325 when 0
     }
@@ -283,6 +296,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             p.out_pos[b * rows + j] = INT32_MAX;
         }
     __syncthreads();
+    if (dbg == 4) return;
     const int nv = s_misc[1];
     unsigned long long thr = ~0ull;                                                   // selection: keys at or above it cannot make the cut
     unsigned long long b0 = ~0ull, b1 = ~0ull;                                        // TOP1: this thread's two smallest keys
@@ -306,8 +320,8 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             int64_t off = 0;
             const int c = c0 + tid;
             if (c < nv) {
-                const int no = (int) pq64_id(s_coarse[c]);
-                const int cum = s_cum[c], take = s_cum[c + 1] - cum;                 // the list's share of the L candidates
+                const int no = (int) pq64_id(order_at(c));
+                const int cum = cum_at(c), take = cum_at(c + 1) - cum;               // the list's share of the L candidates
                 int before = 0;
                 for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
                 const int mylen = p.list_len[no];
@@ -368,6 +382,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     }
     atomicAdd(&s_misc[2], owned);
     __syncthreads();
+    if (dbg == 5) return;
     const int nown = s_misc[2];
     if (collect) {
         if (tid == 0) p.out_nloc[b] = nown < rows ? nown : rows;
@@ -405,12 +420,12 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             int lo = 0, hi = nv;                                                      // the list holding traversal position pos
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (s_cum[mid] <= pos) lo = mid; else hi = mid;
+                if (cum_at(mid) <= pos) lo = mid; else hi = mid;
             }
-            const int no = (int) pq64_id(s_coarse[lo]);
+            const int no = (int) pq64_id(order_at(lo));
             int before = 0;
             for (int g = 0; g < p.rank; ++g) before += p.glen[(size_t) g * nlist + no];
-            id = p.pl_ids[p.pl_off[no] + (pos - s_cum[lo] - before)];
+            id = p.pl_ids[p.pl_off[no] + (pos - cum_at(lo) - before)];
         }
         p.out_ids[b * rows + j] = id;
         p.out_dists[b * rows + j] = d;
@@ -574,7 +589,8 @@ static bool shard_any_clds(int M, int Ks, int nlist)
 }
 static size_t shard_any_fixed(int M, int Ks, int nlist, int64_t w)
 {
-    const size_t coarse = shard_any_clds(M, Ks, nlist) ? (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 : (size_t) (w <= kWhSplitMaxHeap ? w : 0) * 8;
+    const size_t nh = (size_t) (w <= kWhSplitMaxHeap ? w : 0);
+    const size_t coarse = shard_any_clds(M, Ks, nlist) ? (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 : nh * 8 + (nh + 2) * 4;
     return shard_tab_bytes(M, Ks) + coarse + shard_any_misc();
 }
 static int shard_any_nbuf(int M, int Ks, int nlist, int64_t w)
@@ -644,7 +660,8 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
                                : (cl ? ivf_shard_any_kernel<false, true, false> : ivf_shard_any_kernel<false, false, false>));
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, nbuf, collect);
+        static const int dbg_stop = getenv("RII_SHARD_DBG_STOP") ? atoi(getenv("RII_SHARD_DBG_STOP")) : 0;      // measurement only
+        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, nbuf, collect | (dbg_stop << 8));
         return hipGetLastError();
     }
     const size_t smem = shard_smem(M, Ks, nlist, L, w);
