@@ -2651,7 +2651,7 @@ RII_API int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t i
 // Round 5: any L and any topk <= L.  The reference's own billion-scale run uses L = N / nlist = sqrt(N) ~ 31.6 k
 // (examples/benchmark/run_sift1b.py:105-106): the shard kernel selects its k + 1 rows through an LDS buffer with a running bound
 // (ivf_shard_any_kernel), the replay of (4) rebuilds sequences of any length in global scratch (shard_replay_any_kernel), in groups of
-// flagged queries that keep the gathered rows under kShardGatherBudget.  k + 1 rows beyond what a launch can select (> ~7.6 k):
+// flagged queries that keep the gathered rows under kShardGatherBudget.  k + 1 rows beyond what a launch can select (> 6144 above L = 8192):
 // the collect-all route -- every rank sends EVERY candidate it owns (rows = L, by position), in groups of queries, and
 // std::partial_sort replayed on the rebuilt sequence IS the reference's answer (no merge, no flags).
 // Failures: see rii_query_linear_dbsharded_dev.
