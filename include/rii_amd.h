@@ -330,9 +330,10 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *                      of queries [default], 2 = always, 0 = never
  *   "ivf_fused"        1 = one fused launch per batch for the inverted index with per-query exact fallback [default], 0 = the
  *                      std::partial_sort emulation kernels for every query
- *   "ivf_quad"         1 = top-1 batches of >= 768 queries over <= 1024 lists (Ds = 4, Ks = 256, M = 16 / 32, w <= 32) run FOUR queries per
+ *   "ivf_quad"         1 = top-1 batches of >= 768 queries over <= 1024 lists with w <= 7 (Ds = 4, Ks = 256, M = 16 / 32) run FOUR queries per
  *                      block with their tables interleaved in LDS (ivf_quad_kernel: one 16-byte read scores a centre for four queries)
- *                      [default], 2 = at every batch size (tests), 0 = one query per block (ivf_fused_kernel).  Identical results
+ *                      [default], 2 = at every batch size and up to w = 32 (tests), 0 = one query per block (ivf_fused_kernel).
+ *                      Identical results
  *   "ivf_inline_exact" 1 = a block of the fused kernel that flags its own query replays it itself [default], 0 = flag-gated exact
  *                      kernels behind every batch
  *   "ivf_list_codes"   1 = the fused kernel reads its candidates from a second copy of the codes kept in posting order (+N*M bytes of

@@ -1162,7 +1162,9 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             // batched top-1 case; one-query calls, host-resident queries / flags and the other shapes keep the one-query blocks
             // (from 768 queries: below that one-query blocks have CUs -- and each CU's LDS -- to themselves and finish their 16 us chain
             //  before the 21 us chain of a four-query block; measured 16 / 64 / ... / 4096 queries: tools/r5_ivf_phases.py)
-            const bool quad = e->ivf_quad && p.queries && !p.q_host_off && !p.host_flag && p.B >= (e->ivf_quad > 1 ? 1 : 768) &&
+            // (and up to w = 7: the selection's rounds are serial per block -- w = 13, the subset search of configs[3], measured 38.7 us
+            //  against 35.0 for one-query blocks)
+            const bool quad = e->ivf_quad && p.queries && !p.q_host_off && !p.host_flag && (e->ivf_quad > 1 || (p.B >= 768 && w <= 7)) &&
                               ivf_quad_supported(e->M, e->Ks, e->Ds, (int) nlist, w, topk);
             p.kcap = quad ? e->ivf_dbg_stop : 0;
             ScopedTimer t(e, "ivf_fused", st, true);
