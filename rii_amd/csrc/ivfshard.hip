@@ -173,10 +173,50 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
 //   rows = L (every owned candidate: exact-tie replay, and the collect-all route of large k): the row goes to slot `position` of the
 //       query's output; the slots of candidates other ranks own are padding.  No order, no sort: the replay rebuilds by position.
 // ---------------------------------------------------------------------------------------------------------------------
+// Several code rows against one table with their LOADS IN FLIGHT TOGETHER (round 5).  exact_adist() fetches its code inside a loop
+// over a run-time M, so four calls in a row are four dependent global round trips whatever the unrolling around them; here the rows
+// of the wide shapes (M a multiple of 16, <= 64: 16-byte pieces) land in registers first and are scored afterwards -- the same
+// sequential fp32 sum over m per row (RiiCpp::ADist, src/rii.h:386-394).
+template <int U>
+__device__ __forceinline__ void shard_adist_rows(const float *tab, const uint8_t *const (&row)[U], int M, int Ks, float (&out)[U])
+{
+    if ((M & 15) == 0 && M <= 64) {
+        const int MQ = M >> 4;
+        uint4 cv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(row[u]);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                if (qd < MQ) cv[u][qd] = cp[qd];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float dist = 0.f;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                if (qd < MQ) {
+                    const uint32_t wds[4] = {cv[u][qd].x, cv[u][qd].y, cv[u][qd].z, cv[u][qd].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            dist = __fadd_rn(dist, tab[((qd * 4 + i) * 4 + j) * Ks + ((wds[i] >> (8 * j)) & 0xffu)]);
+                }
+            }
+            out[u] = dist;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) out[u] = exact_adist(tab, row[u], M, Ks);
+    }
+}
+
 constexpr int kShardAnyBuf = 8192;       // most keys the selection buffer holds (64 KiB)
 constexpr int kShardGroup = 256;         // visited lists whose descriptors are staged per round
 constexpr int kShardUnroll = 4;          // candidates a thread scores per round: their ids, then their code rows, are in flight together
 constexpr int kShardRound = 256 * kShardUnroll;
+constexpr int kShardFastW = 7;           // the fast coarse selection covers w <= 7 (w + 1 keys per thread in registers)
 
 // CLDS: the coarse order and the cumulative counts of the query in LDS (nlist <= kShardMaxNlistLds), else in global scratch.
 // TOP1: rows == 2 (top-1: the best two owned candidates): every thread keeps its two smallest keys in registers, the block's two
@@ -189,7 +229,8 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     const int nlist = p.nlist;
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
-    const int dbg = collect >> 8;                          // measurement only (env RII_SHARD_DBG_STOP, tools/r5_sharded_ivf.py): return after a phase
+    const int dbg = (collect >> 8) & 0xff;                 // measurement only (env RII_SHARD_DBG_STOP, tools/r5_sharded_ivf.py): return after a phase
+    const int surv_cap = collect >> 16;                    // tests only (env RII_SHARD_SURV_CAP): a small survivor list forces the overflow route
     collect &= 0xff;
     float *lds = reinterpret_cast<float *>(smem);
     const float *tab = GTAB ? p.lut + (size_t) b * MK : lds;
@@ -201,7 +242,10 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     int32_t *s_misc = s_cum_lds + (CLDS ? nlist + 1 : nhead + 2);                    // [8]: ncand, nv, owned, buffered
     int32_t *s_lpos = s_misc + 8, *s_lown = s_lpos + kShardGroup;                   // staged list descriptors
     int64_t *s_loff = reinterpret_cast<int64_t *>(smem + ((reinterpret_cast<unsigned char *>(s_lown + kShardGroup) - smem + 15) & ~(size_t) 15));
-    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_loff + kShardGroup);        // [nbuf] (selection) / [8] (TOP1)
+    pq64_t *s_bh_key = reinterpret_cast<pq64_t *>(s_loff + kShardGroup);                             // !CLDS: [kBhCap] + [kBhCap] ints: the tail entries
+    int *s_bh_idx = reinterpret_cast<int *>(s_bh_key + (CLDS ? 0 : kBhCap));                         //        that can act on the coarse heap
+    pq64_t *s_fast = reinterpret_cast<pq64_t *>(s_bh_idx + (CLDS ? 0 : kBhCap));                     // !CLDS: [4][w + 1] wave picks, [w] the saved head
+    unsigned long long *s_key = s_fast + (CLDS ? 0 : 5 * (kShardFastW + 1));                         // [nbuf] (selection) / [8] (TOP1)
     unsigned char *mine = CLDS ? nullptr : p.scratch + p.per_block * blockIdx.x;
     pq64_t *s_coarse = CLDS ? s_head : reinterpret_cast<pq64_t *>(mine);                            // [nlist] the whole coarse order
     int32_t *s_cum = CLDS ? s_cum_lds : reinterpret_cast<int32_t *>(mine + (size_t) nlist * 8);    // [nlist + 1] cumulative GLOBAL counts
@@ -234,59 +278,141 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     }
     __syncthreads();
     if (dbg == 1) return;
+    // FAST coarse selection (round 5; order in global scratch, w <= kShardFastW): while the centres are scored every thread keeps the
+    // w + 1 smallest keys it has seen (sorted, in registers); afterwards each wave extracts the w + 1 smallest of its lanes' lists with
+    // DPP minima and wave 0 merges the four waves' picks -- the w + 1 smallest (distance, list) keys of the query in ~3 us instead
+    // of the library's heap replayed over thousands of lists (~26 us at 8000 lists).  That IS std::partial_sort's result whenever those
+    // w + 1 distances are pairwise different; exactly tied distances among them, or a walk that has to continue past list w (the
+    // unsorted tail, whose arrangement only the replay knows), fall back to the exact replay -- ivf_fused_kernel's rule, without a
+    // second launch: the original sequence is still in place (head saved, tail untouched).
+    constexpr int kFastR = kShardFastW + 1;
+    const bool fast_ok = !CLDS && w_lds && p.w <= kShardFastW && nlist > (int) p.w + 64 && surv_cap != 0xff;      // (surv_cap = 255: tests force the replay)
+    const int R = (int) p.w + 1;
+    // (three keys per thread, not w + 1: with 256 threads three of the w + 1 smallest keys of a query share a thread in 0.01 - 0.1 % of
+    //  the queries; a thread whose THIRD key is within the picks may have dropped a fourth -- detected, and such a query is replayed.
+    //  Eight sorted slots per thread cost the scoring loop 10 us of insertions at 8000 lists.)
+    constexpr int kFastT = 3;
+    pq64_t best[kFastT];
+#pragma unroll
+    for (int k = 0; k < kFastT; ++k) best[k] = ~0ull;
     for (int c0 = tid; c0 < nlist; c0 += 4 * 256) {                                   // src/rii.h:262-264; four centres' codes in flight per thread
         float dv[4];
+        const uint8_t *crow[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u * 256;
-            dv[u] = c < nlist ? exact_adist(tab, p.centers + (size_t) c * p.M, p.M, p.Ks) : 0.f;
+            crow[u] = p.centers + (size_t) (c < nlist ? c : 0) * p.M;
         }
+        shard_adist_rows<4>(tab, crow, p.M, p.Ks, dv);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u * 256;
             if (c < nlist) {
                 const pq64_t e = pq64_make(dv[u], (uint32_t) c);
                 if (!CLDS && w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
+                if (fast_ok && e < best[kFastT - 1]) {                                 // sorted insertion (keys are distinct: the list id)
+                    best[kFastT - 1] = e;
+#pragma unroll
+                    for (int k = kFastT - 1; k > 0; --k)
+                        if (best[k] < best[k - 1]) { const pq64_t t = best[k]; best[k] = best[k - 1]; best[k - 1] = t; }
+                }
             }
         }
     }
     __syncthreads();
     if (dbg == 2) return;
-    if constexpr (CLDS) {
-        if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);               // src/rii.h:279-280 (wave 0)
-    } else if (w_lds) {
-        if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);
-        __syncthreads();
-        for (int c = tid; c < (int) p.w; c += 256) s_coarse[c] = s_head[c];
-    } else if (tid == 0) {
-        pq64_partial_sort(s_coarse, (long) p.w, (long) nlist);
-    }
-    __syncthreads();
-    if (dbg == 3) return;
-    // the order's first w entries (the sorted heap) and the counts up to list w are read from LDS wherever the order itself lives in
-    // global scratch: the walk leaves them only for stale lists (tail walk), and every such read was a dependent L2 round trip of
-    // the block's chain
     const int nlds = CLDS ? nlist : nhead;
+    // the order's first w entries (the sorted heap) and the counts up to list w are read from LDS wherever the order itself lives in
+    // global scratch: the walk leaves them only for stale lists (tail walk)
     auto order_at = [&](int c) -> pq64_t { return (CLDS || c < nlds) ? s_head[c] : s_coarse[c]; };
     auto cum_at = [&](int c) -> int { return (CLDS || c <= nlds) ? s_cum_lds[c] : s_cum[c]; };
     auto cum_set = [&](int c, int v) { if (CLDS || c <= nlds) s_cum_lds[c] = v; if (!CLDS) s_cum[c] = v; };
-    if (tid == 0) {
-        long long cnt = 0;
-        int nv = 0;
-        bool finished = false;
-        for (int c = 0; c < nlist; ++c) {                                             // src/rii.h:286-321, global lengths
-            const int no = (int) pq64_id(order_at(c));
-            long long len = 0;
-            for (int g = 0; g < p.G; ++g) len += p.glen[(size_t) g * nlist + no];
-            cum_set(c, (int) cnt);
-            if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
-            cnt += len;
-            if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+    bool fast_used = false;
+    if (fast_ok) {
+        const int lane = tid & 63, wave = tid >> 6;
+        const pq64_t third = best[kFastT - 1];                                         // (before the pops below)
+        for (int r = 0; r < R; ++r) {                                                  // level 1: this wave's R smallest
+            const pq64_t got = wave_min_u64(best[0]);
+            if (best[0] == got) {                                                      // (one lane: it hands the key over and moves up its list)
+#pragma unroll
+                for (int k = 0; k + 1 < kFastT; ++k) best[k] = best[k + 1];
+                best[kFastT - 1] = ~0ull;
+            }
+            if (lane == 0) s_fast[wave * kFastR + r] = got;
         }
-        if (!finished) { cnt = 0; nv = 0; }
-        cum_set(nv, (int) cnt);
-        s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = 0; s_misc[3] = 0;
-        p.out_counts[b] = finished ? p.topk : 0;                                      // src/rii.h:324-325 when 0
+        __syncthreads();
+        if (wave == 0) {                                                               // level 2: the block's R smallest, ascending; lane r keeps pick r
+            pq64_t cand = lane < 4 * R ? s_fast[(lane / R) * kFastR + (lane % R)] : ~0ull;
+            pq64_t mysel = ~0ull;
+            for (int r = 0; r < R; ++r) {
+                const pq64_t got = wave_min_u64(cand);
+                if (cand == got) cand = ~0ull;
+                if (lane == r) mysel = got;
+            }
+            const uint32_t myhi = (uint32_t) (mysel >> 32);
+            const uint32_t nxhi = (uint32_t) __shfl_down((int) myhi, 1);
+            const bool tied = lane + 1 < R && myhi == nxhi;                             // exactly tied distances among the w + 1 smallest
+            const int tie = __ballot(tied) != 0ull ? 1 : 0;
+            if (lane == R - 1) s_fast[4 * kFastR + kFastR - 1] = mysel;                 // the largest pick: the bound of the check below
+            if (lane == 0) s_misc[6] = tie;
+            if (lane < (int) p.w) s_fast[lane] = mysel;                                 // (the waves' picks are dead: the block's picks in their place)
+        }
+        __syncthreads();
+        // a thread whose third key is not above the largest pick may have dropped a fourth that belongs among the picks: replay
+        const int lost = __syncthreads_or(third != ~0ull && third <= s_fast[4 * kFastR + kFastR - 1]);
+        fast_used = s_misc[6] == 0 && !lost;
+        if (fast_used && tid < (int) p.w) {
+            const pq64_t pick = s_fast[tid];
+            s_fast[4 * kFastR + tid] = s_head[tid];                                     // the sequence's own first w entries: kept for a replay
+            s_head[tid] = pick;
+        }
+        __syncthreads();
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!fast_used) {                                                              // the library's algorithm, move for move
+            if constexpr (CLDS) {
+                if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);        // src/rii.h:279-280 (wave 0)
+            } else if (w_lds) {
+                if (p.w <= kWhRegHeap && nlist - (int) p.w > 2 * kBhFirst) {
+                    // many lists, a small heap: the whole block scans the tail
+                    bh_partial_sort_split<256>(s_head, s_coarse + p.w, (int) p.w, nlist, tid, s_bh_key, s_bh_idx, s_misc + 4, surv_cap);
+                } else {
+                    if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);
+                    __syncthreads();
+                }
+            } else if (tid == 0) {
+                pq64_partial_sort(s_coarse, (long) p.w, (long) nlist);
+            }
+        }
+        if (!CLDS && w_lds)
+            for (int c = tid; c < (int) p.w; c += 256) s_coarse[c] = s_head[c];
+        __syncthreads();
+        if (dbg == 3) return;
+        if (tid == 0) {
+            long long cnt = 0;
+            int nv = 0;
+            bool finished = false, redo = false;
+            for (int c = 0; c < nlist; ++c) {                                         // src/rii.h:286-321, global lengths
+                if (fast_used && c >= (int) p.w) { redo = true; break; }              // past list w: only the replay knows the tail's order
+                const int no = (int) pq64_id(order_at(c));
+                long long len = 0;
+                for (int g = 0; g < p.G; ++g) len += p.glen[(size_t) g * nlist + no];
+                cum_set(c, (int) cnt);
+                if (cnt + len >= p.L) { cnt = p.L; nv = c + 1; finished = true; break; }
+                cnt += len;
+                if ((long long) (c + 1) == p.w && cnt >= p.topk) { nv = c + 1; finished = true; break; }
+            }
+            if (!finished) { cnt = 0; nv = 0; }
+            cum_set(nv, (int) cnt);
+            s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = 0; s_misc[3] = 0; s_misc[7] = redo ? 1 : 0;
+            p.out_counts[b] = finished ? p.topk : 0;                                  // src/rii.h:324-325 when 0
+        }
+        __syncthreads();
+        if (!s_misc[7]) break;
+        // the walk left the first w lists: restore the sequence's own head and replay the library's sort on it
+        if (tid < (int) p.w) s_head[tid] = s_fast[4 * kFastR + tid];
+        fast_used = false;
+        __syncthreads();
     }
     const int rows = p.rows;
     if (collect)                                                                       // padding everywhere first; owned rows overwrite it
@@ -351,12 +477,13 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
                     idv[u] = li < own ? ((lrows && !collect) ? 0 : ids[li]) : -1;
                 }
                 float dv[kShardUnroll];
+                const uint8_t *row[kShardUnroll];
 #pragma unroll
                 for (int u = 0; u < kShardUnroll; ++u) {                              // ... then their rows (independent loads in flight)
                     const int li = base_li + u * 256 + tid;
-                    const uint8_t *row = lrows ? lrows + (size_t) li * p.M : p.codes + (size_t) idv[u] * p.M;
-                    dv[u] = idv[u] >= 0 ? exact_adist(tab, row, p.M, p.Ks) : 0.f;
+                    row[u] = idv[u] < 0 ? p.codes : (lrows ? lrows + (size_t) li * p.M : p.codes + (size_t) idv[u] * p.M);
                 }
+                shard_adist_rows<kShardUnroll>(tab, row, p.M, p.Ks, dv);
 #pragma unroll
                 for (int u = 0; u < kShardUnroll; ++u) {
                     if (idv[u] < 0) continue;
@@ -590,7 +717,7 @@ static bool shard_any_clds(int M, int Ks, int nlist)
 static size_t shard_any_fixed(int M, int Ks, int nlist, int64_t w)
 {
     const size_t nh = (size_t) (w <= kWhSplitMaxHeap ? w : 0);
-    const size_t coarse = shard_any_clds(M, Ks, nlist) ? (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 : nh * 8 + (nh + 2) * 4;
+    const size_t coarse = shard_any_clds(M, Ks, nlist) ? (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 : nh * 8 + (nh + 2) * 4 + (size_t) kBhCap * 12 + (size_t) 5 * (kShardFastW + 1) * 8;
     return shard_tab_bytes(M, Ks) + coarse + shard_any_misc();
 }
 static int shard_any_nbuf(int M, int Ks, int nlist, int64_t w)
@@ -661,7 +788,8 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         if (e != hipSuccess) return e;
         static const int dbg_stop = getenv("RII_SHARD_DBG_STOP") ? atoi(getenv("RII_SHARD_DBG_STOP")) : 0;      // measurement only
-        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, nbuf, collect | (dbg_stop << 8));
+        const int surv_cap = getenv("RII_SHARD_SURV_CAP") ? (atoi(getenv("RII_SHARD_SURV_CAP")) & 0xff) : 0;            // tests only (read per launch)
+        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, nbuf, collect | ((dbg_stop & 0xff) << 8) | (surv_cap << 16));
         return hipGetLastError();
     }
     const size_t smem = shard_smem(M, Ks, nlist, L, w);

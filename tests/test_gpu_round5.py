@@ -376,3 +376,50 @@ def test_header_merge_for_many_fake_ranks():
         assert bool((oi == -2).all()) and bool(torch.isnan(od).all())
         if k > 1:
             assert int(anyf.item()) & 2 and int(tie.sum().item()) == 0
+
+
+def test_block_wide_coarse_partial_sort_many_lists():
+    """bh_partial_sort_split: with thousands of lists and a heap of w <= 64 the whole block scans the tail of the coarse
+    std::partial_sort (wave 0 replays the first 512 entries, everybody filters the rest against the top reached, wave 0 replays the
+    few survivors in sequence order).  nlist = 5000 duplicated centres (exactly tied coarse distances), w = 4 ... 40, top-1 and top-k,
+    target ids; the same with the survivor list forced to overflow (env RII_SHARD_SURV_CAP: wave 0 scans the rest itself) -- all
+    equal to the oracle on the same lists."""
+    import os
+    from rii_amd import RiiGpu
+    from rii_amd import dist as rd
+    n, nlist = 30011, 5000
+    cw, codes, qs = _tied_problem(n)
+    cen = np.ascontiguousarray(codes[np.random.default_rng(17).integers(0, n, nlist)])
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    o.set_coarse_centers(cen)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.set_coarse_centers(cen)
+    assert g.posting_lists == o.posting_lists
+    idx = rd.DbShardedIndex(g, 0, n)
+    sub = np.sort(np.random.default_rng(6).choice(n, 9000, replace=False)).astype(np.int64)
+    # stale lists (only the first ninth of the codes is listed): most of the 5000 lists are empty, the first w hold fewer than topk
+    # candidates -> the walk continues into the unsorted tail (the fast selection hands over to the exact replay) or finds nothing
+    n9 = n // 9
+    gs = RiiGpu(cw, False, simd_arch="avx512")
+    gs.add_codes(codes[:n9], False)
+    gs.set_coarse_centers(cen)
+    gs.add_codes(codes[n9:], False)
+    os_ = O.OracleRii(cw, False, simd_arch="avx512")
+    os_.add_codes(codes[:n9], False)
+    os_.set_coarse_centers(cen)
+    os_.add_codes(codes[n9:], False)
+    assert gs.posting_lists == os_.posting_lists
+    idxs = rd.DbShardedIndex(gs, 0, n)
+    try:
+        for cap in ("", "2", "40", "255"):                  # 255: the fast selection off, every query through the replay
+            if cap:
+                os.environ["RII_SHARD_SURV_CAP"] = cap
+            for topk, L, t in ((1, 6, None), (1, 60, None), (1, 220, None), (3, 30, None), (1, 9000, None), (2, 40, sub), (1, n, None)):
+                _check_ivf(idx, o, qs, topk, L, t)
+            n_tail = 0
+            for topk, L in ((1, 3), (1, 30), (1, 2), (1, 200)):
+                _check_ivf(idxs, os_, qs, topk, L, None)
+    finally:
+        os.environ.pop("RII_SHARD_SURV_CAP", None)
