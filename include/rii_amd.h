@@ -141,8 +141,8 @@ int rii_query_ivf_dev_to_host(rii_engine *e, const float *d_queries, int64_t B, 
  * examples/benchmark/run_sift1b.py:105-106): up to 8192 candidate keys of a query are sorted in LDS at once; above that the rank's
  * own candidates pass through an LDS selection buffer with a running bound.  `rows` (0 = topk + 1): the rows a launch can SELECT are
  * bounded by rii_ivf_shard_max_select_rows() (8193 while L <= 8192, 6144 above); rows >= L always works and returns EVERY owned
- * candidate -- in (distance, position) order while L <= 8192, at the slot of its traversal position (row j = position j, other
- * ranks' slots padded) above that: the replay below rebuilds the sequence by position either way.  (The coarse order of a query:
+ * candidate -- in (distance, position) order, or (L > 6144) at the slot of its traversal position (row j = position j, other ranks'
+ * slots padded): the replay below rebuilds the sequence by position either way.  (The coarse order of a query:
  * with w <= 7 and the order in global scratch the w + 1 smallest (distance, list) keys come from a register / DPP selection; the
  * library's std::partial_sort (src/rii.h:279-280) is replayed move for move only where its internals can show -- two of those w + 1
  * distances exactly equal, or a walk that continues past list w.  rows = 2, i.e. top-1, never

@@ -748,7 +748,10 @@ bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w, int row
 static bool shard_use_any(int M, int Ks, int nlist, int64_t L, int64_t w, int rows)
 {
     if (rows == 2 && L > 2 && shard_any_fixed(M, Ks, nlist, w) + 64 <= (size_t) 160 * 1024 - 512) return true;
-    return !shard_lds_ok(M, Ks, nlist, L, w);
+    if (!shard_lds_ok(M, Ks, nlist, L, w)) return true;
+    // everything the selection buffer serves: the any-L kernel has the faster candidate loop (rows in flight together, posting-order
+    // rows) and the fast coarse selection; the 8192-key kernel keeps the row counts beyond it (k + 1 up to 8193 at L <= 8192)
+    return rows <= shard_any_max_rows(M, Ks, nlist, w) && shard_any_fixed(M, Ks, nlist, w) + (size_t) shard_any_nbuf(M, Ks, nlist, w) * 8 <= (size_t) 160 * 1024 - 512;
 }
 // bytes of global scratch per query of a launch (coarse order + cumulative counts), 0: everything fits LDS
 size_t ivf_shard_scratch_per_query(int M, int Ks, int nlist, int64_t L, int64_t w)
