@@ -1,7 +1,7 @@
 /* Plain-C client of the multi-GPU entry points of the C ABI (include/rii_amd.h, round 4): a C / C++ caller shards the query path
  * without any Python -- rii_comm_unique_id / rii_comm_init (RCCL behind the library), rii_query_linear_qsharded_dev,
  * rii_query_ivf_qsharded_dev, rii_query_linear_dbsharded_dev, and the device-queries -> host-rows call
- * rii_query_linear_dev_to_host.  GPU box only (world size 1: the collective still runs through RCCL); every row is compared with
+ * rii_query_linear_dev_to_host; round 5: L past 8192 candidates, shard offsets in the record headers, a rank-local failure.  GPU box only (world size 1: the collective still runs through RCCL); every row is compared with
  * the single-engine host-pointer calls. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -102,6 +102,48 @@ int main(void)
             if (got_c[b] != want_c[b]) { fprintf(stderr, "dbsharded ivf count differs at %d\n", b); return 7; }
             if (!same_rows(got_i + b * topk, got_d + b * topk, want_i + b * topk, want_d + b * topk, (int) want_c[b], "dbsharded ivf")) return 7;
         }
+    }
+    /* round 5: the database-sharded inverted index past the 8192 candidates a launch used to sort (the reference's billion-scale run
+     * asks for L = sqrt(N) ~ 31.6 k: examples/benchmark/run_sift1b.py:105-106), top-1 and top-5, exact ties replayed from sequences
+     * rebuilt in global scratch */
+    for (int topk = 1; topk <= 5; topk += 4) {
+        const int64_t L = 30000;
+        CHECK(rii_query_ivf(e, q, B, topk, NULL, 0, L, want_i, want_d, want_c));
+        CHECK(rii_query_ivf_dbsharded_dev(e, c, 0, N, dq, B, topk, NULL, 0, 0, L, d_ids, d_d, d_cnt, d_tie, NULL));
+        CHECK(rii_synchronize(e));
+        HCHECK(hipMemcpy(got_i, d_ids, sizeof(int64_t) * B * topk, hipMemcpyDeviceToHost));
+        HCHECK(hipMemcpy(got_d, d_d, sizeof(float) * B * topk, hipMemcpyDeviceToHost));
+        HCHECK(hipMemcpy(got_c, d_cnt, sizeof(int64_t) * B, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) {
+            if (got_c[b] != want_c[b]) { fprintf(stderr, "dbsharded ivf (L = 30000) count differs at %d\n", b); return 8; }
+            if (!same_rows(got_i + b * topk, got_d + b * topk, want_i + b * topk, want_d + b * topk, (int) want_c[b], "dbsharded ivf L=30000")) return 8;
+        }
+    }
+    /* the shard's first id travels in the record header: another placement of the same shard on the SAME communicator, then back */
+    {
+        const int64_t offs[3] = {123456789, 0, 77};
+        CHECK(rii_query_linear(e, q, B, 1, NULL, 0, want_i, want_d));
+        for (int t = 0; t < 3; ++t) {
+            CHECK(rii_query_linear_dbsharded_dev(e, c, offs[t], dq, B, 1, NULL, 0, 0, d_ids, d_d, NULL, NULL, 0, NULL));
+            CHECK(rii_synchronize(e));
+            HCHECK(hipMemcpy(got_i, d_ids, sizeof(int64_t) * B, hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; ++b)
+                if (got_i[b] != want_i[b] + offs[t]) { fprintf(stderr, "id offset %lld: row %d is %lld\n", (long long) offs[t], b, (long long) got_i[b]); return 9; }
+        }
+    }
+    /* a rank-local failure (more local target ids than local codes) is this rank's error -- the call still took part in its
+     * collective, so the communicator stays in step and the next call works */
+    {
+        int64_t *d_bad;
+        HCHECK(hipMalloc((void **) &d_bad, sizeof(int64_t) * (N + 1)));
+        HCHECK(hipMemset(d_bad, 0, sizeof(int64_t) * (N + 1)));
+        if (rii_query_linear_dbsharded_dev(e, c, 0, dq, B, 1, d_bad, N + 1, 2 * (int64_t) N, d_ids, d_d, NULL, NULL, 0, NULL) == RII_OK) return 10;
+        CHECK(rii_query_linear_dbsharded_dev(e, c, 0, dq, B, 1, NULL, 0, 0, d_ids, d_d, NULL, NULL, 0, NULL));
+        CHECK(rii_synchronize(e));
+        HCHECK(hipMemcpy(got_i, d_ids, sizeof(int64_t) * B, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            if (got_i[b] != want_i[b]) return 11;
+        HCHECK(hipFree(d_bad));
     }
     rii_comm_destroy(c);
     rii_destroy(e);
