@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             if constexpr (CLDS) {
                 if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);        // src/rii.h:279-280 (wave 0)
             } else if (w_lds) {
-                if (p.w <= kWhRegHeap && nlist - (int) p.w > 2 * kBhFirst) {
+                if (p.w <= kBhMaxHeap && nlist - (int) p.w > 2 * kBhFirst) {
                     // many lists, a small heap: the whole block scans the tail
                     bh_partial_sort_split<256>(s_head, s_coarse + p.w, (int) p.w, nlist, tid, s_bh_key, s_bh_idx, s_misc + 4, surv_cap);
                 } else {

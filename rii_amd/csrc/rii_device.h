@@ -543,93 +543,11 @@ __device__ __forceinline__ void wh_partial_sort_split_t(pq64_t *head, pq64_t *ta
         top = wh_adjust_heap<NW>(head, 0, len, v, lane);
     }
 }
-// The same for a heap of at most 64 entries, kept IN REGISTERS (round 5): entry j of the heap lives in lane j of one 64-bit register
-// pair, and libstdc++'s __adjust_heap / __push_heap run as wave-uniform scalar code over v_readlane / v_writelane -- no LDS round
-// trip per level (wh_adjust_heap: ~0.5 us per adjustment; this: ~0.1 us).  The coarse std::partial_sort of the inverted index has
-// w = L nlist / N + 3 = 4 ... 8 heap entries and, over the 8 k - 32 k lists of a billion-scale index, w ln(nlist / w) ~ 30 - 40
-// adjustments per query.  Move for move the library's algorithm (compare pq64_adjust_heap above); the result is written back to head.
-__device__ __forceinline__ pq64_t whr_get(pq64_t hv, int j)
-{
-    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (hv & 0xffffffffu), j);
-    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (hv >> 32), j);
-    return ((pq64_t) hi << 32) | lo;
-}
-__device__ __forceinline__ void whr_set(pq64_t &hv, int j, pq64_t v, int lane)
-{
-    if (lane == j) hv = v;                                 // (a compare and two selects: v_writelane would need the lane index in M0)
-}
-// (inlined on purpose: as a real function -- stack frame in scratch memory, register saves per call -- the coarse sort of a
-//  64 M-code shard took 52 us instead of 26)
-__device__ __forceinline__ void whr_adjust_heap(pq64_t &hv, int hole, int len, pq64_t v, int lane)        // hole, len, v wave-uniform
-{
-    const int top = hole;
-    int child = hole;
-    while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        pq64_t a = whr_get(hv, child);
-        const pq64_t b = whr_get(hv, child - 1);
-        if (pq64_less(a, b)) { child--; a = b; }
-        whr_set(hv, hole, a, lane);
-        hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-        child = 2 * (child + 1);
-        whr_set(hv, hole, whr_get(hv, child - 1), lane);
-        hole = child - 1;
-    }
-    int parent = (hole - 1) / 2;
-    while (hole > top) {                                   // __push_heap
-        const pq64_t pv = whr_get(hv, parent);
-        if (!pq64_less(pv, v)) break;
-        whr_set(hv, hole, pv, lane);
-        hole = parent;
-        parent = (hole - 1) / 2;
-    }
-    whr_set(hv, hole, v, lane);
-}
-constexpr int kWhRegHeap = 64;
-__device__ __forceinline__ void wh_partial_sort_split_reg(pq64_t *head, pq64_t *tail, int middle, int n, int lane)
-{
-    pq64_t hv = lane < middle ? head[lane] : ~0ull;
-    if (middle >= 2)                                        // __make_heap
-        for (int parent = (middle - 2) / 2; parent >= 0; --parent) whr_adjust_heap(hv, parent, middle, whr_get(hv, parent), lane);
-    if (middle > 0) {
-        pq64_t topv = whr_get(hv, 0);
-        constexpr int U = 16;                               // sixteen 64-entry slices of the tail per global round trip
-        for (int i0 = middle; i0 < n; i0 += 64 * U) {
-            pq64_t ev[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + 64 * u + lane;
-                ev[u] = i < n ? tail[i - middle] : ~0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + 64 * u + lane;
-                const pq64_t e = ev[u];
-                unsigned long long m = __ballot(i < n && pq64_less(e, topv));
-                while (m) {
-                    const int j = __builtin_ctzll(m);
-                    m &= m - 1ull;
-                    const pq64_t ej = wh_readlane(e, j);
-                    if (pq64_less(ej, topv)) {              // the library compares with the top of THAT moment
-                        if (lane == 0) tail[i0 + 64 * u + j - middle] = topv;       // __pop_heap(first, middle, i)
-                        whr_adjust_heap(hv, 0, middle, ej, lane);
-                        topv = whr_get(hv, 0);
-                    }
-                }
-            }
-        }
-    }
-    for (int len = middle - 1; len >= 1; --len) {           // __sort_heap
-        const pq64_t v = whr_get(hv, len);
-        whr_set(hv, len, whr_get(hv, 0), lane);
-        whr_adjust_heap(hv, 0, len, v, lane);
-    }
-    if (lane < middle) head[lane] = hv;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
+// (Round 5 measured a REGISTER-resident heap -- entry j in lane j, libstdc++'s __adjust_heap as wave-uniform scalar code over
+//  v_readlane and compare-and-select writes -- against wh_adjust_top above: tools/ubench/heap_sift.hip, k = 100, 1100 sifts: 2297 cycles
+//  per sift against 556 with the heap in LDS.  Every level of the scalar walk is a vector-to-scalar-to-vector round trip; the LDS
+//  form resolves a whole path with one ballot and one gather.  Not kept.)
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The same std::partial_sort with the WHOLE BLOCK scanning the tail (round 5; middle <= 64, blocks of NT threads, all of them call it).
 // __heap_select only acts on a tail entry that is smaller than the heap's top at that moment, and the top never grows.  So wave 0
@@ -640,8 +558,12 @@ __device__ __forceinline__ void wh_partial_sort_split_reg(pq64_t *head, pq64_t *
 // A list that overflows its kBhCap slots (a long descending run) is dropped and wave 0 scans the rest of the tail itself.
 // s_skey [kBhCap] u64, s_sidx [kBhCap] int, s_ctl [4] int: LDS.  cap_override (tests): a smaller capacity to force the overflow route.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kBhFirst = 512, kBhCap = 256;
-__device__ __forceinline__ void bh_tail_step(pq64_t &hv, pq64_t &topv, pq64_t e, bool valid, int pos, pq64_t *tail, int middle, int lane)
+constexpr int kBhFirst = 512, kBhCap = 256, kBhMaxHeap = 64;
+// (forward: the single operations on an LDS heap, defined below)
+__device__ __forceinline__ pq64_t wh_adjust_top(pq64_t *h, int len, pq64_t v, int lane);
+__device__ __forceinline__ void wh_make_heap(pq64_t *h, int len, int lane);
+__device__ __forceinline__ void wh_sort_heap(pq64_t *h, int len0, int lane);
+__device__ __forceinline__ void bh_tail_step(pq64_t *head, pq64_t &topv, pq64_t e, bool valid, int pos, pq64_t *tail, int middle, int lane)
 {
     unsigned long long m = __ballot(valid && pq64_less(e, topv));
     while (m) {
@@ -651,8 +573,7 @@ __device__ __forceinline__ void bh_tail_step(pq64_t &hv, pq64_t &topv, pq64_t e,
         if (pq64_less(ej, topv)) {                          // the library compares with the top of THAT moment
             const int pj = __builtin_amdgcn_readlane(pos, j);
             if (lane == 0) tail[pj - middle] = topv;        // __pop_heap(first, middle, i)
-            whr_adjust_heap(hv, 0, middle, ej, lane);
-            topv = whr_get(hv, 0);
+            topv = wh_adjust_top(head, middle, ej, lane);
         }
     }
 }
@@ -664,12 +585,10 @@ __device__ __forceinline__ void bh_partial_sort_split(pq64_t *head, pq64_t *tail
     const bool w0 = tid < 64;
     const int cap = cap_override > 0 && cap_override < kBhCap ? cap_override : kBhCap;
     const int first_end = middle + kBhFirst < n ? middle + kBhFirst : n;         // wave 0 alone up to here
-    pq64_t hv = ~0ull, topv = 0ull;
+    pq64_t topv = 0ull;
     if (w0) {
-        hv = lane < middle ? head[lane] : ~0ull;
-        if (middle >= 2)                                    // __make_heap
-            for (int parent = (middle - 2) / 2; parent >= 0; --parent) whr_adjust_heap(hv, parent, middle, whr_get(hv, parent), lane);
-        topv = whr_get(hv, 0);
+        wh_make_heap(head, middle, lane);                   // __make_heap
+        topv = wh_uniform(head[0]);
         pq64_t ev[kBhFirst / 64];
 #pragma unroll
         for (int u = 0; u < kBhFirst / 64; ++u) {
@@ -679,7 +598,7 @@ __device__ __forceinline__ void bh_partial_sort_split(pq64_t *head, pq64_t *tail
 #pragma unroll
         for (int u = 0; u < kBhFirst / 64; ++u) {
             const int i = middle + 64 * u + lane;
-            bh_tail_step(hv, topv, ev[u], i < first_end, i, tail, middle, lane);
+            bh_tail_step(head, topv, ev[u], i < first_end, i, tail, middle, lane);
         }
         if (lane == 0) { s_ctl[0] = 0; s_ctl[1] = (int) (uint32_t) (topv >> 32); }
     }
@@ -714,7 +633,7 @@ __device__ __forceinline__ void bh_partial_sort_split(pq64_t *head, pq64_t *tail
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = i0 + 64 * u + lane;
-                    bh_tail_step(hv, topv, ev[u], i < n, i, tail, middle, lane);
+                    bh_tail_step(head, topv, ev[u], i < n, i, tail, middle, lane);
                 }
             }
         } else if (ns > 0) {
@@ -742,15 +661,10 @@ __device__ __forceinline__ void bh_partial_sort_split(pq64_t *head, pq64_t *tail
                 const int j = s0 + lane;
                 const pq64_t e = j < ns ? s_skey[j] : ~0ull;
                 const int pos = j < ns ? s_sidx[j] : 0;
-                bh_tail_step(hv, topv, e, j < ns, pos, tail, middle, lane);
+                bh_tail_step(head, topv, e, j < ns, pos, tail, middle, lane);
             }
         }
-        for (int len = middle - 1; len >= 1; --len) {       // __sort_heap
-            const pq64_t v = whr_get(hv, len);
-            whr_set(hv, len, whr_get(hv, 0), lane);
-            whr_adjust_heap(hv, 0, len, v, lane);
-        }
-        if (lane < middle) head[lane] = hv;
+        wh_sort_heap(head, middle, lane);                   // __sort_heap
     }
     __syncthreads();
 }
@@ -758,8 +672,7 @@ __device__ __forceinline__ void bh_partial_sort_split(pq64_t *head, pq64_t *tail
 constexpr int kWhSplitMaxHeap = 2 * 64 * kWhMaxWords;
 __device__ __forceinline__ void wh_partial_sort_split(pq64_t *head, pq64_t *tail, int middle, int n, int lane)
 {
-    if (middle <= kWhRegHeap) wh_partial_sort_split_reg(head, tail, middle, n, lane);
-    else if (middle <= 129) wh_partial_sort_split_t<1>(head, tail, middle, n, lane);
+    if (middle <= 129) wh_partial_sort_split_t<1>(head, tail, middle, n, lane);
     else wh_partial_sort_split_t<kWhMaxWords>(head, tail, middle, n, lane);
 }
 
