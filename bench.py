@@ -853,7 +853,7 @@ def main_deep_ivf(args, world, rank, local, dev, arch):
                 "lists": obj["lists"]}
         if "cpu_baseline" in obj:
             line["cpu_baseline"] = obj["cpu_baseline"]
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     rd.close_comms()
     if use_dist:
         dist.destroy_process_group()
@@ -1412,7 +1412,8 @@ def main():
             wall["others_s"] = others["seconds_spent"]
         wall["total_s"] = time.perf_counter() - t_start
         line["wall_clock"] = wall
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    rd.close_comms()                       # (the library's own RCCL communicators: destroyed here, not at interpreter exit)
     if use_dist:
         dist.destroy_process_group()
 
