@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--latency", action="store_true",
                     help="per-call latency: fresh queries every call, one synchronisation per call (use with --batch 1)")
     ap.add_argument("--lut-mode", default="exact", choices=["exact", "mfma"])
+    ap.add_argument("--shard-dbg-stop", type=int, default=0,
+                    help="measurement only (--workload deep-ivf): ivf_shard_any_kernel returns after this phase; the rows are wrong then")
     ap.add_argument("--scan-order", type=int, default=1, choices=[0, 1],
                     help="1: scan the LDS-friendly permutation of the codes (default), 0: id order")
     ap.add_argument("--scan-mx", type=int, default=1, choices=[0, 1],
@@ -826,6 +828,8 @@ def main_deep_ivf(args, world, rank, local, dev, arch):
     cw = bd.train_pq(train, M, Ks, iters=5, seed=123, device=dev)
     codes = np.random.default_rng(1000 + rank).integers(0, 256, size=(n_shard, M), dtype=np.uint8)
     eng = RiiGpu(cw, False, simd_arch=arch, device=local)
+    if args.shard_dbg_stop:
+        eng.set_option("shard_dbg_stop", args.shard_dbg_stop)
     eng.add_codes(codes, False)
     q = torch.from_numpy(np.ascontiguousarray(query[:B])).to(dev)
     use_dist = dist.is_initialized()

@@ -156,6 +156,8 @@ struct rii_engine : ScratchSet {
     // profiles/r03_levels_ab.json): 63 -> 124 candidates per query, 127 -> 40, 255 -> 20; the scan itself is 3 % SLOWER with 255 (signed
     // bytes: more switching in the matrix core under a power-limited clock), so 127 -- non-negative bytes, no bias -- is the default.
     int table_levels = 127;
+    int shard_dbg_stop = 0;     // measurement only: ivf_shard_any_kernel returns after phase 1 .. 5 (wrong rows; tools/r5_shard_phases*.sh)
+    int shard_force_replay = 0; // tests only: ivf_shard_any_kernel without its fast coarse selection (every query replays std::partial_sort)
     int ivf_dbg_stop = 0;       // measurement only: ivf_quad_kernel returns after phase 1 .. 3 (wrong rows; tools/r5_ivf_phases.py)
     int ivf_quad = 1;           // option "ivf_quad" (round 5): 1 = top-1 batches of >= 16 queries over <= 1024 lists run four queries per block (ivf_quad_kernel)
     int ivf_inline_exact = 1;   // option "ivf_inline_exact" (round 4): 1 = a block of ivf_fused_kernel that flags its query (tied coarse distances, tail
@@ -2110,7 +2112,8 @@ int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk,
                                  e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
                                  d_out_ids + b0 * (int64_t) rows, d_out_dists + b0 * (int64_t) rows, d_out_pos + b0 * (int64_t) rows,
                                  d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st,
-                                 own_tables ? d_queries + b0 * D : nullptr, e->d_codewords.as<float>(), e->Ds, e->arch, lcodes));
+                                 own_tables ? d_queries + b0 * D : nullptr, e->d_codewords.as<float>(), e->Ds, e->arch, lcodes,
+                                 (e->shard_dbg_stop & 0xff) | ((e->shard_force_replay ? 1 : 0) << 8)));
     }
     return RII_OK;
 }
@@ -2867,6 +2870,10 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->ivf_fused = value ? 1 : 0;
     } else if (k == "ivf_dbg_stop") {
         e->ivf_dbg_stop = (int) value;
+    } else if (k == "shard_dbg_stop") {
+        e->shard_dbg_stop = (int) (value & 0xff);
+    } else if (k == "shard_force_replay") {
+        e->shard_force_replay = value ? 1 : 0;
     } else if (k == "ivf_quad") {
         e->ivf_quad = value < 0 ? 0 : (int) std::min<int64_t>(value, 2);        // 2: at every batch size (tests)
     } else if (k == "ivf_inline_exact") {

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     const int nlist = p.nlist;
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
-    const int dbg = (collect >> 8) & 0xff;                 // measurement only (env RII_SHARD_DBG_STOP, tools/r5_sharded_ivf.py): return after a phase
-    const int surv_cap = collect >> 16;                    // tests only (env RII_SHARD_SURV_CAP): a small survivor list forces the overflow route
+    const int dbg = (collect >> 8) & 0xff;                 // measurement only (option "shard_dbg_stop", tools/r5_shard_phases*.sh): return after a phase
+    const bool force_replay = (collect >> 16) != 0;        // tests only (option "shard_force_replay"): no fast coarse selection
     collect &= 0xff;
     float *lds = reinterpret_cast<float *>(smem);
     const float *tab = GTAB ? p.lut + (size_t) b * MK : lds;
@@ -242,9 +242,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     int32_t *s_misc = s_cum_lds + (CLDS ? nlist + 1 : nhead + 2);                    // [8]: ncand, nv, owned, buffered
     int32_t *s_lpos = s_misc + 8, *s_lown = s_lpos + kShardGroup;                   // staged list descriptors
     int64_t *s_loff = reinterpret_cast<int64_t *>(smem + ((reinterpret_cast<unsigned char *>(s_lown + kShardGroup) - smem + 15) & ~(size_t) 15));
-    pq64_t *s_bh_key = reinterpret_cast<pq64_t *>(s_loff + kShardGroup);                             // !CLDS: [kBhCap] + [kBhCap] ints: the tail entries
-    int *s_bh_idx = reinterpret_cast<int *>(s_bh_key + (CLDS ? 0 : kBhCap));                         //        that can act on the coarse heap
-    pq64_t *s_fast = reinterpret_cast<pq64_t *>(s_bh_idx + (CLDS ? 0 : kBhCap));                     // !CLDS: [4][w + 1] wave picks, [w] the saved head
+    pq64_t *s_fast = reinterpret_cast<pq64_t *>(s_loff + kShardGroup);                               // !CLDS: [4][w + 1] wave picks, [w] the saved head
     unsigned long long *s_key = s_fast + (CLDS ? 0 : 5 * (kShardFastW + 1));                         // [nbuf] (selection) / [8] (TOP1)
     unsigned char *mine = CLDS ? nullptr : p.scratch + p.per_block * blockIdx.x;
     pq64_t *s_coarse = CLDS ? s_head : reinterpret_cast<pq64_t *>(mine);                            // [nlist] the whole coarse order
@@ -286,7 +284,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     // unsorted tail, whose arrangement only the replay knows), fall back to the exact replay -- ivf_fused_kernel's rule, without a
     // second launch: the original sequence is still in place (head saved, tail untouched).
     constexpr int kFastR = kShardFastW + 1;
-    const bool fast_ok = !CLDS && w_lds && p.w <= kShardFastW && nlist > (int) p.w + 64 && surv_cap != 0xff;      // (surv_cap = 255: tests force the replay)
+    const bool fast_ok = !CLDS && w_lds && p.w <= kShardFastW && nlist > (int) p.w + 64 && !force_replay;
     const int R = (int) p.w + 1;
     // (three keys per thread, not w + 1: with 256 threads three of the w + 1 smallest keys of a query share a thread in 0.01 - 0.1 % of
     //  the queries; a thread whose THIRD key is within the picks may have dropped a fourth -- detected, and such a query is replayed.
@@ -373,13 +371,8 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             if constexpr (CLDS) {
                 if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);        // src/rii.h:279-280 (wave 0)
             } else if (w_lds) {
-                if (p.w <= kBhMaxHeap && nlist - (int) p.w > 2 * kBhFirst) {
-                    // many lists, a small heap: the whole block scans the tail
-                    bh_partial_sort_split<256>(s_head, s_coarse + p.w, (int) p.w, nlist, tid, s_bh_key, s_bh_idx, s_misc + 4, surv_cap);
-                } else {
-                    if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);
-                    __syncthreads();
-                }
+                if (tid < 64) wh_partial_sort_split(s_head, s_coarse + p.w, (int) p.w, nlist, tid);      // heap in LDS, tail in global scratch
+                __syncthreads();
             } else if (tid == 0) {
                 pq64_partial_sort(s_coarse, (long) p.w, (long) nlist);
             }
@@ -717,7 +710,7 @@ static bool shard_any_clds(int M, int Ks, int nlist)
 static size_t shard_any_fixed(int M, int Ks, int nlist, int64_t w)
 {
     const size_t nh = (size_t) (w <= kWhSplitMaxHeap ? w : 0);
-    const size_t coarse = shard_any_clds(M, Ks, nlist) ? (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 : nh * 8 + (nh + 2) * 4 + (size_t) kBhCap * 12 + (size_t) 5 * (kShardFastW + 1) * 8;
+    const size_t coarse = shard_any_clds(M, Ks, nlist) ? (size_t) nlist * 8 + (size_t) (nlist + 1) * 4 : nh * 8 + (nh + 2) * 4 + (size_t) 5 * (kShardFastW + 1) * 8;
     return shard_tab_bytes(M, Ks) + coarse + shard_any_misc();
 }
 static int shard_any_nbuf(int M, int Ks, int nlist, int64_t w)
@@ -768,7 +761,7 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st,
-                            const float *d_queries, const float *d_codewords, int Ds, int arch, const uint8_t *d_lcodes)
+                            const float *d_queries, const float *d_codewords, int Ds, int arch, const uint8_t *d_lcodes, int debug)
 {
     if (B == 0) return hipSuccess;
     ShardArgs a;
@@ -790,9 +783,9 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
                                : (cl ? ivf_shard_any_kernel<false, true, false> : ivf_shard_any_kernel<false, false, false>));
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         if (e != hipSuccess) return e;
-        static const int dbg_stop = getenv("RII_SHARD_DBG_STOP") ? atoi(getenv("RII_SHARD_DBG_STOP")) : 0;      // measurement only
-        const int surv_cap = getenv("RII_SHARD_SURV_CAP") ? (atoi(getenv("RII_SHARD_SURV_CAP")) & 0xff) : 0;            // tests only (read per launch)
-        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, nbuf, collect | ((dbg_stop & 0xff) << 8) | (surv_cap << 16));
+        // debug (engine options "shard_dbg_stop" | "shard_force_replay" << 8; 0 in production): bits 8..15 of the kernel's word = return after
+        // that phase (measurement), bit 16 = no fast coarse selection, every query takes the exact replay (tests)
+        hipLaunchKernelGGL(kern, dim3((unsigned) B), dim3(256), smem, st, a, nbuf, collect | ((debug & 0xffff) << 8));
         return hipGetLastError();
     }
     const size_t smem = shard_smem(M, Ks, nlist, L, w);

@@ -548,126 +548,10 @@ __device__ __forceinline__ void wh_partial_sort_split_t(pq64_t *head, pq64_t *ta
 //  per sift against 556 with the heap in LDS.  Every level of the scalar walk is a vector-to-scalar-to-vector round trip; the LDS
 //  form resolves a whole path with one ballot and one gather.  Not kept.)
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same std::partial_sort with the WHOLE BLOCK scanning the tail (round 5; middle <= 64, blocks of NT threads, all of them call it).
-// __heap_select only acts on a tail entry that is smaller than the heap's top at that moment, and the top never grows.  So wave 0
-// replays the first kBhFirst tail entries exactly (register heap), publishes the top T it has reached, every thread of the block
-// then compares its share of the remaining tail with T -- entries >= T can never act -- and appends the few that are smaller
-// (with their positions) to an LDS list; wave 0 puts the list back into sequence order and replays it, exactly as the library would
-// have met those entries: same comparisons against the top of the moment, same evicted tops written into the same tail slots.
-// A list that overflows its kBhCap slots (a long descending run) is dropped and wave 0 scans the rest of the tail itself.
-// s_skey [kBhCap] u64, s_sidx [kBhCap] int, s_ctl [4] int: LDS.  cap_override (tests): a smaller capacity to force the overflow route.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kBhFirst = 512, kBhCap = 256, kBhMaxHeap = 64;
-// (forward: the single operations on an LDS heap, defined below)
-__device__ __forceinline__ pq64_t wh_adjust_top(pq64_t *h, int len, pq64_t v, int lane);
-__device__ __forceinline__ void wh_make_heap(pq64_t *h, int len, int lane);
-__device__ __forceinline__ void wh_sort_heap(pq64_t *h, int len0, int lane);
-__device__ __forceinline__ void bh_tail_step(pq64_t *head, pq64_t &topv, pq64_t e, bool valid, int pos, pq64_t *tail, int middle, int lane)
-{
-    unsigned long long m = __ballot(valid && pq64_less(e, topv));
-    while (m) {
-        const int j = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const pq64_t ej = wh_readlane(e, j);
-        if (pq64_less(ej, topv)) {                          // the library compares with the top of THAT moment
-            const int pj = __builtin_amdgcn_readlane(pos, j);
-            if (lane == 0) tail[pj - middle] = topv;        // __pop_heap(first, middle, i)
-            topv = wh_adjust_top(head, middle, ej, lane);
-        }
-    }
-}
-template <int NT>
-__device__ __forceinline__ void bh_partial_sort_split(pq64_t *head, pq64_t *tail, int middle, int n, int tid, pq64_t *s_skey, int *s_sidx,
-                                                      int *s_ctl, int cap_override)
-{
-    const int lane = tid & 63;
-    const bool w0 = tid < 64;
-    const int cap = cap_override > 0 && cap_override < kBhCap ? cap_override : kBhCap;
-    const int first_end = middle + kBhFirst < n ? middle + kBhFirst : n;         // wave 0 alone up to here
-    pq64_t topv = 0ull;
-    if (w0) {
-        wh_make_heap(head, middle, lane);                   // __make_heap
-        topv = wh_uniform(head[0]);
-        pq64_t ev[kBhFirst / 64];
-#pragma unroll
-        for (int u = 0; u < kBhFirst / 64; ++u) {
-            const int i = middle + 64 * u + lane;
-            ev[u] = i < first_end ? tail[i - middle] : ~0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < kBhFirst / 64; ++u) {
-            const int i = middle + 64 * u + lane;
-            bh_tail_step(head, topv, ev[u], i < first_end, i, tail, middle, lane);
-        }
-        if (lane == 0) { s_ctl[0] = 0; s_ctl[1] = (int) (uint32_t) (topv >> 32); }
-    }
-    __syncthreads();
-    {
-        const uint32_t thi = (uint32_t) s_ctl[1];                                // an entry acts only if its distance is below this
-        for (int i0 = first_end + tid; i0 < n; i0 += NT * 8) {
-            pq64_t e[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) e[u] = i0 + u * NT < n ? tail[i0 + u * NT - middle] : ~0ull;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i0 + u * NT < n && (uint32_t) (e[u] >> 32) < thi) {
-                    const int slot = atomicAdd(&s_ctl[0], 1);
-                    if (slot < cap) { s_skey[slot] = e[u]; s_sidx[slot] = i0 + u * NT; }
-                }
-        }
-    }
-    __syncthreads();
-    if (w0) {
-        const int ns = s_ctl[0];
-        if (ns > cap) {
-            // overflow: the plain scan of the rest of the tail (sixteen slices per round trip)
-            constexpr int U = 16;
-            for (int i0 = first_end; i0 < n; i0 += 64 * U) {
-                pq64_t ev[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + 64 * u + lane;
-                    ev[u] = i < n ? tail[i - middle] : ~0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + 64 * u + lane;
-                    bh_tail_step(head, topv, ev[u], i < n, i, tail, middle, lane);
-                }
-            }
-        } else if (ns > 0) {
-            // back into sequence order: every entry counts the entries in front of it (positions are distinct) and moves to its rank
-            pq64_t mk[kBhCap / 64];
-            int mi[kBhCap / 64], rk[kBhCap / 64];
-#pragma unroll
-            for (int u = 0; u < kBhCap / 64; ++u) {
-                const int j = lane + 64 * u;
-                mk[u] = j < ns ? s_skey[j] : ~0ull;
-                mi[u] = j < ns ? s_sidx[j] : 0x7fffffff;
-                rk[u] = 0;
-            }
-            for (int k = 0; k < ns; ++k) {
-                const int ik = s_sidx[k];
-#pragma unroll
-                for (int u = 0; u < kBhCap / 64; ++u) rk[u] += ik < mi[u] ? 1 : 0;
-            }
-            __builtin_amdgcn_wave_barrier();                // (one wave, in-order LDS: every read above precedes the writes below)
-#pragma unroll
-            for (int u = 0; u < kBhCap / 64; ++u)
-                if (lane + 64 * u < ns) { s_skey[rk[u]] = mk[u]; s_sidx[rk[u]] = mi[u]; }
-            __builtin_amdgcn_wave_barrier();
-            for (int s0 = 0; s0 < ns; s0 += 64) {
-                const int j = s0 + lane;
-                const pq64_t e = j < ns ? s_skey[j] : ~0ull;
-                const int pos = j < ns ? s_sidx[j] : 0;
-                bh_tail_step(head, topv, e, j < ns, pos, tail, middle, lane);
-            }
-        }
-        wh_sort_heap(head, middle, lane);                   // __sort_heap
-    }
-    __syncthreads();
-}
+// (Round 5 also measured the WHOLE BLOCK scanning the tail of this partial_sort -- wave 0 replays the first 512 tail entries, publishes the
+//  top it reached, 256 threads filter the rest of the tail against it and wave 0 replays the few survivors in sequence order: 28 us per
+//  query over 8000 lists against 26-30 us for the split form above, and its 151 VGPRs cost ivf_shard_any_kernel its fourth block per
+//  CU (39 -> 54 us per 1024 queries at SIFT shape).  Removed; the fast selection of ivfshard.hip makes the replay the rare route.)
 
 constexpr int kWhSplitMaxHeap = 2 * 64 * kWhMaxWords;
 __device__ __forceinline__ void wh_partial_sort_split(pq64_t *head, pq64_t *tail, int middle, int n, int lane)

@@ -258,7 +258,7 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st,
                             const float *d_queries = nullptr, const float *d_codewords = nullptr, int Ds = 0, int arch = 0,
-                            const uint8_t *d_lcodes = nullptr);      // d_lcodes: the codes in posting order of d_pl_ids (unfiltered lists), or NULL
+                            const uint8_t *d_lcodes = nullptr, int debug = 0);      // d_lcodes: the codes in posting order of d_pl_ids (unfiltered lists), or NULL
 // true: that launch builds the queries' tables itself when handed (d_queries, d_codewords) -- d_lut may be NULL then
 bool ivf_shard_builds_tables(int M, int Ks, int nlist, int64_t L, int64_t w, int rows);
 size_t shard_replay_scratch(int64_t nf, int rows);    // bytes of d_scratch launch_shard_replay needs (0: the sequences fit LDS)

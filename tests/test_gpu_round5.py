@@ -378,13 +378,12 @@ def test_header_merge_for_many_fake_ranks():
             assert int(anyf.item()) & 2 and int(tie.sum().item()) == 0
 
 
-def test_block_wide_coarse_partial_sort_many_lists():
-    """bh_partial_sort_split: with thousands of lists and a heap of w <= 64 the whole block scans the tail of the coarse
-    std::partial_sort (wave 0 replays the first 512 entries, everybody filters the rest against the top reached, wave 0 replays the
-    few survivors in sequence order).  nlist = 5000 duplicated centres (exactly tied coarse distances), w = 4 ... 40, top-1 and top-k,
-    target ids; the same with the survivor list forced to overflow (env RII_SHARD_SURV_CAP: wave 0 scans the rest itself) -- all
+def test_coarse_selection_and_replay_many_lists():
+    """ivf_shard_any_kernel's coarse step with thousands of lists: the fast selection (three keys per thread -> DPP minima -> merge)
+    must hand over to the exact std::partial_sort replay (src/rii.h:279-280) whenever it cannot prove the library's order --
+    nlist = 5000 duplicated centres (exactly tied coarse distances), w = 4 ... 40, top-1 and top-k, target ids, stale lists (the walk
+    leaves the first w lists) -- and the same with the fast selection off (option shard_force_replay: every query replays): all
     equal to the oracle on the same lists."""
-    import os
     from rii_amd import RiiGpu
     from rii_amd import dist as rd
     n, nlist = 30011, 5000
@@ -413,13 +412,14 @@ def test_block_wide_coarse_partial_sort_many_lists():
     assert gs.posting_lists == os_.posting_lists
     idxs = rd.DbShardedIndex(gs, 0, n)
     try:
-        for cap in ("", "2", "40", "255"):                  # 255: the fast selection off, every query through the replay
-            if cap:
-                os.environ["RII_SHARD_SURV_CAP"] = cap
+        for force in (0, 1):                                # 1: the fast selection off, every query through the replay
+            for e_ in (g, gs):
+                e_.set_option("shard_force_replay", force)
             for topk, L, t in ((1, 6, None), (1, 60, None), (1, 220, None), (3, 30, None), (1, 9000, None), (2, 40, sub), (1, n, None)):
                 _check_ivf(idx, o, qs, topk, L, t)
             n_tail = 0
             for topk, L in ((1, 3), (1, 30), (1, 2), (1, 200)):
                 _check_ivf(idxs, os_, qs, topk, L, None)
     finally:
-        os.environ.pop("RII_SHARD_SURV_CAP", None)
+        for e_ in (g, gs):
+            e_.set_option("shard_force_replay", 0)

@@ -14,6 +14,8 @@ rng = np.random.default_rng(1)
 cw = rng.random((M, 256, 4)).astype(np.float32)
 codes = rng.integers(0, 256, size=(N, M), dtype=np.uint8)
 eng = RiiGpu(cw, False, device=0); eng.add_codes(codes, False)
+if len(sys.argv) > 1:                                    # phase split: the shard kernel cut short (wrong rows)
+    eng.set_option("shard_dbg_stop", int(sys.argv[1]))
 off, ids = bench.modulo_lists(N, nlist)
 eng.set_posting_lists(rng.integers(0, 256, size=(nlist, M), dtype=np.uint8), off, ids)
 comm = rd.get_comm()
