@@ -581,7 +581,7 @@ def roofline_ivf_shard(kernel, B, nlist, M, L, avg_s, launches, steps):
     alg = B * (nlist * M + L * (M + 4))
     r = roofline_hbm(kernel, alg, avg_s, launches, steps, None)
     r["note"] = ("algorithmic bytes = B x (nlist x M centre bytes + L x (M + 4) candidate bytes); one block per query: table staged, "
-                 "coarse scores, std::partial_sort of the coarse order by wave 0, the global walk by one lane, then the owned candidates "
+                 "coarse scores, the w + 1 nearest lists by DPP minima (exact std::partial_sort replay when their order cannot be proven), the global walk by one lane, then the owned candidates "
                  "(rows read from the posting-order copy of the codes: one coalesced run per visited list)")
     return r
 
