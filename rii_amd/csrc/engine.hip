@@ -1421,6 +1421,9 @@ RII_API int rii_set_posting_lists(rii_engine *e, const uint8_t *centers, int64_t
         if (pl_off[i + 1] < pl_off[i]) return set_err(RII_ERR_INVALID, "pl_off must be non-decreasing");
     for (int64_t j = 0; j < pl_off[nlist]; ++j)
         if (pl_ids[j] < 0 || (int64_t) pl_ids[j] >= e->N) return set_err(RII_ERR_INVALID, "posting id %d out of range [0, %lld)", pl_ids[j], (long long) e->N);
+    if (e->Ks < 256)
+        for (size_t j = 0; j < (size_t) nlist * e->M; ++j)
+            if ((int) centers[j] >= e->Ks) return set_err(RII_ERR_INVALID, "centre code %d is not below Ks = %d", (int) centers[j], e->Ks);
     e->centers.assign(centers, centers + (size_t) nlist * e->M);
     RII_TRY(upload_centers(e));
     e->lists.assign((size_t) nlist, std::vector<int32_t>());
