@@ -18,7 +18,7 @@ __device__ __forceinline__ float sq_acc(float acc, float d, bool fused)
 
 // fvec_L2sqr, src/distance.h:117-252, all three compile-time variants (see oracle/rii_oracle.c for the
 // derivation of the lane order and FMA contraction).
-__device__ inline float fvec_l2sqr_dev(const float *__restrict__ x, const float *__restrict__ y, int d, int arch)
+__device__ __forceinline__ float fvec_l2sqr_body(const float *__restrict__ x, const float *__restrict__ y, int d, int arch)
 {
     const bool fused = (arch != RII_SIMD_SSE);
     float l16[16], l8[8], l4[4];
@@ -61,6 +61,20 @@ __device__ inline float fvec_l2sqr_dev(const float *__restrict__ x, const float 
         }
     }
     return __fadd_rn(__fadd_rn(l4[0], l4[1]), __fadd_rn(l4[2], l4[3]));
+}
+__device__ inline float fvec_l2sqr_dev(const float *__restrict__ x, const float *__restrict__ y, int d, int arch)
+{
+    return fvec_l2sqr_body(x, y, d, arch);
+}
+// the same operations for a compile-time dimension with both vectors in registers (the loops fold; no memory access)
+template <int D>
+__device__ __forceinline__ float fvec_l2sqr_regs(const float (&x)[D], const float (&y)[D], int arch)
+{
+    // (one fully folded copy per SIMD variant: with a run-time variant the pointer steps of the body are conditional and the
+    //  register arrays would be demoted to scratch)
+    if (arch == RII_SIMD_AVX512) return fvec_l2sqr_body(x, y, D, RII_SIMD_AVX512);
+    if (arch == RII_SIMD_AVX) return fvec_l2sqr_body(x, y, D, RII_SIMD_AVX);
+    return fvec_l2sqr_body(x, y, D, RII_SIMD_SSE);
 }
 
 // Ds == 4 (the SIFT shape: D=128, M=32) in straight-line form with two 16-byte loads.  Identical for all three SIMD

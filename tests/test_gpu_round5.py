@@ -423,3 +423,28 @@ def test_coarse_selection_and_replay_many_lists():
     finally:
         for e_ in (g, gs):
             e_.set_option("shard_force_replay", 0)
+
+
+@pytest.mark.parametrize("arch", ["sse", "avx", "avx512"])
+@pytest.mark.parametrize("M,Ds", [(16, 6), (16, 8), (32, 2), (16, 3), (8, 20)])
+def test_shard_kernel_builds_its_table_in_every_simd_order(M, Ds, arch):
+    """ivf_shard_any_kernel computes its query's exact table itself (RiiCpp::DTable, src/rii.h:361-373).  For Ds = 2 / 6 / 8 at Ks = 256
+    the codewords of several subspaces are loaded together and fvec_L2sqr's operations (src/distance.h:117-252) run on registers, one
+    folded copy per SIMD variant; other Ds take the plain loop.  Non-integer data: a wrong lane order or a wrong FMA contraction
+    changes low bits of the distances.  Against the oracle built for the same variant, through the database-sharded entry point."""
+    from rii_amd import RiiGpu
+    from rii_amd import dist as rd
+    import bench
+    n, nlist = 6000, 77
+    cw, codes, qs = make_problem(500 + M + Ds, M, 256, Ds, n, "unit")
+    cen = np.random.default_rng(M * Ds).integers(0, 256, size=(nlist, M), dtype=np.uint8)
+    off, ids = bench.modulo_lists(n, nlist)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    g.add_codes(codes, False)
+    g.set_posting_lists(cen, off, ids)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    o.add_codes(codes, False)
+    o.set_csr(cen, off, ids)
+    idx = rd.DbShardedIndex(g, 0, n)
+    for topk, L in ((1, 200), (3, 500), (1, n)):
+        _check_ivf(idx, o, qs, topk, L, None)
