@@ -90,9 +90,31 @@ def parse():
     ap.add_argument("--scan-mx", type=int, default=1, choices=[0, 1],
                     help="1 (default): the filter scan of the M = 16 / 32 shapes sums its table bytes on the matrix cores "
                          "(fscan_mx_kernel); 0: on the vector ALU (fscan_kernel)")
+    ap.add_argument("--full-out", default="",
+                    help="where the long form of the JSON line is written (default gpurun_out/bench_full_<workload>.json); the line "
+                         "printed on stdout is the compact form")
     ap.add_argument("--scan-mode", type=int, default=1, choices=[0, 1],
                     help="1: 8-bit filter + exact re-rank (default), 0: exact scan of every code; identical results")
     return ap.parse_args()
+
+
+def emit(line, args):
+    """Rank 0's output: the long form of the line goes to a side file (--full-out; default gpurun_out/bench_full_<workload>.json
+    under the repo), the line printed LAST on stdout is its compact form (rii_amd/benchline.py: <= 12 KB -- round 5's 20.6 KB line
+    came back from the driver unparsed)."""
+    from rii_amd import benchline
+    path = args.full_out or os.path.join(ROOT, "gpurun_out", "bench_full_%s.json" % args.workload.replace("-", "_"))
+    shown = None
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(line, f)
+            f.write("\n")
+        shown = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError:
+        pass                                     # a read-only tree must not cost the run its line
+    sys.stdout.flush()
+    print(benchline.dumps(line, shown), flush=True)
 
 
 def free_port():
@@ -857,7 +879,7 @@ def main_deep_ivf(args, world, rank, local, dev, arch):
                 "lists": obj["lists"]}
         if "cpu_baseline" in obj:
             line["cpu_baseline"] = obj["cpu_baseline"]
-        print(json.dumps(line), flush=True)
+        emit(line, args)
     rd.close_comms()
     if use_dist:
         dist.destroy_process_group()
@@ -1370,6 +1392,12 @@ def main():
                                    "collective_share": max(0.0, 1.0 - elapsed / elapsed_g)}
         if strong:
             line["strong"] = strong
+            # BASELINE's metric is "batch = 1024 at 1 / 2 / 4 / 8 GPU": the strong-scaling figures at the top level, beside the weak
+            # `value` the contract asks for (the first real SCALE run must be readable without digging)
+            line["strong_query_sharded_value"] = strong.get("query_sharded", {}).get("value")
+            line["strong_db_sharded_value"] = strong.get("db_sharded", {}).get("value")
+        if use_dist:
+            line["rccl_ranks"] = world if dist.get_backend() == "nccl" else 0
         if host is not None:
             line["host_call"] = host
         if fresh is not None:
@@ -1416,7 +1444,7 @@ def main():
             wall["others_s"] = others["seconds_spent"]
         wall["total_s"] = time.perf_counter() - t_start
         line["wall_clock"] = wall
-        print(json.dumps(line), flush=True)
+        emit(line, args)
     rd.close_comms()                       # (the library's own RCCL communicators: destroyed here, not at interpreter exit)
     if use_dist:
         dist.destroy_process_group()

@@ -1,0 +1,92 @@
+"""The ONE JSON line bench.py prints, kept short enough for the driver to parse.
+
+Round 5's line had grown to 20.6 KB (explanatory strings, counter tables, a dozen nested side measurements) and the driver's
+record came back with `parsed: null`.  bench.py now builds the long form as before, writes it to a side file, and prints
+`compact(line)`: the contract's keys, `roofline`, `cpu_baseline`, and one short row per `others` workload.  The structure of
+the long form is kept (the same paths lead to the same numbers); what goes is prose and bulk.
+
+Pure python, no torch: tests/test_benchline.py feeds it canned lines on the CPU."""
+import json
+import math
+
+LINE_LIMIT = 12000          # bytes of the printed line; the driver parsed 15.5 KB (round 4) and not 20.6 KB (round 5)
+
+# prose and bulk that only the long form carries
+DROP_ALWAYS = frozenset((
+    "note", "what", "traffic_source", "counters_from_profiles", "lists", "delivery", "rows_checked", "cold_start_what",
+    "collective", "threads_tried", "traffic_from_profiles", "table_lookups_per_launch", "entry_bytes", "hbm_form",
+    "algorithmic_lane_ops_per_query", "source", "lds_insts", "valu_insts", "gpu_cycles_per_launch", "lds_cycles_per_read",
+    "uninstrumented_value", "launches_per_step", "seconds_spent", "flops_per_launch", "ms_per_query", "steps_timed",
+))
+# dropped only inside `others` rows (the headline keeps them)
+DROP_IN_OTHERS = frozenset((
+    "config", "hbm", "counters_live", "launches", "avg_launch_ms", "p99_ms", "lut_ms_per_step", "rerank_ms_per_step",
+    "gather_ms_per_step", "quant_ms_per_step", "kth_ms_per_step", "tie_ms_per_step", "select_ms_per_step", "sample",
+    "ivf_exact_ms_per_step", "ivf_coarse_ms_per_step", "ivf_plan_ms_per_step", "ivf_scan_ms_per_step", "ivf_select_ms_per_step",
+    "unit", "peak", "achieved", "algorithmic_bytes_per_launch", "steps", "uninstrumented_ms_per_step",
+))
+# second pass, only if the line is still above the limit
+DROP_IF_TIGHT = ("preheat", "results", "pipelined", "fresh_queries", "host_call", "uninstrumented", "wall_clock")
+MAX_STR = 200
+
+
+def _num(x):
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or math.isinf(x):
+        return None
+    if x == 0.0:
+        return 0.0
+    return float("%.5g" % x)
+
+
+def _shrink(o, in_others):
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            if k in DROP_ALWAYS or (in_others and k in DROP_IN_OTHERS):
+                continue
+            out[k] = _shrink(v, in_others)
+        return out
+    if isinstance(o, (list, tuple)):
+        return [_shrink(v, in_others) for v in o]
+    if isinstance(o, str):
+        return o if len(o) <= MAX_STR else o[:MAX_STR - 1] + "~"
+    return _num(o)
+
+
+def compact(line, full_path=None, limit=LINE_LIMIT):
+    """-> the dict bench.py prints.  `line` is the long form (not modified)."""
+    out = {}
+    for k, v in line.items():
+        if k == "others":
+            out[k] = {name: _shrink(row, True) for name, row in v.items() if isinstance(row, dict)}
+        elif k in DROP_ALWAYS:
+            continue
+        else:
+            out[k] = _shrink(v, False)
+    if full_path:
+        out["full_form"] = full_path
+    for k in DROP_IF_TIGHT:
+        if len(json.dumps(out)) <= limit:
+            break
+        out.pop(k, None)
+    if len(json.dumps(out)) > limit and "others" in out:
+        # last resort: the rows keep value / ms_per_step / kernel / kernel_ms / roofline.frac / cpu_baseline.value / ids_match_gpu
+        slim = {}
+        for name, row in out["others"].items():
+            r = {k: row[k] for k in ("value", "ms_per_step", "kernel", "kernel_ms", "error") if k in row}
+            if isinstance(row.get("roofline"), dict):
+                r["roofline"] = {k: row["roofline"].get(k) for k in ("bound", "frac", "traffic")}
+            if isinstance(row.get("cpu_baseline"), dict):
+                r["cpu_baseline"] = {k: row["cpu_baseline"].get(k) for k in ("value", "cores", "kind", "ids_match_gpu")}
+            slim[name] = r
+        out["others"] = slim
+    return out
+
+
+def dumps(line, full_path=None, limit=LINE_LIMIT):
+    s = json.dumps(compact(line, full_path, limit), separators=(",", ":"))
+    if len(s) > limit:
+        raise ValueError("bench line is %d bytes (limit %d): move detail to the long form" % (len(s), limit))
+    return s

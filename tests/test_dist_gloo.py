@@ -778,12 +778,17 @@ def test_bench_default_line_carries_every_baseline_config():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--n-base", "200000", "--steps", "3", "--warmup", "1",
                           "--deep-shard", "400000", "--preheat", "0.02"], env=env, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    printed = [l for l in out.stdout.splitlines() if l.strip()]
+    assert printed[-1].startswith("{") and len([l for l in printed if l.startswith("{")]) == 1, printed[-3:]
+    assert len(printed[-1]) < 12000, len(printed[-1])          # round 5's 20.6 KB line came back from the driver unparsed
+    line = json.loads(printed[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline", "others", "preheat", "uninstrumented"):
+                "dtype", "data", "config", "roofline", "cpu_baseline", "others", "full_form"):
         assert key in line, key
     assert line["steps"] == 3 and line["warmup"] == 1 and line["cpu_baseline"]["ids_match_gpu"] is True
-    assert line["roofline"]["bound"] == "lds-gather" and 0 < line["roofline"]["frac"] <= 1.0 and "counters_from_profiles" in line["roofline"]
+    assert line["roofline"]["bound"] == "lds-gather" and 0 < line["roofline"]["frac"] <= 1.0
+    full = json.load(open(os.path.join(root, line["full_form"])))          # the long form: same numbers, plus the prose
+    assert full["value"] == pytest.approx(line["value"], rel=1e-4) and "note" in full["roofline"] and "preheat" in full
     oth = line["others"]
     for name in ("subset", "ivf", "subset_ivf", "deep_shard"):
         o = oth[name]
