@@ -113,7 +113,14 @@ def emit(line, args):
         shown = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
     except OSError:
         pass                                     # a read-only tree must not cost the run its line
+    # RCCL prints its version banner through C stdio, which is fully buffered when stdout is a pipe: left alone it comes out at
+    # process exit, AFTER the JSON line.  Flushed here, the JSON line is the last line of stdout.
     sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                            # noqa: BLE001
+        pass
     print(benchline.dumps(line, shown), flush=True)
 
 
