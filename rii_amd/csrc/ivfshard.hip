@@ -221,35 +221,7 @@ constexpr int kShardFastW = 7;           // the fast coarse selection covers w <
 // CLDS: the coarse order and the cumulative counts of the query in LDS (nlist <= kShardMaxNlistLds), else in global scratch.
 // TOP1: rows == 2 (top-1: the best two owned candidates): every thread keeps its two smallest keys in registers, the block's two
 //       smallest come out of two DPP minima per wave and eight keys in LDS -- no buffer, no sort, no atomics.
-// The in-kernel table for an even Ds other than 4 at Ks = 256 (thread = ks): the codewords of U subspaces requested together
-// (8-byte loads), then fvec_L2sqr's operations on registers.  The plain loop fetched one subspace at a time -- a chain of M dependent
-// round trips, 8-9 us of latency per block at the Deep1B shape (M = 16, Ds = 6).
-template <int DS, int U>
-__device__ __forceinline__ void shard_table_rows(float *__restrict__ lds, const float *__restrict__ q, const float *__restrict__ codewords,
-                                                 int M, int arch, int tid)
-{
-    static_assert(DS % 2 == 0, "8-byte codeword loads");
-    for (int m0 = 0; m0 < M; m0 += U) {
-        float2 cv[U][DS / 2];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float2 *src = reinterpret_cast<const float2 *>(codewords + ((size_t) (m0 + u < M ? m0 + u : m0) * 256 + tid) * DS);
-#pragma unroll
-            for (int i = 0; i < DS / 2; ++i) cv[u][i] = src[i];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (m0 + u >= M) break;
-            float x[DS], y[DS];
-#pragma unroll
-            for (int i = 0; i < DS; ++i) x[i] = q[(m0 + u) * DS + i];
-#pragma unroll
-            for (int i = 0; i < DS / 2; ++i) { y[2 * i] = cv[u][i].x; y[2 * i + 1] = cv[u][i].y; }
-            lds[(m0 + u) * 256 + tid] = fvec_l2sqr_regs<DS>(x, y, arch);
-        }
-    }
-}
-
+// (the in-kernel table for an even Ds other than 4: table_rows_regs, rii_device.h)
 template <bool GTAB, bool CLDS, bool TOP1>
 __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbuf, int collect)
 {
@@ -292,11 +264,11 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
                         if (m0 + u < p.M) lds[(m0 + u) * 256 + tid] = fvec_l2sqr_ds4v(q4[m0 + u], cv[u]);
                 }
             } else if (p.Ks == 256 && p.Ds == 6) {                                    // Deep1B shape (D = 96, M = 16)
-                shard_table_rows<6, 8>(lds, q, p.codewords, p.M, p.arch, tid);
+                table_rows_regs<6, 8>(lds, q, p.codewords, p.M, p.arch, tid);
             } else if (p.Ks == 256 && p.Ds == 8) {
-                shard_table_rows<8, 4>(lds, q, p.codewords, p.M, p.arch, tid);
+                table_rows_regs<8, 4>(lds, q, p.codewords, p.M, p.arch, tid);
             } else if (p.Ks == 256 && p.Ds == 2) {
-                shard_table_rows<2, 16>(lds, q, p.codewords, p.M, p.arch, tid);
+                table_rows_regs<2, 16>(lds, q, p.codewords, p.M, p.arch, tid);
             } else {
                 for (int m = 0; m < p.M; ++m) {
                     const float *qm = q + (size_t) m * p.Ds;

@@ -972,6 +972,15 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
                     if (i < MK) lds[i] = fvec_l2sqr_ds4v(q4[i / p.Ks], cv[u]);
                 }
             }
+        } else if (p.Ks == 256 && p.Ds == 2) {
+            // round 6: the reference's own harness setting is M = 64 over D = 128, i.e. Ds = 2 (examples/benchmark/ann_methods.py:19-34).
+            // The plain loop below built that table in 72 us of the kernel's 180 (profiles/r06_fused_phases.json): one subspace per
+            // dependent L2 round trip through the generic fvec_L2sqr.  Codewords of 16 subspaces in flight, arithmetic on registers.
+            table_rows_regs<2, 16>(lds, q, p.codewords, p.M, p.arch, tid);
+        } else if (p.Ks == 256 && p.Ds == 6) {
+            table_rows_regs<6, 8>(lds, q, p.codewords, p.M, p.arch, tid);
+        } else if (p.Ks == 256 && p.Ds == 8) {
+            table_rows_regs<8, 4>(lds, q, p.codewords, p.M, p.arch, tid);
         } else
         for (int m = 0; m < p.M; ++m) {           // query sub-vector address is wave-uniform inside this loop
             const float *qm = q + (size_t) m * p.Ds;

@@ -112,6 +112,36 @@ __device__ __forceinline__ float fvec_l2sqr_any(const float *__restrict__ x, con
     return fvec_l2sqr_dev(x, y, d, arch);
 }
 
+// The in-kernel table for an even Ds other than 4 at Ks = 256 (thread = ks): the codewords of U subspaces requested together
+// (8-byte loads), then fvec_L2sqr's operations on registers.  The plain loop fetched one subspace at a time -- a chain of M dependent
+// round trips, 8-9 us of latency per block at the Deep1B shape (M = 16, Ds = 6).
+template <int DS, int U>
+__device__ __forceinline__ void table_rows_regs(float *__restrict__ lds, const float *__restrict__ q, const float *__restrict__ codewords,
+                                                 int M, int arch, int tid)
+{
+    static_assert(DS % 2 == 0, "8-byte codeword loads");
+    for (int m0 = 0; m0 < M; m0 += U) {
+        float2 cv[U][DS / 2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float2 *src = reinterpret_cast<const float2 *>(codewords + ((size_t) (m0 + u < M ? m0 + u : m0) * 256 + tid) * DS);
+#pragma unroll
+            for (int i = 0; i < DS / 2; ++i) cv[u][i] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (m0 + u >= M) break;
+            float x[DS], y[DS];
+#pragma unroll
+            for (int i = 0; i < DS; ++i) x[i] = q[(m0 + u) * DS + i];
+#pragma unroll
+            for (int i = 0; i < DS / 2; ++i) { y[2 * i] = cv[u][i].x; y[2 * i + 1] = cv[u][i].y; }
+            lds[(m0 + u) * 256 + tid] = fvec_l2sqr_regs<DS>(x, y, arch);
+        }
+    }
+}
+
+
 // L2SquaredDistance of src/pqkmeans.cpp:164-173 as auto-vectorised by GCC -Ofast ([objcode] in the oracle).
 __device__ __forceinline__ float hsum_tree(float *t, int w)
 {

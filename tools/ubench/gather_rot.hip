@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -111,10 +112,7 @@ __global__ __launch_bounds__(NT) void rot_kernel(const uint8_t *__restrict__ rco
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = NT / 64, MW = M / 4;
     // table [ks][64 columns]: column c = subspace c mod M (M = 64: one copy)
-    for (int i = tid; i < 256 * 64; i += NT) {
-        const int ks = i >> 6, c = i & 63;
-        lds[i] = tab[(c % M) * 256 + ks] + (float) (blockIdx.x & 7);
-    }
+    for (int i = tid; i < 256 * 64; i += NT) lds[i] = tab[i] + (float) (blockIdx.x & 7);      // (tab: already [ks][64])
     __syncthreads();
     const int phi = lane % M;
     const int ntile = (ncand + 63) / 64;
@@ -131,8 +129,8 @@ __global__ __launch_bounds__(NT) void rot_kernel(const uint8_t *__restrict__ rco
     // column offset of the lane in round 0 (bytes): m = (0 - phi) mod M
     uint32_t laneoff = (uint32_t) (((M - phi) % M) * 4);
     if (M == 16) laneoff += (lane & 16) ? 64u : 0u;                     // second half of a 32-lane DS group: the other 16 banks
-    float keep[VARIANT == 1 ? M : 1];
-    if (VARIANT == 1) {
+    float keep[(VARIANT & 1) ? M : 1];
+    if (VARIANT & 1) {
 #pragma unroll
         for (int j = 0; j < M; ++j) keep[j] = (j == phi) ? 0.f : 1.f;
     }
@@ -144,20 +142,27 @@ __global__ __launch_bounds__(NT) void rot_kernel(const uint8_t *__restrict__ rco
     uint32_t bestp = 0xffffffffu;
     // wave w takes tiles w, w + NW, ...; one drain iteration at the end (the last tile's candidates finish in it)
     const int my_n = ntile > wave ? (ntile - wave + NW - 1) / NW : 0;
-    uint4 nxt[MW / 4];
-    {
-        const uint4 *cp = reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave) * 64 + lane) * (int64_t) M);
+    // the code rows come from L2 / Infinity Cache / HBM (1 - 2 us away): PF tiles are requested ahead of the one being summed
+    constexpr int PF = VARIANT >= 2 ? 3 : 1;
+    uint4 nxt[PF][MW / 4];
 #pragma unroll
-        for (int q = 0; q < MW / 4; ++q) nxt[q] = my_n > 0 ? cp[q] : make_uint4(0, 0, 0, 0);
+    for (int f = 0; f < PF; ++f) {
+        const uint4 *cp = reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave + (int64_t) f * NW) * 64 + lane) * (int64_t) M);
+#pragma unroll
+        for (int q = 0; q < MW / 4; ++q) nxt[f][q] = f < my_n ? cp[q] : make_uint4(0, 0, 0, 0);
     }
     int prev_pos = -1;                                                    // candidate (position) the lane finishes in this iteration
     for (int it = 0; it <= my_n; ++it) {
 #pragma unroll
-        for (int q = 0; q < MW / 4; ++q) { cur[4 * q] = nxt[q].x; cur[4 * q + 1] = nxt[q].y; cur[4 * q + 2] = nxt[q].z; cur[4 * q + 3] = nxt[q].w; }
-        if (it + 1 < my_n) {
-            const uint4 *cp = reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave + (int64_t) (it + 1) * NW) * 64 + lane) * (int64_t) M);
+        for (int q = 0; q < MW / 4; ++q) { cur[4 * q] = nxt[0][q].x; cur[4 * q + 1] = nxt[0][q].y; cur[4 * q + 2] = nxt[0][q].z; cur[4 * q + 3] = nxt[0][q].w; }
 #pragma unroll
-            for (int q = 0; q < MW / 4; ++q) nxt[q] = cp[q];
+        for (int f = 0; f + 1 < PF; ++f)
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) nxt[f][q] = nxt[f + 1][q];
+        if (it + PF < my_n) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave + (int64_t) (it + PF) * NW) * 64 + lane) * (int64_t) M);
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) nxt[PF - 1][q] = cp[q];
         }
         uint32_t x[MW];
 #pragma unroll
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(NT) void rot_kernel(const uint8_t *__restrict__ rco
             if (M == 32) eq |= eq << 32;
             if (M == 16) eq |= (eq << 16) | (eq << 32) | (eq << 48);
             fin = sel_mask(fin, acc, eq);                                   // the lane whose previous candidate is complete keeps its sum
-            if (VARIANT == 1) acc = __builtin_fmaf(acc, keep[j], t);        // ... and starts the next one from t (acc * 0 + t)
+            if (VARIANT & 1) acc = __builtin_fmaf(acc, keep[j], t);        // ... and starts the next one from t (acc * 0 + t)
             else acc = __fadd_rn(sel_mask(acc, 0.f, eq), t);
         }
         // every lane finished the candidate of the previous tile during this iteration
@@ -190,6 +195,287 @@ __global__ __launch_bounds__(NT) void rot_kernel(const uint8_t *__restrict__ rco
         prev_pos = it < my_n ? (wave + it * NW) * 64 + lane : -1;
 #pragma unroll
         for (int d = 0; d < MW; ++d) prev[d] = cur[d];
+    }
+    unsigned long long key = bestp == 0xffffffffu ? ~0ull : (((unsigned long long) f32_ord(__float_as_uint(bestd)) << 32) | bestp);
+    key = wave_min_u64(key);
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(lds + 256 * 64);
+    if (lane == 0) red[wave] = key;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w) key = red[w] < key ? red[w] : key;
+        out[blockIdx.x] = key;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// C: rotated gather, TWO accumulators by candidate parity, one v_pk_fma_f32 per round.
+// In iteration k a lane is on candidate C_k from round phi on and still on C_(k-1) before.  C_k accumulates in acc[k & 1]: the round's
+// table entry t goes to both halves of a packed fma, multiplied by the lane's (1, 0) or (0, 1) for that round -- acc = (t, t) * sel_j + acc
+// adds t to exactly one half, exactly (t * 1 + a, t * 0 + a).  Odd iterations read sel_j with its halves swapped (op_sel).  At the end of
+// iteration k every lane's acc[(k & 1) ^ 1] holds the finished C_(k-1): one compare for all 64 lanes, then it is zeroed for C_(k+1).
+// No capture, no reset, no masks: one v_perm_b32 + one v_pk_fma_f32 per 64 lookups.  2 M lane-constant VGPRs.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int M, int NT, int PF>
+__global__ __launch_bounds__(NT) void par_kernel(const uint8_t *__restrict__ rcodes, int64_t n_tiles_total, int ncand, const float *__restrict__ tab,
+                                                 unsigned long long *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64, MW = M / 4;
+    for (int i = tid; i < 256 * 64; i += NT) lds[i] = tab[i] + (float) (blockIdx.x & 7);
+    __syncthreads();
+    const int phi = lane % M;
+    const int ntile = (ncand + 63) / 64;
+    const int64_t tile0 = (((int64_t) blockIdx.x * 4099) % (n_tiles_total * 64 - ncand)) / 64;
+    uint32_t lowmask[MW];
+#pragma unroll
+    for (int d = 0; d < MW; ++d) {
+        uint32_t mk = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) mk |= (4 * d + b < phi) ? (0xffu << (8 * b)) : 0u;
+        lowmask[d] = mk;
+    }
+    // M <= 32 (doubled rows): constant column offset + immediate 4 j.  M = 64: the four rounds of a code dword take their column offsets
+    // from the four bytes of one lane-constant register (the same v_perm_b32 picks code byte and offset byte).
+    uint32_t laneoff = (uint32_t) (((M - phi) % M) * 4);
+    if (M == 16) laneoff += (lane & 16) ? 64u : 0u;
+    uint32_t offq[M == 64 ? MW : 1];
+    if (M == 64) {
+#pragma unroll
+        for (int d = 0; d < MW; ++d) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o |= (uint32_t) ((((4 * d + b - phi) % M + M) % M) * 4) << (8 * b);
+            offq[d] = o;
+        }
+    }
+    f2 sel[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) sel[j] = phi <= j ? f2{1.f, 0.f} : f2{0.f, 1.f};
+    uint32_t prev[MW], cur[MW];
+#pragma unroll
+    for (int d = 0; d < MW; ++d) prev[d] = 0u;
+    f2 acc = {0.f, 0.f};
+    float bestd = INFINITY;
+    uint32_t bestp = 0xffffffffu;
+    const int my_n = ntile > wave ? (ntile - wave + NW - 1) / NW : 0;
+    uint4 nxt[PF][MW / 4];
+#pragma unroll
+    for (int f = 0; f < PF; ++f) {
+        const uint4 *cp = reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave + (int64_t) f * NW) * 64 + lane) * (int64_t) M);
+#pragma unroll
+        for (int q = 0; q < MW / 4; ++q) nxt[f][q] = f < my_n ? cp[q] : make_uint4(0, 0, 0, 0);
+    }
+    int prev_pos = -1;
+    auto iteration = [&](int it, auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
+#pragma unroll
+        for (int q = 0; q < MW / 4; ++q) { cur[4 * q] = nxt[0][q].x; cur[4 * q + 1] = nxt[0][q].y; cur[4 * q + 2] = nxt[0][q].z; cur[4 * q + 3] = nxt[0][q].w; }
+#pragma unroll
+        for (int f = 0; f + 1 < PF; ++f)
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) nxt[f][q] = nxt[f + 1][q];
+        if (it + PF < my_n) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave + (int64_t) (it + PF) * NW) * 64 + lane) * (int64_t) M);
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) nxt[PF - 1][q] = cp[q];
+        }
+        uint32_t x[MW];
+#pragma unroll
+        for (int d = 0; d < MW; ++d) asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x[d]) : "v"(lowmask[d]), "v"(prev[d]), "v"(cur[d]));
+        // batches of RB rounds: RB addresses and ds_reads first (two rounds' entries share a register pair), then the RB dependent fmas
+        constexpr int RB = 8;
+#pragma unroll
+        for (int j0 = 0; j0 < M; j0 += RB) {
+            f2 t[RB / 2];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int j = j0 + u;
+                float v;
+                if (M == 64) {
+                    const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8) | (uint32_t) (j & 3);     // D.b0 = S1.b(j & 3), D.b1 = S0.b(j & 3)
+                    const uint32_t a = __builtin_amdgcn_perm(x[j >> 2], offq[M == 64 ? (j >> 2) : 0], ps);
+                    v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a);
+                } else {
+                    const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8);
+                    const uint32_t a = __builtin_amdgcn_perm(x[j >> 2], laneoff, ps);
+                    v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a + 4 * j);
+                }
+                if (u & 1) t[u >> 1].y = v; else t[u >> 1].x = v;
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int j = j0 + u;
+                // src0 = the round's entry in both halves (its own half of the pair), src1 = the lane's (1,0)/(0,1) (odd iterations: swapped)
+                if (!ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sel[j]));
+                if (!ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sel[j]));
+                if (ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sel[j]));
+                if (ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sel[j]));
+            }
+        }
+        // the candidate of the previous tile is complete in the other half, for every lane
+        const float fin = ODD ? acc.x : acc.y;
+        if (prev_pos >= 0 && prev_pos < ncand && fin < bestd) { bestd = fin; bestp = (uint32_t) prev_pos; }
+        if (ODD) acc.x = 0.f; else acc.y = 0.f;
+        prev_pos = it < my_n ? (wave + it * NW) * 64 + lane : -1;
+#pragma unroll
+        for (int d = 0; d < MW; ++d) prev[d] = cur[d];
+    };
+    for (int it = 0; it <= my_n; it += 2) {
+        iteration(it, std::false_type{});
+        if (it + 1 <= my_n) iteration(it + 1, std::true_type{});
+    }
+    unsigned long long key = bestp == 0xffffffffu ? ~0ull : (((unsigned long long) f32_ord(__float_as_uint(bestd)) << 32) | bestp);
+    key = wave_min_u64(key);
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(lds + 256 * 64);
+    if (lane == 0) red[wave] = key;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w) key = red[w] < key ? red[w] : key;
+        out[blockIdx.x] = key;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// D: C with (i) min(M, 32) phases (phi = lane mod 32 is all a 32-lane DS group needs: for M = 64 the routing pair is lane-dependent in
+// rounds 0 .. 30 only -- 31 register pairs instead of 64 -- and only the first 8 code dwords straddle two candidates), (ii) NCH
+// independent candidates per lane (chains: tiles 2s and 2s + 1 of the wave), (iii) the next batch's ds_reads issued ahead of the
+// current batch's fma chain.
+// ------------------------------------------------------------------------------------------------------------------
+template <int M, int NT, int NCH>
+__global__ __launch_bounds__(NT) void par2_kernel(const uint8_t *__restrict__ rcodes, int64_t n_tiles_total, int ncand, const float *__restrict__ tab,
+                                                  unsigned long long *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64, MW = M / 4, NPH = M < 32 ? M : 32, NSEL = NPH - 1, LW = (NSEL + 3) / 4, RB = 8, NB = M / RB;
+    for (int i = tid; i < 256 * 64; i += NT) lds[i] = tab[i] + (float) (blockIdx.x & 7);
+    __syncthreads();
+    const int phi = lane % NPH;
+    const int ntile = (ncand + 63) / 64;
+    const int64_t tile0 = (((int64_t) blockIdx.x * 4099) % (n_tiles_total * 64 - ncand)) / 64;
+    uint32_t lowmask[LW];
+#pragma unroll
+    for (int d = 0; d < LW; ++d) {
+        uint32_t mk = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) mk |= (4 * d + b < phi) ? (0xffu << (8 * b)) : 0u;
+        lowmask[d] = mk;
+    }
+    uint32_t laneoff = (uint32_t) (((M - phi) % M) * 4);
+    if (M == 16) laneoff += (lane & 16) ? 64u : 0u;
+    uint32_t offq[M == 64 ? MW : 1];
+    if (M == 64) {
+#pragma unroll
+        for (int d = 0; d < MW; ++d) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o |= (uint32_t) ((((4 * d + b - phi) % M + M) % M) * 4) << (8 * b);
+            offq[d] = o;
+        }
+    }
+    f2 sel[NSEL];
+#pragma unroll
+    for (int j = 0; j < NSEL; ++j) sel[j] = phi <= j ? f2{1.f, 0.f} : f2{0.f, 1.f};
+    const f2 one_zero = {1.f, 0.f};
+    uint32_t x[NCH][MW], plow[NCH][LW];
+    f2 acc[NCH];
+    int prev_pos[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        acc[c] = f2{0.f, 0.f};
+        prev_pos[c] = -1;
+#pragma unroll
+        for (int d = 0; d < LW; ++d) plow[c][d] = 0u;
+    }
+    float bestd = INFINITY;
+    uint32_t bestp = 0xffffffffu;
+    const int my_n = ntile > wave ? (ntile - wave + NW - 1) / NW : 0;       // tiles of this wave: wave, wave + NW, ...
+    const int nstep = (my_n + NCH - 1) / NCH;                                // chain c of step s: the wave's tile s * NCH + c
+    uint4 nxt[NCH][MW / 4];
+    auto request = [&](int s) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = s * NCH + c;
+            const uint4 *cp = reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave + (int64_t) (k < my_n ? k : 0) * NW) * 64 + lane) * (int64_t) M);
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) nxt[c][q] = cp[q];
+        }
+    };
+    request(0);
+    auto loads = [&](int c, int b, f2 (&t)[RB / 2]) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int j = b * RB + u;
+            float v;
+            if (M == 64) {
+                const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8) | (uint32_t) (j & 3);
+                const uint32_t a = __builtin_amdgcn_perm(x[c][j >> 2], offq[M == 64 ? (j >> 2) : 0], ps);
+                v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a);
+            } else {
+                const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8);
+                const uint32_t a = __builtin_amdgcn_perm(x[c][j >> 2], laneoff, ps);
+                v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a + 4 * j);
+            }
+            if (u & 1) t[u >> 1].y = v; else t[u >> 1].x = v;
+        }
+    };
+    auto fmas = [&](int c, int b, const f2 (&t)[RB / 2], auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int j = b * RB + u;
+            const f2 sj = j < NSEL ? sel[j < NSEL ? j : 0] : one_zero;
+            if (!ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[c]) : "v"(t[u >> 1]), "v"(sj));
+            if (!ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[c]) : "v"(t[u >> 1]), "v"(sj));
+            if (ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc[c]) : "v"(t[u >> 1]), "v"(sj));
+            if (ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc[c]) : "v"(t[u >> 1]), "v"(sj));
+        }
+    };
+    auto step = [&](int s, auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            uint32_t cur[MW];
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) { cur[4 * q] = nxt[c][q].x; cur[4 * q + 1] = nxt[c][q].y; cur[4 * q + 2] = nxt[c][q].z; cur[4 * q + 3] = nxt[c][q].w; }
+#pragma unroll
+            for (int d = 0; d < MW; ++d) {
+                if (d < LW) {
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x[c][d]) : "v"(lowmask[d]), "v"(plow[c][d]), "v"(cur[d]));
+                    plow[c][d] = cur[d];
+                } else x[c][d] = cur[d];
+            }
+        }
+        if (s + 1 < nstep) request(s + 1);
+        // software pipeline over the NB batches of RB rounds and the chains: the reads of (batch b + 1) go out before the fmas of batch b
+        f2 t[NCH][2][RB / 2];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) loads(c, 0, t[c][0]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (b + 1 < NB) loads(c, b + 1, t[c][(b + 1) & 1]);
+                fmas(c, b, t[c][b & 1], odd_tag);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float fin = ODD ? acc[c].x : acc[c].y;
+            if (prev_pos[c] >= 0 && prev_pos[c] < ncand && fin < bestd) { bestd = fin; bestp = (uint32_t) prev_pos[c]; }
+            if (ODD) acc[c].x = 0.f; else acc[c].y = 0.f;
+            const int k = s * NCH + c;
+            prev_pos[c] = k < my_n ? (wave + k * NW) * 64 + lane : -1;
+        }
+    };
+    for (int s = 0; s <= nstep; s += 2) {
+        step(s, std::false_type{});
+        if (s + 1 <= nstep) step(s + 1, std::true_type{});
     }
     unsigned long long key = bestp == 0xffffffffu ? ~0ull : (((unsigned long long) f32_ord(__float_as_uint(bestd)) << 32) | bestp);
     key = wave_min_u64(key);
@@ -228,16 +514,57 @@ template <int M, int NT, int V> static float time_rot(const uint8_t *d_rc, int64
     return ms / reps;
 }
 
-template <int M> static void run_shape(int ncand, int blocks)
+template <int M, int NT, int PF> static float time_par(const uint8_t *d_rc, int64_t ntiles, int ncand, const float *d_tab, unsigned long long *d_out, int blocks, int reps)
 {
-    const int64_t n = 1 << 20;                         // code rows (L2 / Infinity-Cache resident, as the visited lists are)
+    const size_t smem = 65536 + 128;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(par_kernel<M, NT, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((par_kernel<M, NT, PF>), dim3(blocks), dim3(NT), smem, 0, d_rc, ntiles, ncand, d_tab, d_out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((par_kernel<M, NT, PF>), dim3(blocks), dim3(NT), smem, 0, d_rc, ntiles, ncand, d_tab, d_out);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+template <int M, int NT, int NCH> static float time_par2(const uint8_t *d_rc, int64_t ntiles, int ncand, const float *d_tab, unsigned long long *d_out, int blocks, int reps)
+{
+    const size_t smem = 65536 + 128;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(par2_kernel<M, NT, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((par2_kernel<M, NT, NCH>), dim3(blocks), dim3(NT), smem, 0, d_rc, ntiles, ncand, d_tab, d_out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((par2_kernel<M, NT, NCH>), dim3(blocks), dim3(NT), smem, 0, d_rc, ntiles, ncand, d_tab, d_out);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+template <int M> static void run_shape(int ncand, int blocks, int log2n)
+{
+    const int64_t n = 1ll << log2n;                         // code rows (L2 / Infinity-Cache resident, as the visited lists are)
     std::vector<uint8_t> codes((size_t) n * M), rc((size_t) n * M);
     uint32_t s = 12345u + M;
     for (auto &c : codes) { s = s * 1664525u + 1013904223u; c = (uint8_t) (s >> 24); }
     for (int64_t r = 0; r < n; ++r)
         for (int j = 0; j < M; ++j) rc[(size_t) r * M + j] = codes[(size_t) r * M + (((j - (int) (r & 63)) % M + M) % M)];
+    std::vector<uint8_t> rc2((size_t) n * M);                  // par2: row r rotated by (r mod 64) mod min(M, 32)
+    {
+        const int nph = M < 32 ? M : 32;
+        for (int64_t r = 0; r < n; ++r)
+            for (int j = 0; j < M; ++j) rc2[(size_t) r * M + j] = codes[(size_t) r * M + (((j - (int) ((r & 63) % nph)) % M + M) % M)];
+    }
     std::vector<float> tab((size_t) M * 256);
     for (auto &t : tab) { s = s * 1664525u + 1013904223u; t = 1000.f + (float) (s >> 8) * (1.0f / 4096.f); }
+    std::vector<float> tabr((size_t) 256 * 64);
+    for (int ks = 0; ks < 256; ++ks)
+        for (int c = 0; c < 64; ++c) tabr[(size_t) ks * 64 + c] = tab[(size_t) (c % M) * 256 + ks];
+    float *d_tabr;
+    CK(hipMalloc(&d_tabr, tabr.size() * 4));
+    CK(hipMemcpy(d_tabr, tabr.data(), tabr.size() * 4, hipMemcpyHostToDevice));
+    uint8_t *d_rc2;
+    CK(hipMalloc(&d_rc2, rc2.size()));
+    CK(hipMemcpy(d_rc2, rc2.data(), rc2.size(), hipMemcpyHostToDevice));
     uint8_t *d_codes, *d_rc; float *d_tab; unsigned long long *d_oa, *d_ob;
     CK(hipMalloc(&d_codes, codes.size())); CK(hipMalloc(&d_rc, rc.size())); CK(hipMalloc(&d_tab, tab.size() * 4));
     CK(hipMalloc(&d_oa, blocks * 8)); CK(hipMalloc(&d_ob, blocks * 8));
@@ -254,8 +581,8 @@ template <int M> static void run_shape(int ncand, int blocks)
             bad = 0;
             for (int i = 0; i < blocks; ++i) bad += ha[i] != hb[i];
         }
-        printf("{\"M\": %d, \"ncand\": %d, \"blocks\": %d, \"kernel\": \"%s\", \"us\": %.2f, \"G_lookups_per_s\": %.1f, \"lds_TBps\": %.2f, \"mismatching_blocks\": %d}\n",
-               M, ncand, blocks, name, ms * 1e3, lookups / ms / 1e6, lookups * 4 / ms / 1e9, bad);
+        printf("{\"log2_rows\": %d, \"M\": %d, \"ncand\": %d, \"blocks\": %d, \"kernel\": \"%s\", \"us\": %.2f, \"G_lookups_per_s\": %.1f, \"lds_TBps\": %.2f, \"mismatching_blocks\": %d}\n",
+               log2n, M, ncand, blocks, name, ms * 1e3, lookups / ms / 1e6, lookups * 4 / ms / 1e9, bad);
     };
     // the blocks of both forms start at a tile-aligned row so that they see the same candidates
     float ms = time_direct<M, 256>(d_codes, n, ncand, d_tab, d_oa, blocks, reps);
@@ -263,9 +590,16 @@ template <int M> static void run_shape(int ncand, int blocks)
     // against a direct run over the rounded start -- done by the host below)
     report("direct/256thr", ms, d_oa, false);
     if (M * 1024 * 2 <= 65536) { ms = time_direct<M, 512>(d_codes, n, ncand, d_tab, d_oa, blocks, reps); report("direct/512thr", ms, d_oa, false); }
-    ms = time_rot<M, 256, 1>(d_rc, n / 64, ncand, d_tab, d_ob, blocks, reps); report("rotated/256thr/fma-keep", ms, d_ob, false);
-    ms = time_rot<M, 256, 0>(d_rc, n / 64, ncand, d_tab, d_ob, blocks, reps); report("rotated/256thr/cndmask-reset", ms, d_ob, false);
-    ms = time_rot<M, 512, 1>(d_rc, n / 64, ncand, d_tab, d_ob, blocks, reps); report("rotated/512thr/fma-keep", ms, d_ob, false);
+    ms = time_rot<M, 256, 1>(d_rc, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("rotated/256thr/fma-keep", ms, d_ob, false);
+    ms = time_rot<M, 256, 0>(d_rc, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("rotated/256thr/cndmask-reset", ms, d_ob, false);
+    ms = time_rot<M, 512, 1>(d_rc, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("rotated/512thr/fma-keep", ms, d_ob, false);
+    ms = time_rot<M, 512, 2>(d_rc, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("rotated/512thr/cndmask-reset/prefetch3", ms, d_ob, false);
+    ms = time_par<M, 256, 1>(d_rc, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity-pkfma/256thr", ms, d_ob, false);
+    ms = time_par<M, 256, 2>(d_rc, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity-pkfma/256thr/prefetch2", ms, d_ob, false);
+    ms = time_par<M, 512, 1>(d_rc, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity-pkfma/512thr", ms, d_ob, false);
+    ms = time_par2<M, 256, 1>(d_rc2, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity2/256thr/1chain", ms, d_ob, false);
+    ms = time_par2<M, 512, 1>(d_rc2, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity2/512thr/1chain", ms, d_ob, false);
+    ms = time_par2<M, 256, 2>(d_rc2, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity2/256thr/2chains", ms, d_ob, false);
     // bit-exactness: host replay of the first minimum over the candidates rot_kernel saw (tile-aligned start)
     CK(hipMemcpy(hb.data(), d_ob, blocks * 8, hipMemcpyDeviceToHost));
     int bad = 0;
@@ -289,9 +623,10 @@ template <int M> static void run_shape(int ncand, int blocks)
 int main(int argc, char **argv)
 {
     const int blocks = argc > 1 ? atoi(argv[1]) : 1024;
-    run_shape<64>(6016, blocks);          // the reference's harness setting: nlist + L = 1000 + 5000 lookups rows per query
-    run_shape<32>(2048, blocks);          // configs[2]: 1024 + 977
-    run_shape<32>(6016, blocks);
-    run_shape<16>(16000, blocks);         // Deep-shaped shard: 8000 + 8000
+    const int log2n = argc > 2 ? atoi(argv[2]) : 20;     // code rows: 2^20 x M bytes live in the Infinity Cache, 2^15 in L2
+    run_shape<64>(6016, blocks, log2n);   // the reference's harness setting: nlist + L = 1000 + 5000 lookups rows per query
+    run_shape<32>(2048, blocks, log2n);   // configs[2]: 1024 + 977
+    run_shape<32>(6016, blocks, log2n);
+    run_shape<16>(16000, blocks, log2n);  // Deep-shaped shard: 8000 + 8000
     return 0;
 }
