@@ -337,6 +337,10 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *                      block with their tables interleaved in LDS (ivf_quad_kernel: one 16-byte read scores a centre for four queries)
  *                      [default], 2 = at every batch size and up to w = 32 (tests), 0 = one query per block (ivf_fused_kernel).
  *                      Identical results
+ *   "ivf_rot"          1 = top-1 batches with L >= 2048 over <= 1024 unfiltered lists (Ks = 256, M = 64, Ds = 2 / 4) use the conflict-free
+ *                      table gather (ivf_rot_kernel: table [ks][64 columns], lanes skewed in time over rotated 64-row tiles of the centres
+ *                      and of the posting-order codes; + ~N*M bytes of device memory, rebuilt with the lists) [default], 2 = wherever the
+ *                      kernel applies (M = 32 too: tests), 0 = off.  Identical results
  *   "ivf_inline_exact" 1 = a block of the fused kernel that flags its own query replays it itself [default], 0 = flag-gated exact
  *                      kernels behind every batch
  *   "ivf_list_codes"   1 = the fused kernel reads its candidates from a second copy of the codes kept in posting order (+N*M bytes of

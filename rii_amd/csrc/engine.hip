@@ -159,6 +159,9 @@ struct rii_engine : ScratchSet {
     int shard_dbg_stop = 0;     // measurement only: ivf_shard_any_kernel returns after phase 1 .. 5 (wrong rows; tools/r5_shard_phases*.sh)
     int shard_force_replay = 0; // tests only: ivf_shard_any_kernel without its fast coarse selection (every query replays std::partial_sort)
     int ivf_dbg_stop = 0;       // measurement only: ivf_quad_kernel returns after phase 1 .. 3 (wrong rows; tools/r5_ivf_phases.py)
+    int ivf_rot = 1;            // option "ivf_rot" (round 6): 1 = top-1 batches with L >= 2048 candidates over <= 1024 lists at M = 64: the conflict-free
+                                // table gather (ivf_rot_kernel; at M = 32 its 64 KiB table costs more blocks per CU than the conflicts did:
+                                // profiles/r06_rot_ab.json); 2 = wherever the kernel applies (tests); 0 = off
     int ivf_quad = 1;           // option "ivf_quad" (round 5): 1 = top-1 batches of >= 16 queries over <= 1024 lists run four queries per block (ivf_quad_kernel)
     int ivf_inline_exact = 1;   // option "ivf_inline_exact" (round 4): 1 = a block of ivf_fused_kernel that flags its query (tied coarse distances, tail
                                 // walk, ties at the cut) replays it itself; 0 = the flag-gated exact kernels behind every batch (round 3)
@@ -180,6 +183,9 @@ struct rii_engine : ScratchSet {
     // device state
     DevBuf d_codewords, d_cnorm, d_codes, d_centers, d_symtab, d_pl_off, d_pl_ids, d_list_len;
     DevBuf d_lcodes; bool lcodes_valid = false;      // codes in posting order (option ivf_list_codes), rebuilt with the CSR
+    // round 6 (option ivf_rot): centres and posting-order codes in rotated 64-row tiles for ivf_rot_kernel (every list on a tile boundary)
+    DevBuf d_rcent, d_rlcodes, d_rl_toff; bool rot_valid = false;
+    int64_t rot_launches = 0;   // ivf_rot_kernel launches so far (get_option "ivf_rot_launches": tests assert the kernel under test really ran)
     // LDS-friendly scan order of the filter stage (scanorder.hip): codes gathered in scan order + position -> id.
     // Windows of 1024 codes are independent, so appends only (re)order the windows past `scan_cov`.
     DevBuf d_scan_codes, d_scan_perm;
@@ -323,6 +329,7 @@ int upload_centers(rii_engine *e)
     RII_TRY(e->d_centers.ensure(e->centers.size()));
     HIP_TRY(hipMemcpyAsync(e->d_centers.p, e->centers.data(), e->centers.size(), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->rot_valid = false;
     return RII_OK;
 }
 
@@ -351,6 +358,7 @@ int sync_lists(rii_engine *e)
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->lists_dirty = false;
     e->lcodes_valid = false;
+    e->rot_valid = false;
     return RII_OK;
 }
 
@@ -364,6 +372,32 @@ int sync_list_codes(rii_engine *e, hipStream_t st)
     HIP_TRY(launch_gather_codes_i32(e->d_codes.as<uint8_t>(), e->M, e->d_pl_ids.as<int32_t>(), n, e->d_lcodes.as<uint8_t>(), st));
     HIP_TRY(hipStreamSynchronize(st));        // engine-level state (like the CSR itself): a call on the other lane's stream may read it next
     e->lcodes_valid = true;
+    return RII_OK;
+}
+
+// option ivf_rot: the centres and the posting-order codes in rotated tiles of 64 rows (ivf_rot_kernel, kernels.hip); list i starts at
+// tile rl_toff[i] of d_rlcodes.  Built from d_centers / d_lcodes on the first query that wants them after the lists changed.
+int sync_rot_codes(rii_engine *e, hipStream_t st)
+{
+    if (e->rot_valid) return RII_OK;
+    RII_TRY(sync_list_codes(e, st));
+    const int64_t nlist = (int64_t) e->lists.size();
+    std::vector<int32_t> toff((size_t) nlist + 1, 0);
+    for (int64_t i = 0; i < nlist; ++i) {
+        const int64_t t = (int64_t) toff[(size_t) i] + ((int64_t) e->lists[(size_t) i].size() + 63) / 64;
+        if (t > INT32_MAX) return set_err(RII_ERR_UNSUPPORTED, "rotated list tiles exceed int32");
+        toff[(size_t) i + 1] = (int32_t) t;
+    }
+    const int64_t ntl = toff[(size_t) nlist], ntc = (nlist + 63) / 64;
+    RII_TRY(e->d_rl_toff.ensure(toff.size() * sizeof(int32_t)));
+    RII_TRY(e->d_rcent.ensure((size_t) std::max<int64_t>(ntc, 1) * 64 * e->M));
+    RII_TRY(e->d_rlcodes.ensure((size_t) std::max<int64_t>(ntl, 1) * 64 * e->M));
+    HIP_TRY(hipMemcpyAsync(e->d_rl_toff.p, toff.data(), toff.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_rot_rows(e->d_centers.as<uint8_t>(), nlist, e->M, e->d_rcent.as<uint8_t>(), ntc, st));
+    HIP_TRY(launch_rot_lists(e->d_lcodes.as<uint8_t>(), e->d_pl_off.as<int64_t>(), e->d_rl_toff.as<int32_t>(), (int) nlist, e->M,
+                             e->d_rlcodes.as<uint8_t>(), ntl, st));
+    HIP_TRY(hipStreamSynchronize(st));        // (toff is a local; engine-level state like the CSR)
+    e->rot_valid = true;
     return RII_OK;
 }
 
@@ -1169,8 +1203,19 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             const bool quad = e->ivf_quad && p.queries && !p.q_host_off && !p.host_flag && (e->ivf_quad > 1 || (p.B >= 768 && w <= 7)) &&
                               ivf_quad_supported(e->M, e->Ks, e->Ds, (int) nlist, w, topk);
             p.kcap = quad ? e->ivf_dbg_stop : 0;
+            // round 6: the conflict-free table gather where the candidate phase carries the kernel (L >= 2048: the reference's own
+            // harness runs L = 5000 at M = 64); needs the rotated tile copies, so unfiltered lists only
+            bool rot = !quad && e->ivf_rot && p.lcodes && p.queries && !p.q_host_off && !p.host_flag && (e->ivf_rot > 1 || (L >= 2048 && e->M == 64)) &&
+                       ivf_rot_supported(e->M, e->Ks, e->Ds, (int) nlist, w, topk);
+            if (rot) {
+                if (sync_rot_codes(e, st) == RII_OK) {
+                    p.rcent = e->d_rcent.as<uint8_t>(); p.rlcodes = e->d_rlcodes.as<uint8_t>(); p.rl_toff = e->d_rl_toff.as<int32_t>();
+                } else { (void) hipGetLastError(); rot = false; }               // (the copies are an optimisation, never a precondition)
+            }
+            if (rot) p.kcap = e->ivf_dbg_stop;
             ScopedTimer t(e, "ivf_fused", st, true);
-            HIP_TRY(quad ? launch_ivf_quad(p, st) : launch_ivf_fused(p, st));
+            HIP_TRY(quad ? launch_ivf_quad(p, st) : rot ? launch_ivf_rot(p, st) : launch_ivf_fused(p, st));
+            if (rot) e->rot_launches++;
             p.host_flag = nullptr;                   // (the deferred fallback re-uses p: nothing after this launch publishes)
             if (defer) {
                 e->spin_used = e->spin_flag != nullptr;
@@ -1296,7 +1341,8 @@ int end_on(rii_engine *e, hipStream_t st)
 void free_all(rii_engine *e)
 {
     DevBuf *bufs[] = {&e->d_codewords, &e->d_cnorm, &e->d_codes, &e->d_centers, &e->d_symtab, &e->d_pl_off,
-                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->d_fcodes, &e->d_lcodes};
+                      &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->d_fcodes, &e->d_lcodes, &e->d_rcent, &e->d_rlcodes,
+                      &e->d_rl_toff};
     for (DevBuf *b : bufs) b->release();
     e->release_all();
     e->parked.release_all();
@@ -2879,11 +2925,14 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->shard_force_replay = value ? 1 : 0;
     } else if (k == "ivf_quad") {
         e->ivf_quad = value < 0 ? 0 : (int) std::min<int64_t>(value, 2);        // 2: at every batch size (tests)
+    } else if (k == "ivf_rot") {
+        e->ivf_rot = value < 0 ? 0 : (int) std::min<int64_t>(value, 2);
+        if (!value) { e->d_rcent.release(); e->d_rlcodes.release(); e->d_rl_toff.release(); e->rot_valid = false; }
     } else if (k == "ivf_inline_exact") {
         e->ivf_inline_exact = value ? 1 : 0;
     } else if (k == "ivf_list_codes") {
         e->ivf_list_codes = value ? 1 : 0;
-        if (!value) { e->d_lcodes.release(); e->lcodes_valid = false; }
+        if (!value) { e->d_lcodes.release(); e->lcodes_valid = false; e->d_rlcodes.release(); e->rot_valid = false; }
     } else if (k == "ivf_force_exact") {
         e->ivf_force_exact = value ? 1 : 0;
     } else if (k == "fused_tables") {
@@ -2944,6 +2993,8 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_force_exact") return e->ivf_force_exact;
     if (k == "ivf_inline_exact") return e->ivf_inline_exact;
     if (k == "ivf_quad") return e->ivf_quad;
+    if (k == "ivf_rot") return e->ivf_rot;
+    if (k == "ivf_rot_launches") return e->rot_launches;
     if (k == "ivf_list_codes") return e->ivf_list_codes;
     if (k == "fused_tables") return e->fused_tables;
     if (k == "table_levels") return e->table_levels;

@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
                         if (m0 + u < p.M) lds[(m0 + u) * 256 + tid] = fvec_l2sqr_ds4v(q4[m0 + u], cv[u]);
                 }
             } else if (p.Ks == 256 && p.Ds == 6) {                                    // Deep1B shape (D = 96, M = 16)
-                table_rows_regs<6, 8>(lds, q, p.codewords, p.M, p.arch, tid);
+                if (p.M == 16) table_rows_regs<6, 8, 16>(lds, q, p.codewords, p.M, p.arch, tid);      // (Deep1B: D = 96, M = 16)
+                else table_rows_regs<6, 8>(lds, q, p.codewords, p.M, p.arch, tid);
             } else if (p.Ks == 256 && p.Ds == 8) {
                 table_rows_regs<8, 4>(lds, q, p.codewords, p.M, p.arch, tid);
             } else if (p.Ks == 256 && p.Ds == 2) {

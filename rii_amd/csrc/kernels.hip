@@ -15,6 +15,7 @@
 // Why the scan is not a GEMM: see DESIGN.md.  The scan is an LDS-gather kernel: the M x Ks table of QT
 // queries lives in LDS as [m][ks][QT] so that ONE ds_read_b128 returns the entries of four queries for one
 // code byte; codes stream from HBM/L2 as coalesced 16-byte loads; accumulation is sequential over m.
+#include <type_traits>
 #include "rii_internal.h"
 #include "rii_device.h"
 #include <float.h>
@@ -976,7 +977,8 @@ __global__ __launch_bounds__(256) void ivf_fused_kernel(IvfParams p)
             // round 6: the reference's own harness setting is M = 64 over D = 128, i.e. Ds = 2 (examples/benchmark/ann_methods.py:19-34).
             // The plain loop below built that table in 72 us of the kernel's 180 (profiles/r06_fused_phases.json): one subspace per
             // dependent L2 round trip through the generic fvec_L2sqr.  Codewords of 16 subspaces in flight, arithmetic on registers.
-            table_rows_regs<2, 16>(lds, q, p.codewords, p.M, p.arch, tid);
+            if (p.M == 64) table_rows_regs<2, 16, 64>(lds, q, p.codewords, p.M, p.arch, tid);
+            else table_rows_regs<2, 16>(lds, q, p.codewords, p.M, p.arch, tid);
         } else if (p.Ks == 256 && p.Ds == 6) {
             table_rows_regs<6, 8>(lds, q, p.codewords, p.M, p.arch, tid);
         } else if (p.Ks == 256 && p.Ds == 8) {
@@ -1790,6 +1792,466 @@ hipError_t launch_ivf_quad(const IvfParams &p0, hipStream_t st)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_quad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     launch_timed(ivf_quad_kernel, dim3((unsigned) ((p.B + kQuadQ - 1) / kQuadQ)), dim3(kQuadThreads), smem, st, p);
+    return hipGetLastError();
+}
+
+// ===================================================================================================
+// ivf_rot_kernel (round 6): the one-query inverted-index block with a CONFLICT-FREE table gather.
+//
+// ivf_fused_kernel looks a table entry up as lds[m * 256 + code[m]] with thread = candidate: the 32 lanes of a DS service group hit
+// banks code % 32 at random, ~3.5 rows on the busiest bank -- 65 % of that kernel's LDS cycles were bank-conflict replays at the
+// reference's own harness setting (M = 64, L = 5000: profiles/r05_refharness_pmc.json), 81 of its 129 us the candidate phase.
+// Here (tools/ubench/gather_rot.hip measured the loop alone: 111 -> 64 us for 6016 rows at M = 64, bit-identical sums):
+//   table     [ks][64 columns] floats, column c = subspace c mod M (M = 32: two copies, so the rotation below never wraps inside a
+//             row), 64 KiB whatever M: the ADDRESS of an entry is { byte 1 = code byte, byte 0 = 4 x column } -- one v_perm_b32;
+//   lanes     skewed in time: in round j lane l works on subspace m = (j - phi) mod M of ITS OWN row, phi = l mod 32, so the 32
+//             lanes of a DS group read 32 different columns = 32 different banks whatever the code bytes are.  A row is still summed
+//             by one lane in the order m = 0 .. M-1 (RiiCpp::ADist, src/rii.h:375-394): the distance bits are the reference's;
+//   rows      come from tile copies (64 rows per tile, row r rotated by r mod 32 bytes: in round j every lane uses byte j of its
+//             registers).  A lane is between two rows inside an iteration (tile k's row from round phi on, tile k-1's before): the
+//             first 8 code dwords of the two rows are merged once per iteration with v_bfi_b32;
+//   sums      two accumulators by row parity in one register pair: acc = (t, t) * sel_j + acc with the lane's (1,0) / (0,1) for that
+//             round (one v_pk_fma_f32; exact: t * 1 + a, t * 0 + a).  Odd iterations read sel_j with its halves swapped.  At the end
+//             of iteration k the other half holds the finished row of tile k-1 for EVERY lane: one compare, then it is zeroed.
+//             Rounds >= 31 need no lane-dependent pair (every lane is on its new row): 31 register pairs.
+// Work: coarse scores = tiles of the rotated centres (wave w takes tiles w, w + 4, ...); candidates = tiles of the visited lists in
+// the rotated posting-order copy (every list starts on a tile boundary there), same distribution; one drain iteration per wave and
+// phase.  Selection of the w + 1 nearest lists, the walk's stop rule and the flag protocol are ivf_fused_kernel's; a flagged query
+// rebuilds the plain [m][ks] table in place and runs the exact replay (or hands the table to the flag-gated kernels).
+// ===================================================================================================
+typedef float rot_f2 __attribute__((ext_vector_type(2)));
+
+template <int M> struct RotLane {
+    static constexpr int NPH = M < 32 ? M : 32, NSEL = NPH - 1, LW = (NSEL + 3) / 4, MW = M / 4;
+    uint32_t lowmask[LW];              // bytes of code dword d whose round 4 d + b is < phi: still the previous tile's row
+    uint32_t laneoff;                  // M <= 32: 4 x the lane's column in round 0 (the immediate offset adds 4 j)
+    uint32_t offq[M == 64 ? MW : 1];   // M = 64: 4 x the lane's column in the four rounds of code dword d, one byte each
+    rot_f2 sel[NSEL];                  // round j < 31: (1, 0) = the lane is on its new row, (0, 1) = still on the previous one
+    __device__ __forceinline__ void init(int lane)
+    {
+        const int phi = lane % NPH;
+#pragma unroll
+        for (int d = 0; d < LW; ++d) {
+            uint32_t mk = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mk |= (4 * d + b < phi) ? (0xffu << (8 * b)) : 0u;
+            lowmask[d] = mk;
+        }
+        laneoff = (uint32_t) (((M - phi) % M) * 4);
+        if (M == 16) laneoff += (lane & 16) ? 64u : 0u;          // (16 subspaces: the second half of a DS group takes the other 16 banks)
+        if (M == 64) {
+#pragma unroll
+            for (int d = 0; d < MW; ++d) {
+                uint32_t o = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) o |= (uint32_t) ((((4 * d + b - phi) % M + M) % M) * 4) << (8 * b);
+                offq[M == 64 ? d : 0] = o;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NSEL; ++j) sel[j] = phi <= j ? rot_f2{1.f, 0.f} : rot_f2{0.f, 1.f};
+    }
+};
+
+// n_items rows of this lane, one per iteration: row_of(k) -> the lane's rotated row of item k (16-byte pieces); emit(k, sum) once
+// item k's sum is complete (at the end of iteration k + 1).  Wave-uniform control flow, no barrier.  The table sits at LDS address 0.
+template <int M, class RowOf, class Emit>
+__device__ __forceinline__ void rot_gather(const RotLane<M> &rl, int n_items, RowOf row_of, Emit emit)
+{
+    constexpr int MW = M / 4, LW = RotLane<M>::LW, NSEL = RotLane<M>::NSEL, RB = 8, NB = M / RB;
+    if (n_items <= 0) return;
+    uint32_t x[MW], plow[LW];
+#pragma unroll
+    for (int d = 0; d < LW; ++d) plow[d] = 0u;
+    rot_f2 acc = {0.f, 0.f};
+    const rot_f2 one_zero = {1.f, 0.f};
+    uint4 nxt[MW / 4];
+    {
+        const uint4 *cp = row_of(0);
+#pragma unroll
+        for (int q = 0; q < MW / 4; ++q) nxt[q] = cp[q];
+    }
+    auto loads = [&](int b, rot_f2 (&t)[RB / 2]) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int j = b * RB + u;
+            float v;
+            if (M == 64) {
+                const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8) | (uint32_t) (j & 3);       // D.b0 = S1.b(j & 3), D.b1 = S0.b(j & 3)
+                const uint32_t a = __builtin_amdgcn_perm(x[j >> 2], rl.offq[M == 64 ? (j >> 2) : 0], ps);
+                v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a);
+            } else {
+                const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8);                             // D.b0 = S1.b0, D.b1 = S0.b(j & 3)
+                const uint32_t a = __builtin_amdgcn_perm(x[j >> 2], rl.laneoff, ps);
+                v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a + 4 * j);
+            }
+            if (u & 1) t[u >> 1].y = v; else t[u >> 1].x = v;
+        }
+    };
+    auto fmas = [&](int b, const rot_f2 (&t)[RB / 2], auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int j = b * RB + u;
+            const rot_f2 sj = j < NSEL ? rl.sel[j < NSEL ? j : 0] : one_zero;
+            // src0 = the round's entry for both halves (it sits in one half of a pair), src1 = the routing pair (odd iterations: swapped)
+            if (!ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
+            if (!ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
+            if (ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
+            if (ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
+        }
+    };
+    auto step = [&](int s, auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
+        {
+            uint32_t cur[MW];
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) { cur[4 * q] = nxt[q].x; cur[4 * q + 1] = nxt[q].y; cur[4 * q + 2] = nxt[q].z; cur[4 * q + 3] = nxt[q].w; }
+#pragma unroll
+            for (int d = 0; d < MW; ++d) {
+                if (d < LW) {
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x[d]) : "v"(rl.lowmask[d < LW ? d : 0]), "v"(plow[d < LW ? d : 0]), "v"(cur[d]));
+                    plow[d < LW ? d : 0] = cur[d];
+                } else x[d] = cur[d];
+            }
+        }
+        if (s + 1 < n_items) {                                   // the next item's row: requested an iteration ahead
+            const uint4 *cp = row_of(s + 1);
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) nxt[q] = cp[q];
+        }
+        rot_f2 t[2][RB / 2];                                     // the reads of batch b + 1 go out ahead of batch b's dependent fmas
+        loads(0, t[0]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b + 1 < NB) loads(b + 1, t[(b + 1) & 1]);
+            fmas(b, t[b & 1], odd_tag);
+        }
+        const float fin = ODD ? acc.x : acc.y;                   // the row of the previous item, complete in every lane
+        if (s >= 1) emit(s - 1, fin);
+        if (ODD) acc.x = 0.f; else acc.y = 0.f;
+    };
+    for (int s = 0; s <= n_items; s += 2) {
+        step(s, std::false_type{});
+        if (s + 1 <= n_items) step(s + 1, std::true_type{});
+    }
+}
+
+// table in the rotated layout: thread = ks, row ks = [64 columns]; the entries of 16 (8) subspaces on registers, written as 16-byte
+// pieces (a column-wise 4-byte store would put the 32 lanes of a DS group on one bank)
+template <int M, int DS>
+__device__ __forceinline__ void rot_table_rows(float *__restrict__ lds, const float *__restrict__ q, const float *__restrict__ codewords, int arch, int tid)
+{
+    constexpr int U = DS <= 4 ? 16 : 8, COPIES = 64 / M, NV = DS == 4 ? 1 : DS / 2;
+    static_assert(M % U == 0, "subspaces per batch");
+    static_assert(DS <= 4, "one SIMD variant");
+    // the codewords of batch b + 1 are requested before batch b is worked on (the block has nothing else to hide an L2 round trip behind)
+    typedef typename std::conditional<DS == 4, float4, float2>::type V;
+    V cv[2][U][NV];
+    auto request = [&](int m0, V (&dst)[U][NV]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const V *src = reinterpret_cast<const V *>(codewords + ((size_t) (m0 + u) * 256 + tid) * DS);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) dst[u][i] = src[i];
+        }
+    };
+    request(0, cv[0]);
+#pragma unroll
+    for (int b = 0; b < M / U; ++b) {
+        const int m0 = b * U;
+        if (b + 1 < M / U) request(m0 + U, cv[(b + 1) & 1]);
+        float ent[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (DS == 4) {
+                ent[u] = fvec_l2sqr_ds4v(reinterpret_cast<const float4 *>(q)[m0 + u], cv[b & 1][u][0]);
+            } else {
+                float xq[DS], yc[DS];
+#pragma unroll
+                for (int i = 0; i < DS; ++i) xq[i] = q[(m0 + u) * DS + i];
+#pragma unroll
+                for (int i = 0; i < DS / 2; ++i) { yc[2 * i] = cv[b & 1][u][i].x; yc[2 * i + 1] = cv[b & 1][u][i].y; }
+                ent[u] = fvec_l2sqr_body(xq, yc, DS, RII_SIMD_AVX512);         // (Ds <= 4: the three SIMD variants coincide -- table_rows_regs, rii_device.h)
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < U / 4; ++g) {
+            const float4 v = make_float4(ent[4 * g], ent[4 * g + 1], ent[4 * g + 2], ent[4 * g + 3]);
+#pragma unroll
+            for (int c = 0; c < COPIES; ++c) *reinterpret_cast<float4 *>(lds + tid * 64 + c * M + m0 + 4 * g) = v;
+        }
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void ivf_rot_kernel(IvfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SC = kFusedMaxW + 2, kTab = 256 * 64 * 4;
+    float *lds = reinterpret_cast<float *>(smem);                                         // [256][64]: LDS address 0 (rot_gather)
+    unsigned char *base = smem + kTab;
+    unsigned long long *s_sel = reinterpret_cast<unsigned long long *>(base);            // [SC]
+    unsigned long long *s_red = s_sel + SC;                                              // [2]
+    unsigned long long *s_wsel = s_red + 2;                                              // [4][kFusedMaxW + 1] the waves' own picks
+    int *s_cum = reinterpret_cast<int *>(s_wsel + 4 * (kFusedMaxW + 1));                 // [SC + 2] candidates before visited list i
+    int *s_misc = s_cum + (SC + 2);                                                      // [4]: ncand, nv, flag
+    int *s_len = s_misc + 4;                                                             // [SC + 2]
+    int *s_poff = s_len + (SC + 2);                                                      // [SC + 2] first posting of the selected lists
+    int *s_toff = s_poff + (SC + 2);                                                     // [SC + 2] ... their first tile in rlcodes
+    int *s_tcum = s_toff + (SC + 2);                                                     // [SC + 2] tiles before visited list i
+    const int64_t bl = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nlist = p.nlist, w = (int) p.w, MK = M * 256;
+    if (bl == 0 && tid == 0 && p.nflag_next) *p.nflag_next = 0;
+    if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char *) smem) != 0) __builtin_trap();
+    const float *q = p.queries + (p.b0 + bl) * (int64_t) (M * p.Ds);
+    if (p.kcap == 9) return;                               // (measurement only: launch cost alone)
+
+    // ---- table (RiiCpp::DTable, src/rii.h:361-373; fvec_L2sqr's order) ----
+    if (p.Ds == 4) rot_table_rows<M, 4>(lds, q, p.codewords, p.arch, tid);
+    else rot_table_rows<M, 2>(lds, q, p.codewords, p.arch, tid);
+    __syncthreads();
+    if (p.kcap == 1) return;                               // (measurement only -- option "ivf_dbg_stop": the phases' shares, tools/r6_rot_ab.py)
+    RotLane<M> rl;
+    rl.init(lane);
+
+    // ---- coarse scores (src/rii.h:259-264): tiles of the rotated centres; the keys of the (<= 4) lists a lane scores stay in registers ----
+    const int rounds = (w + 1 < nlist) ? w + 1 : nlist;
+    unsigned long long kkey[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    {
+        const int ntc = (nlist + 63) >> 6;
+        const int n_my = ntc > wave ? (ntc - wave + 3) >> 2 : 0;
+        rot_gather<M>(rl, n_my,
+                      [&](int k) { return reinterpret_cast<const uint4 *>(p.rcent + ((size_t) (wave + 4 * k) * 64 + lane) * M); },
+                      [&](int k, float dv) {
+                          const int c = (wave + 4 * k) * 64 + lane;
+                          const unsigned long long key = c < nlist ? (((unsigned long long) f32_orderable(__float_as_uint(dv)) << 32) | (uint32_t) c) : ~0ull;
+                          if (k == 0) kkey[0] = key; else if (k == 1) kkey[1] = key; else if (k == 2) kkey[2] = key; else kkey[3] = key;
+                      });
+    }
+    if (p.kcap == 2) { if (kkey[0] == 1ull) p.out_ids[bl] = 0; return; }
+    // ---- the w + 1 smallest (distance, list) keys, ascending: every wave extracts its own with DPP minima, wave 0 merges them and
+    // evaluates the stop rule of the walk (src/rii.h:283-326) across its lanes -- ivf_fused_kernel's selection ----
+    {
+        unsigned long long last = 0ull;
+        for (int r = 0; r < rounds; ++r) {
+            unsigned long long best = ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((r == 0 || kkey[u] > last) && kkey[u] < best) best = kkey[u];
+            last = wave_min_u64(best);
+            if (lane == 0) s_wsel[wave * (kFusedMaxW + 1) + r] = last;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long cand[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = lane + 64 * u;
+            cand[u] = i < 4 * rounds ? s_wsel[(i / rounds) * (kFusedMaxW + 1) + (i % rounds)] : ~0ull;
+        }
+        unsigned long long prev = 0ull, mysel = ~0ull;                     // lane r keeps pick r
+        for (int r = 0; r < rounds; ++r) {
+            unsigned long long best = ~0ull;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if ((r == 0 || cand[u] > prev) && cand[u] < best) best = cand[u];
+            prev = wave_min_u64(best);
+            if (lane == r) mysel = prev;
+        }
+        const int wl = w < nlist ? w : nlist;
+        const uint32_t myhi = (uint32_t) (mysel >> 32);
+        const uint32_t nxhi = (uint32_t) __shfl_down((int) myhi, 1);
+        const bool tied = lane + 1 < rounds && myhi == nxhi;               // exactly tied coarse distances among the w + 1 picks
+        int len = 0, off = 0, toff = 0;
+        if (lane < wl) {
+            const int no = (int) (mysel & 0xffffffffu);
+            len = p.list_len[no];
+            off = (int) p.pl_off[no];                                       // N < 2^31
+            toff = p.rl_toff[no];
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int excl = incl - len;
+        int flag = (p.force_flag || __ballot(tied) != 0ull) ? 1 : 0;
+        const unsigned long long hit = __ballot(lane < wl && (long long) incl >= p.L);        // first list that completes L candidates
+        int nv = 0;
+        long long cnt = 0;
+        if (hit) {
+            nv = __ffsll((long long) hit);
+            cnt = p.L;
+        } else if ((long long) wl == p.w) {                                 // all w lists walked: enough for topk?
+            const int tot = __shfl(incl, wl - 1);
+            if (tot >= p.topk) { nv = wl; cnt = tot; } else flag = 1;
+        } else flag = 1;                                                    // tail walk / empty return: exact path
+        if (flag) { nv = 0; cnt = 0; }
+        // tiles of the visited lists (the last one cut at L)
+        const int take = lane < nv ? ((lane == nv - 1) ? (int) cnt - excl : len) : 0;
+        const int ntl = (take + 63) >> 6;
+        int tincl = ntl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(tincl, o);
+            if (lane >= o) tincl += t;
+        }
+        if (lane < wl) { s_len[lane] = len; s_poff[lane] = off; s_toff[lane] = toff; }
+        if (lane < nv) { s_cum[lane] = excl; s_tcum[lane] = tincl - ntl; }
+        if (lane == (nv > 0 ? nv - 1 : 0)) s_tcum[nv] = nv > 0 ? tincl : 0;
+        if (lane == 0) {
+            s_cum[nv] = (int) cnt;
+            s_misc[0] = (int) cnt; s_misc[1] = nv; s_misc[2] = flag;
+            p.flag[bl] = p.inl_scratch ? 0 : flag;
+            if (flag && p.flag_list && !p.inl_scratch) p.flag_list[atomicAdd(p.nflag, 1)] = (int32_t) bl;
+            if (!flag) { p.ncand[bl] = (int) cnt; p.nvis[bl] = nv; }
+            s_red[1] = ~0ull;
+        }
+    }
+    __syncthreads();
+    if (s_misc[2]) {
+        // flagged (exactly tied coarse distances, a walk past list w, not found): the plain [m][ks] table in place, then the exact replay
+        // by this block (ivf_exact_big_query: sequences in this query's global scratch slice, heaps behind the table) or the hand-over
+        __syncthreads();
+        if (p.Ds == 4) {
+            const float4 *cw4 = reinterpret_cast<const float4 *>(p.codewords);
+            const float4 *q4 = reinterpret_cast<const float4 *>(q);
+            for (int m0 = 0; m0 < M; m0 += 16) {
+                float4 cv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) cv[u] = cw4[(m0 + u) * 256 + tid];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) lds[(m0 + u) * 256 + tid] = fvec_l2sqr_ds4v(q4[m0 + u], cv[u]);
+            }
+        } else {
+            table_rows_regs<2, 16>(lds, q, p.codewords, M, p.arch, tid);
+        }
+        __syncthreads();
+        if (p.inl_scratch) {
+            pq64_t *s_head = reinterpret_cast<pq64_t *>(smem + (((size_t) MK * 4 + 15) & ~(size_t) 15));
+            int32_t *xmisc = reinterpret_cast<int32_t *>(s_head + p.inl_hcap);
+            if (tid == 0) { p.flag[bl] = 0; if (p.nflag) atomicAdd(p.nflag, 1); }       // (the counter: statistics only)
+            ivf_exact_big_query(p, bl, lds, s_head, xmisc, p.inl_scratch + p.inl_per_q * (size_t) bl, tid);
+        } else {
+            float *dst = const_cast<float *>(p.lut) + (size_t) (p.b0 + bl) * MK;
+            for (int i = tid; i < MK; i += 256) dst[i] = lds[i];
+        }
+        return;
+    }
+    if (p.kcap == 3) return;
+    // ---- candidates (src/rii.h:283-305): the tiles of the visited lists, in traversal order; first minimum by (distance, position) ----
+    const int nv = s_misc[1];
+    float bestd = INFINITY;
+    uint32_t bestp = 0xffffffffu;
+    int32_t bestpp = -1;
+    {
+        const int T = s_tcum[nv];
+        const int n_my = T > wave ? (T - wave + 3) >> 2 : 0;
+        int ci = 0, ce = 0;                                                 // visited list of the item requested / completed last (both only move forward)
+        rot_gather<M>(rl, n_my,
+                      [&](int k) {
+                          const int g = wave + 4 * k;
+                          while (ci + 1 < nv && s_tcum[ci + 1] <= g) ++ci;
+                          return reinterpret_cast<const uint4 *>(p.rlcodes + ((size_t) (s_toff[ci] + (g - s_tcum[ci])) * 64 + lane) * M);
+                      },
+                      [&](int k, float dv) {
+                          const int g = wave + 4 * k;
+                          while (ce + 1 < nv && s_tcum[ce + 1] <= g) ++ce;
+                          const int r = (g - s_tcum[ce]) * 64 + lane;       // row inside the list
+                          const int c0 = s_cum[ce];
+                          if (r < s_cum[ce + 1] - c0 && dv < bestd) { bestd = dv; bestp = (uint32_t) (c0 + r); bestpp = s_poff[ce] + r; }
+                      });
+    }
+    unsigned long long key = bestp == 0xffffffffu ? ~0ull : (((unsigned long long) f32_orderable(__float_as_uint(bestd)) << 32) | bestp);
+    const unsigned long long mine = key;
+    key = wave_min_u64(key);
+    if (lane == 0 && key != ~0ull) atomicMin(&s_red[1], key);
+    __syncthreads();
+    if (mine != ~0ull && mine == s_red[1]) {                                // (distance, position) keys are distinct: one winner
+        p.out_ids[bl] = p.pl_ids[(size_t) bestpp];
+        p.out_dists[bl] = bestd;
+        p.out_counts[bl] = 1;
+    }
+}
+
+static size_t ivf_rot_smem() { return (size_t) 256 * 64 * 4 + (size_t) (kFusedMaxW + 2 + 2 + 4 * (kFusedMaxW + 1)) * 8 + (size_t) (5 * (kFusedMaxW + 4) + 4) * 4 + 64; }
+bool ivf_rot_supported(int M, int Ks, int Ds, int nlist, int64_t w, int topk)
+{
+    return topk == 1 && Ks == 256 && (M == 32 || M == 64) && (Ds == 2 || Ds == 4) && nlist >= 1 && nlist <= 1024 && w <= kFusedMaxW;
+}
+hipError_t launch_ivf_rot(const IvfParams &p0, hipStream_t st)
+{
+    if (p0.B == 0) return hipSuccess;
+    if (!p0.rcent || !p0.rlcodes || !p0.rl_toff || !p0.queries) return hipErrorInvalidValue;
+    IvfParams p = p0;
+    size_t smem = ivf_rot_smem();
+    if (p.inl_scratch) {
+        p.inl_hcap = ivf_exact_big_heap_cap(p.w, p.topk);
+        smem = std::max(smem, (((size_t) p.M * p.Ks * 4 + 15) & ~(size_t) 15) + (size_t) p.inl_hcap * 8 + 64);
+        if (smem > (size_t) 160 * 1024) return hipErrorInvalidValue;
+    }
+    auto kern = p.M == 64 ? ivf_rot_kernel<64> : ivf_rot_kernel<32>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    launch_timed(kern, dim3((unsigned) p.B), dim3(256), smem, st, p);
+    return hipGetLastError();
+}
+
+// ---- the rotated tile copies ----
+// one thread per output dword: tile row tr = tile * 64 + r, rotation (r mod 64) mod min(M, 32)
+__global__ void rot_rows_kernel(const uint8_t *__restrict__ src, int64_t n_rows, int M, uint8_t *__restrict__ dst, int64_t n_tiles)
+{
+    const int MW = M >> 2;
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles * 64 * MW) return;
+    const int64_t tr = i / MW;
+    const int d = (int) (i - tr * MW);
+    const int rot = (int) (tr & 63) % (M < 32 ? M : 32);
+    uint32_t v = 0;
+    if (tr < n_rows)
+        for (int b = 0; b < 4; ++b) v |= (uint32_t) src[tr * M + ((4 * d + b - rot) % M + M) % M] << (8 * b);
+    reinterpret_cast<uint32_t *>(dst)[i] = v;
+}
+__global__ void rot_lists_kernel(const uint8_t *__restrict__ lcodes, const int64_t *__restrict__ pl_off, const int32_t *__restrict__ rl_toff, int nlist, int M,
+                                 uint8_t *__restrict__ dst, int64_t n_tiles)
+{
+    const int MW = M >> 2;
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles * 64 * MW) return;
+    const int64_t tr = i / MW;
+    const int d = (int) (i - tr * MW);
+    const int tile = (int) (tr >> 6), r = (int) (tr & 63);
+    int lo = 0, hi = nlist;                                                 // the list whose tiles contain `tile`: rl_toff[lo] <= tile < rl_toff[lo + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rl_toff[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const int64_t row = (int64_t) (tile - rl_toff[lo]) * 64 + r;
+    const int rot = r % (M < 32 ? M : 32);
+    uint32_t v = 0;
+    if (row < pl_off[lo + 1] - pl_off[lo]) {
+        const uint8_t *s = lcodes + (pl_off[lo] + row) * M;
+        for (int b = 0; b < 4; ++b) v |= (uint32_t) s[((4 * d + b - rot) % M + M) % M] << (8 * b);
+    }
+    reinterpret_cast<uint32_t *>(dst)[i] = v;
+}
+hipError_t launch_rot_rows(const uint8_t *d_src, int64_t n_rows, int M, uint8_t *d_dst, int64_t n_tiles, hipStream_t st)
+{
+    const int64_t n = n_tiles * 64 * (M >> 2);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rot_rows_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_src, n_rows, M, d_dst, n_tiles);
+    return hipGetLastError();
+}
+hipError_t launch_rot_lists(const uint8_t *d_lcodes, const int64_t *d_pl_off, const int32_t *d_rl_toff, int nlist, int M, uint8_t *d_dst,
+                            int64_t n_tiles, hipStream_t st)
+{
+    const int64_t n = n_tiles * 64 * (M >> 2);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rot_lists_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_lcodes, d_pl_off, d_rl_toff, nlist, M, d_dst, n_tiles);
     return hipGetLastError();
 }
 

@@ -115,11 +115,13 @@ __device__ __forceinline__ float fvec_l2sqr_any(const float *__restrict__ x, con
 // The in-kernel table for an even Ds other than 4 at Ks = 256 (thread = ks): the codewords of U subspaces requested together
 // (8-byte loads), then fvec_L2sqr's operations on registers.  The plain loop fetched one subspace at a time -- a chain of M dependent
 // round trips, 8-9 us of latency per block at the Deep1B shape (M = 16, Ds = 6).
-template <int DS, int U>
-__device__ __forceinline__ void table_rows_regs(float *__restrict__ lds, const float *__restrict__ q, const float *__restrict__ codewords,
-                                                 int M, int arch, int tid)
+template <int DS, int U, int ARCH, int MC>
+__device__ __forceinline__ void table_rows_regs_arch(float *__restrict__ lds, const float *__restrict__ q, const float *__restrict__ codewords, int Mrt, int tid)
 {
     static_assert(DS % 2 == 0, "8-byte codeword loads");
+    static_assert(MC % U == 0, "a compile-time M is a whole number of batches");
+    const int M = MC ? MC : Mrt;             // MC != 0: M known at compile time -- no bounds test between the loads, the batches unroll
+#pragma unroll
     for (int m0 = 0; m0 < M; m0 += U) {
         float2 cv[U][DS / 2];
 #pragma unroll
@@ -136,9 +138,22 @@ __device__ __forceinline__ void table_rows_regs(float *__restrict__ lds, const f
             for (int i = 0; i < DS; ++i) x[i] = q[(m0 + u) * DS + i];
 #pragma unroll
             for (int i = 0; i < DS / 2; ++i) { y[2 * i] = cv[u][i].x; y[2 * i + 1] = cv[u][i].y; }
-            lds[(m0 + u) * 256 + tid] = fvec_l2sqr_regs<DS>(x, y, arch);
+            lds[(m0 + u) * 256 + tid] = fvec_l2sqr_body(x, y, DS, ARCH);
         }
     }
+}
+// The SIMD variant is decided ONCE, outside the loops (round 6): with the run-time switch inside fvec_l2sqr_regs every entry sat behind
+// its own branches, the query's sub-vector was fetched by a global load in front of each of them, and the M x Ds loads of a thread
+// became M dependent L2 round trips -- 9.5 of the 11.6 us a block of the reference's harness shape (M = 64, Ds = 2) spent on its table.
+// Up to 4 floats the three variants are the same operations (one chunk into zeroed lanes: fma(t, t, +0) is the rounded square), so one
+// copy serves them; from 5 on the SSE build's second accumulation is mul-then-add, the AVX builds' a fused multiply-add.
+template <int DS, int U, int MC = 0>
+__device__ __forceinline__ void table_rows_regs(float *__restrict__ lds, const float *__restrict__ q, const float *__restrict__ codewords,
+                                                 int M, int arch, int tid)
+{
+    if (DS <= 4 || arch == RII_SIMD_AVX512) table_rows_regs_arch<DS, U, RII_SIMD_AVX512, MC>(lds, q, codewords, M, tid);
+    else if (arch == RII_SIMD_AVX) table_rows_regs_arch<DS, U, RII_SIMD_AVX, MC>(lds, q, codewords, M, tid);
+    else table_rows_regs_arch<DS, U, RII_SIMD_SSE, MC>(lds, q, codewords, M, tid);
 }
 
 

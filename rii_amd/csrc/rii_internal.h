@@ -121,6 +121,10 @@ struct IvfParams {
     unsigned char *inl_scratch = nullptr; size_t inl_per_q = 0; int inl_hcap = 0;
     int q_host_off = 0;           // != 0: `queries` is coherent HOST memory (Ds = 4, Ks = 256): fetched once per block into LDS (the launcher
                                   // turns the flag into the byte offset of that staging area)
+    // round 6, ivf_rot_kernel only: the centres and the posting-order codes once more, in tiles of 64 rows with row r rotated by
+    // (r mod 64) mod min(M, 32) bytes (stored byte j = code[(j - rot) mod M]); every list starts on a tile boundary of rlcodes
+    // (rl_toff[i] = its first tile), the last tile of a list is zero-filled
+    const uint8_t *rcent = nullptr; const uint8_t *rlcodes = nullptr; const int32_t *rl_toff = nullptr;
 };
 hipError_t launch_ivf_coarse(const IvfParams &p, hipStream_t st);
 bool ivf_fused_supported(int M, int Ks, int nlist, int64_t w, int topk);
@@ -130,6 +134,14 @@ hipError_t launch_ivf_fused(const IvfParams &p, hipStream_t st);
 // Ds = 4, Ks = 256, M = 16 / 32, nlist <= 1024, w <= 32; same IvfParams, same flag protocol, no host_flag / q_host_off
 bool ivf_quad_supported(int M, int Ks, int Ds, int nlist, int64_t w, int topk);
 hipError_t launch_ivf_quad(const IvfParams &p, hipStream_t st);
+// round 6: conflict-free table gather (table [ks][64 columns], lanes skewed in time: ivf_rot_kernel in kernels.hip); top-1, Ks = 256,
+// M = 32 / 64, Ds = 2 / 4, nlist <= 1024, w <= 32, unfiltered lists (needs rcent / rlcodes / rl_toff); same flag protocol
+bool ivf_rot_supported(int M, int Ks, int Ds, int nlist, int64_t w, int topk);
+hipError_t launch_ivf_rot(const IvfParams &p, hipStream_t st);
+// the rotated tile copies: rows [n_rows][M] -> tiles; lists: list i's rows pl_off[i] .. of `lcodes` -> tiles rl_toff[i] ..
+hipError_t launch_rot_rows(const uint8_t *d_src, int64_t n_rows, int M, uint8_t *d_dst, int64_t n_tiles, hipStream_t st);
+hipError_t launch_rot_lists(const uint8_t *d_lcodes, const int64_t *d_pl_off, const int32_t *d_rl_toff, int nlist, int M, uint8_t *d_dst,
+                            int64_t n_tiles, hipStream_t st);
 hipError_t launch_ivf_plan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_scan(const IvfParams &p, hipStream_t st);
 hipError_t launch_ivf_select(const IvfParams &p, hipStream_t st);
