@@ -346,15 +346,16 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *   "ivf_list_codes"   1 = the fused kernel reads its candidates from a second copy of the codes kept in posting order (+N*M bytes of
  *                      device memory, rebuilt with the lists) [default], 0 = rows gathered by id.  Identical results
  *   "ivf_force_exact"  tests / measurement: 1 = every query of the fused path is flagged [0]
- *   "ivf_dbg_stop"     measurement only: ivf_quad_kernel returns after its table (1) / coarse (2) / selection (3) phase -- the rows are
- *                      NOT answers then (tools/r5_ivf_phases.py) [0]
+ *   "ivf_dbg_stop"     measurement only: ivf_quad_kernel / ivf_rot_kernel return after their table (1) / coarse (2) / selection (3)
+ *                      phase (ivf_rot_kernel: 9 = at once) -- the rows are NOT answers then (tools/r5_ivf_phases.py, r6_rot_ab.py) [0]
  *   "shard_dbg_stop"   measurement only: ivf_shard_any_kernel (database-sharded inverted index) returns after its phase 1 .. 5 -- the rows
  *                      are NOT answers then (tools/r5_shard_phases*.sh) [0]
  *   "shard_force_replay" tests only: 1 = that kernel's fast coarse selection off, every query replays std::partial_sort over the coarse
  *                      distances.  Identical results [0]
  *   "lanes"            scratch-buffer sets: 2 [default] or 1 (see Threading below)
  *   "timing"           0 [default] / 1 (HIP events around every kernel) / 2 (only around the dominant kernel of a step): rii_timing_read
- * Read-only (rii_get_option): "lut_tile", "n_cu", "cand_total", "cand_max" (debug counters of the last filter pass; synchronise).
+ * Read-only (rii_get_option): "lut_tile", "n_cu", "cand_total", "cand_max" (debug counters of the last filter pass; synchronise),
+ *   "ivf_rot_launches" (ivf_rot_kernel launches so far: tests assert that the kernel under test really ran).
  *
  * Threading: every entry point locks the engine, concurrent callers are serialised.  The *_dev calls return after
  * enqueueing.  The engine keeps two sets of scratch buffers ("lanes"): a caller that issues successive batches alternately

@@ -1206,7 +1206,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             // round 6: the conflict-free table gather where the candidate phase carries the kernel (L >= 2048: the reference's own
             // harness runs L = 5000 at M = 64); needs the rotated tile copies, so unfiltered lists only
             bool rot = !quad && e->ivf_rot && p.lcodes && p.queries && !p.q_host_off && !p.host_flag && (e->ivf_rot > 1 || (L >= 2048 && e->M == 64)) &&
-                       ivf_rot_supported(e->M, e->Ks, e->Ds, (int) nlist, w, topk);
+                       ivf_rot_supported(e->M, e->Ks, e->Ds, (int) nlist, w, topk) && ivf_rot_fits(L, w);
             if (rot) {
                 if (sync_rot_codes(e, st) == RII_OK) {
                     p.rcent = e->d_rcent.as<uint8_t>(); p.rlcodes = e->d_rlcodes.as<uint8_t>(); p.rl_toff = e->d_rl_toff.as<int32_t>();

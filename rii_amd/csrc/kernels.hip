@@ -1855,85 +1855,79 @@ template <int M> struct RotLane {
 
 // n_items rows of this lane, one per iteration: row_of(k) -> the lane's rotated row of item k (16-byte pieces); emit(k, sum) once
 // item k's sum is complete (at the end of iteration k + 1).  Wave-uniform control flow, no barrier.  The table sits at LDS address 0.
+// Two row buffers in alternation (even iterations sum the row in A and request the next one into B, odd ones the reverse): the buffer
+// about to be overwritten is the PREVIOUS row, whose first 8 dwords the merge has just read -- no register copies between iterations.
+template <int N> __device__ __forceinline__ uint32_t rot_dw(const uint4 (&r)[N], int d)
+{
+    return (d & 3) == 0 ? r[d >> 2].x : (d & 3) == 1 ? r[d >> 2].y : (d & 3) == 2 ? r[d >> 2].z : r[d >> 2].w;
+}
 template <int M, class RowOf, class Emit>
 __device__ __forceinline__ void rot_gather(const RotLane<M> &rl, int n_items, RowOf row_of, Emit emit)
 {
     constexpr int MW = M / 4, LW = RotLane<M>::LW, NSEL = RotLane<M>::NSEL, RB = 8, NB = M / RB;
     if (n_items <= 0) return;
-    uint32_t x[MW], plow[LW];
-#pragma unroll
-    for (int d = 0; d < LW; ++d) plow[d] = 0u;
     rot_f2 acc = {0.f, 0.f};
     const rot_f2 one_zero = {1.f, 0.f};
-    uint4 nxt[MW / 4];
+    uint4 bufA[MW / 4], bufB[MW / 4];
     {
         const uint4 *cp = row_of(0);
 #pragma unroll
-        for (int q = 0; q < MW / 4; ++q) nxt[q] = cp[q];
+        for (int q = 0; q < MW / 4; ++q) { bufA[q] = cp[q]; bufB[q] = make_uint4(0u, 0u, 0u, 0u); }
     }
-    auto loads = [&](int b, rot_f2 (&t)[RB / 2]) {
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int j = b * RB + u;
-            float v;
-            if (M == 64) {
-                const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8) | (uint32_t) (j & 3);       // D.b0 = S1.b(j & 3), D.b1 = S0.b(j & 3)
-                const uint32_t a = __builtin_amdgcn_perm(x[j >> 2], rl.offq[M == 64 ? (j >> 2) : 0], ps);
-                v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a);
-            } else {
-                const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8);                             // D.b0 = S1.b0, D.b1 = S0.b(j & 3)
-                const uint32_t a = __builtin_amdgcn_perm(x[j >> 2], rl.laneoff, ps);
-                v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a + 4 * j);
-            }
-            if (u & 1) t[u >> 1].y = v; else t[u >> 1].x = v;
-        }
-    };
-    auto fmas = [&](int b, const rot_f2 (&t)[RB / 2], auto odd_tag) {
+    auto step = [&](uint4 (&cur)[MW / 4], uint4 (&prev)[MW / 4], int s, auto odd_tag) {
         constexpr bool ODD = decltype(odd_tag)::value;
+        uint32_t xl[LW];                                         // rounds < 31: the previous row's bytes before the lane's phase, this row's after
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int j = b * RB + u;
-            const rot_f2 sj = j < NSEL ? rl.sel[j < NSEL ? j : 0] : one_zero;
-            // src0 = the round's entry for both halves (it sits in one half of a pair), src1 = the routing pair (odd iterations: swapped)
-            if (!ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
-            if (!ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
-            if (ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
-            if (ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
-        }
-    };
-    auto step = [&](int s, auto odd_tag) {
-        constexpr bool ODD = decltype(odd_tag)::value;
-        {
-            uint32_t cur[MW];
-#pragma unroll
-            for (int q = 0; q < MW / 4; ++q) { cur[4 * q] = nxt[q].x; cur[4 * q + 1] = nxt[q].y; cur[4 * q + 2] = nxt[q].z; cur[4 * q + 3] = nxt[q].w; }
-#pragma unroll
-            for (int d = 0; d < MW; ++d) {
-                if (d < LW) {
-                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x[d]) : "v"(rl.lowmask[d < LW ? d : 0]), "v"(plow[d < LW ? d : 0]), "v"(cur[d]));
-                    plow[d < LW ? d : 0] = cur[d];
-                } else x[d] = cur[d];
-            }
-        }
-        if (s + 1 < n_items) {                                   // the next item's row: requested an iteration ahead
+        for (int d = 0; d < LW; ++d) asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(xl[d]) : "v"(rl.lowmask[d]), "v"(rot_dw(prev, d)), "v"(rot_dw(cur, d)));
+        if (s + 1 < n_items) {                                   // the next item's row: requested an iteration ahead, over the previous row
             const uint4 *cp = row_of(s + 1);
 #pragma unroll
-            for (int q = 0; q < MW / 4; ++q) nxt[q] = cp[q];
+            for (int q = 0; q < MW / 4; ++q) prev[q] = cp[q];
         }
+        auto loads = [&](int b, rot_f2 (&t)[RB / 2]) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int j = b * RB + u;
+                const uint32_t xw = (j >> 2) < LW ? xl[(j >> 2) < LW ? (j >> 2) : 0] : rot_dw(cur, j >> 2);
+                float v;
+                if (M == 64) {
+                    const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8) | (uint32_t) (j & 3);   // D.b0 = S1.b(j & 3), D.b1 = S0.b(j & 3)
+                    const uint32_t a = __builtin_amdgcn_perm(xw, rl.offq[M == 64 ? (j >> 2) : 0], ps);
+                    v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a);
+                } else {
+                    const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8);                         // D.b0 = S1.b0, D.b1 = S0.b(j & 3)
+                    const uint32_t a = __builtin_amdgcn_perm(xw, rl.laneoff, ps);
+                    v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a + 4 * j);
+                }
+                if (u & 1) t[u >> 1].y = v; else t[u >> 1].x = v;
+            }
+        };
+        auto fmas = [&](int b, const rot_f2 (&t)[RB / 2]) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int j = b * RB + u;
+                const rot_f2 sj = j < NSEL ? rl.sel[j < NSEL ? j : 0] : one_zero;
+                // src0 = the round's entry for both halves (it sits in one half of a pair), src1 = the routing pair (odd iterations: swapped)
+                if (!ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
+                if (!ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
+                if (ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
+                if (ODD && (u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
+            }
+        };
         rot_f2 t[2][RB / 2];                                     // the reads of batch b + 1 go out ahead of batch b's dependent fmas
         loads(0, t[0]);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (b + 1 < NB) loads(b + 1, t[(b + 1) & 1]);
-            fmas(b, t[b & 1], odd_tag);
+            fmas(b, t[b & 1]);
         }
         const float fin = ODD ? acc.x : acc.y;                   // the row of the previous item, complete in every lane
         if (s >= 1) emit(s - 1, fin);
         if (ODD) acc.x = 0.f; else acc.y = 0.f;
     };
     for (int s = 0; s <= n_items; s += 2) {
-        step(s, std::false_type{});
-        if (s + 1 <= n_items) step(s + 1, std::true_type{});
+        step(bufA, bufB, s, std::false_type{});
+        if (s + 1 <= n_items) step(bufB, bufA, s + 1, std::true_type{});
     }
 }
 
@@ -1942,7 +1936,7 @@ __device__ __forceinline__ void rot_gather(const RotLane<M> &rl, int n_items, Ro
 template <int M, int DS>
 __device__ __forceinline__ void rot_table_rows(float *__restrict__ lds, const float *__restrict__ q, const float *__restrict__ codewords, int arch, int tid)
 {
-    constexpr int U = DS <= 4 ? 16 : 8, COPIES = 64 / M, NV = DS == 4 ? 1 : DS / 2;
+    constexpr int U = 16, COPIES = 64 / M, NV = DS == 4 ? 1 : DS / 2;
     static_assert(M % U == 0, "subspaces per batch");
     static_assert(DS <= 4, "one SIMD variant");
     // the codewords of batch b + 1 are requested before batch b is worked on (the block has nothing else to hide an L2 round trip behind)
@@ -1975,11 +1969,23 @@ __device__ __forceinline__ void rot_table_rows(float *__restrict__ lds, const fl
                 ent[u] = fvec_l2sqr_body(xq, yc, DS, RII_SIMD_AVX512);         // (Ds <= 4: the three SIMD variants coincide -- table_rows_regs, rii_device.h)
             }
         }
+        // 16-byte stores.  The rows of neighbouring lanes are 256 bytes apart -- the same banks -- so the 8 lanes of a DS store group
+        // would all land on one bank quad (8-way: 56 of the 64 cycles of every store, a fifth of the kernel's LDS cycles:
+        // profiles/r06_refharness_pmc_counters_table_store_conflicts.txt).  Store step g of lane l takes the quad (g + l) mod 4 of the
+        // batch: four different quads per group, 2-way.
+        static_assert(U == 16, "four quads per batch");
+        const int r = tid & 3;
 #pragma unroll
-        for (int g = 0; g < U / 4; ++g) {
-            const float4 v = make_float4(ent[4 * g], ent[4 * g + 1], ent[4 * g + 2], ent[4 * g + 3]);
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
 #pragma unroll
-            for (int c = 0; c < COPIES; ++c) *reinterpret_cast<float4 *>(lds + tid * 64 + c * M + m0 + 4 * g) = v;
+            for (int c = 0; c < 4; ++c) {
+                const float a0 = ent[4 * (g & 3) + c], a1 = ent[4 * ((g + 1) & 3) + c], a2 = ent[4 * ((g + 2) & 3) + c], a3 = ent[4 * ((g + 3) & 3) + c];
+                v[c] = r == 0 ? a0 : r == 1 ? a1 : r == 2 ? a2 : a3;
+            }
+            const int qd = (g + r) & 3;
+#pragma unroll
+            for (int c = 0; c < COPIES; ++c) *reinterpret_cast<float4 *>(lds + tid * 64 + c * M + m0 + 4 * qd) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -2150,20 +2156,29 @@ __global__ __launch_bounds__(256) void ivf_rot_kernel(IvfParams p)
     int32_t bestpp = -1;
     {
         const int T = s_tcum[nv];
-        const int n_my = T > wave ? (T - wave + 3) >> 2 : 0;
-        int ci = 0, ce = 0;                                                 // visited list of the item requested / completed last (both only move forward)
+        const int n_my = T > wave ? (T - wave + 3) >> 2 : 0;                // (launcher: at most 128 tiles per wave)
+        // the wave's items described once, lane k (and k + 64) for item k: tile in rlcodes, first position / posting of the tile, rows
+        // that count.  The iterations fetch them with v_readlane -- no LDS round trip, no search in front of a row request.
+        int d_gt[2], d_p0[2], d_pp0[2], d_nr[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int g = wave + 4 * (lane + 64 * h);
+            d_gt[h] = 0; d_p0[h] = 0; d_pp0[h] = 0; d_nr[h] = 0;
+            if (g < T) {
+                int i = 0;
+                for (int c = 1; c < nv; ++c) i = s_tcum[c] <= g ? c : i;
+                const int t = g - s_tcum[i], c0 = s_cum[i], left = s_cum[i + 1] - c0 - t * 64;
+                d_gt[h] = s_toff[i] + t;
+                d_p0[h] = c0 + t * 64;
+                d_pp0[h] = s_poff[i] + t * 64;
+                d_nr[h] = left < 64 ? left : 64;
+            }
+        }
+        auto item = [&](const int (&d)[2], int k) { return k < 64 ? __builtin_amdgcn_readlane(d[0], k) : __builtin_amdgcn_readlane(d[1], k - 64); };
         rot_gather<M>(rl, n_my,
-                      [&](int k) {
-                          const int g = wave + 4 * k;
-                          while (ci + 1 < nv && s_tcum[ci + 1] <= g) ++ci;
-                          return reinterpret_cast<const uint4 *>(p.rlcodes + ((size_t) (s_toff[ci] + (g - s_tcum[ci])) * 64 + lane) * M);
-                      },
+                      [&](int k) { return reinterpret_cast<const uint4 *>(p.rlcodes + ((size_t) item(d_gt, k) * 64 + lane) * M); },
                       [&](int k, float dv) {
-                          const int g = wave + 4 * k;
-                          while (ce + 1 < nv && s_tcum[ce + 1] <= g) ++ce;
-                          const int r = (g - s_tcum[ce]) * 64 + lane;       // row inside the list
-                          const int c0 = s_cum[ce];
-                          if (r < s_cum[ce + 1] - c0 && dv < bestd) { bestd = dv; bestp = (uint32_t) (c0 + r); bestpp = s_poff[ce] + r; }
+                          if (lane < item(d_nr, k) && dv < bestd) { bestd = dv; bestp = (uint32_t) (item(d_p0, k) + lane); bestpp = item(d_pp0, k) + lane; }
                       });
     }
     unsigned long long key = bestp == 0xffffffffu ? ~0ull : (((unsigned long long) f32_orderable(__float_as_uint(bestd)) << 32) | bestp);
@@ -2183,6 +2198,8 @@ bool ivf_rot_supported(int M, int Ks, int Ds, int nlist, int64_t w, int topk)
 {
     return topk == 1 && Ks == 256 && (M == 32 || M == 64) && (Ds == 2 || Ds == 4) && nlist >= 1 && nlist <= 1024 && w <= kFusedMaxW;
 }
+// (the kernel describes at most 128 tiles per wave in registers: L / 64 full tiles + one partial tile per visited list)
+bool ivf_rot_fits(int64_t L, int64_t w) { return L / 64 + w + 1 <= 4 * 128; }
 hipError_t launch_ivf_rot(const IvfParams &p0, hipStream_t st)
 {
     if (p0.B == 0) return hipSuccess;

@@ -137,6 +137,7 @@ hipError_t launch_ivf_quad(const IvfParams &p, hipStream_t st);
 // round 6: conflict-free table gather (table [ks][64 columns], lanes skewed in time: ivf_rot_kernel in kernels.hip); top-1, Ks = 256,
 // M = 32 / 64, Ds = 2 / 4, nlist <= 1024, w <= 32, unfiltered lists (needs rcent / rlcodes / rl_toff); same flag protocol
 bool ivf_rot_supported(int M, int Ks, int Ds, int nlist, int64_t w, int topk);
+bool ivf_rot_fits(int64_t L, int64_t w);
 hipError_t launch_ivf_rot(const IvfParams &p, hipStream_t st);
 // the rotated tile copies: rows [n_rows][M] -> tiles; lists: list i's rows pl_off[i] .. of `lcodes` -> tiles rl_toff[i] ..
 hipError_t launch_rot_rows(const uint8_t *d_src, int64_t n_rows, int M, uint8_t *d_dst, int64_t n_tiles, hipStream_t st);
