@@ -350,12 +350,17 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *                      phase (ivf_rot_kernel: 9 = at once) -- the rows are NOT answers then (tools/r5_ivf_phases.py, r6_rot_ab.py) [0]
  *   "shard_dbg_stop"   measurement only: ivf_shard_any_kernel (database-sharded inverted index) returns after its phase 1 .. 5 -- the rows
  *                      are NOT answers then (tools/r5_shard_phases*.sh) [0]
+ *   "shard_pre"        1 = the database-sharded inverted index (rii_query_ivf_shard_dev / _dbsharded_dev) runs the coarse phase of a batch of
+ *                      >= 256 queries over >= 4096 lists as a pre-pass with FOUR queries per block (shard_coarse_quad_kernel: tables interleaved [m][ks][query],
+ *                      one 16-byte LDS read scores a centre for four queries; Ks = 256, M = 16 / 32, even Ds <= 8, w <= 7, coarse order
+ *                      not in LDS) and the walk kernel starts from its picks [default], 2 = at every batch size, 0 = off.  Identical results
  *   "shard_force_replay" tests only: 1 = that kernel's fast coarse selection off, every query replays std::partial_sort over the coarse
  *                      distances.  Identical results [0]
  *   "lanes"            scratch-buffer sets: 2 [default] or 1 (see Threading below)
  *   "timing"           0 [default] / 1 (HIP events around every kernel) / 2 (only around the dominant kernel of a step): rii_timing_read
  * Read-only (rii_get_option): "lut_tile", "n_cu", "cand_total", "cand_max" (debug counters of the last filter pass; synchronise),
- *   "ivf_rot_launches" (ivf_rot_kernel launches so far: tests assert that the kernel under test really ran).
+ *   "ivf_rot_launches", "shard_pre_launches" (ivf_rot_kernel / shard_coarse_quad_kernel launches so far: tests assert that the
+ *   kernel under test really ran).
  *
  * Threading: every entry point locks the engine, concurrent callers are serialised.  The *_dev calls return after
  * enqueueing.  The engine keeps two sets of scratch buffers ("lanes"): a caller that issues successive batches alternately
@@ -371,7 +376,7 @@ int64_t rii_get_option(const rii_engine *e, const char *key);
  * "ivf_fused", "ivf_scan" -- two event records per step instead of ten): events are recorded on the launch stream
  * around every launch of the named kernel; reading synchronises the stream.
  * names: "lut", "scan", "ivf_coarse", "ivf_plan", "ivf_scan", "ivf_select", "assign", "gather", "select", "quant", "rerank",
- * "ivf_fused", "ivf_exact", "kth", "scan_order", "tie", "format", "ivf_shard". */
+ * "ivf_fused", "ivf_exact", "kth", "scan_order", "tie", "format", "ivf_shard", "shard_coarse". */
 int rii_timing_read(rii_engine *e, const char *kernel, double *total_ms, int64_t *launches);
 int rii_timing_reset(rii_engine *e);
 int rii_synchronize(rii_engine *e);

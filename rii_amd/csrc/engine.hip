@@ -157,6 +157,8 @@ struct rii_engine : ScratchSet {
     // bytes: more switching in the matrix core under a power-limited clock), so 127 -- non-negative bytes, no bias -- is the default.
     int table_levels = 127;
     int shard_dbg_stop = 0;     // measurement only: ivf_shard_any_kernel returns after phase 1 .. 5 (wrong rows; tools/r5_shard_phases*.sh)
+    int shard_pre = 1;          // option "shard_pre": the database-sharded inverted index runs its coarse phase as a pre-pass (shard_coarse_quad_kernel)
+    int64_t shard_pre_launches = 0;
     int shard_force_replay = 0; // tests only: ivf_shard_any_kernel without its fast coarse selection (every query replays std::partial_sort)
     int ivf_dbg_stop = 0;       // measurement only: ivf_quad_kernel returns after phase 1 .. 3 (wrong rows; tools/r5_ivf_phases.py)
     int ivf_rot = 1;            // option "ivf_rot" (round 6): 1 = top-1 batches with L >= 2048 candidates over <= 1024 lists at M = 64: the conflict-free
@@ -251,7 +253,7 @@ int64_t nlist_of(const rii_engine *e) { return e->M ? (int64_t) (e->centers.size
 bool timer_wanted(const rii_engine *e, const char *name)
 {
     if (e->timing == 1) return true;
-    if (e->timing == 2) return !strcmp(name, "scan") || !strcmp(name, "ivf_fused") || !strcmp(name, "ivf_scan") || !strcmp(name, "ivf_shard");
+    if (e->timing == 2) return !strcmp(name, "scan") || !strcmp(name, "ivf_fused") || !strcmp(name, "ivf_scan") || !strcmp(name, "ivf_shard") || !strcmp(name, "shard_coarse");
     return false;
 }
 hipEvent_t timer_event(rii_engine *e)
@@ -2154,15 +2156,35 @@ int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk,
         const int64_t cur = std::min<int64_t>(step, B - b0);
         const int64_t D = (int64_t) e->M * e->Ds;
         // round 5: the any-L kernel builds its query's exact table itself (exact mode): no table launch, no table round trip
-        const bool own_tables = e->lut_mode == RII_LUT_EXACT && ivf_shard_builds_tables(e->M, e->Ks, (int) nlist, L, w, rows);
-        if (!own_tables) RII_TRY(build_lut(e, d_queries + b0 * D, cur, st, false, 1));
+        bool own_tables = e->lut_mode == RII_LUT_EXACT && ivf_shard_builds_tables(e->M, e->Ks, (int) nlist, L, w, rows);
+        // round 6: the batch's coarse phase as a pre-pass (four queries per block, one 16-byte LDS read per centre lookup,
+        // shard_coarse_quad_kernel): tables + picks for the walk kernel, which then neither scores a centre nor writes a coarse key
+        // (measured, tools/r6_shard_pre_ab.py: it pays where the coarse phase is a large part of the walk kernel -- thousands of lists -- and the
+        //  batch fills the chip; at nlist = 1024 or a few dozen queries the extra launch costs more than the shared lookups save)
+        const bool pre = own_tables && e->shard_pre && (e->shard_pre > 1 || (cur >= 256 && nlist >= 4096)) &&
+                         shard_coarse_supported(e->M, e->Ks, e->Ds, (int) nlist, L, w, rows);
+        const unsigned long long *picks = nullptr;
+        const int32_t *pick_ok = nullptr;
+        if (pre) {
+            RII_TRY(e->s_lut.ensure((size_t) cur * e->M * e->Ks * sizeof(float)));
+            RII_TRY(e->s_coarse_d.ensure((size_t) cur * kShardPickStride * 8));
+            RII_TRY(e->s_coarse_i.ensure((size_t) cur * 4));
+            e->lut_valid = false;
+            ScopedTimer t(e, "shard_coarse", st);
+            HIP_TRY(launch_shard_coarse(d_queries + b0 * D, e->d_codewords.as<float>(), e->d_centers.as<uint8_t>(), e->M, e->Ds, e->arch, (int) nlist, w,
+                                        cur, e->s_lut.as<float>(), e->s_coarse_d.as<unsigned long long>(), e->s_coarse_i.as<int32_t>(), st,
+                                        e->shard_dbg_stop > 10 ? e->shard_dbg_stop - 10 : 0));
+            picks = e->s_coarse_d.as<unsigned long long>(); pick_ok = e->s_coarse_i.as<int32_t>();
+            own_tables = false;
+            e->shard_pre_launches++;
+        } else if (!own_tables) RII_TRY(build_lut(e, d_queries + b0 * D, cur, st, false, 1));
         ScopedTimer t(e, "ivf_shard", st);
         HIP_TRY(launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, own_tables ? nullptr : e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
                                  e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
                                  d_out_ids + b0 * (int64_t) rows, d_out_dists + b0 * (int64_t) rows, d_out_pos + b0 * (int64_t) rows,
                                  d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st,
                                  own_tables ? d_queries + b0 * D : nullptr, e->d_codewords.as<float>(), e->Ds, e->arch, lcodes,
-                                 (e->shard_dbg_stop & 0xff) | ((e->shard_force_replay ? 1 : 0) << 8)));
+                                 (e->shard_dbg_stop & 0xff) | ((e->shard_force_replay ? 1 : 0) << 8), picks, pick_ok));
     }
     return RII_OK;
 }
@@ -2923,6 +2945,9 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->shard_dbg_stop = (int) (value & 0xff);
     } else if (k == "shard_force_replay") {
         e->shard_force_replay = value ? 1 : 0;
+    } else if (k == "shard_pre") {
+        if (value < 0 || value > 2) return set_err(RII_ERR_INVALID, "shard_pre must be 0, 1 or 2");
+        e->shard_pre = (int) value;
     } else if (k == "ivf_quad") {
         e->ivf_quad = value < 0 ? 0 : (int) std::min<int64_t>(value, 2);        // 2: at every batch size (tests)
     } else if (k == "ivf_rot") {
@@ -2995,6 +3020,8 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_quad") return e->ivf_quad;
     if (k == "ivf_rot") return e->ivf_rot;
     if (k == "ivf_rot_launches") return e->rot_launches;
+    if (k == "shard_pre_launches") return e->shard_pre_launches;
+    if (k == "shard_pre") return e->shard_pre;
     if (k == "ivf_list_codes") return e->ivf_list_codes;
     if (k == "fused_tables") return e->fused_tables;
     if (k == "table_levels") return e->table_levels;

@@ -40,6 +40,9 @@ struct ShardArgs {
     // round 5, ivf_shard_any_kernel: the codes in POSTING order (row pp = the code of posting pp of pl_ids: the engine's lcodes copy,
     // unfiltered lists only) -- a list's candidates are one contiguous, coalesced run instead of one random 64-byte HBM sector each
     const uint8_t *lcodes = nullptr;
+    // round 6, ivf_shard_any_kernel behind shard_coarse_quad_kernel: the batch's coarse picks ([b][kShardPickStride] keys, ascending) and
+    // whether they are conclusive; the tables come in through `lut` then
+    const unsigned long long *picks = nullptr; const int32_t *pick_ok = nullptr;
 };
 
 // BIG (nlist above kShardMaxNlistLds -- the reference's default sqrt(N) is 11 k lists at a 125 M-code shard): the coarse order and
@@ -212,17 +215,252 @@ __device__ __forceinline__ void shard_adist_rows(const float *tab, const uint8_t
     }
 }
 
+
+constexpr int kShardFastW = 7;           // the fast coarse selection covers w <= 7 (w + 1 keys per thread in registers)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// shard_coarse_quad_kernel (round 6): the coarse phase of a whole batch in front of ivf_shard_any_kernel, FOUR queries per block.
+//
+// Inside the one-query block the coarse scores were nlist x M random 4-byte LDS gathers per query (31 of the kernel's 85 us at the
+// Deep1B shape: nlist = 8000, M = 16; 65 % of its LDS cycles bank-conflict replays, profiles/r05_deepivf_pmc.json), every block read
+// every centre, and every one of the B x nlist coarse keys went out to global scratch (64 MB per launch) for a replay that one query
+// in thousands takes.  Here -- ivf_quad_kernel's layout, for any even Ds --
+//   tables   four queries' tables interleaved [m][ks][query] in 16-byte rows (thread = (ks, quarter of the subspaces): one codeword
+//            load serves four queries; fvec_L2sqr's operations, src/distance.h:117-252), and each query's plain table written to
+//            global memory once (M x Ks x 4 bytes, coalesced) for the walk kernel to load instead of rebuilding it;
+//   scores   thread = centre: its code is read once per FOUR queries and each of its M lookups is one ds_read_b128 that returns the
+//            four queries' entries (sequential fp32 adds over m per query, src/rii.h:375-384);
+//   picks    the fast selection of ivf_shard_any_kernel (three smallest keys per thread and query in registers, the w + 1 smallest per
+//            wave by DPP minima, one wave per query merges the sixteen waves' picks); `ok` = the w + 1 smallest distances are
+//            pairwise different and no thread can have dropped a key that belongs among them -- std::partial_sort's first w entries
+//            ARE picks[0 .. w) then (src/rii.h:279-280).  A query without `ok`, or whose walk leaves the first w lists, is scored
+//            and replayed by its own block of the walk kernel exactly as before.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kCoarseQ = 4;
+constexpr int kCoarseThreads = 1024;
+constexpr int kCoarseR = kShardFastW + 1;
+static_assert(kCoarseR == kShardPickStride, "the picks' row stride");
+constexpr int kCoarseT = 3;              // keys a thread keeps per query
+
+struct CoarseArgs {
+    const float *queries, *codewords;
+    const uint8_t *centers;
+    int M, nlist, w, arch, dbg;
+    int64_t B;
+    float *lut;                          // [B][M * 256] plain tables (out)
+    pq64_t *picks;                       // [B][kCoarseR] the w + 1 smallest (distance, list) keys, ascending (out)
+    int32_t *ok;                         // [B] 1 = picks conclusive (out)
+};
+
+// s_q: the block's four queries staged in LDS ([4][M * DS], padding queries = the block's first): a thread's query values are
+// wave-uniform broadcast reads.  (Fetched straight from global memory they came as VECTOR loads, one dependent round trip per subspace
+// -- the table stores may alias them, which rules scalar loads out: four round trips in front of the scores.)
+template <int DS, int ARCH, int M>
+__device__ __forceinline__ void coarse_quad_tables(const CoarseArgs &p, float4 *__restrict__ lds4, float *__restrict__ s_q, int64_t q0, int nq, int tid)
+{
+    static_assert(DS % 2 == 0, "8-byte codeword loads");
+    constexpr int MK = M * 256, D = M * DS, mper = M / 4, U = DS >= 8 ? 2 : 4;
+    const int ks = tid & 255, mg = tid >> 8;
+    float *dst[kCoarseQ];
+#pragma unroll
+    for (int q = 0; q < kCoarseQ; ++q) dst[q] = p.lut + (size_t) (q0 + (q < nq ? q : 0)) * MK + ks;       // (padding: the first query's values again)
+    float2 cv[2][U][DS / 2];
+    auto request = [&](float2 (&c)[U][DS / 2], int u0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float2 *src = reinterpret_cast<const float2 *>(p.codewords + ((size_t) (mg * mper + u0 + u) * 256 + ks) * DS);
+#pragma unroll
+            for (int i = 0; i < DS / 2; ++i) c[u][i] = src[i];
+        }
+    };
+    constexpr bool DB = DS < 8;                                  // the next batch's codewords in flight behind this batch's entries
+    request(cv[0], 0);
+    for (int i = tid; i < kCoarseQ * D; i += kCoarseThreads) {
+        const int q = i / D;
+        s_q[i] = p.queries[(q0 + (q < nq ? q : 0)) * (int64_t) D + (i - q * D)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u0 = 0; u0 < mper; u0 += U) {
+        const int cur = DB ? (u0 / U) & 1 : 0;
+        if (DB && u0 + U < mper) request(cv[cur ^ 1], u0 + U);
+        if (!DB && u0) request(cv[0], u0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = mg * mper + u0 + u;
+            float y[DS], r[kCoarseQ];
+#pragma unroll
+            for (int i = 0; i < DS / 2; ++i) { y[2 * i] = cv[cur][u][i].x; y[2 * i + 1] = cv[cur][u][i].y; }
+#pragma unroll
+            for (int q = 0; q < kCoarseQ; ++q) {
+                float x[DS];
+#pragma unroll
+                for (int i = 0; i < DS / 2; ++i) {
+                    const float2 t = *reinterpret_cast<const float2 *>(s_q + q * D + m * DS + 2 * i);
+                    x[2 * i] = t.x; x[2 * i + 1] = t.y;
+                }
+                r[q] = fvec_l2sqr_body(x, y, DS, ARCH);
+            }
+            lds4[m * 256 + ks] = make_float4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+            for (int q = 0; q < kCoarseQ; ++q) dst[q][m * 256] = r[q];
+        }
+    }
+}
+
+// MQ = M / 16 (16-byte pieces of a centre's code)
+template <int DS, int MQ>
+__global__ __launch_bounds__(kCoarseThreads) void shard_coarse_quad_kernel(CoarseArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int M = 16 * MQ, MK = M * 256;
+    constexpr int CH = MQ == 1 ? 2 : 1;                                                   // centres per thread in flight (two such sets)
+    const int nlist = p.nlist;
+    float4 *lds4 = reinterpret_cast<float4 *>(smem);                                      // [MK] rows of four queries' entries
+    pq64_t *s_wsel = reinterpret_cast<pq64_t *>(smem + (size_t) MK * 16);                 // [4][16][kCoarseR] the waves' picks
+    pq64_t *s_bound = s_wsel + kCoarseQ * 16 * kCoarseR;                                  // [4] the largest pick
+    int *s_tie = reinterpret_cast<int *>(s_bound + kCoarseQ);                             // [4]
+    float *s_q = reinterpret_cast<float *>(s_tie + kCoarseQ);                             // [4][M * DS] the block's queries
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q0 = (int64_t) blockIdx.x * kCoarseQ;
+    const int nq = (int) (p.B - q0 < kCoarseQ ? p.B - q0 : kCoarseQ);
+    const int R = p.w + 1;
+    // the codes of this thread's first centres are requested before anything else: their round trip passes behind the table phase
+    uint4 cen[2][CH][MQ];
+    auto request = [&](uint4 (&dst)[CH][MQ], int c0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int c = c0 + u * kCoarseThreads;
+            const uint4 *cp = reinterpret_cast<const uint4 *>(p.centers + (size_t) (c < nlist ? c : 0) * M);
+#pragma unroll
+            for (int qd = 0; qd < MQ; ++qd) dst[u][qd] = cp[qd];
+        }
+    };
+    request(cen[0], tid);
+    // (up to four floats the three SIMD variants are the same operations: table_rows_regs, rii_device.h)
+    if (DS <= 4 || p.arch == RII_SIMD_AVX512) coarse_quad_tables<DS, RII_SIMD_AVX512, M>(p, lds4, s_q, q0, nq, tid);
+    else if (p.arch == RII_SIMD_AVX) coarse_quad_tables<DS, RII_SIMD_AVX, M>(p, lds4, s_q, q0, nq, tid);
+    else coarse_quad_tables<DS, RII_SIMD_SSE, M>(p, lds4, s_q, q0, nq, tid);
+    __syncthreads();
+    if (p.dbg == 1) return;
+    // ---- scores: thread = centre, four queries per lookup; the next CH centres' codes are in flight while these are scored ----
+    pq64_t best[kCoarseQ][kCoarseT];
+#pragma unroll
+    for (int q = 0; q < kCoarseQ; ++q)
+#pragma unroll
+        for (int k = 0; k < kCoarseT; ++k) best[q][k] = ~0ull;
+    auto score = [&](const uint4 (&cv)[CH][MQ], int c0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int c = c0 + u * kCoarseThreads;
+            if (c >= nlist) break;
+            float acc[kCoarseQ] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qd = 0; qd < MQ; ++qd) {
+                uint32_t wds[4] = {cv[u][qd].x, cv[u][qd].y, cv[u][qd].z, cv[u][qd].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // eight rows (32 registers) in flight at a time: the code bytes of the next eight lookups "depend" on the sums so far
+                    // (left alone the scheduler hoists all 16 MQ reads of a centre -- 64 MQ registers -- and spills)
+                    if ((i & 1) == 0 && (qd | i)) {
+                        asm volatile("" : "+v"(wds[i]), "+v"(wds[i + 1]) : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 row = lds4[((qd * 4 + i) * 4 + j) * 256 + ((wds[i] >> (8 * j)) & 0xffu)];
+                        acc[0] = __fadd_rn(acc[0], row.x);
+                        acc[1] = __fadd_rn(acc[1], row.y);
+                        acc[2] = __fadd_rn(acc[2], row.z);
+                        acc[3] = __fadd_rn(acc[3], row.w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kCoarseQ; ++q) {
+                const pq64_t e = pq64_make(acc[q], (uint32_t) c);
+                if (e < best[q][kCoarseT - 1]) {                                           // sorted insertion (keys are distinct: the list id)
+                    best[q][kCoarseT - 1] = e;
+#pragma unroll
+                    for (int k = kCoarseT - 1; k > 0; --k)
+                        if (best[q][k] < best[q][k - 1]) { const pq64_t t = best[q][k]; best[q][k] = best[q][k - 1]; best[q][k - 1] = t; }
+                }
+            }
+        }
+    };
+    for (int c0 = tid; c0 < nlist; c0 += 2 * CH * kCoarseThreads) {
+        const int c1 = c0 + CH * kCoarseThreads;
+        if (c1 < nlist) request(cen[1], c1);
+        score(cen[0], c0);
+        if (c1 < nlist) {
+            if (c1 + CH * kCoarseThreads < nlist) request(cen[0], c1 + CH * kCoarseThreads);
+            score(cen[1], c1);
+        }
+    }
+    if (p.dbg == 2) return;
+    pq64_t third[kCoarseQ];
+#pragma unroll
+    for (int q = 0; q < kCoarseQ; ++q) third[q] = best[q][kCoarseT - 1];                   // (before the pops below)
+    // ---- level 1: the R smallest keys of this wave's lanes per query (the four queries' DPP ladders in lockstep) ----
+    for (int r = 0; r < R; ++r) {
+        unsigned long long got[kCoarseQ] = {best[0][0], best[1][0], best[2][0], best[3][0]};
+        wave_min_u64_x4(got);
+#pragma unroll
+        for (int q = 0; q < kCoarseQ; ++q) {
+            if (best[q][0] == got[q]) {                                                    // (one lane: it hands the key over and moves up its list)
+#pragma unroll
+                for (int k = 0; k + 1 < kCoarseT; ++k) best[q][k] = best[q][k + 1];
+                best[q][kCoarseT - 1] = ~0ull;
+            }
+            if (lane == 0) s_wsel[(q * 16 + wave) * kCoarseR + r] = got[q];
+        }
+    }
+    __syncthreads();
+    // ---- level 2: wave q merges the sixteen waves' picks of query q (16 R <= 128 keys: two per lane); lane r keeps pick r ----
+    if (wave < kCoarseQ) {
+        const int q = wave;
+        pq64_t cand[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = lane + 64 * u;
+            cand[u] = i < 16 * R ? s_wsel[(q * 16 + i / R) * kCoarseR + (i % R)] : ~0ull;
+        }
+        pq64_t mysel = ~0ull;
+        for (int r = 0; r < R; ++r) {
+            const pq64_t got = wave_min_u64(cand[0] < cand[1] ? cand[0] : cand[1]);
+            if (cand[0] == got) cand[0] = ~0ull;
+            if (cand[1] == got) cand[1] = ~0ull;
+            if (lane == r) mysel = got;
+        }
+        const uint32_t myhi = (uint32_t) (mysel >> 32);
+        const uint32_t nxhi = (uint32_t) __shfl_down((int) myhi, 1);
+        const bool tied = lane + 1 < R && myhi == nxhi;                                    // exactly tied distances among the w + 1 smallest
+        const int tie = __ballot(tied) != 0ull ? 1 : 0;
+        if (lane == R - 1) s_bound[q] = mysel;
+        if (lane == 0) s_tie[q] = tie;
+        if (q < nq && lane < R) p.picks[(size_t) (q0 + q) * kCoarseR + lane] = mysel;
+    }
+    __syncthreads();
+    // a thread whose third key is not above the largest pick may have dropped a fourth that belongs among the picks
+    int lostm = 0;
+#pragma unroll
+    for (int q = 0; q < kCoarseQ; ++q) lostm |= (third[q] != ~0ull && third[q] <= s_bound[q]) ? (1 << q) : 0;
+    lostm = __syncthreads_or(lostm);
+    if (tid < nq) p.ok[q0 + tid] = (s_tie[tid] == 0 && !((lostm >> tid) & 1)) ? 1 : 0;
+}
+
+static size_t shard_coarse_smem(int M, int Ds) { return (size_t) M * 256 * 16 + (size_t) kCoarseQ * 16 * kCoarseR * 8 + kCoarseQ * 8 + kCoarseQ * 4 + (size_t) kCoarseQ * M * Ds * 4 + 64; }
+
 constexpr int kShardAnyBuf = 8192;       // most keys the selection buffer holds (64 KiB)
 constexpr int kShardGroup = 256;         // visited lists whose descriptors are staged per round
 constexpr int kShardUnroll = 4;          // candidates a thread scores per round: their ids, then their code rows, are in flight together
 constexpr int kShardRound = 256 * kShardUnroll;
-constexpr int kShardFastW = 7;           // the fast coarse selection covers w <= 7 (w + 1 keys per thread in registers)
 
 // CLDS: the coarse order and the cumulative counts of the query in LDS (nlist <= kShardMaxNlistLds), else in global scratch.
 // TOP1: rows == 2 (top-1: the best two owned candidates): every thread keeps its two smallest keys in registers, the block's two
 //       smallest come out of two DPP minima per wave and eight keys in LDS -- no buffer, no sort, no atomics.
 // (the in-kernel table for an even Ds other than 4: table_rows_regs, rii_device.h)
-template <bool GTAB, bool CLDS, bool TOP1>
+// PRE (round 6): launched behind shard_coarse_quad_kernel -- tables from `lut`, the coarse order from `picks`
+template <bool GTAB, bool CLDS, bool TOP1, bool PRE = false>
 __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbuf, int collect)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -279,7 +517,13 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             }
         } else {
             const float *src = p.lut + (size_t) b * MK;
-            for (int i = tid; i < MK; i += 256) lds[i] = src[i];
+            if ((MK & 3) == 0) {
+                const float4 *s4 = reinterpret_cast<const float4 *>(src);
+                float4 *d4 = reinterpret_cast<float4 *>(lds);
+                for (int i = tid; i < (MK >> 2); i += 256) d4[i] = s4[i];
+            } else {
+                for (int i = tid; i < MK; i += 256) lds[i] = src[i];
+            }
         }
     }
     __syncthreads();
@@ -292,89 +536,125 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     // unsorted tail, whose arrangement only the replay knows), fall back to the exact replay -- ivf_fused_kernel's rule, without a
     // second launch: the original sequence is still in place (head saved, tail untouched).
     constexpr int kFastR = kShardFastW + 1;
-    const bool fast_ok = !CLDS && w_lds && p.w <= kShardFastW && nlist > (int) p.w + 64 && !force_replay;
+    // round 6: the batch's coarse phase ran in shard_coarse_quad_kernel (four queries per block, one 16-byte LDS read per centre lookup):
+    // this block starts from that kernel's picks unless they were inconclusive -- no coarse scores, no coarse keys written anywhere
+    static_assert(!PRE || (!CLDS && !GTAB), "the pre-pass serves the order-in-scratch, table-in-LDS form");
+    bool pre_ok = PRE && !force_replay && p.pick_ok[b] != 0;                           // (block-uniform)
+    const bool fast_ok = !PRE && !CLDS && w_lds && p.w <= kShardFastW && nlist > (int) p.w + 64 && !force_replay;
     const int R = (int) p.w + 1;
-    // (three keys per thread, not w + 1: with 256 threads three of the w + 1 smallest keys of a query share a thread in 0.01 - 0.1 % of
-    //  the queries; a thread whose THIRD key is within the picks may have dropped a fourth -- detected, and such a query is replayed.
-    //  Eight sorted slots per thread cost the scoring loop 10 us of insertions at 8000 lists.)
-    constexpr int kFastT = 3;
-    pq64_t best[kFastT];
-#pragma unroll
-    for (int k = 0; k < kFastT; ++k) best[k] = ~0ull;
-    for (int c0 = tid; c0 < nlist; c0 += 4 * 256) {                                   // src/rii.h:262-264; four centres' codes in flight per thread
-        float dv[4];
-        const uint8_t *crow[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * 256;
-            crow[u] = p.centers + (size_t) (c < nlist ? c : 0) * p.M;
-        }
-        shard_adist_rows<4>(tab, crow, p.M, p.Ks, dv);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * 256;
-            if (c < nlist) {
-                const pq64_t e = pq64_make(dv[u], (uint32_t) c);
-                if (!CLDS && w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
-                if (fast_ok && e < best[kFastT - 1]) {                                 // sorted insertion (keys are distinct: the list id)
-                    best[kFastT - 1] = e;
-#pragma unroll
-                    for (int k = kFastT - 1; k > 0; --k)
-                        if (best[k] < best[k - 1]) { const pq64_t t = best[k]; best[k] = best[k - 1]; best[k - 1] = t; }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (dbg == 2) return;
     const int nlds = CLDS ? nlist : nhead;
     // the order's first w entries (the sorted heap) and the counts up to list w are read from LDS wherever the order itself lives in
     // global scratch: the walk leaves them only for stale lists (tail walk)
     auto order_at = [&](int c) -> pq64_t { return (CLDS || c < nlds) ? s_head[c] : s_coarse[c]; };
     auto cum_at = [&](int c) -> int { return (CLDS || c <= nlds) ? s_cum_lds[c] : s_cum[c]; };
     auto cum_set = [&](int c, int v) { if (CLDS || c <= nlds) s_cum_lds[c] = v; if (!CLDS) s_cum[c] = v; };
-    bool fast_used = false;
-    if (fast_ok) {
-        const int lane = tid & 63, wave = tid >> 6;
-        const pq64_t third = best[kFastT - 1];                                         // (before the pops below)
-        for (int r = 0; r < R; ++r) {                                                  // level 1: this wave's R smallest
-            const pq64_t got = wave_min_u64(best[0]);
-            if (best[0] == got) {                                                      // (one lane: it hands the key over and moves up its list)
+    bool fast_used = false, scored = false;
+    // scores every centre (the sequence std::partial_sort works on: head in LDS, tail in scratch) and, without a pre-pass, picks;
+    // true = the measurement stop after this phase
+    auto score_and_pick = [&]() -> bool {
+        // (three keys per thread, not w + 1: with 256 threads three of the w + 1 smallest keys of a query share a thread in 0.01 - 0.1 % of
+        //  the queries; a thread whose THIRD key is within the picks may have dropped a fourth -- detected, and such a query is replayed.
+        //  Eight sorted slots per thread cost the scoring loop 10 us of insertions at 8000 lists.)
+        constexpr int kFastT = 3;
+        pq64_t best[kFastT];
 #pragma unroll
-                for (int k = 0; k + 1 < kFastT; ++k) best[k] = best[k + 1];
-                best[kFastT - 1] = ~0ull;
+        for (int k = 0; k < kFastT; ++k) best[k] = ~0ull;
+        if constexpr (PRE) {                                                       // (rare: one centre at a time keeps this form's registers low)
+            for (int c = tid; c < nlist; c += 256) {
+                const pq64_t e = pq64_make(exact_adist(tab, p.centers + (size_t) c * p.M, p.M, p.Ks), (uint32_t) c);
+                if (w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
             }
-            if (lane == 0) s_fast[wave * kFastR + r] = got;
-        }
-        __syncthreads();
-        if (wave == 0) {                                                               // level 2: the block's R smallest, ascending; lane r keeps pick r
-            pq64_t cand = lane < 4 * R ? s_fast[(lane / R) * kFastR + (lane % R)] : ~0ull;
-            pq64_t mysel = ~0ull;
-            for (int r = 0; r < R; ++r) {
-                const pq64_t got = wave_min_u64(cand);
-                if (cand == got) cand = ~0ull;
-                if (lane == r) mysel = got;
+        } else
+        for (int c0 = tid; c0 < nlist; c0 += 4 * 256) {                           // src/rii.h:262-264; four centres' codes in flight per thread
+            float dv[4];
+            const uint8_t *crow[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 256;
+                crow[u] = p.centers + (size_t) (c < nlist ? c : 0) * p.M;
             }
-            const uint32_t myhi = (uint32_t) (mysel >> 32);
-            const uint32_t nxhi = (uint32_t) __shfl_down((int) myhi, 1);
-            const bool tied = lane + 1 < R && myhi == nxhi;                             // exactly tied distances among the w + 1 smallest
-            const int tie = __ballot(tied) != 0ull ? 1 : 0;
-            if (lane == R - 1) s_fast[4 * kFastR + kFastR - 1] = mysel;                 // the largest pick: the bound of the check below
-            if (lane == 0) s_misc[6] = tie;
-            if (lane < (int) p.w) s_fast[lane] = mysel;                                 // (the waves' picks are dead: the block's picks in their place)
+            shard_adist_rows<4>(tab, crow, p.M, p.Ks, dv);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 256;
+                if (c < nlist) {
+                    const pq64_t e = pq64_make(dv[u], (uint32_t) c);
+                    if (!CLDS && w_lds && c < (int) p.w) s_head[c] = e; else s_coarse[c] = e;
+                    if (fast_ok && e < best[kFastT - 1]) {                         // sorted insertion (keys are distinct: the list id)
+                        best[kFastT - 1] = e;
+#pragma unroll
+                        for (int k = kFastT - 1; k > 0; --k)
+                            if (best[k] < best[k - 1]) { const pq64_t t = best[k]; best[k] = best[k - 1]; best[k - 1] = t; }
+                    }
+                }
+            }
         }
         __syncthreads();
-        // a thread whose third key is not above the largest pick may have dropped a fourth that belongs among the picks: replay
-        const int lost = __syncthreads_or(third != ~0ull && third <= s_fast[4 * kFastR + kFastR - 1]);
-        fast_used = s_misc[6] == 0 && !lost;
-        if (fast_used && tid < (int) p.w) {
-            const pq64_t pick = s_fast[tid];
-            s_fast[4 * kFastR + tid] = s_head[tid];                                     // the sequence's own first w entries: kept for a replay
-            s_head[tid] = pick;
+        if (dbg == 2) return true;
+        // FAST coarse selection (round 5; order in global scratch, w <= kShardFastW, no pre-pass): every thread kept its three smallest
+        // keys while the centres were scored; each wave extracts the w + 1 smallest of its lanes' lists with DPP minima and wave 0
+        // merges the four waves' picks -- the w + 1 smallest (distance, list) keys of the query in ~3 us instead of the library's heap
+        // replayed over thousands of lists (~26 us at 8000 lists).  That IS std::partial_sort's result whenever those w + 1 distances
+        // are pairwise different; exactly tied distances among them, or a walk that has to continue past list w (the unsorted tail,
+        // whose arrangement only the replay knows), fall back to the exact replay -- ivf_fused_kernel's rule, without a second
+        // launch: the original sequence is still in place (head saved, tail untouched).
+        if (fast_ok) {
+            const int lane = tid & 63, wave = tid >> 6;
+            const pq64_t third = best[kFastT - 1];                                 // (before the pops below)
+            for (int r = 0; r < R; ++r) {                                          // level 1: this wave's R smallest
+                const pq64_t got = wave_min_u64(best[0]);
+                if (best[0] == got) {                                              // (one lane: it hands the key over and moves up its list)
+#pragma unroll
+                    for (int k = 0; k + 1 < kFastT; ++k) best[k] = best[k + 1];
+                    best[kFastT - 1] = ~0ull;
+                }
+                if (lane == 0) s_fast[wave * kFastR + r] = got;
+            }
+            __syncthreads();
+            if (wave == 0) {                                                       // level 2: the block's R smallest, ascending; lane r keeps pick r
+                pq64_t cand = lane < 4 * R ? s_fast[(lane / R) * kFastR + (lane % R)] : ~0ull;
+                pq64_t mysel = ~0ull;
+                for (int r = 0; r < R; ++r) {
+                    const pq64_t got = wave_min_u64(cand);
+                    if (cand == got) cand = ~0ull;
+                    if (lane == r) mysel = got;
+                }
+                const uint32_t myhi = (uint32_t) (mysel >> 32);
+                const uint32_t nxhi = (uint32_t) __shfl_down((int) myhi, 1);
+                const bool tied = lane + 1 < R && myhi == nxhi;                     // exactly tied distances among the w + 1 smallest
+                const int tie = __ballot(tied) != 0ull ? 1 : 0;
+                if (lane == R - 1) s_fast[4 * kFastR + kFastR - 1] = mysel;         // the largest pick: the bound of the check below
+                if (lane == 0) s_misc[6] = tie;
+                if (lane < (int) p.w) s_fast[lane] = mysel;                         // (the waves' picks are dead: the block's picks in their place)
+            }
+            __syncthreads();
+            // a thread whose third key is not above the largest pick may have dropped a fourth that belongs among the picks: replay
+            const int lost = __syncthreads_or(third != ~0ull && third <= s_fast[4 * kFastR + kFastR - 1]);
+            fast_used = s_misc[6] == 0 && !lost;
+            if (fast_used && tid < (int) p.w) {
+                const pq64_t pick = s_fast[tid];
+                s_fast[4 * kFastR + tid] = s_head[tid];                             // the sequence's own first w entries: kept for a replay
+                s_head[tid] = pick;
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        return false;
+    };
+    if constexpr (!PRE) {
+        if (score_and_pick()) return;
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
+        if constexpr (PRE) {
+            if (!pre_ok && !scored) {
+                scored = true;
+                if (score_and_pick()) return;
+            } else if (dbg == 2) return;
+        }
+        if (PRE && pre_ok) {                                                           // std::partial_sort's first w entries, from the pre-pass
+            if (tid < (int) p.w) s_head[tid] = p.picks[(size_t) b * kFastR + tid];
+            fast_used = true;
+            __syncthreads();
+        }
         if (!fast_used) {                                                              // the library's algorithm, move for move
             if constexpr (CLDS) {
                 if (tid < 64) wh_partial_sort(s_coarse, (int) p.w, nlist, tid);        // src/rii.h:279-280 (wave 0)
@@ -410,8 +690,10 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
         }
         __syncthreads();
         if (!s_misc[7]) break;
-        // the walk left the first w lists: restore the sequence's own head and replay the library's sort on it
-        if (tid < (int) p.w) s_head[tid] = s_fast[4 * kFastR + tid];
+        // the walk left the first w lists.  In-kernel picks: the sequence's own head comes back and the library's sort is replayed on
+        // it; pre-pass picks: the sequence was never written -- score the centres now, then replay
+        if (pre_ok) pre_ok = false;
+        else if (tid < (int) p.w) s_head[tid] = s_fast[4 * kFastR + tid];
         fast_used = false;
         __syncthreads();
     }
@@ -467,6 +749,73 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
             const int lpos = s_lpos[l];
             const int32_t *ids = p.pl_ids + s_loff[l];
             const uint8_t *lrows = p.lcodes ? p.lcodes + (size_t) s_loff[l] * p.M : nullptr;
+            if constexpr (!GTAB) {
+                // round 6: posting-order rows of the common shapes (M = 16 / 32, Ks = 256) -- the NEXT round's rows are requested before
+                // this round's are scored: the rows stream from HBM (a 1 GB shard), and with one round in flight per block its ~2 us
+                // round trip stood in front of every 1024 candidates
+                if (lrows && !collect && p.Ks == 256 && (p.M == 16 || p.M == 32)) {
+                    auto run = [&](auto mq_tag) {
+                        constexpr int MQ = decltype(mq_tag)::value, MM = 16 * MQ;
+                        uint4 rv[2][kShardUnroll][MQ];
+                        auto req = [&](uint4 (&d)[kShardUnroll][MQ], int base_li) {
+#pragma unroll
+                            for (int u = 0; u < kShardUnroll; ++u) {
+                                const int li = base_li + u * 256 + tid;
+                                const uint4 *cp = reinterpret_cast<const uint4 *>(lrows + (size_t) (li < own ? li : 0) * MM);
+#pragma unroll
+                                for (int qd = 0; qd < MQ; ++qd) d[u][qd] = cp[qd];
+                            }
+                        };
+                        auto score = [&](const uint4 (&d)[kShardUnroll][MQ], int base_li) {
+                            if (!TOP1 && __syncthreads_or(s_misc[3] + 2 * kShardRound > nbuf)) flush();       // (see the general loop below)
+                            float prev = 0.f;
+                            unsigned long long x0 = b0, x1 = b1;          // (value copies: updated through the captured references the pair is demoted to scratch)
+                            int nown = 0;
+#pragma unroll
+                            for (int u = 0; u < kShardUnroll; ++u) {
+                                float dist = 0.f;
+#pragma unroll
+                                for (int qd = 0; qd < MQ; ++qd) {
+                                    uint32_t wds[4] = {d[u][qd].x, d[u][qd].y, d[u][qd].z, d[u][qd].w};
+                                    // one row piece (16 lookups) in flight at a time: its code bytes "depend" on the sums so far (left alone
+                                    // the scheduler hoists every read of the round -- 128 MQ registers -- and the kernel loses two blocks per CU)
+                                    asm volatile("" : "+v"(wds[0]), "+v"(wds[1]), "+v"(wds[2]), "+v"(wds[3]) : "v"(prev), "v"(dist));
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j)
+                                            dist = __fadd_rn(dist, lds[((qd * 4 + i) * 4 + j) * 256 + ((wds[i] >> (8 * j)) & 0xffu)]);
+                                }
+                                prev = dist;
+                                const int li = base_li + u * 256 + tid;
+                                if (li >= own) continue;
+                                ++nown;
+                                const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(dist)) << 32) | (uint32_t) (lpos + li);
+                                if constexpr (TOP1) {
+                                    const bool lt0 = key < x0, lt1 = key < x1;
+                                    x1 = lt0 ? x0 : (lt1 ? key : x1);
+                                    x0 = lt0 ? key : x0;
+                                } else {
+                                    if (key < thr) s_key[atomicAdd(&s_misc[3], 1)] = key;
+                                }
+                            }
+                            b0 = x0; b1 = x1; owned += nown;
+                        };
+                        req(rv[0], 0);
+                        for (int base_li = 0; base_li < own; base_li += 2 * kShardRound) {
+                            const int nxt = base_li + kShardRound;
+                            if (nxt < own) req(rv[1], nxt);
+                            score(rv[0], base_li);
+                            if (nxt < own) {
+                                if (nxt + kShardRound < own) req(rv[0], nxt + kShardRound);
+                                score(rv[1], nxt);
+                            }
+                        }
+                    };
+                    if (p.M == 16) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 2>{});
+                    continue;
+                }
+            }
             for (int base_li = 0; base_li < own; base_li += kShardRound) {
                 // a thread reads the fill behind its own insertions of the round before, not behind everyone's: up to one round
                 // short of the truth, hence two rounds of slack; the OR makes the decision the block's
@@ -765,14 +1114,40 @@ bool ivf_shard_builds_tables(int M, int Ks, int nlist, int64_t L, int64_t w, int
 {
     return !shard_gtab(M, Ks) && shard_use_any(M, Ks, nlist, L, w, rows);
 }
+// round 6: the coarse pre-pass in front of ivf_shard_any_kernel (shard_coarse_quad_kernel).  Applies where that kernel would build its own
+// table and keep the coarse order in global scratch, for the shapes the four-query table fits LDS.
+bool shard_coarse_supported(int M, int Ks, int Ds, int nlist, int64_t L, int64_t w, int rows)
+{
+    return Ks == 256 && (M == 16 || M == 32) && (Ds == 2 || Ds == 4 || Ds == 6 || Ds == 8) && w <= kShardFastW && nlist > (int) w + 64 &&
+           !shard_gtab(M, Ks) && shard_use_any(M, Ks, nlist, L, w, rows) && !shard_any_clds(M, Ks, nlist) &&
+           shard_coarse_smem(M, Ds) <= (size_t) 160 * 1024 - 512;
+}
+hipError_t launch_shard_coarse(const float *d_queries, const float *d_codewords, const uint8_t *d_centers, int M, int Ds, int arch, int nlist,
+                               int64_t w, int64_t B, float *d_lut, unsigned long long *d_picks, int32_t *d_pick_ok, hipStream_t st, int debug)
+{
+    if (B == 0) return hipSuccess;
+    CoarseArgs a;
+    a.dbg = debug;
+    a.queries = d_queries; a.codewords = d_codewords; a.centers = d_centers; a.M = M; a.nlist = nlist; a.w = (int) w; a.arch = arch; a.B = B;
+    a.lut = d_lut; a.picks = d_picks; a.ok = d_pick_ok;
+    auto kern = M == 16 ? (Ds == 2 ? shard_coarse_quad_kernel<2, 1> : Ds == 4 ? shard_coarse_quad_kernel<4, 1> : Ds == 6 ? shard_coarse_quad_kernel<6, 1> : shard_coarse_quad_kernel<8, 1>)
+                        : (Ds == 2 ? shard_coarse_quad_kernel<2, 2> : Ds == 4 ? shard_coarse_quad_kernel<4, 2> : Ds == 6 ? shard_coarse_quad_kernel<6, 2> : shard_coarse_quad_kernel<8, 2>);
+    const size_t smem = shard_coarse_smem(M, Ds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned) ((B + kCoarseQ - 1) / kCoarseQ)), dim3(kCoarseThreads), smem, st, a);
+    return hipGetLastError();
+}
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st,
-                            const float *d_queries, const float *d_codewords, int Ds, int arch, const uint8_t *d_lcodes, int debug)
+                            const float *d_queries, const float *d_codewords, int Ds, int arch, const uint8_t *d_lcodes, int debug,
+                            const unsigned long long *d_picks, const int32_t *d_pick_ok)
 {
     if (B == 0) return hipSuccess;
     ShardArgs a;
+    a.picks = d_picks; a.pick_ok = d_pick_ok;
     a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch; a.lcodes = d_lcodes;
     a.codes = d_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.centers = d_centers; a.nlist = nlist; a.pl_off = d_pl_off;
     a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w; a.rows = rows;
@@ -785,10 +1160,12 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
         if (collect && (int64_t) rows < L) return hipErrorInvalidValue;
         const size_t smem = shard_any_fixed(M, Ks, nlist, w) + (top1 ? 64 : (collect ? 0 : (size_t) nbuf * 8));
         const bool gt = shard_gtab(M, Ks), cl = shard_any_clds(M, Ks, nlist);
+        const bool pre = d_picks && d_pick_ok && d_lut && !gt && !cl;
+        if (d_picks && !pre) return hipErrorInvalidValue;
         auto kern = top1 ? (gt ? (cl ? ivf_shard_any_kernel<true, true, true> : ivf_shard_any_kernel<true, false, true>)
-                               : (cl ? ivf_shard_any_kernel<false, true, true> : ivf_shard_any_kernel<false, false, true>))
+                               : (cl ? ivf_shard_any_kernel<false, true, true> : pre ? ivf_shard_any_kernel<false, false, true, true> : ivf_shard_any_kernel<false, false, true>))
                          : (gt ? (cl ? ivf_shard_any_kernel<true, true, false> : ivf_shard_any_kernel<true, false, false>)
-                               : (cl ? ivf_shard_any_kernel<false, true, false> : ivf_shard_any_kernel<false, false, false>));
+                               : (cl ? ivf_shard_any_kernel<false, true, false> : pre ? ivf_shard_any_kernel<false, false, false, true> : ivf_shard_any_kernel<false, false, false>));
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         if (e != hipSuccess) return e;
         // debug (engine options "shard_dbg_stop" | "shard_force_replay" << 8; 0 in production): bits 8..15 of the kernel's word = return after

@@ -271,7 +271,15 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st,
                             const float *d_queries = nullptr, const float *d_codewords = nullptr, int Ds = 0, int arch = 0,
-                            const uint8_t *d_lcodes = nullptr, int debug = 0);      // d_lcodes: the codes in posting order of d_pl_ids (unfiltered lists), or NULL
+                            const uint8_t *d_lcodes = nullptr, int debug = 0,       // d_lcodes: the codes in posting order of d_pl_ids (unfiltered lists), or NULL
+                            const unsigned long long *d_picks = nullptr, const int32_t *d_pick_ok = nullptr);    // the pre-pass's output (with d_lut), or NULL
+// round 6: the batch's coarse phase in front of that launch -- four queries per block, tables interleaved [m][ks][query]
+// (shard_coarse_quad_kernel): writes the queries' plain tables to d_lut ([B][M * 256]), the w + 1 smallest (distance, list) keys per
+// query to d_picks ([B][kShardPickStride]) and whether they are conclusive to d_pick_ok ([B])
+constexpr int kShardPickStride = 8;
+bool shard_coarse_supported(int M, int Ks, int Ds, int nlist, int64_t L, int64_t w, int rows);
+hipError_t launch_shard_coarse(const float *d_queries, const float *d_codewords, const uint8_t *d_centers, int M, int Ds, int arch, int nlist,
+                               int64_t w, int64_t B, float *d_lut, unsigned long long *d_picks, int32_t *d_pick_ok, hipStream_t st, int debug = 0);
 // true: that launch builds the queries' tables itself when handed (d_queries, d_codewords) -- d_lut may be NULL then
 bool ivf_shard_builds_tables(int M, int Ks, int nlist, int64_t L, int64_t w, int rows);
 size_t shard_replay_scratch(int64_t nf, int rows);    // bytes of d_scratch launch_shard_replay needs (0: the sequences fit LDS)

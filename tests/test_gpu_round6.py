@@ -93,3 +93,88 @@ def test_ivf_rot_copies_follow_the_lists():
     o.set_csr(cen, off, ids)
     check(2100, "after set_posting_lists")
     assert g.get_option("ivf_rot_launches") == 4
+
+
+def _sharded_check(idx, o, Q, topk, L, what):
+    import torch
+    gi, gd, gc = idx.query_ivf_batch(torch.from_numpy(Q).cuda(), topk, None, L)
+    gi, gd, gc = gi.cpu().numpy(), gd.cpu().numpy(), gc.cpu().numpy()
+    for b in range(Q.shape[0]):
+        n = int(gc[b])
+        assert_same_result((gi[b, :n], gd[b, :n]), o.query_ivf(Q[b], topk, E, L), "%s k=%d L=%d b=%d" % (what, topk, L, b))
+
+
+@pytest.mark.parametrize("arch", ["sse", "avx", "avx512"])
+@pytest.mark.parametrize("M,Ds,nlist,scale", [(16, 6, 2000, "unit"), (16, 8, 2000, "sift"), (32, 4, 600, "sift"), (32, 2, 600, "unit"), (16, 4, 2500, "sift"),
+                                              (32, 6, 500, "unit")])
+def test_shard_coarse_prepass_equals_the_walk_kernels_own_coarse_phase_and_the_oracle(M, Ds, nlist, scale, arch):
+    """shard_coarse_quad_kernel (round 6: the coarse phase of the database-sharded inverted index as a pre-pass, four queries per
+    block, tables interleaved [m][ks][query], picks by the fast selection) + ivf_shard_any_kernel<PRE> against the walk kernel doing its
+    own coarse phase (option shard_pre = 0) and against the oracle, ids and distance bits: every even Ds of the pre-pass in the three
+    SIMD orders (src/distance.h:117-252: the low bits of the table), batches that end inside a four-query block (53, 7, 1 queries),
+    top-1 and top-k (the register path and the selection buffer of the walk kernel), integer-valued data with duplicated rows (exactly
+    tied coarse distances among the w + 1 picks -> `ok` = 0 -> the query's own block scores the centres and replays std::partial_sort),
+    every query through that route (shard_force_replay), L from a handful to what w = 7 allows."""
+    if Ds <= 4 and arch != "avx512":
+        pytest.skip("up to four floats the three SIMD orders coincide")
+    from rii_amd import RiiGpu
+    from rii_amd import dist as rd
+    N = 30011
+    cw, codes, qs = make_problem(1600 + M + nlist + Ds, M, 256, Ds, N, scale, dup=3000 if scale == "sift" else 0)
+    rng = np.random.default_rng(61)
+    Q = np.concatenate([qs, rng.permutation(qs.reshape(-1)).reshape(qs.shape), qs * 0.5, qs[:5] + 1.0]).astype(np.float32)      # 53 queries
+    cen = np.ascontiguousarray(codes[rng.integers(0, N, nlist)])
+    if scale == "sift":
+        Q = np.round(Q)
+        cen[rng.integers(0, nlist, nlist // 3)] = cen[rng.integers(0, nlist, nlist // 3)]       # duplicated centres: tied coarse distances
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    o.add_codes(codes, False)
+    o.set_coarse_centers(cen)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    g.add_codes(codes, False)
+    g.set_coarse_centers(cen)
+    assert g.posting_lists == o.posting_lists
+    idx = rd.DbShardedIndex(g, 0, N)
+    L0 = max(1, N // nlist)
+    try:
+        n0 = g.get_option("shard_pre_launches")
+        ncall = 0
+        for B in (53, 7, 1):
+            for topk, L in ((1, L0), (1, 4 * L0), (3, 2 * L0), (1, 5), (10, 3 * L0)):
+                for pre, force in ((2, 0), (0, 0), (2, 1)):
+                    g.set_option("shard_pre", pre)
+                    g.set_option("shard_force_replay", force)
+                    _sharded_check(idx, o, Q[:B], topk, L, "pre=%d force=%d M=%d Ds=%d nlist=%d B=%d" % (pre, force, M, Ds, nlist, B))
+                    ncall += pre == 2
+        assert g.get_option("shard_pre_launches") - n0 >= ncall          # the pre-pass really ran wherever it was asked for
+    finally:
+        g.set_option("shard_pre", 1)
+        g.set_option("shard_force_replay", 0)
+
+
+def test_shard_coarse_prepass_stale_lists_and_the_tail_walk():
+    """Stale lists (codes added after the lists were built: most lists empty): the walk leaves the first w lists, whose order only
+    std::partial_sort's replay knows -- the pre-pass's picks are dropped, the query's block scores the centres itself and replays."""
+    from rii_amd import RiiGpu
+    from rii_amd import dist as rd
+    N, nlist, M, Ds = 20011, 2000, 16, 6
+    cw, codes, qs = make_problem(1777, M, 256, Ds, N, "unit")
+    cen = np.ascontiguousarray(codes[np.random.default_rng(5).integers(0, N, nlist)])
+    n9 = N // 9
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes[:n9], False)
+    g.set_coarse_centers(cen)
+    g.add_codes(codes[n9:], False)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes[:n9], False)
+    o.set_coarse_centers(cen)
+    o.add_codes(codes[n9:], False)
+    assert g.posting_lists == o.posting_lists
+    idx = rd.DbShardedIndex(g, 0, N)
+    try:
+        for pre in (2, 0):
+            g.set_option("shard_pre", pre)
+            for topk, L in ((1, 3), (1, 30), (1, 2), (2, 20), (5, 40)):
+                _sharded_check(idx, o, qs, topk, L, "stale pre=%d" % pre)
+    finally:
+        g.set_option("shard_pre", 1)
