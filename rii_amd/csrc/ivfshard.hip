@@ -320,7 +320,8 @@ __global__ __launch_bounds__(kCoarseThreads) void shard_coarse_quad_kernel(Coars
     pq64_t *s_wsel = reinterpret_cast<pq64_t *>(smem + (size_t) MK * 16);                 // [4][16][kCoarseR] the waves' picks
     pq64_t *s_bound = s_wsel + kCoarseQ * 16 * kCoarseR;                                  // [4] the largest pick
     int *s_tie = reinterpret_cast<int *>(s_bound + kCoarseQ);                             // [4]
-    float *s_q = reinterpret_cast<float *>(s_tie + kCoarseQ);                             // [4][M * DS] the block's queries
+    int *s_cnt = s_tie + kCoarseQ, *s_over = s_cnt + kCoarseQ;                            // [4] listed keys, [4] list overflow
+    float *s_q = reinterpret_cast<float *>(s_over + kCoarseQ);                            // [4][M * DS] the block's queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q0 = (int64_t) blockIdx.x * kCoarseQ;
     const int nq = (int) (p.B - q0 < kCoarseQ ? p.B - q0 : kCoarseQ);
@@ -400,37 +401,50 @@ __global__ __launch_bounds__(kCoarseThreads) void shard_coarse_quad_kernel(Coars
     pq64_t third[kCoarseQ];
 #pragma unroll
     for (int q = 0; q < kCoarseQ; ++q) third[q] = best[q][kCoarseT - 1];                   // (before the pops below)
-    // ---- level 1: the R smallest keys of this wave's lanes per query (the four queries' DPP ladders in lockstep) ----
-    for (int r = 0; r < R; ++r) {
+    // ---- picks.  (First version: every wave extracted its R smallest keys per query -- R lockstep DPP ladders of ~150 instructions on
+    // sixteen waves, 5.4 of the kernel's 26 us.)  One ladder per wave: the wave's smallest key per query; the R-th smallest of the
+    // sixteen wave minima bounds the R smallest keys of the block from above (the R minima at or below it are R keys already), so
+    // only keys at or below that bound -- a handful -- are listed, and one wave per query orders the list. ----
+    {
         unsigned long long got[kCoarseQ] = {best[0][0], best[1][0], best[2][0], best[3][0]};
         wave_min_u64_x4(got);
-#pragma unroll
-        for (int q = 0; q < kCoarseQ; ++q) {
-            if (best[q][0] == got[q]) {                                                    // (one lane: it hands the key over and moves up its list)
-#pragma unroll
-                for (int k = 0; k + 1 < kCoarseT; ++k) best[q][k] = best[q][k + 1];
-                best[q][kCoarseT - 1] = ~0ull;
-            }
-            if (lane == 0) s_wsel[(q * 16 + wave) * kCoarseR + r] = got[q];
-        }
+        if (lane < kCoarseQ) s_wsel[lane * 16 + wave] = lane == 0 ? got[0] : lane == 1 ? got[1] : lane == 2 ? got[2] : got[3];
+        if (tid < kCoarseQ) s_cnt[tid] = 0;
     }
     __syncthreads();
-    // ---- level 2: wave q merges the sixteen waves' picks of query q (16 R <= 128 keys: two per lane); lane r keeps pick r ----
+    if (wave < kCoarseQ) {
+        pq64_t cand = lane < 16 ? s_wsel[wave * 16 + lane] : ~0ull;
+        pq64_t got = ~0ull;
+        for (int r = 0; r < R; ++r) {
+            got = wave_min_u64(cand);
+            if (cand == got) cand = ~0ull;
+        }
+        if (lane == 0) s_bound[wave] = got;                                               // (~0 with fewer than R live waves: everything is listed)
+    }
+    __syncthreads();
+    pq64_t *s_list = s_wsel + kCoarseQ * 16;                                              // [4][64]
+#pragma unroll
+    for (int q = 0; q < kCoarseQ; ++q) {
+        const pq64_t bound = s_bound[q];
+#pragma unroll
+        for (int k = 0; k < kCoarseT; ++k)
+            if (best[q][k] != ~0ull && best[q][k] <= bound) {
+                const int slot = atomicAdd(&s_cnt[q], 1);
+                if (slot < 64) s_list[q * 64 + slot] = best[q][k];
+            }
+    }
+    __syncthreads();
     if (wave < kCoarseQ) {
         const int q = wave;
-        pq64_t cand[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = lane + 64 * u;
-            cand[u] = i < 16 * R ? s_wsel[(q * 16 + i / R) * kCoarseR + (i % R)] : ~0ull;
-        }
+        const int n = s_cnt[q];
+        pq64_t cand = lane < n ? s_list[q * 64 + lane] : ~0ull;
         pq64_t mysel = ~0ull;
         for (int r = 0; r < R; ++r) {
-            const pq64_t got = wave_min_u64(cand[0] < cand[1] ? cand[0] : cand[1]);
-            if (cand[0] == got) cand[0] = ~0ull;
-            if (cand[1] == got) cand[1] = ~0ull;
+            const pq64_t got = wave_min_u64(cand);
+            if (cand == got) cand = ~0ull;
             if (lane == r) mysel = got;
         }
+        if (lane == 0) s_over[q] = n > 64 ? 1 : 0;                                        // (more keys at the bound than the list holds: the query is replayed)
         const uint32_t myhi = (uint32_t) (mysel >> 32);
         const uint32_t nxhi = (uint32_t) __shfl_down((int) myhi, 1);
         const bool tied = lane + 1 < R && myhi == nxhi;                                    // exactly tied distances among the w + 1 smallest
@@ -445,10 +459,10 @@ __global__ __launch_bounds__(kCoarseThreads) void shard_coarse_quad_kernel(Coars
 #pragma unroll
     for (int q = 0; q < kCoarseQ; ++q) lostm |= (third[q] != ~0ull && third[q] <= s_bound[q]) ? (1 << q) : 0;
     lostm = __syncthreads_or(lostm);
-    if (tid < nq) p.ok[q0 + tid] = (s_tie[tid] == 0 && !((lostm >> tid) & 1)) ? 1 : 0;
+    if (tid < nq) p.ok[q0 + tid] = (s_tie[tid] == 0 && s_over[tid] == 0 && !((lostm >> tid) & 1)) ? 1 : 0;
 }
 
-static size_t shard_coarse_smem(int M, int Ds) { return (size_t) M * 256 * 16 + (size_t) kCoarseQ * 16 * kCoarseR * 8 + kCoarseQ * 8 + kCoarseQ * 4 + (size_t) kCoarseQ * M * Ds * 4 + 64; }
+static size_t shard_coarse_smem(int M, int Ds) { return (size_t) M * 256 * 16 + (size_t) kCoarseQ * 16 * kCoarseR * 8 + kCoarseQ * 8 + 3 * kCoarseQ * 4 + (size_t) kCoarseQ * M * Ds * 4 + 64; }
 
 constexpr int kShardAnyBuf = 8192;       // most keys the selection buffer holds (64 KiB)
 constexpr int kShardGroup = 256;         // visited lists whose descriptors are staged per round
