@@ -358,7 +358,7 @@ def timed_loop(fn, steps, barrier):
     return time.perf_counter() - t0
 
 
-DOMINANT = ("scan", "ivf_fused", "ivf_scan", "ivf_shard")
+DOMINANT = ("scan", "ivf_fused", "ivf_scan", "ivf_shard", "shard_coarse")
 OTHER_KERNELS = ("lut", "quant", "rerank", "kth", "tie", "select", "gather", "ivf_exact", "ivf_coarse", "ivf_plan", "ivf_scan",
                  "ivf_select")
 
@@ -603,15 +603,24 @@ def modulo_lists(n, nlist):
     return off, ids
 
 
-def roofline_ivf_shard(kernel, B, nlist, M, L, avg_s, launches, steps):
-    """Database-sharded inverted index: per query the shard kernel reads the nlist coarse centres (M bytes each) and, of the L
-    candidates of the global walk, the ids (4 B) and codes (M B) of those this rank owns -- SURVEY 8(d)'s IVF form with the rank's
-    share; HBM-form figure (the working set of a batch is L2-resident: what binds the kernel is latency / issue, like ivf_fused)."""
-    alg = B * (nlist * M + L * (M + 4))
-    r = roofline_hbm(kernel, alg, avg_s, launches, steps, None)
-    r["note"] = ("algorithmic bytes = B x (nlist x M centre bytes + L x (M + 4) candidate bytes); one block per query: table staged, "
-                 "coarse scores, the w + 1 nearest lists by DPP minima (exact std::partial_sort replay when their order cannot be proven), the global walk by one lane, then the owned candidates "
-                 "(rows read from the posting-order copy of the codes: one coalesced run per visited list)")
+def roofline_ivf_shard(kernel, B, nlist, M, L, avg_s, launches, steps, traffic=None, coarse_s=0.0):
+    """Database-sharded inverted index.  HBM form, compulsory bytes only (the old form counted every query's pass over the
+    L2-resident centres and the 4-byte ids the posting-order rows made unnecessary): of the L candidates of a query's walk the rows
+    this rank owns (M bytes each, read by exactly one query: they stream from HBM at any shard that outgrows the caches) + the centres
+    once.  `avg_s` = the walk kernel + (round 6) the coarse pre-pass of the same batch.  The centre scores -- B x nlist x M table
+    gathers that never leave the chip -- are in `lds_form`."""
+    alg = B * L * M + nlist * M
+    r = roofline_hbm(kernel, alg, avg_s, launches, steps, traffic)
+    gathers = B * (nlist + L) * M * 4
+    r["lds_form"] = {"table_gather_bytes_per_launch": gathers, "achieved": gathers / avg_s / 1e9 if avg_s > 0 else 0.0,
+                     "peak": 78643.0, "unit": "GB/s", "frac": (gathers / avg_s / 1e9 / 78643.0) if avg_s > 0 else 0.0,
+                     "note": "(nlist + L) x M fp32 table gathers per query against the ds_read_b32 peak (128 B/clk/CU)"}
+    if coarse_s:
+        r["coarse_prepass_ms"] = coarse_s * 1e3
+        r["walk_kernel_ms"] = (avg_s - coarse_s) * 1e3
+    r["note"] = ("algorithmic bytes = B x L x M candidate-row bytes + nlist x M centre bytes; coarse phase of the batch in "
+                 "shard_coarse_quad_kernel (four queries per block, one 16-byte LDS read per centre lookup), then one block per query: "
+                 "table loaded, the walk by one lane, the owned candidates (posting-order rows, next round prefetched)")
     return r
 
 
@@ -757,8 +766,11 @@ def ref_harness_workload(args, torch, dev, arch, barrier, base_codes_src):
     k_ms, k_n = dom[kname]
     avg_s = (k_ms / max(args.steps, 1)) * 1e-3
     w = min(nlist, int(np.round(L * nlist / N)) + 3)
-    roof = roofline_ivf(B, nlist, M, Ks, D // M, w, N // nlist, L, avg_s, k_n, args.steps, None)
-    roof["kernel"] = kname + "_kernel"
+    key = "ref-harness/M=%d/N=%d/B=%d/nlist=%d/L=%d" % (M, N, B, nlist, L)
+    roof = roofline_ivf(B, nlist, M, Ks, D // M, w, N // nlist, L, avg_s, k_n, args.steps,
+                        profile_table("traffic.json").get(key, {}).get("hbm_bytes_per_launch"))
+    # (the engine times its one-launch inverted-index kernels under one name; round 6's conflict-free gather is a kernel of its own)
+    roof["kernel"] = "ivf_rot_kernel" if (kname == "ivf_fused" and eng.get_option("ivf_rot_launches") > 0) else kname + "_kernel"
     roof.update(shares)
     E = np.array([], np.int64)
     ts, one_ids = [], []
@@ -807,8 +819,12 @@ def deep_ivf_on(eng, comm, args, torch, dev, barrier, q, n_shard, n_global, rank
     elapsed, dom, shares = measure(eng, step, steps, 2, barrier, torch.cuda.synchronize, heat=8)
     plain = timed_loop(step, steps, barrier)
     k_ms, k_n = dom["ivf_shard"]
-    avg_s = (k_ms / max(steps, 1)) * 1e-3
-    roof = roofline_ivf_shard("ivf_shard_any_kernel" if (L > 8192 or topk == 1) else "ivf_shard_kernel", B, nlist, M, L, avg_s, k_n, steps)
+    c_ms, c_n = dom["shard_coarse"]
+    avg_s = ((k_ms + c_ms) / max(steps, 1)) * 1e-3
+    kname = "ivf_shard_any_kernel" if (L > 8192 or topk == 1) else "ivf_shard_kernel"
+    key = "deep-ivf/M=%d/N=%d/B=%d/nlist=%d/L=%d" % (M, n_shard, B, nlist, L)
+    roof = roofline_ivf_shard(("shard_coarse_quad_kernel + " if c_n else "") + kname, B, nlist, M, L, avg_s, k_n, steps,
+                              profile_table("traffic.json").get(key, {}).get("hbm_bytes_per_launch"), (c_ms / max(steps, 1)) * 1e-3)
     roof.update(shares)
     obj = {"config": "Deep1B-shaped database-sharded inverted index: D=96 M=16 Ks=256, %d codes per GPU (%d in all), nlist=%d "
                      "(= sqrt(N)), L=%d (= N / nlist), batch=%d, topk=%d" % (n_shard, n_global, nlist, L, B, topk),

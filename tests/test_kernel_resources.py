@@ -67,6 +67,7 @@ def test_every_hot_kernel_is_in_the_library(resources):
     ("ivf_fused_kernel", 4),              # 256 threads, four blocks per CU at M = 32
     ("ivf_shard_kernel", 4),
     ("ivf_quad_kernel", 4),               # 1024 threads = four waves per SIMD: one block per CU
+    ("shard_coarse_quad_kernel", 4),      # likewise (round 6: the coarse pre-pass of the database-sharded inverted index)
     ("fscan_mx_kernel", 4),
     ("fscan_mx_dual_kernel", 4),
     ("rerank_top1_kernel", 8),
@@ -88,7 +89,8 @@ def test_headline_scan_has_no_scratch(resources, name):
     assert int(d["private_segment_fixed_size"]) == 0 and int(d["vgpr_spill_count"]) == 0, d
 
 
-@pytest.mark.parametrize("stem", ["ivf_shard_any_kernel", "ivf_fused_kernel", "ivf_shard_kernel", "rerank_top1_kernel", "lut_build_kernel"])
+@pytest.mark.parametrize("stem", ["ivf_shard_any_kernel", "ivf_fused_kernel", "ivf_shard_kernel", "rerank_top1_kernel", "lut_build_kernel",
+                                  "shard_coarse_quad_kernel"])
 def test_no_scratch_in_the_one_block_per_query_kernels(resources, stem):
     for name, d in _named(resources, stem).items():
         assert int(d["private_segment_fixed_size"]) == 0, "%s uses %s bytes of scratch per lane" % (name, d["private_segment_fixed_size"])
