@@ -2646,20 +2646,24 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int v = keep[r];
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                const int o = __shfl_xor(v, off);
-                v = o < v ? o : v;
-            }
+            // the row's minimum on the DPP path (row_shr 1, 2, 4, 8: lane 15 of the row ends up with all sixteen).  (__shfl_xor: its
+            // ds_bpermute lane addresses are pure functions of the lane id, were shared with the fused tail's shuffles behind the scan
+            // loop and so kept -- spilled -- across it: the 28 bytes per lane of scratch of the <0, true> instantiation.)
+#define RII_ROW_MIN_STEP(CTRL) { const int o = __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, 0xf, 0xf, false); v = o < v ? o : v; }
+            RII_ROW_MIN_STEP(0x111) RII_ROW_MIN_STEP(0x112) RII_ROW_MIN_STEP(0x114) RII_ROW_MIN_STEP(0x118)
+#undef RII_ROW_MIN_STEP
             const int q = qoff + 4 * gq + r, b = qbase + q;
-            if (col == 0 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[q], fs_thr_of((uint32_t) v, s_slk[q]));
+            if (col == 15 && v != 0x7fffffff && b < p.B) atomicMin(&s_thr[q], fs_thr_of((uint32_t) v, s_slk[q]));
         }
     };
     auto adopt = [&](bool first) {
-        const int q = tid & 63;
-        if (MODE == 0 && tid < 64 && q < NQ) {
+        if (MODE == 0 && tid < 64) {
+            // the lane's query, re-derived HERE (round 6): as a loop invariant the two addresses below (8 + 4 bytes per lane) were kept
+            // across the scan loop, which has no register to spare -- 24 bytes per lane of scratch (profiles/r05_deep_kernel_stats.txt)
+            int q;                                          // (the lane id INSIDE the asm: the builtin form is pure, hoisted and spilled again)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(q));
             const int b = qbase + q;
-            if (b < p.B) {
+            if (q < NQ && b < p.B) {
                 const uint32_t g = __hip_atomic_load(&p.gthr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (first) {
                     const uint32_t mine = s_thr[q];
@@ -2669,8 +2673,8 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             }
         }
     };
-    auto slow_group = [&](int64_t gi, bool minima) {
-        const W w = fc[(size_t) gi * 64];
+    auto slow_group = [&](const W *fcp, int64_t gi, bool minima) {
+        const W w = fcp[(size_t) gi * 64];
         v4i_t r[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -2694,15 +2698,15 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
             judge(accB, thrB, (uint32_t) n, 16);
         }
     };
-    auto tail = [&](bool minima) {
-        for (int gi = wave; gi < tail_groups; gi += kFsThreads / 64) slow_group((int64_t) full * 64 + gi, minima);
+    auto tail = [&](const W *fcp, bool minima) {
+        for (int gi = wave; gi < tail_groups; gi += kFsThreads / 64) slow_group(fcp, (int64_t) full * 64 + gi, minima);
     };
     if constexpr (MODE == 0) {
         if (full > 0) {
 #pragma unroll 1
-            for (int j = 0; j < 4; ++j) slow_group(wave * 4 + j, true);
+            for (int j = 0; j < 4; ++j) slow_group(fc, wave * 4 + j, true);
         } else {
-            tail(true);
+            tail(fc, true);
         }
         publish(keepA, 0);
         publish(keepB, 16);
@@ -2770,7 +2774,12 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
         fs_mx_wait<0>(rb);
         fs_mx_vmwait<0>(q[0]); fs_mx_vmwait<0>(q[1]); fs_mx_vmwait<0>(q[2]); fs_mx_vmwait<0>(q[3]);
     }
-    tail(MODE == 1);
+    {
+        // the lane's code pointer re-derived behind the scan loop (round 6): kept live across it, it was spilled (see adopt)
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        tail(reinterpret_cast<const W *>(p.codes) + (size_t) (c_begin / 16) * 64 + ln, MODE == 1);
+    }
 
     if (MODE == 0 && p.lcap > 0) {
         __syncthreads();
@@ -2795,9 +2804,11 @@ __global__ __launch_bounds__(kFsThreads) void fscan_mx_dual_kernel(FsArgs p)
         asm volatile("" : "+s"(pa));
         bool spilled = false;
         for (int q = 0; q < NQ; ++q) spilled |= s_lcnt[q] > (uint32_t) pa->lcap;
-        if (fs_tail_arrive(pa, s_lcnt, tid, spilled)) {        // the last chunk-block of the tile pair re-ranks its 32 queries
-            if (pa->tail.Ds == 4) fs_tail_rerank<float4, 32>(pa, qbase, smem, tid);
-            else fs_tail_rerank<float2, 32>(pa, qbase, smem, tid);
+        int t2 = tid;                                          // (opaque: what the tail derives from the thread index is derived behind the
+        asm volatile("" : "+v"(t2));                           //  scan loop, not kept -- and spilled -- across it)
+        if (fs_tail_arrive(pa, s_lcnt, t2, spilled)) {         // the last chunk-block of the tile pair re-ranks its 32 queries
+            if (pa->tail.Ds == 4) fs_tail_rerank<float4, 32>(pa, qbase, smem, t2);
+            else fs_tail_rerank<float2, 32>(pa, qbase, smem, t2);
         }
     }
     if constexpr (MODE == 1) {

@@ -82,6 +82,10 @@ def test_blocks_per_cu_budget(resources, stem, min_waves):
 @pytest.mark.parametrize("name", [
     "_ZN6riiamd15fscan_mx_kernelILi8ELi0ELi16ELb0ELb0EEEvNS_6FsArgsE",           # the headline scan (M = 32, all codes)
     "_ZN6riiamd15fscan_mx_kernelILi4ELi0ELi16ELb0ELb0EEEvNS_6FsArgsE",           # M = 16
+    "_ZN6riiamd20fscan_mx_dual_kernelILi0ELb0EEEvNS_6FsArgsE",                   # M = 16, two tiles per block (config 5's scan): 24 B/lane until round 6
+    "_ZN6riiamd20fscan_mx_dual_kernelILi0ELb1EEEvNS_6FsArgsE",                   # ... with the fused re-rank tail (28 B/lane until round 6)
+    "_ZN6riiamd20fscan_mx_dual_kernelILi1ELb0EEEvNS_6FsArgsE",
+    "_ZN6riiamd20fscan_mx_dual_kernelILi2ELb0EEEvNS_6FsArgsE",
 ])
 def test_headline_scan_has_no_scratch(resources, name):
     assert name in resources, "instantiation renamed? " + name
