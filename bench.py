@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--deep-shard", type=int, default=64_000_000,
                     help="codes of the `others.deep_shard` measurement (default 64 M codes = 1 GB: four times the 256 MB Infinity Cache, so "
                          "the code stream really comes from HBM; 125000000 = the per-GPU shard of Deep1B over 8 GPUs)")
+    ap.add_argument("--deep-structured", type=int, default=10_000_000,
+                    help="`others.deep_structured`: vectors of the structured Deep1B-shaped set (0 = skip)")
     ap.add_argument("--preheat", type=float, default=0.15,
                     help="seconds of untimed steps before the W warm-up steps (clock ramp; 0 under rocprofv3 counter passes)")
     ap.add_argument("--latency", action="store_true",
@@ -732,6 +734,117 @@ def deep_shard_workload(args, torch, dev, arch, barrier):
                                            cw, codes, arch)
     except Exception as ex:                                      # noqa: BLE001
         obj["ivf_dbsharded"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    del eng
+    return obj
+
+
+def deep_structured_workload(args, torch, dev, arch, barrier):
+    """configs[4] as a SEARCH (the 64 M-code leg is uniform random bytes with a synthetic partition -- bandwidth only): a
+    structured Deep1B-shaped set (--deep-structured vectors, D = 96, unit-norm clustered descriptors), its own PQ codec (M = 16,
+    Ks = 256), a REAL reconfigure(sqrt(N)) on the GPU (timed: row f1 of SURVEY 8 at scale -- PQk-means on the sample + the assignment
+    of every code, src/rii.h:108-156), then linear and inverted-index search (L = N / nlist, examples/benchmark/run_sift1b.py:72-106)
+    with recall@1 against the exact fp32 neighbours, beside the real reference on a few queries (it receives the GPU engine's centres
+    and lists through its own pickle state, src/main.cpp:39-52)."""
+    from rii_amd import RiiGpu
+    from rii_amd import bench_data as bd
+    B, M, Ks, D = args.batch, 16, 256, 96
+    n = args.deep_structured
+    t_all = time.perf_counter()
+    base = bd.deep_like_torch(n, D, seed=77, device=dev)
+    train = bd.deep_like_torch(100_000, D, seed=77, device=dev, stream=1)
+    query = bd.deep_like_torch(B, D, seed=77, device=dev, stream=2)
+    cw = bd.train_pq(train.cpu().numpy(), M, Ks, iters=8, seed=123, device=dev)
+    codes_dev = bd.encode_pq_torch(base, cw)
+    gt = bd.exact_nn_torch(base, query)
+    del base, train
+    codes = codes_dev.cpu().numpy()
+    del codes_dev
+    eng = RiiGpu(cw, False, simd_arch=arch, device=dev.index)
+    eng.add_codes(codes, False)
+    if getattr(args, "table_levels", 0):
+        eng.set_option("generic_table_levels", args.table_levels)
+    if getattr(args, "cand_cap", 0):
+        eng.set_option("cand_cap", args.cand_cap)
+    nlist = int(np.round(np.sqrt(n)))
+    L = int(np.round(n / nlist))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.reconfigure(nlist, 5)
+    eng.synchronize()
+    t_reconf = time.perf_counter() - t0
+    setup_s = time.perf_counter() - t_all
+    q = query.contiguous()
+    oi = torch.empty((B, 1), dtype=torch.int64, device=dev)
+    od = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    oc = torch.empty((B,), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    steps = max(3, min(args.steps, 10))
+    obj = {"config": "structured Deep1B-shaped set: D=96 M=16 Ks=256, N=%d unit-norm clustered vectors, own PQ codec, nlist=%d "
+                     "(reconfigure on the GPU), L=%d, batch=%d, topk=1" % (n, nlist, L, B),
+           "reconfigure_s": t_reconf, "reconfigure": "rii_reconfigure(nlist=%d, iter=5): PQk-means on min(N, 100 nlist) sampled codes + "
+                                                     "assignment of all %d codes (N x nlist x M = %.1e table gathers)" % (nlist, n, float(n) * nlist * M),
+           "setup_s": setup_s}
+    res = {}
+    for name in ("ivf", "linear"):
+        def step(name=name):
+            if name == "ivf":
+                eng.query_ivf_dev(q.data_ptr(), B, 1, 0, 0, L, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), stream)
+            else:
+                eng.query_linear_dev(q.data_ptr(), B, 1, 0, 0, oi.data_ptr(), od.data_ptr(), stream)
+        elapsed, dom, shares = measure(eng, step, steps, 2, barrier, torch.cuda.synchronize)
+        kn = ("ivf_fused" if dom["ivf_fused"][1] else "ivf_scan") if name == "ivf" else "scan"
+        k_ms, k_n = dom[kn]
+        ids = oi.cpu().numpy().copy()
+        res[name] = ids
+        row = {"value": B * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "kernel_ms": k_ms / steps,
+               "recall_at_1": float(bd.recall_at_r(ids, gt[:B], 1))}
+        if name == "linear":
+            row["filter_candidates_per_query"] = eng.get_option("cand_total") / float(B)
+            row["table_levels"] = eng.get_option("generic_table_levels") or 255
+        if name == "ivf":
+            obj.update(row)
+            obj["kernel"] = "ivf_fused_kernel"
+            obj["counts_all_one"] = bool((oc.cpu().numpy() == 1).all())
+        else:
+            row["kernel"] = filter_kernel_name(args.scan_mx, M)
+            obj["linear"] = row
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        ref, _arch, flav = O.load_reference()
+        t0 = time.perf_counter()
+        if ref is not None:
+            ce = ref.RiiCpp.__new__(ref.RiiCpp)
+            ce.__setstate__(eng.__getstate__())
+            kind = "reference"
+        else:
+            ce = O.OracleRii(cw, False, simd_arch=arch)
+            ce.add_codes(codes, False)
+            ce.centers = np.array(eng.coarse_centers, np.uint8)
+            ce._lists = eng.posting_lists
+            kind = "port"
+        t_state = time.perf_counter() - t0
+        E = np.array([], np.int64)
+        qh = query.cpu().numpy()
+        nq = min(16, B)
+        ce.query_ivf(qh[0], 1, E, L)
+        t0 = time.perf_counter()
+        cpu_ivf = [ce.query_ivf(qh[b], 1, E, L)[0] for b in range(nq)]
+        dt = time.perf_counter() - t0
+        cb = {"value": nq / dt, "unit": "queries/s", "cores": 1, "kind": kind,
+              "sample": "inverted index nlist=%d L=%d over %d codes, %d queries, one per call; state handed over through the reference's "
+                        "pickle hook in %.1f s%s" % (nlist, L, n, nq, t_state, (", build flavour " + flav) if flav else "")}
+        cb["ids_match_gpu"] = bool(all(list(res["ivf"][b]) == list(cpu_ivf[b]) for b in range(nq)))
+        cb["queries_compared"] = nq
+        obj["cpu_baseline"] = cb
+        nl = min(8, B)
+        ce.query_linear(qh[0], 1, E)
+        t0 = time.perf_counter()
+        cpu_lin = [ce.query_linear(qh[b], 1, E)[0] for b in range(nl)]
+        dt = time.perf_counter() - t0
+        obj["linear"]["cpu_baseline"] = {"value": nl / dt, "unit": "queries/s", "cores": os.cpu_count() or 1, "kind": kind,
+                                         "ids_match_gpu": bool(all(list(res["linear"][b]) == list(cpu_lin[b]) for b in range(nl))),
+                                         "queries_compared": nl}
+        del ce
     del eng
     return obj
 
@@ -1462,6 +1575,8 @@ def main():
             others["ref_harness"] = guarded(ref_harness_workload, args, torch, dev, arch, barrier, harness_data)
             if args.deep_shard > 0:
                 others["deep_shard"] = guarded(deep_shard_workload, args, torch, dev, arch, barrier)
+            if args.deep_structured > 0:
+                others["deep_structured"] = guarded(deep_structured_workload, args, torch, dev, arch, barrier)
             others["seconds_spent"] = time.perf_counter() - t_oth
             line["others"] = others
             wall["others_s"] = others["seconds_spent"]

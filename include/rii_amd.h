@@ -322,6 +322,9 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *   "fused_tables"     1 = byte tables of M = 16 / 32, Ks = 256, Ds = 4 / 2 from ONE launch (qlut_fused_kernel), top-1 re-ranked from the
  *                      codebook [default]; 0 = the two-launch tile path
  *   "table_levels"     quantisation levels of those tables: 63, 127 [default] or 255
+ *   "generic_table_levels" quantisation levels of the byte tables of every OTHER shape (any Ds: the Deep1B shape D = 96, M = 16 among
+ *                      them) when the matrix-core scan of M = 16 / 32 reads them: 0 = automatic: 255 [default], or 63 / 127 / 255.  (Round 6: 63 levels sent
+ *                      8 % of a structured 10 M-vector set through the candidate path -- 157 ms per 1024 queries against 7 with 255.)
  *   "fused_rerank"     1 = the top-1 re-rank runs as the tail of the scan launch (one launch per batch, one host flag per tile for
  *                      rii_query_linear_dev_to_host); 0 = rerank_top1_direct_kernel [default: measured equal or faster]
  *   "small_topk"       1 = a small batch over a small index (<= ~13 800 codes at M = 32) in ONE launch (small_topk_kernel) [default]

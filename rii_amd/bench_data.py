@@ -112,3 +112,53 @@ def recall_at_r(I, gt, r=1):
     I = np.asarray(I)
     gt = np.asarray(gt).reshape(-1, 1)
     return float((I[:, :r] == gt[:, :1]).any(axis=1).mean())
+
+
+# ---- Deep1B-shaped structured data, generated and kept ON the device (round 6: bench.py's `deep_structured` leg) ----
+def deep_like_torch(n, D=96, seed=77, n_clusters=16384, sigma=0.8, decay=0.7, device=None, stream=0, chunk=1 << 20):
+    """Unit-norm clustered vectors shaped like Deep1B's (PCA-compressed, L2-normalised CNN descriptors, D = 96): coordinate k carries
+    the weight (1 + k)^-decay of a PCA spectrum, cluster means and N(0, sigma^2) within-cluster noise are drawn in the unweighted
+    space, the weighted sum is re-normalised.  Seeded; generated chunk by chunk on `device`; -> device tensor [n, D].
+    `stream` != 0 draws fresh vectors around the SAME means (queries / training sets)."""
+    import torch
+    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    gm = torch.Generator(device="cpu").manual_seed(seed)
+    means = torch.randn((n_clusters, D), generator=gm).to(dev)
+    wgt = (1.0 + torch.arange(D, dtype=torch.float32, device=dev)) ** (-decay)
+    g = torch.Generator(device="cpu").manual_seed(seed * 1000003 + stream)
+    out = torch.empty((n, D), dtype=torch.float32, device=dev)
+    for s0 in range(0, n, chunk):
+        m = min(chunk, n - s0)
+        c = torch.randint(0, n_clusters, (m,), generator=g).to(dev)
+        x = (means[c] + torch.randn((m, D), generator=g).to(dev) * sigma) * wgt
+        out[s0:s0 + m] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+def encode_pq_torch(x, codewords, chunk=1 << 20):
+    """encode_pq for a device tensor: -> uint8 device tensor [n, M]."""
+    import torch
+    M, Ks, Ds = codewords.shape
+    cw = torch.from_numpy(codewords).to(x.device)
+    out = torch.empty((x.shape[0], M), dtype=torch.uint8, device=x.device)
+    for s0 in range(0, x.shape[0], chunk):
+        xs = x[s0:s0 + chunk]
+        for m in range(M):
+            out[s0:s0 + chunk, m] = torch.cdist(xs[:, m * Ds:(m + 1) * Ds].contiguous(), cw[m]).argmin(1).to(torch.uint8)
+    return out
+
+
+def exact_nn_torch(base, query, chunk=1 << 18):
+    """exact_nn for device tensors (squared distances through one matrix product per chunk)."""
+    import torch
+    qn = (query * query).sum(1, keepdim=True)
+    best_d = torch.full((query.shape[0],), float("inf"), device=query.device)
+    best_i = torch.zeros((query.shape[0],), dtype=torch.int64, device=query.device)
+    for s0 in range(0, base.shape[0], chunk):
+        b = base[s0:s0 + chunk]
+        d = qn + (b * b).sum(1)[None, :] - 2.0 * (query @ b.T)
+        dm, im = d.min(1)
+        upd = dm < best_d
+        best_d = torch.where(upd, dm, best_d)
+        best_i = torch.where(upd, im + s0, best_i)
+    return best_i.cpu().numpy()

@@ -23,7 +23,8 @@ DROP_IN_OTHERS = frozenset((
     "config", "hbm", "counters_live", "launches", "avg_launch_ms", "p99_ms", "lut_ms_per_step", "rerank_ms_per_step",
     "gather_ms_per_step", "quant_ms_per_step", "kth_ms_per_step", "tie_ms_per_step", "select_ms_per_step", "sample",
     "ivf_exact_ms_per_step", "ivf_coarse_ms_per_step", "ivf_plan_ms_per_step", "ivf_scan_ms_per_step", "ivf_select_ms_per_step",
-    "unit", "peak", "achieved", "algorithmic_bytes_per_launch", "steps", "uninstrumented_ms_per_step",
+    "unit", "peak", "achieved", "algorithmic_bytes_per_launch", "steps", "uninstrumented_ms_per_step", "lds_form", "reconfigure",
+    "setup_s",
 ))
 # second pass, only if the line is still above the limit
 DROP_IF_TIGHT = ("preheat", "results", "pipelined", "fresh_queries", "host_call", "uninstrumented", "wall_clock")

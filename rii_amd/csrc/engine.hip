@@ -150,12 +150,15 @@ struct rii_engine : ScratchSet {
     int scan_mode = 1;          // 1 = 8-bit filter + exact re-rank for top-1 (fastscan.hip), 0 = exact scan only
     int fast_min_batch = 33;    // top-1 batches below this take the exact scan (option "fast_min_batch"; tools/sweep_fast_min.py)
     int cand_cap = 4096;        // candidate slots per query for the re-rank stage (lower bound; grows for small batches)
+    DevBuf d_cand_peak;         // longest candidate list the top-1 re-rank has seen (device word) ...
+    unsigned int *h_cand_peak = nullptr;   // ... and its pinned host copy, refreshed behind every batch
     bool cand_cap_forced = false;   // set by option "cand_cap" (tests force tiny buffers to reach the overflow path)
     int ivf_fused = 1;          // 1 = one fused launch for the common IVF case (exact fallback per query), 0 = off
     // option "table_levels": quantisation levels of the fused tables (qlut_fused_kernel).  Measured at the bench shape (tools/levels_ab.py,
     // profiles/r03_levels_ab.json): 63 -> 124 candidates per query, 127 -> 40, 255 -> 20; the scan itself is 3 % SLOWER with 255 (signed
     // bytes: more switching in the matrix core under a power-limited clock), so 127 -- non-negative bytes, no bias -- is the default.
     int table_levels = 127;
+    int generic_levels = 0;     // option "generic_table_levels": 0 = automatic (255 on the matrix-core scans), else 63 / 127 / 255
     int shard_dbg_stop = 0;     // measurement only: ivf_shard_any_kernel returns after phase 1 .. 5 (wrong rows; tools/r5_shard_phases*.sh)
     int shard_pre = 1;          // option "shard_pre": the database-sharded inverted index runs its coarse phase as a pre-pass (shard_coarse_quad_kernel)
     int64_t shard_pre_launches = 0;
@@ -453,6 +456,16 @@ int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
     return RII_OK;
 }
 
+// quantisation levels of the byte tables the generic (any Ds) quantisers produce: the matrix-core scans understand 127 / 255
+// (255 whatever "table_levels" says for the fused tables: this path serves the shapes the fused kernel does not -- Ds other than 2 / 4,
+// the Deep1B shape among them -- and there the step decides between a handful and thousands of candidates per query; 63 where only the
+// byte-packed vector scan applies)
+// (M = 16 / 32: the shapes whose scans the fused tables already drive with 127 / 255 levels; M = 64 keeps 63)
+int generic_table_levels(const rii_engine *e)
+{
+    return (e->scan_mx && (e->M == 16 || e->M == 32) && fs_rot_supported(e->M, e->Ks, 1)) ? (e->generic_levels ? e->generic_levels : 255) : 63;
+}
+
 // need_fp32 = false: the caller only needs the byte tables of the filter (top-1 over a shape whose re-rank works from the codebook)
 int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, bool want_quant = false, int qt = 0,
               bool alloc_only = false, bool need_fp32 = true)
@@ -500,11 +513,14 @@ int build_lut(rii_engine *e, const float *d_queries, int64_t B, hipStream_t st, 
         }
         RII_TRY(e->s_qc.ensure((size_t) B * e->M * e->Ks));
         ScopedTimer t(e, "lut", st);
+        // round 6: the matrix-core scans take the finer tables here too (option table_levels; the Deep1B shape, Ds = 6, comes this way)
+        const int lv = generic_table_levels(e);
         HIP_TRY(launch_lut_build_quant(d_queries, B, e->d_codewords.as<float>(), e->M, e->Ks, e->Ds, e->arch,
                                        e->s_lut.as<float>(), e->s_qc.as<uint8_t>(), e->s_qlut.as<uint8_t>(),
                                        e->s_slack.as<int32_t>(),
-                                       e->s_cand_cnt.as<unsigned int>(), e->s_gthr.as<uint32_t>(), e->scan_mx, st));
+                                       e->s_cand_cnt.as<unsigned int>(), e->s_gthr.as<uint32_t>(), e->scan_mx, st, lv));
         e->qlut_ready = true;            // ... and the candidate counters / shared thresholds are already reset
+        e->qlut_levels = lv;
         return RII_OK;
     }
     ScopedTimer t(e, "lut", st);
@@ -712,6 +728,31 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
             // candidate slots per query: small batches are cut into many chunks (each with its own running minimum,
             // hence more candidates per query), and can afford far more slots: ~128 MiB of slots in total
             int cap = (int) std::min<int64_t>(262144, std::max<int64_t>(e->cand_cap, ((int64_t) 1 << 24) / std::max<int64_t>(B, 1)));
+            // round 6: the longest candidate list of the batches before (a word the re-rank keeps, copied to pinned memory behind every
+            // batch -- read here without a synchronisation, so possibly one batch old).  A list that outgrows its slots sends its query
+            // through an exhaustive pass by ONE block (36 ms over 10 M codes); on a structured Deep-shaped set the lists of a 16-byte
+            // code average 13 k entries with a long tail (profiles/r06_deep_structured_levels.json), so the slots follow what the data
+            // needs: up to 4 GiB of them
+            if (!e->h_cand_peak && topk == 1 && !e->cand_cap_forced) {       // (first filter pass of the engine)
+                void *hp = nullptr;
+                if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess && e->d_cand_peak.ensure(64) == RII_OK &&
+                    hipMemsetAsync(e->d_cand_peak.p, 0, 64, st) == hipSuccess) {
+                    e->h_cand_peak = static_cast<unsigned int *>(hp);
+                    *e->h_cand_peak = 0u;
+                } else {
+                    if (hp) (void) hipHostFree(hp);
+                    (void) hipGetLastError();
+                }
+            }
+            if (e->h_cand_peak && topk == 1) {
+                const int64_t peak = (int64_t) *reinterpret_cast<volatile unsigned int *>(e->h_cand_peak);
+                const int64_t lim = std::min<int64_t>((int64_t) 1 << 20, ((int64_t) 1 << 29) / std::max<int64_t>(B, 1));
+                if (peak > cap / 2) {
+                    int64_t want = 1;
+                    while (want < peak * 2) want <<= 1;
+                    cap = (int) std::max<int64_t>(cap, std::min<int64_t>(lim, want));
+                }
+            }
             if (e->cand_cap_forced) cap = e->cand_cap;
             if (topk > 1) cap = std::max(cap, 16 * topk * stride);
             const int32_t *d_perm = nullptr;
@@ -749,8 +790,10 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
             if (!e->qlut_ready) {
                 ScopedTimer t(e, "quant", st);
                 RII_TRY(e->s_qc.ensure((size_t) B * e->M * e->Ks));
+                const int lv = generic_table_levels(e);
                 HIP_TRY(launch_lut_quantize(e->s_lut.as<float>(), B, e->M, e->Ks, e->lut_qt, e->s_qc.as<uint8_t>(),
-                                            e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), e->scan_mx, st));
+                                            e->s_qlut.as<uint8_t>(), e->s_slack.as<int32_t>(), e->scan_mx, st, lv));
+                e->qlut_levels = lv;
             }
             if (!e->qlut_ready) HIP_TRY(hipMemsetAsync(e->s_cand_cnt.p, 0, (size_t) B * sizeof(unsigned int), st));
             e->last_fs_B = B;
@@ -793,7 +836,9 @@ int scan_topk(rii_engine *e, const float *d_queries, int64_t B, int topk, const 
                 HIP_TRY(launch_rerank_top1(d_rr, n_codes, e->M, e->Ks, e->s_lut.as<float>(), e->lut_qt,
                                            e->s_slack.as<int32_t>(), e->s_cand.as<unsigned long long>(),
                                            e->s_cand_cnt.as<unsigned int>(), cap, d_remap, d_perm, B, d_out_ids, d_out_dists, topk,
-                                           indirect, st));
+                                           indirect, st, e->d_cand_peak.as<unsigned int>()));
+                if (e->h_cand_peak && e->d_cand_peak.p)
+                    HIP_TRY(hipMemcpyAsync(e->h_cand_peak, e->d_cand_peak.p, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
                 return RII_OK;
             }
             // top-k: pass 1 = per-lane-segment minima of the quantised sums, k-th smallest of them bounds the k-th
@@ -1344,8 +1389,10 @@ void free_all(rii_engine *e)
 {
     DevBuf *bufs[] = {&e->d_codewords, &e->d_cnorm, &e->d_codes, &e->d_centers, &e->d_symtab, &e->d_pl_off,
                       &e->d_pl_ids, &e->d_list_len, &e->d_scan_codes, &e->d_scan_perm, &e->d_fcodes, &e->d_lcodes, &e->d_rcent, &e->d_rlcodes,
-                      &e->d_rl_toff};
+                      &e->d_rl_toff, &e->d_cand_peak};
     for (DevBuf *b : bufs) b->release();
+    if (e->h_cand_peak) (void) hipHostFree(e->h_cand_peak);
+    e->h_cand_peak = nullptr;
     e->release_all();
     e->parked.release_all();
     for (auto &kv : e->timers)
@@ -2962,6 +3009,9 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->ivf_force_exact = value ? 1 : 0;
     } else if (k == "fused_tables") {
         e->fused_tables = value ? 1 : 0;
+    } else if (k == "generic_table_levels") {
+        if (value != 0 && value != 63 && value != 127 && value != 255) return set_err(RII_ERR_INVALID, "generic_table_levels must be 0, 63, 127 or 255");
+        e->generic_levels = (int) value;
     } else if (k == "table_levels") {
         if (value != 63 && value != 127 && value != 255) return set_err(RII_ERR_INVALID, "table_levels must be 63, 127 or 255");
         e->table_levels = (int) value;
@@ -3025,6 +3075,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_list_codes") return e->ivf_list_codes;
     if (k == "fused_tables") return e->fused_tables;
     if (k == "table_levels") return e->table_levels;
+    if (k == "generic_table_levels") return e->generic_levels;
     if (k == "scan_order") return e->scan_order;
     if (k == "lanes") return e->lanes;
     if (k == "scan_mx") return e->scan_mx;

@@ -38,8 +38,13 @@ static_assert(kFsFlush * kFsLevels <= 255 && (kFsFlush == 4 || kFsFlush == 8), "
 // shared body: T(i) returns the exact fp32 entry i = m*Ks + ks of query b's table
 template <typename Getter>
 __device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M, int Ks,
-                                               uint8_t *__restrict__ qc, int32_t *__restrict__ slack)
+                                               uint8_t *__restrict__ qc, int32_t *__restrict__ slack, int levels = kFsLevels)
 {
+    // levels (round 6): 63 = the byte tables every filter kernel understands; 127 / 255 for the matrix-core scans (fscan_mx_*), 255 stored
+    // as level - 128 (signed bytes, the scan's accumulators start at 128 M: qlut_fused_kernel).  The slack below comes from the MEASURED
+    // residuals of the levels actually stored, so it is proven for any step.  (Deep1B shape, Ds = 6: this generic path served it with
+    // 63 levels -- a filter 4x coarser than the fused tables' -- and a structured 10 M-vector set sent thousands of codes per query
+    // through the candidate path: 157 ms per 1024 queries, profiles/r06_deep_structured*.json.)
     __shared__ float s_lo[256], s_hi[256];          // per-m extrema (M <= 256)
     __shared__ double s_rlo[256], s_rhi[256];
     __shared__ float s_delta;
@@ -65,13 +70,14 @@ __device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M
     if (tid == 0) {
         float range = 0.f;
         for (int m = 0; m < M; ++m) range = fmaxf(range, s_hi[m] - s_lo[m]);
-        float d = range / (float) kFsLevels;
+        float d = range / (float) levels;
         if (!(d > 0.f) || !isfinite(d)) d = 1.0f;
         s_delta = d * 1.000001f;
     }
     __syncthreads();
     const float delta = s_delta;
     const double ddelta = (double) delta;
+    const int sub = levels > 127 ? 128 : 0;
     // 2. codes + residual extrema per m
     uint8_t *dst = qc + (size_t) b * MK;          // compact [b][M*Ks]: coalesced byte stores; qlut_interleave_kernel
                                                   // then builds the [tile][M*Ks][QR] rows the scan reads
@@ -81,8 +87,8 @@ __device__ __forceinline__ void quantize_table(const Getter &T, int64_t b, int M
         for (int ks = lane; ks < Ks; ks += 64) {
             const float t = T(m * Ks + ks);
             const float x = floorf((t - lo) / delta + 0.5f);
-            const int c = (x >= (float) kFsLevels) ? kFsLevels : (x > 0.f ? (int) x : 0);
-            dst[m * Ks + ks] = (uint8_t) c;
+            const int c = (x >= (float) levels) ? levels : (x > 0.f ? (int) x : 0);
+            dst[m * Ks + ks] = (uint8_t) (c - sub);
             const double r = (double) t - ((double) lo + (double) c * ddelta);
             rlo = fmin(rlo, r);
             rhi = fmax(rhi, r);
@@ -118,11 +124,11 @@ struct LdsLutGetter {
 
 __global__ __launch_bounds__(256) void lut_quantize_kernel(const float *__restrict__ lut, int64_t B, int M, int Ks,
                                                            int QT, uint8_t *__restrict__ qc,
-                                                           int32_t *__restrict__ slack)
+                                                           int32_t *__restrict__ slack, int levels)
 {
     const int64_t b = blockIdx.x;
     GlobalLutGetter g{lut + (size_t) (b / QT) * M * Ks * QT + (b % QT), QT};
-    quantize_table(g, b, M, Ks, qc, slack);
+    quantize_table(g, b, M, Ks, qc, slack, levels);
 }
 
 // The common shapes (Ds == 4, M <= 32, Ks <= 256) keep the whole table of a query in registers: wave w owns the subspaces
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
                                                               int arch, float *__restrict__ lut,
                                                               uint8_t *__restrict__ qc, int32_t *__restrict__ slack,
                                                               unsigned int *__restrict__ cand_cnt,
-                                                              uint32_t *__restrict__ gthr)
+                                                              uint32_t *__restrict__ gthr, int levels)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_t = reinterpret_cast<float *>(smem);
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void lut_build_quant_kernel(const float *__res
     }
     __syncthreads();
     LdsLutGetter g{s_t};
-    quantize_table(g, b, M, Ks, qc, slack);
+    quantize_table(g, b, M, Ks, qc, slack, levels);
 }
 
 // the register-resident variant as its own kernel (its register budget must not be set by the generic paths above)
@@ -464,10 +470,11 @@ hipError_t launch_fcodes_format(const uint8_t *d_codes, const int64_t *d_ids, in
 }
 
 hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qc, uint8_t *d_qlut,
-                               int32_t *d_slack, int mx, hipStream_t st)
+                               int32_t *d_slack, int mx, hipStream_t st, int levels)
 {
     if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned) B), dim3(256), 0, st, d_lut, B, M, Ks, QT, d_qc, d_slack);
+    if (levels != 63 && levels != 127 && levels != 255) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned) B), dim3(256), 0, st, d_lut, B, M, Ks, QT, d_qc, d_slack, levels);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, mx, st);
@@ -890,10 +897,11 @@ hipError_t launch_lut_tile_build_quant(const float *d_queries, int64_t B, const 
 // fused: exact table in the plain [b][M*Ks] layout + quantisation
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
                                   int arch, float *d_lut, uint8_t *d_qc, uint8_t *d_qlut, int32_t *d_slack,
-                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, int mx, hipStream_t st)
+                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, int mx, hipStream_t st, int levels)
 {
     if (B == 0) return hipSuccess;
-    if (Ds == 4 && M <= 32 && Ks <= 256) {          // Ds == 4: all three fvec_L2sqr variants coincide (rii_device.h)
+    if (levels != 63 && levels != 127 && levels != 255) return hipErrorInvalidValue;
+    if (levels == 63 && Ds == 4 && M <= 32 && Ks <= 256) {   // Ds == 4: all three fvec_L2sqr variants coincide (rii_device.h)
         hipLaunchKernelGGL(lut_build_quant_regs_kernel, dim3((unsigned) B), dim3(256), 0, st, d_queries, B, d_codewords, M, Ks,
                            d_lut, d_qc, d_slack, d_cand_cnt, d_gthr);
         hipError_t e0 = hipGetLastError();
@@ -905,7 +913,7 @@ hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lut_build_quant_kernel, dim3((unsigned) B), dim3(256), smem, st, d_queries, B, d_codewords, M, Ks,
-                       Ds, arch, d_lut, d_qc, d_slack, d_cand_cnt, d_gthr);
+                       Ds, arch, d_lut, d_qc, d_slack, d_cand_cnt, d_gthr, levels);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_qlut_interleave(d_qc, B, M, Ks, d_qlut, mx, st);
@@ -3035,6 +3043,7 @@ struct RrArgs {
     int indirect = 0;                // 1: `codes` is the whole database and position n stands for the code remap[n] (subset search)
     int32_t *flag_list = nullptr;    // top-k: queries whose k+1 smallest distances hold an exact tie (redone by tieorder.hip)
     int *nflag = nullptr;
+    unsigned int *peak = nullptr;    // top-1 (round 6): running maximum of the candidate counts -- the engine sizes the next batch's buffers by it
 };
 
 __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
@@ -3059,6 +3068,7 @@ __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
     }
     __syncthreads();
     const unsigned int cnt = p.cand_count[b];
+    if (tid == 0 && p.peak && cnt > (unsigned int) p.cap / 2) atomicMax(p.peak, cnt);     // (rare: only lists that come near the buffer's end)
     unsigned long long best = ~0ull;
     if (cnt <= (unsigned int) p.cap) {
         const unsigned long long *cand = p.cand + (size_t) b * p.cap;
@@ -3231,12 +3241,13 @@ hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, in
                               const int32_t *d_slack, const unsigned long long *d_cand,
                               const unsigned int *d_cand_count, int cap, const int64_t *d_remap,
                               const int32_t *d_perm, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
-                              int indirect, hipStream_t st)
+                              int indirect, hipStream_t st, unsigned int *d_peak)
 {
     if (B == 0) return hipSuccess;
     RrArgs a;
     a.indirect = indirect;
     a.perm = d_perm;
+    a.peak = d_peak;
     a.codes = d_codes; a.n_codes = n_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.QT = QT; a.slack = d_slack;
     a.cand = d_cand; a.cand_count = d_cand_count; a.cap = cap; a.remap = d_remap; a.out_ids = d_out_ids;
     a.out_dists = d_out_dists; a.topk = topk;

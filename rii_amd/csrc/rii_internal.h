@@ -177,10 +177,11 @@ int lut_tile_for(int M, int Ks);
 bool fastscan_supported(int M, int Ks);
 int fastscan_rows(int M, int Ks);
 hipError_t launch_lut_quantize(const float *d_lut, int64_t B, int M, int Ks, int QT, uint8_t *d_qc, uint8_t *d_qlut,
-                               int32_t *d_slack, int mx, hipStream_t st);
+                               int32_t *d_slack, int mx, hipStream_t st, int levels = 63);     // levels: 63, or 127 / 255 for fscan_mx_*
 hipError_t launch_lut_build_quant(const float *d_queries, int64_t B, const float *d_codewords, int M, int Ks, int Ds,
                                   int arch, float *d_lut, uint8_t *d_qc, uint8_t *d_qlut, int32_t *d_slack,
-                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, int mx, hipStream_t st);
+                                  unsigned int *d_cand_cnt, uint32_t *d_gthr, int mx, hipStream_t st, int levels = 63);
+bool fs_rot_supported(int M, int Ks, int mx);
 // round 4: the top-1 re-rank folded into the filter scan's tail (fscan_mx_kernel / fscan_mx_dual_kernel, M = 16 / 32, Ks = 256,
 // Ds = 4 / 2: the shapes of rerank_top1_direct_kernel).  The chunk-blocks of a tile publish their candidates write-through and
 // count themselves on tile_done[blockIdx.y]; the LAST one re-ranks the tile's queries from the codebook and writes the rows --
@@ -242,7 +243,7 @@ hipError_t launch_rerank_top1(const uint8_t *d_codes, int64_t n_codes, int M, in
                               const int32_t *d_slack, const unsigned long long *d_cand,
                               const unsigned int *d_cand_count, int cap, const int64_t *d_remap,
                               const int32_t *d_perm, int64_t B, int64_t *d_out_ids, float *d_out_dists, int topk,
-                              int indirect, hipStream_t st);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
+                              int indirect, hipStream_t st, unsigned int *d_peak = nullptr);   // QT in {4,2,1,0}; 0 = table does not fit LDS (unsupported shape)
 
 // tieorder.hip: the reference's std::partial_sort order for the queries whose k+1 smallest distances tie exactly
 bool linear_tie_supported(int M, int Ks);

@@ -178,3 +178,45 @@ def test_shard_coarse_prepass_stale_lists_and_the_tail_walk():
                 _sharded_check(idx, o, qs, topk, L, "stale pre=%d" % pre)
     finally:
         g.set_option("shard_pre", 1)
+
+
+@pytest.mark.parametrize("M,Ds", [(16, 6), (32, 6), (16, 10), (32, 2)])
+def test_generic_quantiser_levels_and_growing_candidate_buffers(M, Ds):
+    """Round 6: the byte tables of the shapes the fused table kernel does not serve (any Ds: the Deep1B shape M = 16, Ds = 6) come from
+    the generic quantiser, now at 63 / 127 / 255 levels for the matrix-core scans (option generic_table_levels; 255 = signed bytes, the
+    scan's accumulators biased by 128 M).  The slack is proven from the residuals of the levels actually stored, so every setting
+    must give the reference's rows -- on tight clusters (thousands of codes within the slack of the minimum: long candidate lists),
+    with buffers that overflow (cand_cap forced small: the exhaustive fallback) and with the buffers the engine grows by itself
+    from the longest list it has seen.  Linear top-1 and top-k against the oracle, ids and distance bits."""
+    from rii_amd import RiiGpu
+    N = 40000
+    rng = np.random.default_rng(900 + M + Ds)
+    cw = rng.random((M, 256, Ds)).astype(np.float32)
+    # tight clusters: 40 distinct codes, the rest differ from one of them in one or two subspaces
+    base = rng.integers(0, 256, size=(40, M), dtype=np.uint8)
+    codes = base[rng.integers(0, 40, N)].copy()
+    for _ in range(2):
+        rows = rng.integers(0, N, N // 2)
+        codes[rows, rng.integers(0, M, N // 2)] = rng.integers(0, 256, N // 2, dtype=np.uint8)
+    qs = rng.random((40, M * Ds)).astype(np.float32)
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    want1 = [o.query_linear(qs[b], 1, E) for b in range(len(qs))]
+    want5 = [o.query_linear(qs[b], 5, E) for b in range(8)]
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.set_option("fast_min_batch", 0)
+    for levels in (0, 63, 127, 255):
+        g.set_option("generic_table_levels", levels)
+        for rep in range(3):                                  # (the second and third call run with the buffers the first one asked for)
+            ids, d = g.query_linear_batch(qs, 1, E)
+            for b in range(len(qs)):
+                assert_same_result((ids[b], d[b]), want1[b], "generic levels=%d rep=%d M=%d Ds=%d b=%d" % (levels, rep, M, Ds, b))
+        ids, d = g.query_linear_batch(qs[:8], 5, E)
+        for b in range(8):
+            assert_same_result((ids[b], d[b]), want5[b], "generic levels=%d top-5 M=%d Ds=%d b=%d" % (levels, M, Ds, b))
+    cand = g.get_option("cand_max")
+    g.set_option("cand_cap", 64)                              # every list overflows: the exhaustive fallback
+    ids, d = g.query_linear_batch(qs, 1, E)
+    for b in range(len(qs)):
+        assert_same_result((ids[b], d[b]), want1[b], "generic overflow M=%d Ds=%d b=%d (longest list %d)" % (M, Ds, b, cand))
