@@ -15,9 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     src, ksub, key, label = sys.argv[1:5]
     tab = json.load(open(src))
-    names = [k for k in tab if ksub in k]
-    assert len(names) == 1, names
-    c = tab[names[0]]
+    # "a+b": the step is two kernels (round 6: the sharded inverted index = coarse pre-pass + walk) -- their counters are added
+    names = []
+    for sub in ksub.split("+"):
+        hit = [k for k in tab if sub in k]
+        assert len(hit) == 1, (sub, hit)
+        names.append(hit[0])
+    c = dict(tab[names[0]])
+    for extra in names[1:]:
+        for k, v in tab[extra].items():
+            if isinstance(v, (int, float)) and not k.startswith("_"):
+                c[k] = c.get(k, 0.0) + v
+    names = [" + ".join(names)]
     n_cu, n_simd, n_xcd = 256, 1024, 8
     cycles = c["GRBM_GUI_ACTIVE"] / n_xcd                       # shader cycles of one launch
     pmc = {"kernel": names[0], "source": label,

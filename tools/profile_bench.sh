@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
 OUT=gpurun_out/prof_summary; RAW=/tmp/rii_prof_raw
 mkdir -p $OUT; rm -rf $RAW; mkdir -p $RAW
-KREGEX='scan_order|scan_kernel|lut_build|ivf_|assign_kernel|finalize|fscan|rerank|lut_quant|gather_codes|linear_tie|qlut|fcodes|merge_topk'
+KREGEX='scan_order|scan_kernel|lut_build|ivf_|shard_coarse|assign_kernel|finalize|fscan|rerank|lut_quant|gather_codes|linear_tie|qlut|fcodes|merge_topk'
 BENCH="python bench.py --no-cpu-baseline --no-host-call --no-others --no-fresh --no-pipelined --no-live-counters $*"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/kt -o kt -- $BENCH --steps 10 --warmup 2 --preheat 0.05 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $RAW/kt.err
