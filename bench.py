@@ -452,6 +452,7 @@ def sift_workload(name, eng, args, torch, dev, stream, q_dev, cw, codes, barrier
         else:
             eng.query_linear_dev(q_dev.data_ptr(), B, topk, d_tids, S, out_ids.data_ptr(), out_d.data_ptr(), stream)
 
+    nq0, nr0 = eng.get_option("ivf_quad_launches"), eng.get_option("ivf_rot_launches")
     elapsed, dom, shares = measure(eng, step, args.steps, max(args.warmup, 2), barrier, torch.cuda.synchronize)
     plain = timed_loop(step, args.steps, barrier)          # the same K steps without the two events on the dominant kernel's dispatch
     res_ids = out_ids.cpu().numpy().copy()
@@ -464,6 +465,11 @@ def sift_workload(name, eng, args, torch, dev, stream, q_dev, cw, codes, barrier
         key = workload_key(name.replace("_", "-"), args.scan_mode, args.scan_mx, M, N, B, topk)
         roof = roofline_ivf(B, nlist, M, Ks, Ds, w, N // nlist, L, avg_s, k_n, args.steps,
                             profile_table("traffic.json").get(key, {}).get("hbm_bytes_per_launch"))
+        # (the engine times its one-launch inverted-index kernels under one name: which of them served the timed steps)
+        if eng.get_option("ivf_quad_launches") > nq0:
+            roof["kernel"] = "ivf_quad_kernel"
+        elif eng.get_option("ivf_rot_launches") > nr0:
+            roof["kernel"] = "ivf_rot_kernel"
     else:
         filt = bool(args.scan_mode and (topk > 1 or B >= eng.get_option("fast_min_batch")))
         key = workload_key(name, args.scan_mode, args.scan_mx, M, n_scanned, B, topk)

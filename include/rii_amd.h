@@ -362,7 +362,7 @@ int rii_fscan_lane_subspace(int M, int lane, int t);
  *   "lanes"            scratch-buffer sets: 2 [default] or 1 (see Threading below)
  *   "timing"           0 [default] / 1 (HIP events around every kernel) / 2 (only around the dominant kernel of a step): rii_timing_read
  * Read-only (rii_get_option): "lut_tile", "n_cu", "cand_total", "cand_max" (debug counters of the last filter pass; synchronise),
- *   "ivf_rot_launches", "shard_pre_launches" (ivf_rot_kernel / shard_coarse_quad_kernel launches so far: tests assert that the
+ *   "ivf_rot_launches", "ivf_quad_launches", "shard_pre_launches" (ivf_rot_kernel / ivf_quad_kernel / shard_coarse_quad_kernel launches so far: tests assert that the
  *   kernel under test really ran).
  *
  * Threading: every entry point locks the engine, concurrent callers are serialised.  The *_dev calls return after

@@ -190,6 +190,7 @@ struct rii_engine : ScratchSet {
     DevBuf d_lcodes; bool lcodes_valid = false;      // codes in posting order (option ivf_list_codes), rebuilt with the CSR
     // round 6 (option ivf_rot): centres and posting-order codes in rotated 64-row tiles for ivf_rot_kernel (every list on a tile boundary)
     DevBuf d_rcent, d_rlcodes, d_rl_toff; bool rot_valid = false;
+    int64_t quad_launches = 0;  // ivf_quad_kernel launches so far (get_option "ivf_quad_launches")
     int64_t rot_launches = 0;   // ivf_rot_kernel launches so far (get_option "ivf_rot_launches": tests assert the kernel under test really ran)
     // LDS-friendly scan order of the filter stage (scanorder.hip): codes gathered in scan order + position -> id.
     // Windows of 1024 codes are independent, so appends only (re)order the windows past `scan_cov`.
@@ -1263,6 +1264,7 @@ int query_ivf_dev(rii_engine *e, const float *d_queries, int64_t B, int topk, co
             ScopedTimer t(e, "ivf_fused", st, true);
             HIP_TRY(quad ? launch_ivf_quad(p, st) : rot ? launch_ivf_rot(p, st) : launch_ivf_fused(p, st));
             if (rot) e->rot_launches++;
+            if (quad) e->quad_launches++;
             p.host_flag = nullptr;                   // (the deferred fallback re-uses p: nothing after this launch publishes)
             if (defer) {
                 e->spin_used = e->spin_flag != nullptr;
@@ -3070,6 +3072,7 @@ RII_API int64_t rii_get_option(const rii_engine *e, const char *key)
     if (k == "ivf_quad") return e->ivf_quad;
     if (k == "ivf_rot") return e->ivf_rot;
     if (k == "ivf_rot_launches") return e->rot_launches;
+    if (k == "ivf_quad_launches") return e->quad_launches;
     if (k == "shard_pre_launches") return e->shard_pre_launches;
     if (k == "shard_pre") return e->shard_pre;
     if (k == "ivf_list_codes") return e->ivf_list_codes;
