@@ -230,9 +230,11 @@ int rii_merge_topk_hdr_dev(const void *d_gathered, int G, int64_t B, int k, int 
  * the batch's all-gather and returns its error afterwards; its peers return from the same call too -- query sharding: the failed
  * rank's rows read ids -1 / distances NaN / counts -1; database sharding: every record carries a 16-byte header {int64 id offset,
  * int32 status} and a non-zero status poisons the whole batch on every rank (ids -2, distances NaN), the top-k paths (which read one
- * word per batch anyway) also return RII_ERR_STATE -- so the ranks stay in step and the communicator stays usable.  Only when a
- * collective ITSELF fails (or a rank cannot allocate its exchange records) is the communicator marked unusable: every later call on
- * it returns RII_ERR_STATE; destroy it. */
+ * word per batch anyway) also return RII_ERR_STATE -- so the ranks stay in step and the communicator stays usable.  The top-1 paths
+ * are asynchronous and return RII_OK on the healthy ranks: THEIR callers recognise a poisoned batch by ids -2 (inverted index: also
+ * counts -1).  Only when a collective ITSELF fails, a rank cannot allocate its exchange records, cannot write its record header or
+ * cannot order its own stream (a device that is gone) is the communicator marked unusable -- the peers of that one call wait in
+ * their all-gather; every later call on it returns RII_ERR_STATE; destroy it. */
 #define RII_COMM_ID_BYTES 128
 typedef struct rii_comm rii_comm;
 int rii_comm_unique_id(void *id_out /* RII_COMM_ID_BYTES */);

@@ -308,7 +308,8 @@ hipError_t launch_ivf_pack(const int64_t *d_ids, const int32_t *d_pos, const flo
     return hipGetLastError();
 }
 // merged rows [B, k1] (payload ids, distances) -> outputs [B, topk]: a query the reference answers with ({}, {}) (count 0) gets
-// ids -1 / distances +inf; its tie flag is cleared (nothing to replay), as it is for top-1
+// ids -1 / distances +inf; its tie flag is cleared (nothing to replay), as it is for top-1; a batch a peer poisoned (ids -2,
+// distances NaN) gets counts -1
 __global__ __launch_bounds__(256) void ivf_finish_kernel(const int64_t *__restrict__ mi, const float *__restrict__ md, const int64_t *__restrict__ cnt,
                                                          int64_t B, int k1, int topk, int64_t *__restrict__ out_ids, float *__restrict__ out_d,
                                                          int64_t *__restrict__ out_cnt, int32_t *__restrict__ tie, int32_t *__restrict__ any)
@@ -316,10 +317,12 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(const int64_t *__restri
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < B * topk; i += (int64_t) gridDim.x * blockDim.x) {
         const int64_t b = i / topk, j = i - b * topk;
         const bool found = cnt[b] > 0;
-        out_ids[i] = found ? mi[b * k1 + j] : (int64_t) -1;
-        out_d[i] = found ? md[b * k1 + j] : INFINITY;
+        const bool poisoned = mi[b * k1] == (int64_t) -2;        // (merge.hip's kPeerFailedId: a peer's header reported a failure)
+        out_ids[i] = (found || poisoned) ? mi[b * k1 + j] : (int64_t) -1;
+        out_d[i] = (found || poisoned) ? md[b * k1 + j] : INFINITY;
         if (j == 0) {
-            out_cnt[b] = cnt[b];
+            // the local count of a poisoned row said "found" -- top-1 callers, who get no status word, read counts -1 there
+            out_cnt[b] = poisoned ? (int64_t) -1 : cnt[b];
             const int t = (found && topk > 1) ? tie[b] : 0;
             tie[b] = t;
             if (t) atomicOr(any, 1);

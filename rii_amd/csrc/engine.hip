@@ -188,6 +188,8 @@ struct rii_engine : ScratchSet {
     // device state
     DevBuf d_codewords, d_cnorm, d_codes, d_centers, d_symtab, d_pl_off, d_pl_ids, d_list_len;
     DevBuf d_lcodes; bool lcodes_valid = false;      // codes in posting order (option ivf_list_codes), rebuilt with the CSR
+    bool lcodes_failed = false, rot_failed = false;  // the copy did not fit last time: not retried -- one failing hipMalloc per query otherwise --
+                                                     // until the lists change or the option is set again
     // round 6 (option ivf_rot): centres and posting-order codes in rotated 64-row tiles for ivf_rot_kernel (every list on a tile boundary)
     DevBuf d_rcent, d_rlcodes, d_rl_toff; bool rot_valid = false;
     int64_t quad_launches = 0;  // ivf_quad_kernel launches so far (get_option "ivf_quad_launches")
@@ -365,13 +367,14 @@ int sync_lists(rii_engine *e)
     e->lists_dirty = false;
     e->lcodes_valid = false;
     e->rot_valid = false;
+    e->lcodes_failed = false;
+    e->rot_failed = false;
     return RII_OK;
 }
 
 // option ivf_list_codes: row pp of d_lcodes = the code of posting pp of the CSR id array (every id sits in exactly one list: N rows)
-int sync_list_codes(rii_engine *e, hipStream_t st)
+static int sync_list_codes_try(rii_engine *e, hipStream_t st)
 {
-    if (e->lcodes_valid) return RII_OK;
     int64_t n = 0;
     for (const auto &l : e->lists) n += (int64_t) l.size();
     RII_TRY(e->d_lcodes.ensure((size_t) std::max<int64_t>(n, 1) * e->M));
@@ -380,12 +383,31 @@ int sync_list_codes(rii_engine *e, hipStream_t st)
     e->lcodes_valid = true;
     return RII_OK;
 }
+// (callers fall back to gathering rows by id: the copy is an optimisation.  A failure is remembered and the caller's error text kept)
+int sync_list_codes(rii_engine *e, hipStream_t st)
+{
+    if (e->lcodes_valid) return RII_OK;
+    if (e->lcodes_failed) return RII_ERR_HIP;
+    const std::string keep = g_err;
+    const int r = sync_list_codes_try(e, st);
+    if (r != RII_OK) { e->lcodes_failed = true; g_err = keep; }
+    return r;
+}
 
 // option ivf_rot: the centres and the posting-order codes in rotated tiles of 64 rows (ivf_rot_kernel, kernels.hip); list i starts at
 // tile rl_toff[i] of d_rlcodes.  Built from d_centers / d_lcodes on the first query that wants them after the lists changed.
+static int sync_rot_codes_try(rii_engine *e, hipStream_t st);
 int sync_rot_codes(rii_engine *e, hipStream_t st)
 {
     if (e->rot_valid) return RII_OK;
+    if (e->rot_failed) return RII_ERR_HIP;
+    const std::string keep = g_err;
+    const int r = sync_rot_codes_try(e, st);
+    if (r != RII_OK) { e->rot_failed = true; g_err = keep; }
+    return r;
+}
+static int sync_rot_codes_try(rii_engine *e, hipStream_t st)
+{
     RII_TRY(sync_list_codes(e, st));
     const int64_t nlist = (int64_t) e->lists.size();
     std::vector<int32_t> toff((size_t) nlist + 1, 0);
@@ -2687,7 +2709,7 @@ RII_API int rii_query_linear_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t i
         ((lr = c->tmp_i.ensure((size_t) B * k_local * 8)) != RII_OK || (lr = c->tmp_d.ensure((size_t) B * k_local * 4)) != RII_OK)) {}
     int64_t *rec_i = reinterpret_cast<int64_t *>(c->rec.as<unsigned char>() + kRecHeader);
     float *rec_d = reinterpret_cast<float *>(c->rec.as<unsigned char>() + kRecHeader + (size_t) B * rows * 8);
-    RII_TRY(begin_on(e, st));
+    if (const int rb = begin_on(e, st)) { c->broken = true; return rb; }      // (see rii_query_ivf_dbsharded_dev)
     int r = RII_OK;
     do {
         if (lr == RII_OK) {
@@ -2813,7 +2835,9 @@ RII_API int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_o
     // the whole batch on the collect-all route
     const int64_t per_q_all = (int64_t) G * L * 20;
     const int64_t group = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t) kShardGatherBudget / std::max<int64_t>(per_q_all, 1)));
-    RII_TRY(begin_on(e, st));
+    // (a rank that cannot even order its stream leaves the call before its all-gathers -- the communicator is marked
+    //  unusable, as for a failed collective: include/rii_amd.h)
+    if (const int rb = begin_on(e, st)) { c->broken = true; return rb; }
     int r = RII_OK;
     do {
         int lr = RII_OK;                       // rank-local outcome; the collectives below are issued regardless
@@ -3001,11 +3025,13 @@ RII_API int rii_set_option(rii_engine *e, const char *key, int64_t value)
         e->ivf_quad = value < 0 ? 0 : (int) std::min<int64_t>(value, 2);        // 2: at every batch size (tests)
     } else if (k == "ivf_rot") {
         e->ivf_rot = value < 0 ? 0 : (int) std::min<int64_t>(value, 2);
+        e->rot_failed = false;
         if (!value) { e->d_rcent.release(); e->d_rlcodes.release(); e->d_rl_toff.release(); e->rot_valid = false; }
     } else if (k == "ivf_inline_exact") {
         e->ivf_inline_exact = value ? 1 : 0;
     } else if (k == "ivf_list_codes") {
         e->ivf_list_codes = value ? 1 : 0;
+        e->lcodes_failed = false; e->rot_failed = false;
         if (!value) { e->d_lcodes.release(); e->lcodes_valid = false; e->d_rlcodes.release(); e->rot_valid = false; }
     } else if (k == "ivf_force_exact") {
         e->ivf_force_exact = value ? 1 : 0;

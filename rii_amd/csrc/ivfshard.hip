@@ -1104,7 +1104,8 @@ int ivf_shard_max_select_rows(int M, int Ks, int nlist, int64_t L, int64_t w)
 }
 bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w, int rows)
 {
-    if (shard_lds_ok(M, Ks, nlist, L, w)) return rows <= kShardMaxL + 1;      // (rows = k + 1 with k = L = 8192)
+    // rows >= L (every owned candidate) is always served: by the 8192-key kernel while it holds them, else by the collect form
+    if (shard_lds_ok(M, Ks, nlist, L, w)) return rows <= kShardMaxL + 1 || (int64_t) rows >= L;      // (rows = k + 1 with k = L = 8192)
     return rows <= shard_any_max_rows(M, Ks, nlist, w) || (int64_t) rows >= L;
 }
 // which kernel: top-1 (rows = 2) always takes the register path of ivf_shard_any_kernel (sorting L keys to keep two of them is what
@@ -1113,6 +1114,7 @@ static bool shard_use_any(int M, int Ks, int nlist, int64_t L, int64_t w, int ro
 {
     if (rows == 2 && L > 2 && shard_any_fixed(M, Ks, nlist, w) + 64 <= (size_t) 160 * 1024 - 512) return true;
     if (!shard_lds_ok(M, Ks, nlist, L, w)) return true;
+    if (rows > kShardMaxL + 1) return true;                  // (rows >= L beyond the 8192-key kernel's rows -> the collect form)
     // everything the selection buffer serves: the any-L kernel has the faster candidate loop (rows in flight together, posting-order
     // rows) and the fast coarse selection; the 8192-key kernel keeps the row counts beyond it (k + 1 up to 8193 at L <= 8192)
     return rows <= shard_any_max_rows(M, Ks, nlist, w) && shard_any_fixed(M, Ks, nlist, w) + (size_t) shard_any_nbuf(M, Ks, nlist, w) * 8 <= (size_t) 160 * 1024 - 512;

@@ -249,7 +249,10 @@ def get_comm(group=None):
     rank, w = world(group)
     key = (group, dev)
     c = _COMMS.get(key)
-    if c is None or c.rank != rank or c.size != w:
+    if c is not None and (c.rank != rank or c.size != w):
+        c.close()                # (collective, like close_comms(): the stale RCCL communicator is not left to __del__ at an arbitrary time)
+        c = None
+    if c is None:
         if w > 1 or (dist.is_available() and dist.is_initialized()):
             box = [core.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)

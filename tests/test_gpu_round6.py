@@ -220,3 +220,42 @@ def test_generic_quantiser_levels_and_growing_candidate_buffers(M, Ds):
     ids, d = g.query_linear_batch(qs, 1, E)
     for b in range(len(qs)):
         assert_same_result((ids[b], d[b]), want1[b], "generic overflow M=%d Ds=%d b=%d (longest list %d)" % (M, Ds, b, cand))
+
+
+def test_shard_rows_beyond_8193_with_a_small_L_take_the_collect_form():
+    """rows >= L is documented as always served (every owned candidate at the slot of its position), but a request like
+    L = 100, rows = 10000 was rejected -- past the 8192-key kernel's row count, the collect form never tried.  Now: the first L slots
+    equal what rows = L returns, the rest is padding."""
+    import torch
+    from rii_amd import RiiGpu
+    N, nlist, M, Ds, L, B = 20000, 50, 8, 4, 100, 5
+    cw, codes, qs = make_problem(4242, M, 256, Ds, N, "unit")
+    o = O.OracleRii(cw, False, simd_arch="avx512")
+    o.add_codes(codes, False)
+    o.reconfigure(nlist, 2)
+    g = RiiGpu(cw, False, simd_arch="avx512")
+    g.add_codes(codes, False)
+    g.set_coarse_centers(np.array(o.coarse_centers, np.uint8))
+    dev = torch.device("cuda", 0)
+    q = torch.from_numpy(qs[:B]).to(dev)
+    glen = torch.tensor([len(l) for l in g.posting_lists], dtype=torch.int32, device=dev)
+    got = {}
+    for rows in (L, 10000):
+        oi = torch.full((B, rows), -7, dtype=torch.int64, device=dev); od = torch.zeros((B, rows), dtype=torch.float32, device=dev)
+        op = torch.zeros((B, rows), dtype=torch.int32, device=dev); on = torch.zeros((B,), dtype=torch.int32, device=dev)
+        oc = torch.zeros((B,), dtype=torch.int64, device=dev)
+        g.query_ivf_shard_dev(q.data_ptr(), B, 1, 0, 0, 0, L, N, glen.data_ptr(), 1, 0, oi.data_ptr(), od.data_ptr(), op.data_ptr(), on.data_ptr(),
+                              oc.data_ptr(), 0, rows)
+        torch.cuda.synchronize()
+        got[rows] = (oi.cpu().numpy(), od.cpu().numpy(), op.cpu().numpy(), on.cpu().numpy())
+    a, b = got[L], got[10000]
+    assert np.array_equal(a[3], b[3]) and int(a[3].min()) == L                      # one rank owns every candidate
+    for bq in range(B):                    # (the 8192-key kernel hands its rows over sorted by (distance, position), the collect form by position)
+        oa = np.argsort(a[2][bq])
+        assert np.array_equal(a[2][bq][oa], np.arange(L)) and np.array_equal(b[2][bq, :L], np.arange(L))
+        assert np.array_equal(a[0][bq][oa], b[0][bq, :L]) and np.array_equal(a[1][bq][oa].view(np.uint32), b[1][bq, :L].view(np.uint32))
+    assert bool((b[0][:, L:] == -1).all()) and bool(np.isinf(b[1][:, L:]).all())
+    for bq in range(B):                                                                # ... and the L candidates hold the oracle's top-1
+        wi, wd = o.query_ivf(qs[bq], 1, E, L)
+        j = int(np.lexsort((a[2][bq], a[1][bq]))[0])
+        assert int(a[0][bq, j]) == wi[0] and np.float32(a[1][bq, j]).view(np.uint32) == np.float32(wd[0]).view(np.uint32)
