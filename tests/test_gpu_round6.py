@@ -95,13 +95,13 @@ def test_ivf_rot_copies_follow_the_lists():
     assert g.get_option("ivf_rot_launches") == 4
 
 
-def _sharded_check(idx, o, Q, topk, L, what):
+def _sharded_check(idx, o, Q, topk, L, what, tids=None):
     import torch
-    gi, gd, gc = idx.query_ivf_batch(torch.from_numpy(Q).cuda(), topk, None, L)
+    gi, gd, gc = idx.query_ivf_batch(torch.from_numpy(Q).cuda(), topk, tids, L)
     gi, gd, gc = gi.cpu().numpy(), gd.cpu().numpy(), gc.cpu().numpy()
     for b in range(Q.shape[0]):
         n = int(gc[b])
-        assert_same_result((gi[b, :n], gd[b, :n]), o.query_ivf(Q[b], topk, E, L), "%s k=%d L=%d b=%d" % (what, topk, L, b))
+        assert_same_result((gi[b, :n], gd[b, :n]), o.query_ivf(Q[b], topk, E if tids is None else tids, L), "%s k=%d L=%d b=%d" % (what, topk, L, b))
 
 
 @pytest.mark.parametrize("arch", ["sse", "avx", "avx512"])
@@ -147,6 +147,12 @@ def test_shard_coarse_prepass_equals_the_walk_kernels_own_coarse_phase_and_the_o
                     _sharded_check(idx, o, Q[:B], topk, L, "pre=%d force=%d M=%d Ds=%d nlist=%d B=%d" % (pre, force, M, Ds, nlist, B))
                     ncall += pre == 2
         assert g.get_option("shard_pre_launches") - n0 >= ncall          # the pre-pass really ran wherever it was asked for
+        # subset search behind the pre-pass: filtered lists (no posting-order rows: the walk kernel gathers by id), w from |S|
+        sub = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.int64)
+        for pre in (2, 0):
+            g.set_option("shard_pre", pre)
+            for topk, L in ((1, L0), (3, L0 // 2 + 1)):
+                _sharded_check(idx, o, Q[:21], topk, L, "subset pre=%d M=%d Ds=%d nlist=%d" % (pre, M, Ds, nlist), sub)
     finally:
         g.set_option("shard_pre", 1)
         g.set_option("shard_force_replay", 0)
