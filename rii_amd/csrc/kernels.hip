@@ -1864,7 +1864,7 @@ template <int N> __device__ __forceinline__ uint32_t rot_dw(const uint4 (&r)[N],
 template <int M, class RowOf, class Emit>
 __device__ __forceinline__ void rot_gather(const RotLane<M> &rl, int n_items, RowOf row_of, Emit emit)
 {
-    constexpr int MW = M / 4, LW = RotLane<M>::LW, NSEL = RotLane<M>::NSEL, RB = 8, NB = M / RB;
+    constexpr int MW = M / 4, LW = RotLane<M>::LW, NSEL = RotLane<M>::NSEL, RB = 16, NB = M / RB;
     if (n_items <= 0) return;
     rot_f2 acc = {0.f, 0.f};
     const rot_f2 one_zero = {1.f, 0.f};
@@ -1906,6 +1906,13 @@ __device__ __forceinline__ void rot_gather(const RotLane<M> &rl, int n_items, Ro
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 const int j = b * RB + u;
+                if (j >= NSEL) {
+                    // from round 31 on every lane is on its new row: a plain add into that half of the pair (exactly what t * 1 + acc
+                    // computes) -- the dependent chain of a row then runs on v_add_f32's latency for its second half, not v_pk_fma_f32's
+                    const float tv = (u & 1) ? t[u >> 1].y : t[u >> 1].x;
+                    if (!ODD) acc.x = __fadd_rn(acc.x, tv); else acc.y = __fadd_rn(acc.y, tv);
+                    continue;
+                }
                 const rot_f2 sj = j < NSEL ? rl.sel[j < NSEL ? j : 0] : one_zero;
                 // src0 = the round's entry for both halves (it sits in one half of a pair), src1 = the routing pair (odd iterations: swapped)
                 if (!ODD && !(u & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t[u >> 1]), "v"(sj));
