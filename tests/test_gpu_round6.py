@@ -265,3 +265,50 @@ def test_shard_rows_beyond_8193_with_a_small_L_take_the_collect_form():
         wi, wd = o.query_ivf(qs[bq], 1, E, L)
         j = int(np.lexsort((a[2][bq], a[1][bq]))[0])
         assert int(a[0][bq, j]) == wi[0] and np.float32(a[1][bq, j]).view(np.uint32) == np.float32(wd[0]).view(np.uint32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_sharded_ivf_prepass_against_oracle(seed):
+    """Differential fuzz of the sharded inverted index with the coarse pre-pass forced on (shard_pre = 2) and off: random shape within
+    the pre-pass's reach (M = 16 / 32, even Ds <= 8, a SIMD order, lists by the hundreds or thousands so that the coarse order lives in
+    global scratch), random scale (integer-valued data with duplicated rows and centres: ties), random batch size, L (w <= 7 or
+    beyond: the pre-pass then steps aside), topk, target ids or none -- ids and distance bits against the oracle."""
+    from rii_amd import RiiGpu
+    from rii_amd import dist as rd
+    rng = np.random.default_rng(7000 + seed)
+    M = int(rng.choice([16, 32]))
+    Ds = int(rng.choice([2, 4, 6, 8]))
+    arch = str(rng.choice(["avx512", "avx", "sse"]))
+    scale = str(rng.choice(["unit", "sift"]))
+    N = int(rng.integers(8000, 30000))
+    nlist = int(rng.integers(2000, 3000)) if M == 16 else int(rng.integers(450, 900))
+    cw, codes, qs = make_problem(7100 + seed, M, 256, Ds, N, scale, dup=(N // 5 if scale == "sift" else 0))
+    cen = np.ascontiguousarray(codes[rng.integers(0, N, nlist)])
+    if scale == "sift":
+        cen[rng.integers(0, nlist, nlist // 4)] = cen[rng.integers(0, nlist, nlist // 4)]
+    Q = np.concatenate([qs, qs[::-1] * 0.5, rng.permutation(qs.reshape(-1)).reshape(qs.shape)]).astype(np.float32)
+    if scale == "sift":
+        Q = np.round(Q)
+    o = O.OracleRii(cw, False, simd_arch=arch)
+    o.add_codes(codes, False)
+    o.set_coarse_centers(cen)
+    g = RiiGpu(cw, False, simd_arch=arch)
+    g.add_codes(codes, False)
+    g.set_coarse_centers(cen)
+    idx = rd.DbShardedIndex(g, 0, N)
+    L0 = max(1, N // nlist)
+    try:
+        for trial in range(6):
+            B = int(rng.choice([1, 3, 4, 5, 17, 48]))
+            tids = np.sort(rng.choice(N, int(rng.integers(N // 3, N)), replace=False)).astype(np.int64) if rng.random() < 0.35 else None
+            pool = N if tids is None else len(tids)
+            L = int(rng.choice([1, L0, 2 * L0 + 1, 4 * L0, 9 * L0, 40 * L0]))
+            L = max(1, min(L, pool))
+            topk = 1 if rng.random() < 0.5 else int(rng.integers(1, min(L, 12) + 1))
+            for pre in (2, 0):
+                g.set_option("shard_pre", pre)
+                _sharded_check(idx, o, Q[:B], topk, L, "fuzz seed=%d trial=%d pre=%d M=%d Ds=%d %s %s nlist=%d N=%d B=%d" %
+                               (seed, trial, pre, M, Ds, arch, scale, nlist, N, B), tids)
+        assert g.get_option("shard_pre_launches") > 0                      # (some trial of every seed is within the pre-pass's reach)
+    finally:
+        g.set_option("shard_pre", 1)
