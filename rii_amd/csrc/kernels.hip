@@ -1582,7 +1582,35 @@ __global__ __launch_bounds__(kQuadThreads) void ivf_quad_kernel(IvfParams p)
     }
     // ---- level 1: the `rounds` smallest keys of this wave's 64 centres, per query, ascending (the four queries' DPP ladders in
     // lockstep: wave_min_u64_x4) ----
-    {
+    // Round 6, `listed`: with at least `rounds` waves that hold centres, ONE ladder per wave gives the wave minima, the `rounds`-th
+    // smallest of them bounds the block's `rounds` smallest keys from above (the minima at or below it are that many keys already), only
+    // keys at or below the bound -- a handful -- are listed, and wave q orders query q's list: `rounds` lockstep ladders on sixteen
+    // waves (1.7 us of the kernel at w = 4) become one, plus two short ones on four waves (shard_coarse_quad_kernel's selection).
+    // More than 64 keys at or below the bound (masses of exactly tied distances): the query is flagged.
+    const bool listed = rounds <= 16 && nlist > (rounds - 1) * 64;                      // (block-uniform)
+    unsigned long long *s_list = s_wsel + kQuadQ * 16;                                  // [4][64], behind the wave minima [4][16]
+    if (listed) {
+        unsigned long long got[kQuadQ] = {kkey[0], kkey[1], kkey[2], kkey[3]};
+        wave_min_u64_x4(got);
+        if (lane < kQuadQ) s_wsel[lane * 16 + wave] = lane == 0 ? got[0] : lane == 1 ? got[1] : lane == 2 ? got[2] : got[3];
+        if (tid < kQuadQ) s_misc[tid * 4 + 3] = 0;
+        __syncthreads();
+        if (wave < kQuadQ) {
+            unsigned long long cand = lane < 16 ? s_wsel[wave * 16 + lane] : ~0ull, bound = ~0ull;
+            for (int r = 0; r < rounds; ++r) {
+                bound = wave_min_u64(cand);
+                if (cand == bound) cand = ~0ull;
+            }
+            if (lane == 0) s_red[wave] = bound;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kQuadQ; ++q)
+            if (kkey[q] != ~0ull && kkey[q] <= s_red[q]) {
+                const int slot = atomicAdd(&s_misc[q * 4 + 3], 1);
+                if (slot < 64) s_list[q * 64 + slot] = kkey[q];
+            }
+    } else {
         unsigned long long mykey[kQuadQ] = {kkey[0], kkey[1], kkey[2], kkey[3]};
         for (int r = 0; r < rounds; ++r) {
             unsigned long long got[kQuadQ] = {mykey[0], mykey[1], mykey[2], mykey[3]};
@@ -1601,6 +1629,17 @@ __global__ __launch_bounds__(kQuadThreads) void ivf_quad_kernel(IvfParams p)
         const int q = wave;
         const int ncnd = 16 * rounds;                                                   // <= 528 keys: up to nine per lane
         unsigned long long mysel = ~0ull;                                               // lane r keeps pick r
+        bool over = false;
+        if (listed) {
+            const int n = s_misc[q * 4 + 3];
+            over = n > 64;
+            unsigned long long cand = lane < n && lane < 64 ? s_list[q * 64 + lane] : ~0ull;
+            for (int r = 0; r < rounds; ++r) {
+                const unsigned long long got = wave_min_u64(cand);
+                if (cand == got) cand = ~0ull;
+                if (lane == r) mysel = got;
+            }
+        }
         auto merge = [&](auto ns) {
             constexpr int NS = decltype(ns)::value;
             unsigned long long cand[NS];
@@ -1620,7 +1659,7 @@ __global__ __launch_bounds__(kQuadThreads) void ivf_quad_kernel(IvfParams p)
                 if (lane == r) mysel = got;
             }
         };
-        if (ncnd <= 128) merge(std::integral_constant<int, 2>{}); else merge(std::integral_constant<int, 9>{});
+        if (!listed) { if (ncnd <= 128) merge(std::integral_constant<int, 2>{}); else merge(std::integral_constant<int, 9>{}); }
         // the stop rule of the walk across the lanes (the wave-0 code of ivf_fused_kernel, per query)
         const int wl = w < nlist ? w : nlist;
         const uint32_t myhi = (uint32_t) (mysel >> 32);
@@ -1639,7 +1678,7 @@ __global__ __launch_bounds__(kQuadThreads) void ivf_quad_kernel(IvfParams p)
             if (lane >= o) incl += t;
         }
         const int excl = incl - len;
-        int flag = (p.force_flag || __ballot(tied) != 0ull) ? 1 : 0;
+        int flag = (p.force_flag || over || __ballot(tied) != 0ull) ? 1 : 0;
         const unsigned long long hit = __ballot(lane < wl && (long long) incl >= p.L);    // first list that completes L candidates
         int nv = 0;
         long long cnt = 0;
