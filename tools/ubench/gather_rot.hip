@@ -489,6 +489,106 @@ __global__ __launch_bounds__(NT) void par2_kernel(const uint8_t *__restrict__ rc
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// E (round 6, M = 16 only): C's skewed lanes over a COMPACT table -- [ks][32 columns] = 32 KiB (two copies of the 16 subspaces: lanes
+// 0-15 of a DS group read columns (j - phi) mod 16, lanes 16-31 the same + 16: 32 different banks), four blocks per CU instead of the
+// two the 64-column layout allows.  The column wraps inside a row, so it cannot ride in the DS offset: the address is TWO
+// instructions (v_perm_b32: { byte 1 = code byte, byte 0 = 8 x column }, then >> 1: 128 x code + 4 x column).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void par16c_kernel(const uint8_t *__restrict__ rcodes, int64_t n_tiles_total, int ncand, const float *__restrict__ tab16,
+                                                    unsigned long long *__restrict__ out)
+{
+    constexpr int M = 16, MW = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+    for (int i = tid; i < 256 * 32; i += NT) lds[i] = tab16[(size_t) (i >> 5) * 16 + (i & 15)] + (float) (blockIdx.x & 7);
+    __syncthreads();
+    const int phi = lane & 15, half = (lane >> 4) & 1;
+    const int ntile = (ncand + 63) / 64;
+    const int64_t tile0 = (((int64_t) blockIdx.x * 4099) % (n_tiles_total * 64 - ncand)) / 64;
+    uint32_t lowmask[MW], colq[MW];
+#pragma unroll
+    for (int d = 0; d < MW; ++d) {
+        uint32_t mk = 0, cq = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            mk |= (4 * d + b < phi) ? (0xffu << (8 * b)) : 0u;
+            cq |= (uint32_t) (((((4 * d + b - phi) & 15) + 16 * half) << 3)) << (8 * b);
+        }
+        lowmask[d] = mk; colq[d] = cq;
+    }
+    f2 sel[M - 1];
+#pragma unroll
+    for (int j = 0; j < M - 1; ++j) sel[j] = phi <= j ? f2{1.f, 0.f} : f2{0.f, 1.f};
+    uint4 bufA = make_uint4(0, 0, 0, 0), bufB = make_uint4(0, 0, 0, 0);
+    f2 acc = {0.f, 0.f};
+    float bestd = INFINITY;
+    uint32_t bestp = 0xffffffffu;
+    const int my_n = ntile > wave ? (ntile - wave + NW - 1) / NW : 0;
+    if (my_n > 0) bufA = *reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave) * 64 + lane) * (int64_t) M);
+    int prev_pos = -1;
+    auto iteration = [&](uint4 &cur, uint4 &prv, int it, auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
+        uint32_t x[MW];
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x[0]) : "v"(lowmask[0]), "v"(prv.x), "v"(cur.x));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x[1]) : "v"(lowmask[1]), "v"(prv.y), "v"(cur.y));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x[2]) : "v"(lowmask[2]), "v"(prv.z), "v"(cur.z));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x[3]) : "v"(lowmask[3]), "v"(prv.w), "v"(cur.w));
+        if (it + 1 < my_n) prv = *reinterpret_cast<const uint4 *>(rcodes + ((tile0 + wave + (int64_t) (it + 1) * NW) * 64 + lane) * (int64_t) M);
+        f2 t[8];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t ps = 0x0c0c0000u | ((4u + (j & 3)) << 8) | (uint32_t) (j & 3);     // D.b0 = S1.b(j & 3), D.b1 = S0.b(j & 3)
+            const uint32_t a = __builtin_amdgcn_perm(x[j >> 2], colq[j >> 2], ps) >> 1;
+            const float v = *reinterpret_cast<const __attribute__((address_space(3))) float *>(a);
+            if (j & 1) t[j >> 1].y = v; else t[j >> 1].x = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j == 15) {                                       // every lane is on its new row
+                const float tv = t[7].y;
+                if (!ODD) acc.x = acc.x + tv; else acc.y = acc.y + tv;
+                continue;
+            }
+            if (!ODD && !(j & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t[j >> 1]), "v"(sel[j < 15 ? j : 0]));
+            if (!ODD && (j & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(t[j >> 1]), "v"(sel[j < 15 ? j : 0]));
+            if (ODD && !(j & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(t[j >> 1]), "v"(sel[j < 15 ? j : 0]));
+            if (ODD && (j & 1)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(t[j >> 1]), "v"(sel[j < 15 ? j : 0]));
+        }
+        const float fin = ODD ? acc.x : acc.y;
+        if (prev_pos >= 0 && prev_pos < ncand && fin < bestd) { bestd = fin; bestp = (uint32_t) prev_pos; }
+        if (ODD) acc.x = 0.f; else acc.y = 0.f;
+        prev_pos = it < my_n ? (wave + it * NW) * 64 + lane : -1;
+    };
+    for (int it = 0; it <= my_n; it += 2) {
+        iteration(bufA, bufB, it, std::false_type{});
+        if (it + 1 <= my_n) iteration(bufB, bufA, it + 1, std::true_type{});
+    }
+    unsigned long long key = bestp == 0xffffffffu ? ~0ull : (((unsigned long long) f32_ord(__float_as_uint(bestd)) << 32) | bestp);
+    key = wave_min_u64(key);
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(lds + 256 * 32);
+    if (lane == 0) red[wave] = key;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w) key = red[w] < key ? red[w] : key;
+        out[blockIdx.x] = key;
+    }
+}
+template <int NT> static float time_par16c(const uint8_t *d_rc, int64_t ntiles, int ncand, const float *d_tab16, unsigned long long *d_out, int blocks, int reps)
+{
+    const size_t smem = 256 * 32 * 4 + 64;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(par16c_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((par16c_kernel<NT>), dim3(blocks), dim3(NT), smem, 0, d_rc, ntiles, ncand, d_tab16, d_out);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((par16c_kernel<NT>), dim3(blocks), dim3(NT), smem, 0, d_rc, ntiles, ncand, d_tab16, d_out);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
 template <int M, int NT> static float time_direct(const uint8_t *d_codes, int64_t n, int ncand, const float *d_tab, unsigned long long *d_out, int blocks, int reps)
 {
     const size_t smem = (size_t) M * 1024 + 128;
@@ -600,6 +700,17 @@ template <int M> static void run_shape(int ncand, int blocks, int log2n)
     ms = time_par2<M, 256, 1>(d_rc2, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity2/256thr/1chain", ms, d_ob, false);
     ms = time_par2<M, 512, 1>(d_rc2, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity2/512thr/1chain", ms, d_ob, false);
     ms = time_par2<M, 256, 2>(d_rc2, n / 64, ncand, d_tabr, d_ob, blocks, reps); report("parity2/256thr/2chains", ms, d_ob, false);
+    if (M == 16) {                                             // E: compact [ks][16] table in global memory, staged as [ks][32] (validated by the replay below)
+        std::vector<float> t16((size_t) 256 * 16);
+        for (int ks = 0; ks < 256; ++ks)
+            for (int c = 0; c < 16; ++c) t16[(size_t) ks * 16 + c] = tab[(size_t) c * 256 + ks];
+        float *d_t16;
+        CK(hipMalloc(&d_t16, t16.size() * 4));
+        CK(hipMemcpy(d_t16, t16.data(), t16.size() * 4, hipMemcpyHostToDevice));
+        ms = time_par16c<512>(d_rc2, n / 64, ncand, d_t16, d_ob, blocks, reps); report("compact32/512thr", ms, d_ob, false);
+        ms = time_par16c<256>(d_rc2, n / 64, ncand, d_t16, d_ob, blocks, reps); report("compact32/256thr", ms, d_ob, false);
+        CK(hipFree(d_t16));
+    }
     // bit-exactness: host replay of the first minimum over the candidates rot_kernel saw (tile-aligned start)
     CK(hipMemcpy(hb.data(), d_ob, blocks * 8, hipMemcpyDeviceToHost));
     int bad = 0;
@@ -624,6 +735,7 @@ int main(int argc, char **argv)
 {
     const int blocks = argc > 1 ? atoi(argv[1]) : 1024;
     const int log2n = argc > 2 ? atoi(argv[2]) : 20;     // code rows: 2^20 x M bytes live in the Infinity Cache, 2^15 in L2
+    if (argc > 3 && atoi(argv[3]) == 16) { run_shape<16>(8000, blocks, log2n); run_shape<16>(16000, blocks, log2n); return 0; }
     run_shape<64>(6016, blocks, log2n);   // the reference's harness setting: nlist + L = 1000 + 5000 lookups rows per query
     run_shape<32>(2048, blocks, log2n);   // configs[2]: 1024 + 977
     run_shape<32>(6016, blocks, log2n);
