@@ -469,6 +469,10 @@ int append_codes(rii_engine *e, const uint8_t *codes, int64_t n)
     const size_t M = (size_t) e->M;
     const size_t old_bytes = (size_t) e->N * M, add = (size_t) n * M;
     if (e->N < e->scan_cov) e->scan_cov = 0;         // the code array was restarted (clear / set_state)
+    if (e->N == 0 && e->h_cand_peak && e->d_cand_peak.p) {     // a new database: the candidate slots start from the default again
+        *e->h_cand_peak = 0u;
+        HIP_TRY(hipMemsetAsync(e->d_cand_peak.p, 0, 64, e->stream));
+    }
     if (e->N < e->fc_cov) e->fc_cov = 0;
     e->scan_N = -1;
     e->codes.insert(e->codes.end(), codes, codes + add);
