@@ -2164,7 +2164,10 @@ RII_API int rii_ivf_list_lengths_dev(rii_engine *e, const int64_t *d_tids, int64
 
 namespace {
 // the bodies of rii_ivf_list_lengths_dev / rii_query_ivf_shard_dev: the caller holds e->mu and has begun on `st`
-int ivf_list_lengths_locked(rii_engine *e, const int64_t *d_tids, int64_t S, int64_t S_global, int32_t *d_out_len, hipStream_t st)
+// d_out_len == NULL (round 6): no copy -- *where = the engine's own (filtered) lengths, for a caller that hands them straight to a
+// collective on the same stream
+int ivf_list_lengths_locked(rii_engine *e, const int64_t *d_tids, int64_t S, int64_t S_global, int32_t *d_out_len, hipStream_t st,
+                            const int32_t **where = nullptr)
 {
     const int64_t nlist = nlist_of(e);
     RII_TRY(sync_lists(e));
@@ -2173,7 +2176,8 @@ int ivf_list_lengths_locked(rii_engine *e, const int64_t *d_tids, int64_t S, int
         RII_TRY(filter_lists_by_targets(e, d_tids, S, st));
         src = e->s_flen.as<int32_t>();
     }
-    HIP_TRY(hipMemcpyAsync(d_out_len, src, (size_t) nlist * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (where) *where = src;
+    if (d_out_len) HIP_TRY(hipMemcpyAsync(d_out_len, src, (size_t) nlist * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return RII_OK;
 }
 int ivf_shard_w(const rii_engine *e, int64_t S_global, int64_t L, int64_t N_global)
@@ -2205,8 +2209,9 @@ int ivf_shard_check(const rii_engine *e, int64_t B, int topk, int64_t S_global, 
 }
 int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S, int64_t S_global, int64_t L,
                      int64_t w, const int32_t *d_glen, int G, int rank, int rows, int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos,
-                     int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st)
+                     int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st, void *d_rec = nullptr, int64_t id_offset = 0)
 {
+    // d_rec (round 6): the exchange record for the B x rows selected rows, written by the kernel next to the plain outputs (NULL: none)
     const int64_t nlist = nlist_of(e);
     RII_TRY(sync_lists(e));
     const int32_t *pl_ids = e->d_pl_ids.as<int32_t>();
@@ -2253,13 +2258,22 @@ int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk,
             own_tables = false;
             e->shard_pre_launches++;
         } else if (!own_tables) RII_TRY(build_lut(e, d_queries + b0 * D, cur, st, false, 1));
+        ShardPack pk;
+        if (d_rec) {
+            const int64_t n = B * (int64_t) rows;
+            unsigned char *r = static_cast<unsigned char *>(d_rec);
+            pk.rec_pos = reinterpret_cast<int64_t *>(r) + b0 * (int64_t) rows;
+            pk.rec_id = reinterpret_cast<int64_t *>(r + (size_t) n * 8) + b0 * (int64_t) rows;
+            pk.rec_d = reinterpret_cast<float *>(r + (size_t) n * 16) + b0 * (int64_t) rows;
+            pk.id_offset = id_offset;
+        }
         ScopedTimer t(e, "ivf_shard", st);
         HIP_TRY(launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, own_tables ? nullptr : e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
                                  e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
                                  d_out_ids + b0 * (int64_t) rows, d_out_dists + b0 * (int64_t) rows, d_out_pos + b0 * (int64_t) rows,
                                  d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st,
                                  own_tables ? d_queries + b0 * D : nullptr, e->d_codewords.as<float>(), e->Ds, e->arch, lcodes,
-                                 (e->shard_dbg_stop & 0xff) | ((e->shard_force_replay ? 1 : 0) << 8), picks, pick_ok));
+                                 (e->shard_dbg_stop & 0xff) | ((e->shard_force_replay ? 1 : 0) << 8), picks, pick_ok, d_rec ? &pk : nullptr));
     }
     return RII_OK;
 }
@@ -2846,10 +2860,15 @@ RII_API int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_o
     do {
         int lr = RII_OK;                       // rank-local outcome; the collectives below are issued regardless
         // (1) list lengths of every rank (a rank that failed sends zeros: an empty shard, a consistent walk on every peer)
-        lr = ivf_list_lengths_locked(e, d_tids_local, S_local, S_global, mylen, st);
-        if (lr != RII_OK && hipMemsetAsync(mylen, 0, lens_bytes, st) != hipSuccess) { c->broken = true; r = RII_ERR_HIP; break; }
+        // (round 6: gathered straight from the engine's own array -- a device-to-device copy into the send slot was a launch per batch)
+        const int32_t *lens_src = nullptr;
+        lr = ivf_list_lengths_locked(e, d_tids_local, S_local, S_global, nullptr, st, &lens_src);
+        if (lr != RII_OK) {
+            if (hipMemsetAsync(mylen, 0, lens_bytes, st) != hipSuccess) { c->broken = true; r = RII_ERR_HIP; break; }
+            lens_src = mylen;
+        }
         std::string local_msg = g_err;
-        if ((r = comm_gather(c, mylen, glen, lens_bytes, st)) != RII_OK) break;
+        if ((r = comm_gather(c, lens_src, glen, lens_bytes, st)) != RII_OK) break;
         if (collect_all) {
             // ---- every candidate of every query, group by group; the replay is the answer ----
             const size_t nr = (size_t) group * (size_t) L, rec2 = merge_record_bytes(group, (int) L, 1);
@@ -2892,13 +2911,12 @@ RII_API int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_o
              (msc && (lr = c->seq.ensure(msc)) != RII_OK))) {}
         int32_t *pos = c->qf.as<int32_t>(), *nloc = pos + n1;
         int64_t *cnt = c->bound.as<int64_t>();
+        // (round 6: the shard kernel writes the exchange record itself -- one launch less per batch than a pack kernel behind it)
         if (lr == RII_OK)
             lr = ivf_shard_locked(e, d_queries, B, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, (int) k1, c->tmp_i.as<int64_t>(),
-                                  c->tmp_d.as<float>(), pos, nloc, cnt, st);
+                                  c->tmp_d.as<float>(), pos, nloc, cnt, st, c->rec.as<unsigned char>() + kRecHeader, id_offset);
         // (3) one all-gather + merge under (distance, position), the global ids as payload
         int32_t *d_tie = d_out_tie ? d_out_tie : c->tie.as<int32_t>();
-        if (lr == RII_OK && launch_ivf_pack(c->tmp_i.as<int64_t>(), pos, c->tmp_d.as<float>(), (int64_t) n1, id_offset, c->rec.as<unsigned char>() + kRecHeader, st) != hipSuccess)
-            lr = set_err(RII_ERR_HIP, "pack failed");
         if (lr != RII_OK) local_msg = g_err;
         if (comm_set_header(c, 0, lr != RII_OK ? 1 : 0, st) != RII_OK) { c->broken = true; r = RII_ERR_HIP; break; }
         if ((r = comm_gather(c, c->rec.p, c->gathered.p, stride, st)) != RII_OK) break;

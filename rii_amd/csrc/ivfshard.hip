@@ -43,6 +43,9 @@ struct ShardArgs {
     // round 6, ivf_shard_any_kernel behind shard_coarse_quad_kernel: the batch's coarse picks ([b][kShardPickStride] keys, ascending) and
     // whether they are conclusive; the tables come in through `lut` then
     const unsigned long long *picks = nullptr; const int32_t *pick_ok = nullptr;
+    // round 6: the rows written a second time in the exchange record's form (rii_query_ivf_dbsharded_dev: int64 positions | int64 GLOBAL
+    // ids | f32 distances -- what ivf_pack_kernel made of the plain outputs in a launch of its own), or NULL
+    int64_t *rec_pos = nullptr, *rec_id = nullptr; float *rec_d = nullptr; int64_t id_offset = 0;
 };
 
 // BIG (nlist above kShardMaxNlistLds -- the reference's default sqrt(N) is 11 k lists at a 125 M-code shard): the coarse order and
@@ -161,6 +164,11 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
         p.out_ids[b * k1 + j] = id;
         p.out_dists[b * k1 + j] = d;
         p.out_pos[b * k1 + j] = pos;
+        if (p.rec_pos) {
+            p.rec_pos[b * k1 + j] = (int64_t) pos;
+            p.rec_id[b * k1 + j] = id >= 0 ? id + p.id_offset : id;
+            p.rec_d[b * k1 + j] = d;
+        }
     }
 }
 
@@ -921,6 +929,11 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
         p.out_ids[b * rows + j] = id;
         p.out_dists[b * rows + j] = d;
         p.out_pos[b * rows + j] = pos;
+        if (p.rec_pos) {
+            p.rec_pos[b * rows + j] = (int64_t) pos;
+            p.rec_id[b * rows + j] = id >= 0 ? id + p.id_offset : id;
+            p.rec_d[b * rows + j] = d;
+        }
     }
 }
 
@@ -1159,11 +1172,12 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st,
                             const float *d_queries, const float *d_codewords, int Ds, int arch, const uint8_t *d_lcodes, int debug,
-                            const unsigned long long *d_picks, const int32_t *d_pick_ok)
+                            const unsigned long long *d_picks, const int32_t *d_pick_ok, const ShardPack *pack)
 {
     if (B == 0) return hipSuccess;
     ShardArgs a;
     a.picks = d_picks; a.pick_ok = d_pick_ok;
+    if (pack && pack->rec_pos) { a.rec_pos = pack->rec_pos; a.rec_id = pack->rec_id; a.rec_d = pack->rec_d; a.id_offset = pack->id_offset; }
     a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch; a.lcodes = d_lcodes;
     a.codes = d_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.centers = d_centers; a.nlist = nlist; a.pl_off = d_pl_off;
     a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w; a.rows = rows;
@@ -1174,6 +1188,7 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
         const int nbuf = shard_any_nbuf(M, Ks, nlist, w);
         const int collect = (!top1 && rows > shard_any_max_rows(M, Ks, nlist, w)) ? 1 : 0;
         if (collect && (int64_t) rows < L) return hipErrorInvalidValue;
+        if (collect && a.rec_pos) return hipErrorInvalidValue;       // (the packed form is the selected-rows form's)
         const size_t smem = shard_any_fixed(M, Ks, nlist, w) + (top1 ? 64 : (collect ? 0 : (size_t) nbuf * 8));
         const bool gt = shard_gtab(M, Ks), cl = shard_any_clds(M, Ks, nlist);
         const bool pre = d_picks && d_pick_ok && d_lut && !gt && !cl;

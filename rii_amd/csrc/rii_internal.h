@@ -267,13 +267,16 @@ hipError_t launch_sorted_tie_flag(const unsigned long long *d_sorted, int64_t bc
 bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w, int rows);
 int ivf_shard_max_select_rows(int M, int Ks, int nlist, int64_t L, int64_t w);
 size_t ivf_shard_scratch_per_query(int M, int Ks, int nlist, int64_t L, int64_t w);   // global scratch per query of a launch (0: everything fits LDS)
+// the exchange record of rii_query_ivf_dbsharded_dev written by the shard kernel itself ([n] int64 positions | [n] int64 global ids | [n] f32)
+struct ShardPack { int64_t *rec_pos = nullptr, *rec_id = nullptr; float *rec_d = nullptr; int64_t id_offset = 0; };
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
                             int32_t *d_out_pos, int32_t *d_out_nloc, int64_t *d_out_counts, void *d_scratch, hipStream_t st,
                             const float *d_queries = nullptr, const float *d_codewords = nullptr, int Ds = 0, int arch = 0,
                             const uint8_t *d_lcodes = nullptr, int debug = 0,       // d_lcodes: the codes in posting order of d_pl_ids (unfiltered lists), or NULL
-                            const unsigned long long *d_picks = nullptr, const int32_t *d_pick_ok = nullptr);    // the pre-pass's output (with d_lut), or NULL
+                            const unsigned long long *d_picks = nullptr, const int32_t *d_pick_ok = nullptr,     // the pre-pass's output (with d_lut), or NULL
+                            const ShardPack *pack = nullptr);
 // round 6: the batch's coarse phase in front of that launch -- four queries per block, tables interleaved [m][ks][query]
 // (shard_coarse_quad_kernel): writes the queries' plain tables to d_lut ([B][M * 256]), the w + 1 smallest (distance, list) keys per
 // query to d_picks ([B][kShardPickStride]) and whether they are conclusive to d_pick_ok ([B])
