@@ -2209,7 +2209,7 @@ int ivf_shard_check(const rii_engine *e, int64_t B, int topk, int64_t S_global, 
 }
 int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk, const int64_t *d_tids, int64_t S, int64_t S_global, int64_t L,
                      int64_t w, const int32_t *d_glen, int G, int rank, int rows, int64_t *d_out_ids, float *d_out_dists, int32_t *d_out_pos,
-                     int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st, void *d_rec = nullptr, int64_t id_offset = 0)
+                     int32_t *d_out_nloc, int64_t *d_out_counts, hipStream_t st, void *d_rec = nullptr, int64_t id_offset = 0, int32_t *d_zero2 = nullptr)
 {
     // d_rec (round 6): the exchange record for the B x rows selected rows, written by the kernel next to the plain outputs (NULL: none)
     const int64_t nlist = nlist_of(e);
@@ -2267,13 +2267,14 @@ int ivf_shard_locked(rii_engine *e, const float *d_queries, int64_t B, int topk,
             pk.rec_d = reinterpret_cast<float *>(r + (size_t) n * 16) + b0 * (int64_t) rows;
             pk.id_offset = id_offset;
         }
+        if (b0 == 0) pk.zero2 = d_zero2;                    // (the first launch of the batch clears the merge's flag words)
         ScopedTimer t(e, "ivf_shard", st);
         HIP_TRY(launch_ivf_shard(e->d_codes.as<uint8_t>(), e->M, e->Ks, own_tables ? nullptr : e->s_lut.as<float>(), e->d_centers.as<uint8_t>(), (int) nlist,
                                  e->d_pl_off.as<int64_t>(), pl_ids, list_len, d_glen, G, rank, cur, topk, L, w, rows,
                                  d_out_ids + b0 * (int64_t) rows, d_out_dists + b0 * (int64_t) rows, d_out_pos + b0 * (int64_t) rows,
                                  d_out_nloc + b0, d_out_counts + b0, e->s_big.p, st,
                                  own_tables ? d_queries + b0 * D : nullptr, e->d_codewords.as<float>(), e->Ds, e->arch, lcodes,
-                                 (e->shard_dbg_stop & 0xff) | ((e->shard_force_replay ? 1 : 0) << 8), picks, pick_ok, d_rec ? &pk : nullptr));
+                                 (e->shard_dbg_stop & 0xff) | ((e->shard_force_replay ? 1 : 0) << 8), picks, pick_ok, (d_rec || pk.zero2) ? &pk : nullptr));
     }
     return RII_OK;
 }
@@ -2914,14 +2915,14 @@ RII_API int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_o
         // (round 6: the shard kernel writes the exchange record itself -- one launch less per batch than a pack kernel behind it)
         if (lr == RII_OK)
             lr = ivf_shard_locked(e, d_queries, B, topk, d_tids_local, S_local, S_global, L, w, glen, G, c->rank, (int) k1, c->tmp_i.as<int64_t>(),
-                                  c->tmp_d.as<float>(), pos, nloc, cnt, st, c->rec.as<unsigned char>() + kRecHeader, id_offset);
+                                  c->tmp_d.as<float>(), pos, nloc, cnt, st, c->rec.as<unsigned char>() + kRecHeader, id_offset, c->anyf.as<int32_t>());
         // (3) one all-gather + merge under (distance, position), the global ids as payload
         int32_t *d_tie = d_out_tie ? d_out_tie : c->tie.as<int32_t>();
         if (lr != RII_OK) local_msg = g_err;
         if (comm_set_header(c, 0, lr != RII_OK ? 1 : 0, st) != RII_OK) { c->broken = true; r = RII_ERR_HIP; break; }
         if ((r = comm_gather(c, c->rec.p, c->gathered.p, stride, st)) != RII_OK) break;
         if (lr != RII_OK) { g_err = local_msg; r = lr; break; }          // the peers learn it from this rank's header
-        if (hipMemsetAsync(c->anyf.p, 0, 8, st) != hipSuccess) { r = set_err(RII_ERR_HIP, "memset failed"); break; }
+        // (c->anyf's two words were cleared by block 0 of the shard kernel: round 6, a memset launch less per batch)
         // (keys = positions -> r_i, payload = ids -> mi; the merge's own OR of the flags goes to the second word: the finishing kernel
         //  recomputes it over the queries that were found)
         if (launch_merge_topk(c->gathered.p, G, B, (int) k1, (int) k1, 1, c->r_i.as<int64_t>(), c->md.as<float>(), c->mi.as<int64_t>(), st, nullptr, (int) k1, d_tie,

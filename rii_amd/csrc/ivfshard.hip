@@ -46,6 +46,7 @@ struct ShardArgs {
     // round 6: the rows written a second time in the exchange record's form (rii_query_ivf_dbsharded_dev: int64 positions | int64 GLOBAL
     // ids | f32 distances -- what ivf_pack_kernel made of the plain outputs in a launch of its own), or NULL
     int64_t *rec_pos = nullptr, *rec_id = nullptr; float *rec_d = nullptr; int64_t id_offset = 0;
+    int32_t *zero2 = nullptr;            // two words block 0 clears (the merge's flag words: a memset launch per batch otherwise)
 };
 
 // BIG (nlist above kShardMaxNlistLds -- the reference's default sqrt(N) is 11 k lists at a 125 M-code shard): the coarse order and
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void ivf_shard_kernel(ShardArgs p)
     unsigned long long *s_key = reinterpret_cast<unsigned long long *>(
         smem + ((reinterpret_cast<unsigned char *>(s_misc + 4) - smem + 15) & ~(size_t) 15));      // [pow2 >= L]
 
+    if (b == 0 && tid == 0 && p.zero2) { p.zero2[0] = 0; p.zero2[1] = 0; }
     if constexpr (!GTAB) {
         const float *src = p.lut + (size_t) b * MK;
         for (int i = tid; i < MK; i += 256) lds[i] = src[i];
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(256) void ivf_shard_any_kernel(ShardArgs p, int nbu
     const int nlist = p.nlist;
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
+    if (b == 0 && tid == 0 && p.zero2) { p.zero2[0] = 0; p.zero2[1] = 0; }
     const int dbg = (collect >> 8) & 0xff;                 // measurement only (option "shard_dbg_stop", tools/r5_shard_phases*.sh): return after a phase
     const bool force_replay = (collect >> 16) != 0;        // tests only (option "shard_force_replay"): no fast coarse selection
     collect &= 0xff;
@@ -1178,6 +1181,7 @@ hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *
     ShardArgs a;
     a.picks = d_picks; a.pick_ok = d_pick_ok;
     if (pack && pack->rec_pos) { a.rec_pos = pack->rec_pos; a.rec_id = pack->rec_id; a.rec_d = pack->rec_d; a.id_offset = pack->id_offset; }
+    if (pack) a.zero2 = pack->zero2;
     a.queries = d_queries; a.codewords = d_codewords; a.Ds = Ds; a.arch = arch; a.lcodes = d_lcodes;
     a.codes = d_codes; a.M = M; a.Ks = Ks; a.lut = d_lut; a.centers = d_centers; a.nlist = nlist; a.pl_off = d_pl_off;
     a.pl_ids = d_pl_ids; a.list_len = d_list_len; a.glen = d_glen; a.G = G; a.rank = rank; a.topk = topk; a.L = L; a.w = w; a.rows = rows;

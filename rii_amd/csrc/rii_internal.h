@@ -268,7 +268,7 @@ bool ivf_shard_supported(int M, int Ks, int nlist, int64_t L, int64_t w, int row
 int ivf_shard_max_select_rows(int M, int Ks, int nlist, int64_t L, int64_t w);
 size_t ivf_shard_scratch_per_query(int M, int Ks, int nlist, int64_t L, int64_t w);   // global scratch per query of a launch (0: everything fits LDS)
 // the exchange record of rii_query_ivf_dbsharded_dev written by the shard kernel itself ([n] int64 positions | [n] int64 global ids | [n] f32)
-struct ShardPack { int64_t *rec_pos = nullptr, *rec_id = nullptr; float *rec_d = nullptr; int64_t id_offset = 0; };
+struct ShardPack { int64_t *rec_pos = nullptr, *rec_id = nullptr; float *rec_d = nullptr; int64_t id_offset = 0; int32_t *zero2 = nullptr; };
 hipError_t launch_ivf_shard(const uint8_t *d_codes, int M, int Ks, const float *d_lut, const uint8_t *d_centers, int nlist,
                             const int64_t *d_pl_off, const int32_t *d_pl_ids, const int32_t *d_list_len, const int32_t *d_glen,
                             int G, int rank, int64_t B, int topk, int64_t L, int64_t w, int rows, int64_t *d_out_ids, float *d_out_dists,
