@@ -2925,6 +2925,11 @@ RII_API int rii_query_ivf_dbsharded_dev(rii_engine *e, rii_comm *c, int64_t id_o
         // (c->anyf's two words were cleared by block 0 of the shard kernel: round 6, a memset launch less per batch)
         // (keys = positions -> r_i, payload = ids -> mi; the merge's own OR of the flags goes to the second word: the finishing kernel
         //  recomputes it over the queries that were found)
+        if (topk == 1) {                      // round 6: merge + finish of a top-1 batch in one thread-per-query launch
+            if (launch_ivf_merge_top1(c->gathered.p, G, B, kRecHeader, cnt, d_out_ids, d_out_dists, d_out_counts, d_tie, c->anyf.as<int32_t>(), st) != hipSuccess)
+                r = set_err(RII_ERR_HIP, "merge failed");
+            break;
+        }
         if (launch_merge_topk(c->gathered.p, G, B, (int) k1, (int) k1, 1, c->r_i.as<int64_t>(), c->md.as<float>(), c->mi.as<int64_t>(), st, nullptr, (int) k1, d_tie,
                               c->anyf.as<int32_t>() + 1, kRecHeader, c->seq.p) != hipSuccess ||
             launch_ivf_finish(c->mi.as<int64_t>(), c->md.as<float>(), cnt, B, (int) k1, topk, d_out_ids, d_out_dists, d_out_counts, d_tie, c->anyf.as<int32_t>(), st) != hipSuccess) {

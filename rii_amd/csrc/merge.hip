@@ -142,6 +142,59 @@ size_t merge_topk_scratch(int G, int64_t B, int k)
     return (size_t) merge_group(G, B, k) * n2 * 8;
 }
 
+// Round 6: the database-sharded inverted index's top-1 batch -- merge + finish in ONE launch, a thread per query.  merge_topk_kernel
+// (one 256-thread block and a 64-key bitonic sort per query, whatever G x k is) took 10.2 us for 1024 queries x 2 rows, ivf_finish_kernel
+// another launch behind it.  Records as above with payload (keys = traversal positions, payload = global ids), k = 2 rows per query
+// and rank, 16-byte headers; the winner is the first minimum under (distance, position) -- positions are unique across ranks --;
+// `cnt` (> 0 = found: the global walk's verdict, the same on every rank) decides between the row and ({}, {}); a non-zero status in
+// any header poisons the batch (ids -2, distances NaN, counts -1, bit 1 of *out_any) exactly as the two kernels did.
+__global__ __launch_bounds__(256) void ivf_merge_top1_kernel(const unsigned char *__restrict__ gathered_raw, int G, int64_t B, int hdr,
+                                                             const int64_t *__restrict__ cnt, int64_t *__restrict__ out_ids,
+                                                             float *__restrict__ out_d, int64_t *__restrict__ out_cnt,
+                                                             int32_t *__restrict__ out_tie, int32_t *__restrict__ out_any)
+{
+    const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t Bk = B * 2;
+    const size_t rec = mrg_rec_bytes(Bk, 1) + (size_t) hdr;
+    const unsigned char *gathered = gathered_raw + hdr;
+    int bad = 0;
+    for (int g = 0; g < G; ++g) bad |= reinterpret_cast<const int32_t *>(gathered_raw + rec * g)[2];
+    if (out_tie) out_tie[b] = 0;
+    if (bad) {
+        out_ids[b] = kPeerFailedId;
+        out_d[b] = __uint_as_float(0x7fc00000u);
+        out_cnt[b] = -1;
+        if (out_any && threadIdx.x == 0) atomicOr(out_any, 2);
+        return;
+    }
+    unsigned long long bestk = ~0ull;                       // (orderable distance, position): positions fit 32 bits (L <= INT32_MAX - 1)
+    int64_t bestid = -1;
+    for (int g = 0; g < G; ++g) {
+        const int64_t *pos = mrg_ids(gathered, rec, g);
+        const int64_t *ids = mrg_pay(gathered, rec, g, Bk);
+        const float *dd = mrg_d(gathered, rec, g, Bk, 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t ps = pos[b * 2 + j];
+            const unsigned long long kk = ((unsigned long long) f32_orderable(__float_as_uint(dd[b * 2 + j])) << 32) | (uint32_t) ps;
+            if (ps >= 0 && ps < (int64_t) INT32_MAX && kk < bestk) { bestk = kk; bestid = ids[b * 2 + j]; }
+        }
+    }
+    const bool found = cnt[b] > 0 && bestk != ~0ull;
+    out_ids[b] = found ? bestid : (int64_t) -1;
+    out_d[b] = found ? __uint_as_float(f32_unorderable((uint32_t) (bestk >> 32))) : INFINITY;
+    out_cnt[b] = cnt[b];
+}
+hipError_t launch_ivf_merge_top1(const void *d_gathered, int G, int64_t B, int hdr, const int64_t *d_cnt, int64_t *d_out_ids, float *d_out_d,
+                                 int64_t *d_out_cnt, int32_t *d_out_tie, int32_t *d_out_any, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(ivf_merge_top1_kernel, dim3((unsigned) ((B + 255) / 256)), dim3(256), 0, st, static_cast<const unsigned char *>(d_gathered), G, B, hdr,
+                       d_cnt, d_out_ids, d_out_d, d_out_cnt, d_out_tie, d_out_any);
+    return hipGetLastError();
+}
+
 size_t merge_record_bytes(int64_t B, int k, int payload) { return mrg_rec_bytes(B * k, payload); }
 
 hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_ids,

@@ -295,6 +295,10 @@ int merge_topk_max_keys();
 size_t merge_record_bytes(int64_t B, int k, int payload);
 // id_offsets: host array of G per-rank offsets added to the (non-padding) keys, or NULL; d_out_tie [B] / d_out_any [1]: optional
 // tie flags over the first tie_cols merged distances (d_out_any must be zeroed by the caller)
+// round 6: the sharded inverted index's top-1 batch (k = 2 rows per query and rank, payload records with 16-byte headers): merge under
+// (distance, position) + the finishing step in one launch, a thread per query
+hipError_t launch_ivf_merge_top1(const void *d_gathered, int G, int64_t B, int hdr, const int64_t *d_cnt, int64_t *d_out_ids, float *d_out_d,
+                                 int64_t *d_out_cnt, int32_t *d_out_tie, int32_t *d_out_any, hipStream_t st);
 hipError_t launch_merge_topk(const void *d_gathered, int G, int64_t B, int k, int k_out, int payload, int64_t *d_out_ids,
                              float *d_out_dists, int64_t *d_out_payload, hipStream_t st, const int64_t *id_offsets = nullptr,
                              int tie_cols = 0, int32_t *d_out_tie = nullptr, int32_t *d_out_any = nullptr, int hdr = 0,
