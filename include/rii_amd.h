@@ -218,6 +218,15 @@ int rii_merge_topk_hdr_dev(const void *d_gathered, int G, int64_t B, int k, int 
                            int64_t *d_out_payload, int tie_cols, int32_t *d_out_tie, int32_t *d_out_any, void *d_scratch,
                            int64_t scratch_bytes, void *stream);
 
+/* Round 6: the merge AND the finishing step of the database-sharded inverted index's TOP-1 batch in one launch (a thread per query;
+ * what rii_query_ivf_dbsharded_dev runs behind its all-gather when topk == 1).  Records as rii_merge_topk_hdr_dev's with payload
+ * (rii_merge_hdr_record_bytes(B, 2, 1) per rank: keys = traversal positions, payload = global ids, k = 2 rows per query -- the two
+ * best candidates each rank owns, padding rows: position INT32_MAX, distance +inf).  d_counts [B]: the global walk's verdict (> 0 =
+ * found, the same on every rank: rii_query_ivf_shard_dev's counts).  Out: the first minimum under (distance, position), or -1 / +inf /
+ * count 0 where the reference returns ({}, {}); a non-zero status in any header: ids -2, distances NaN, counts -1, bit 1 of *d_out_any. */
+int rii_ivf_merge_top1_hdr_dev(const void *d_gathered, int G, int64_t B, const int64_t *d_counts, int64_t *d_out_ids, float *d_out_dists,
+                               int64_t *d_out_counts, int32_t *d_out_any, void *stream);
+
 /* ---- Multi-GPU behind the C ABI (NEW, round 4; not in the reference: it has no multi-device code) ----
  * One rii_comm per process and GPU = one RCCL communicator (over xGMI inside a node).  RCCL is bound at run time (dlopen of the
  * copy already in the process -- PyTorch-ROCm ships one -- else the system's librccl.so.1); without it rii_comm_init fails with

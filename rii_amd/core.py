@@ -145,6 +145,7 @@ def _lib():
         "rii_merge_hdr_record_bytes": (c_i64, [c_i64, c_int, c_int]),
         "rii_merge_hdr_scratch_bytes": (c_i64, [c_int, c_i64, c_int]),
         "rii_merge_topk_hdr_dev": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+        "rii_ivf_merge_top1_hdr_dev": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "rii_comm_unique_id": (c_int, [c_vp]),
         "rii_comm_init": (c_int, [c_vp, c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
         "rii_comm_destroy": (None, [c_vp]),
@@ -212,6 +213,12 @@ def merge_topk_hdr_dev(d_gathered, G, B, k, k_out, d_out_keys, d_out_dists, d_ou
     _check(_lib().rii_merge_topk_hdr_dev(d_gathered, int(G), int(B), int(k), int(k_out), int(bool(d_out_payload)), d_out_keys, d_out_dists,
                                          d_out_payload or None, int(tie_cols), d_out_tie or None, d_out_any or None, d_scratch or None,
                                          int(scratch_bytes), stream or None))
+
+
+def ivf_merge_top1_hdr_dev(d_gathered, G, B, d_counts, d_out_ids, d_out_dists, d_out_counts, d_out_any=0, stream=0):
+    """rii_ivf_merge_top1_hdr_dev: merge + finish of the sharded inverted index's top-1 batch (records with payload and header, k = 2)."""
+    _check(_lib().rii_ivf_merge_top1_hdr_dev(d_gathered, int(G), int(B), d_counts, d_out_ids, d_out_dists, d_out_counts, d_out_any or None,
+                                             stream or None))
 
 
 def ivf_shard_replay_scratch_bytes(nf, rows):

@@ -2473,6 +2473,16 @@ RII_API int rii_merge_topk_hdr_dev(const void *d_gathered, int G, int64_t B, int
     return RII_OK;
 }
 
+// Round 6: merge + finish of the database-sharded inverted index's TOP-1 batch in one launch, for callers who gather themselves (what
+// rii_query_ivf_dbsharded_dev runs behind its all-gather): records with payload and header, k = 2 rows per query and rank
+RII_API int rii_ivf_merge_top1_hdr_dev(const void *d_gathered, int G, int64_t B, const int64_t *d_counts, int64_t *d_out_ids, float *d_out_dists,
+                                       int64_t *d_out_counts, int32_t *d_out_any, void *stream)
+{
+    if (!d_gathered || G < 1 || B < 0 || (B > 0 && (!d_counts || !d_out_ids || !d_out_dists || !d_out_counts))) return set_err(RII_ERR_INVALID, "bad arguments");
+    HIP_TRY(launch_ivf_merge_top1(d_gathered, G, B, kRecHeader, d_counts, d_out_ids, d_out_dists, d_out_counts, nullptr, d_out_any, (hipStream_t) stream));
+    return RII_OK;
+}
+
 // Query sharding, for callers that run the collective themselves: the record of a rank and the unpack of the G gathered records
 // (what rii_query_*_qsharded_dev do internally).  Stateless.
 RII_API int64_t rii_qshard_begin(int64_t B, int G, int rank) { return (G < 1 || rank < 0 || rank > G || B < 0) ? -1 : qshard_begin(B, G, rank); }

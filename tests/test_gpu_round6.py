@@ -312,3 +312,55 @@ def test_fuzz_sharded_ivf_prepass_against_oracle(seed):
         assert g.get_option("shard_pre_launches") > 0                      # (some trial of every seed is within the pre-pass's reach)
     finally:
         g.set_option("shard_pre", 1)
+
+
+def test_ivf_top1_merge_for_many_fake_ranks():
+    """rii_ivf_merge_top1_hdr_dev (round 6: merge + finish of the sharded inverted index's top-1 batch in one thread-per-query launch) on
+    records built by hand for G = 1 ... 70 fake ranks: two rows per query and rank (position, global id, distance), padding rows,
+    exactly tied distances across ranks (the smaller POSITION wins: first minimum in traversal order), queries the walk did not find
+    (count 0 -> -1 / +inf), and a non-zero status in one header poisoning the batch (ids -2, NaN, counts -1, bit 1 of the word)."""
+    import torch
+    from rii_amd import core
+    rng = np.random.default_rng(66)
+    for G, B in ((1, 7), (2, 5), (3, 300), (8, 1000), (70, 9)):
+        k = 2
+        L = 5000
+        pos = np.full((G, B, k), np.iinfo(np.int32).max, np.int64)
+        gid = np.full((G, B, k), -1, np.int64)
+        d = np.full((G, B, k), np.inf, np.float32)
+        for b in range(B):
+            n_own = rng.integers(0, 3, G)                                         # rows each rank owns for this query (0 .. 2)
+            ps = rng.choice(L, int(n_own.sum()), replace=False) if n_own.sum() else np.zeros(0, np.int64)
+            dd = rng.integers(0, 6, int(n_own.sum())).astype(np.float32)         # many exact ties
+            at = 0
+            for g in range(G):
+                rows = sorted(zip(dd[at:at + n_own[g]], ps[at:at + n_own[g]]))
+                for j, (dv, pv) in enumerate(rows):
+                    pos[g, b, j] = pv; d[g, b, j] = dv; gid[g, b, j] = 1000 * pv + g
+                at += n_own[g]
+        cnt = (rng.random(B) < 0.85).astype(np.int64)
+        rec = core.merge_hdr_record_bytes(B, k, 1)
+        buf = torch.zeros((G, rec), dtype=torch.uint8)
+        n = B * k
+        for g in range(G):
+            buf[g, 16:16 + n * 8] = torch.from_numpy(np.ascontiguousarray(pos[g])).reshape(-1).view(torch.uint8)
+            buf[g, 16 + n * 8:16 + n * 16] = torch.from_numpy(np.ascontiguousarray(gid[g])).reshape(-1).view(torch.uint8)
+            buf[g, 16 + n * 16:16 + n * 20] = torch.from_numpy(np.ascontiguousarray(d[g])).reshape(-1).view(torch.uint8)
+        dbuf = buf.cuda()
+        dcnt = torch.from_numpy(cnt).cuda()
+        oi = torch.empty(B, dtype=torch.int64, device="cuda"); od = torch.empty(B, dtype=torch.float32, device="cuda")
+        oc = torch.empty(B, dtype=torch.int64, device="cuda"); anyf = torch.zeros(1, dtype=torch.int32, device="cuda")
+        core.ivf_merge_top1_hdr_dev(dbuf.data_ptr(), G, B, dcnt.data_ptr(), oi.data_ptr(), od.data_ptr(), oc.data_ptr(), anyf.data_ptr())
+        torch.cuda.synchronize()
+        for b in range(B):
+            rows = sorted((float(d[g, b, j]), int(pos[g, b, j]), int(gid[g, b, j])) for g in range(G) for j in range(k) if np.isfinite(d[g, b, j]))
+            if cnt[b] > 0 and rows:
+                assert (int(oi[b]), float(od[b]), int(oc[b])) == (rows[0][2], rows[0][0], int(cnt[b])), (G, B, b)
+            else:
+                assert int(oi[b]) == -1 and np.isinf(float(od[b])) and int(oc[b]) == int(cnt[b]), (G, B, b)
+        assert int(anyf.item()) == 0
+        buf[G // 2, 8:12] = torch.tensor([3], dtype=torch.int32).view(torch.uint8)
+        dbuf = buf.cuda()
+        core.ivf_merge_top1_hdr_dev(dbuf.data_ptr(), G, B, dcnt.data_ptr(), oi.data_ptr(), od.data_ptr(), oc.data_ptr(), anyf.data_ptr())
+        torch.cuda.synchronize()
+        assert bool((oi == -2).all()) and bool(torch.isnan(od).all()) and bool((oc == -1).all()) and int(anyf.item()) & 2
