@@ -3086,6 +3086,40 @@ __global__ __launch_bounds__(256) void rerank_top1_kernel(RrArgs p)
         if ((tid & 63) == 0) atomicMin(&red[0], amin);
         __syncthreads();
         const unsigned long long lim = red[0] + (unsigned long long) (uint32_t) p.slack[b];
+        if (p.M == 16 && p.Ks == 256 && !p.indirect) {
+            // round 6: long lists (a structured Deep-shaped set leaves ~13 k candidates per query, profiles/r06_deep_structured_levels.json):
+            // four candidates per thread with their 16-byte code rows in flight together -- one at a time, each row was a dependent
+            // round trip behind its record (1.4 ms of that 7 ms step)
+            for (unsigned int i0 = tid; i0 < cnt; i0 += 4 * blockDim.x) {
+                unsigned long long c[4];
+                uint4 row[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned int i = i0 + u * blockDim.x;
+                    c[u] = i < cnt ? cand[i] : ~0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool live = c[u] != ~0ull && (c[u] >> 32) <= lim;
+                    if (!live) c[u] = ~0ull;
+                    row[u] = *reinterpret_cast<const uint4 *>(p.codes + (size_t) (live ? (uint32_t) (c[u] & 0xffffffffu) : 0u) * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (c[u] == ~0ull) continue;
+                    const uint32_t wds[4] = {row[u].x, row[u].y, row[u].z, row[u].w};
+                    float d = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d = __fadd_rn(d, lds[(a * 4 + j) * 256 + ((wds[a] >> (8 * j)) & 0xffu)]);
+                    const uint32_t n = (uint32_t) (c[u] & 0xffffffffu);
+                    const uint32_t id = p.perm ? (uint32_t) p.perm[n] : n;
+                    const unsigned long long key = ((unsigned long long) f32_orderable(__float_as_uint(d)) << 32) | id;
+                    best = key < best ? key : best;
+                }
+            }
+        } else
         for (unsigned int i = tid; i < cnt; i += blockDim.x) {
             const unsigned long long c = cand[i];
             if ((c >> 32) > lim) continue;
